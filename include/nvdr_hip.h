@@ -1,0 +1,215 @@
+/* nvdr_hip.h -- C ABI of libnvdr_hip.so: the MI355X-native replacement for the two native
+ * plugins of NVlabs/nvdiffrecmc's differentiable Monte-Carlo direct-lighting path.
+ *
+ * The reference has no C ABI; its native surface is two pybind11 torch extensions:
+ *   optixutils_plugin   render/optixutils/c_src/torch_bindings.cpp:321-328
+ *   renderutils_plugin  render/renderutils/c_src/torch_bindings.cpp:866-888
+ * Every entry point below replaces one of those bindings (cited per function).  The contract:
+ *   - plain pointers + sizes + element strides, no torch types;
+ *   - all pointers are DEVICE pointers (HBM) unless the name says host;
+ *   - outputs are caller-allocated, contiguous, and fully overwritten (zero-filled where the
+ *     reference relies on torch::zeros) by the callee;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing
+ *     synchronises the host (the reference blocks in cudaStreamSynchronize after every env-shade
+ *     launch, torch_bindings.cpp:185,269 -- deliberately not reproduced);
+ *   - every function returns 0 on success, otherwise a hipError_t value (or -1 for argument
+ *     errors); nvdr_last_error() gives the message.  The reference swallows CUDA/OptiX errors
+ *     (render/optixutils/c_src/common.h:37-61) -- deliberately not reproduced.
+ *
+ * INTEGRATION.md shows the Python (ctypes) binding a maintainer of the reference would add.
+ */
+#ifndef NVDR_HIP_H
+#define NVDR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A strided view of up to 4 dims.  Strides are in ELEMENTS.  A dim of size 1 broadcasts on read,
+ * exactly like fetch3()/fetch2() in render/optixutils/c_src/common.h:13-27 and Tensor::nhwcIndex in
+ * render/renderutils/c_src/tensor.h:31.  Unused leading/trailing dims have size 1, stride 0. */
+typedef struct nvdr_tensor {
+    void   *data;
+    int64_t size[4];
+    int64_t stride[4];
+} nvdr_tensor;
+
+typedef struct nvdr_ctx nvdr_ctx; /* replaces OptiXStateWrapper, optix_wrapper.h:17-37 */
+
+const char *nvdr_last_error(void);
+int nvdr_version(void);
+
+/* ---- context: owns the BVH buffers, replaces OptiXStateWrapper ctor/dtor (optix_wrapper.cpp:306-348) */
+int nvdr_ctx_create(nvdr_ctx **out, int device);
+int nvdr_ctx_destroy(nvdr_ctx *ctx);
+
+/* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
+ * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);
+ * rebuild == 0: refit the bounds of the existing hierarchy to moved vertices (OPTIX_BUILD_OPERATION_UPDATE). */
+int nvdr_bvh_build(nvdr_ctx *ctx, const float *verts, int64_t n_verts, const int32_t *tris, int64_t n_tris,
+                   int rebuild, void *stream);
+
+/* Introspection / test hooks (additive; no reference counterpart). */
+typedef struct nvdr_bvh_info {
+    int64_t n_tris;
+    int64_t n_nodes;      /* internal nodes = n_tris - 1 (0 for a single triangle) */
+    int32_t height;       /* longest root-to-leaf path, in internal nodes */
+    int32_t root;         /* index of the root node */
+    float   aabb_min[3];
+    float   aabb_max[3];
+} nvdr_bvh_info;
+int nvdr_bvh_info_get(nvdr_ctx *ctx, nvdr_bvh_info *out_host, void *stream); /* synchronises `stream` */
+/* copy the device BVH to host buffers: nodes = n_nodes*16 floats (layout in DESIGN.md),
+ * tri_records = n_tris*12 floats (v0, e1, e2, {orig index bits, 0, 0}) */
+int nvdr_bvh_export(nvdr_ctx *ctx, float *nodes_host, float *tri_records_host, void *stream);
+
+/* Any-hit visibility of R rays against the BVH: out_vis[r] = 1 if NO triangle is hit for
+ * t in (0, 1e16) (same convention as shadow_test(), kernel.cu:101-118: 1 = unoccluded).
+ * ro, rd f32[R,3] contiguous.  counters (optional, may be NULL): uint64[2] device accumulators
+ * {box tests, triangle tests} used for the algorithmic-byte roofline figure. */
+int nvdr_trace_visibility(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis,
+                          unsigned long long *counters, void *stream);
+
+/* Closest hit of R rays: out_t f32[R] (<0 = miss), out_tri i32[R] (original triangle index, -1 = miss),
+ * out_uv f32[R,2] barycentrics of v1, v2.  G-buffer producer building block. */
+int nvdr_trace_closest(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, float *out_t,
+                       int32_t *out_tri, float *out_uv, void *stream);
+
+/* ---- env_shade_fwd / env_shade_bwd (torch_bindings.cpp:123-272; raygen program kernel.cu:463-542) */
+typedef struct nvdr_env_shade_args {
+    nvdr_tensor mask;        /* f32 [N,H,W]    (>0 = covered)                     params.h:17 */
+    nvdr_tensor ro;          /* f32 [N,H,W,3]  shadow-ray origins                 params.h:14 */
+    nvdr_tensor gb_pos;      /* f32 [N,H,W,3]                                      params.h:18 */
+    nvdr_tensor gb_normal;   /* f32 [N,H,W,3]                                      params.h:20 */
+    nvdr_tensor gb_view_pos; /* f32 [N,1,1,3] or [N,H,W,3]                         params.h:22 */
+    nvdr_tensor gb_kd;       /* f32 [N,H,W,3]                                      params.h:23 */
+    nvdr_tensor gb_ks;       /* f32 [N,H,W,3]  (occlusion, roughness, metalness)   params.h:25 */
+    nvdr_tensor light;       /* f32 [Hl,Wl,3]  lat-long radiance                   params.h:29 */
+    nvdr_tensor pdf;         /* f32 [Hl,Wl]                                        params.h:31 */
+    nvdr_tensor rows;        /* f32 [Hl]       row CDF                             params.h:32 */
+    nvdr_tensor cols;        /* f32 [Hl,Wl]    per-row column CDF                  params.h:33 */
+    nvdr_tensor perms;       /* i32 [NP,S]     stratum permutation table           params.h:42 */
+    uint32_t bsdf;           /* 0 'pbr', 1 'diffuse', 2 'white'   (ops.py:136) */
+    uint32_t n_samples_x;    /* S = n_samples_x^2 strata, 2 shadow rays per stratum */
+    uint32_t rnd_seed;
+    float    shadow_scale;
+    uint32_t pixel_index_offset; /* added to the linear pixel index that seeds the RNG (kernel.cu:504);
+                                    0 reproduces the reference; rank*H*W makes a one-view-per-GPU
+                                    shard draw the same streams as the single-GPU batch */
+    /* forward outputs, f32 [N,H,W,3] contiguous */
+    float *diff;
+    float *spec;
+    /* backward inputs */
+    nvdr_tensor diff_grad;   /* f32 [N,H,W,3] */
+    nvdr_tensor spec_grad;   /* f32 [N,H,W,3] */
+    /* backward outputs, contiguous: four f32 [N,H,W,3] and light_grad f32 [Hl,Wl,3] */
+    float *gb_pos_grad;
+    float *gb_normal_grad;
+    float *gb_kd_grad;
+    float *gb_ks_grad;
+    float *light_grad;
+    /* optional visibility cache, uint32 [N*H*W, ceil(2S/32)]: written by fwd when non-NULL; when
+       non-NULL in bwd the shadow rays are NOT re-traced (valid only for identical seed/inputs). */
+    uint32_t *vis_cache;
+} nvdr_env_shade_args;
+int nvdr_env_shade_fwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
+int nvdr_env_shade_bwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
+/* number of covered pixels seen by the last env-shade launch on this ctx (device counter read back;
+ * synchronises `stream`).  rays per pass = 2 * S * this. */
+int nvdr_env_shade_last_pixel_count(nvdr_ctx *ctx, int64_t *out_host, void *stream);
+
+/* ---- bilateral_denoiser_fwd/bwd (torch_bindings.cpp:274-319; kernels denoising.cu:14-130).
+ * col [N,H,W,3], nrm [N,H,W,3], zdz [N,H,W,2] strided views; out f32 [N,H,W,4] contiguous
+ * (rgb*w sum, max(sum w, 1e-4)); out_grad [N,H,W,4] strided; col_grad f32 [N,H,W,3] contiguous. */
+int nvdr_bilateral_denoiser_fwd(const nvdr_tensor *col, const nvdr_tensor *nrm, const nvdr_tensor *zdz, float sigma,
+                                float *out, void *stream);
+int nvdr_bilateral_denoiser_bwd(const nvdr_tensor *col, const nvdr_tensor *nrm, const nvdr_tensor *zdz, float sigma,
+                                const nvdr_tensor *out_grad, float *col_grad, void *stream);
+
+/* ---- renderutils_plugin (render/renderutils/c_src/torch_bindings.cpp).  All tensors are NHWC
+ * 4-d views with size-1 broadcasting; the launch extent is the per-dim max over the inputs
+ * (update_grid, torch_bindings.cpp:87-101); outputs and gradients are contiguous at that extent
+ * (gradients of broadcast inputs are summed by the caller, tensor.h:60-62). */
+
+/* image_loss_fwd/bwd (torch_bindings.cpp:727-798, loss.cu:105-228).
+ * loss: 0 l1, 1 mse, 2 relmse, 3 smape, 4 n2n;  tonemapper: 0 none, 1 log_srgb.
+ * fwd writes ONE partial sum per workgroup into `partials` (n_partials from nvdr_image_loss_num_partials);
+ * the caller sums and divides by N*H*W (ops.py:494).  bwd: d_out is the scalar upstream gradient
+ * already divided by N*H*W, broadcast to every pixel. */
+int64_t nvdr_image_loss_num_partials(int64_t n, int64_t h, int64_t w);
+int nvdr_image_loss_fwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper, float *partials,
+                        void *stream);
+int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper, float d_out,
+                        float *img_grad, float *target_grad, void *stream);
+
+/* prepare_shading_normal_fwd/bwd (torch_bindings.cpp:148-219, normal.cu:95-179) */
+int nvdr_prepare_shading_normal_fwd(const nvdr_tensor *pos, const nvdr_tensor *view_pos, const nvdr_tensor *perturbed_nrm,
+                                    const nvdr_tensor *smooth_nrm, const nvdr_tensor *smooth_tng,
+                                    const nvdr_tensor *geom_nrm, int two_sided_shading, int opengl, float *out,
+                                    void *stream);
+int nvdr_prepare_shading_normal_bwd(const nvdr_tensor *pos, const nvdr_tensor *view_pos, const nvdr_tensor *perturbed_nrm,
+                                    const nvdr_tensor *smooth_nrm, const nvdr_tensor *smooth_tng,
+                                    const nvdr_tensor *geom_nrm, const nvdr_tensor *d_out, int two_sided_shading,
+                                    int opengl, float *pos_grad, float *view_pos_grad, float *perturbed_nrm_grad,
+                                    float *smooth_nrm_grad, float *smooth_tng_grad, float *geom_nrm_grad, void *stream);
+
+/* xfm_fwd/bwd (torch_bindings.cpp:803-864, mesh.cu:19-91).  points [1|B,V,3], matrix [B,4,4] (contiguous),
+ * out [B,V,4] (is_points) or [B,V,3]; points_grad [B,V,3]. */
+int nvdr_xfm_fwd(const float *points, int64_t points_batch, int64_t n_points, const float *matrix, int64_t batch,
+                 int is_points, float *out, void *stream);
+int nvdr_xfm_bwd(const float *matrix, int64_t batch, int64_t n_points, const float *d_out, int is_points,
+                 float *points_grad, void *stream);
+
+/* stand-alone BSDF ops (torch_bindings.cpp:224-722, bsdf.cu:382-707) */
+int nvdr_lambert_fwd(const nvdr_tensor *nrm, const nvdr_tensor *wi, float *out, void *stream);
+int nvdr_lambert_bwd(const nvdr_tensor *nrm, const nvdr_tensor *wi, const nvdr_tensor *d_out, float *nrm_grad,
+                     float *wi_grad, void *stream);
+int nvdr_frostbite_fwd(const nvdr_tensor *nrm, const nvdr_tensor *wi, const nvdr_tensor *wo,
+                       const nvdr_tensor *linear_roughness, float *out, void *stream);
+int nvdr_frostbite_bwd(const nvdr_tensor *nrm, const nvdr_tensor *wi, const nvdr_tensor *wo,
+                       const nvdr_tensor *linear_roughness, const nvdr_tensor *d_out, float *nrm_grad, float *wi_grad,
+                       float *wo_grad, float *linear_roughness_grad, void *stream);
+int nvdr_fresnel_shlick_fwd(const nvdr_tensor *f0, const nvdr_tensor *f90, const nvdr_tensor *cos_theta, float *out,
+                            void *stream);
+int nvdr_fresnel_shlick_bwd(const nvdr_tensor *f0, const nvdr_tensor *f90, const nvdr_tensor *cos_theta,
+                            const nvdr_tensor *d_out, float *f0_grad, float *f90_grad, float *cos_theta_grad,
+                            void *stream);
+int nvdr_ndf_ggx_fwd(const nvdr_tensor *alpha_sqr, const nvdr_tensor *cos_theta, float *out, void *stream);
+int nvdr_ndf_ggx_bwd(const nvdr_tensor *alpha_sqr, const nvdr_tensor *cos_theta, const nvdr_tensor *d_out,
+                     float *alpha_sqr_grad, float *cos_theta_grad, void *stream);
+int nvdr_lambda_ggx_fwd(const nvdr_tensor *alpha_sqr, const nvdr_tensor *cos_theta, float *out, void *stream);
+int nvdr_lambda_ggx_bwd(const nvdr_tensor *alpha_sqr, const nvdr_tensor *cos_theta, const nvdr_tensor *d_out,
+                        float *alpha_sqr_grad, float *cos_theta_grad, void *stream);
+int nvdr_masking_smith_fwd(const nvdr_tensor *alpha_sqr, const nvdr_tensor *cos_theta_i, const nvdr_tensor *cos_theta_o,
+                           float *out, void *stream);
+int nvdr_masking_smith_bwd(const nvdr_tensor *alpha_sqr, const nvdr_tensor *cos_theta_i, const nvdr_tensor *cos_theta_o,
+                           const nvdr_tensor *d_out, float *alpha_sqr_grad, float *cos_theta_i_grad,
+                           float *cos_theta_o_grad, void *stream);
+int nvdr_pbr_specular_fwd(const nvdr_tensor *col, const nvdr_tensor *nrm, const nvdr_tensor *wo, const nvdr_tensor *wi,
+                          const nvdr_tensor *alpha, float min_roughness, float *out, void *stream);
+int nvdr_pbr_specular_bwd(const nvdr_tensor *col, const nvdr_tensor *nrm, const nvdr_tensor *wo, const nvdr_tensor *wi,
+                          const nvdr_tensor *alpha, float min_roughness, const nvdr_tensor *d_out, float *col_grad,
+                          float *nrm_grad, float *wo_grad, float *wi_grad, float *alpha_grad, void *stream);
+int nvdr_pbr_bsdf_fwd(const nvdr_tensor *kd, const nvdr_tensor *arm, const nvdr_tensor *pos, const nvdr_tensor *nrm,
+                      const nvdr_tensor *view_pos, const nvdr_tensor *light_pos, float min_roughness, int bsdf,
+                      float *out, void *stream);
+int nvdr_pbr_bsdf_bwd(const nvdr_tensor *kd, const nvdr_tensor *arm, const nvdr_tensor *pos, const nvdr_tensor *nrm,
+                      const nvdr_tensor *view_pos, const nvdr_tensor *light_pos, float min_roughness, int bsdf,
+                      const nvdr_tensor *d_out, float *kd_grad, float *arm_grad, float *pos_grad, float *nrm_grad,
+                      float *view_pos_grad, float *light_pos_grad, void *stream);
+
+/* ---- EnvironmentLight.update_pdf (render/light.py:46-59) fused on device: base f32 [Hl,Wl,3] contiguous ->
+ * pdf [Hl,Wl], cols [Hl,Wl], rows [Hl] (the reference materialises rows as [Hl,Wl] with identical
+ * columns and passes rows[:,0], render.py:114). */
+int nvdr_light_update_pdf(const float *base, int64_t hl, int64_t wl, float *pdf, float *cols, float *rows,
+                          void *stream);
+
+/* ---- test hook: evaluate include/nvdr_detmath.h on device.  op: 0 sin, 1 cos, 2 acos, 3 atan2(x,y). */
+int nvdr_test_detmath(int op, const float *x, const float *y, int64_t n, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVDR_HIP_H */

@@ -1,0 +1,155 @@
+"""ctypes binding of libnvdr_hip.so (C ABI: include/nvdr_hip.h).
+
+This is the binding a maintainer of the reference would write in place of the two
+torch.utils.cpp_extension.load() calls (render/optixutils/ops.py:67-72,
+render/renderutils/ops.py:78-83).  There is NO fallback: if the HIP library is missing or a
+call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: maps the HIP runtime the library binds to)
+
+from . import _build
+
+c_void_p, c_int, c_int64, c_float, c_uint32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
+
+
+class NvdrTensor(ctypes.Structure):
+    _fields_ = [('data', c_void_p), ('size', c_int64 * 4), ('stride', c_int64 * 4)]
+
+
+class NvdrBvhInfo(ctypes.Structure):
+    _fields_ = [('n_tris', c_int64), ('n_nodes', c_int64), ('height', ctypes.c_int32), ('root', ctypes.c_int32),
+                ('aabb_min', c_float * 3), ('aabb_max', c_float * 3)]
+
+
+class NvdrEnvShadeArgs(ctypes.Structure):
+    _fields_ = [(n, NvdrTensor) for n in ('mask', 'ro', 'gb_pos', 'gb_normal', 'gb_view_pos', 'gb_kd', 'gb_ks',
+                                          'light', 'pdf', 'rows', 'cols', 'perms')] + [
+        ('bsdf', c_uint32), ('n_samples_x', c_uint32), ('rnd_seed', c_uint32), ('shadow_scale', c_float),
+        ('pixel_index_offset', c_uint32),
+        ('diff', c_void_p), ('spec', c_void_p),
+        ('diff_grad', NvdrTensor), ('spec_grad', NvdrTensor),
+        ('gb_pos_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_kd_grad', c_void_p), ('gb_ks_grad', c_void_p),
+        ('light_grad', c_void_p), ('vis_cache', c_void_p)]
+
+
+_T = ctypes.POINTER(NvdrTensor)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGNATURES = {
+    'nvdr_last_error': [],
+    'nvdr_version': [],
+    'nvdr_ctx_create': [ctypes.POINTER(c_void_p), c_int],
+    'nvdr_ctx_destroy': [c_void_p],
+    'nvdr_bvh_build': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
+    'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
+    'nvdr_bvh_export': [c_void_p, c_void_p, c_void_p, c_void_p],
+    'nvdr_trace_visibility': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    'nvdr_trace_closest': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    'nvdr_env_shade_fwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
+    'nvdr_env_shade_bwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
+    'nvdr_env_shade_last_pixel_count': [c_void_p, ctypes.POINTER(c_int64), c_void_p],
+    'nvdr_bilateral_denoiser_fwd': [_T, _T, _T, c_float, c_void_p, c_void_p],
+    'nvdr_bilateral_denoiser_bwd': [_T, _T, _T, c_float, _T, c_void_p, c_void_p],
+    'nvdr_image_loss_num_partials': [c_int64, c_int64, c_int64],
+    'nvdr_image_loss_fwd': [_T, _T, c_int, c_int, c_void_p, c_void_p],
+    'nvdr_image_loss_bwd': [_T, _T, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    'nvdr_prepare_shading_normal_fwd': [_T] * 6 + [c_int, c_int, c_void_p, c_void_p],
+    'nvdr_prepare_shading_normal_bwd': [_T] * 7 + [c_int, c_int] + [c_void_p] * 6 + [c_void_p],
+    'nvdr_xfm_fwd': [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p],
+    'nvdr_xfm_bwd': [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p],
+    'nvdr_lambert_fwd': [_T, _T, c_void_p, c_void_p],
+    'nvdr_lambert_bwd': [_T, _T, _T, c_void_p, c_void_p, c_void_p],
+    'nvdr_frostbite_fwd': [_T] * 4 + [c_void_p, c_void_p],
+    'nvdr_frostbite_bwd': [_T] * 5 + [c_void_p] * 4 + [c_void_p],
+    'nvdr_fresnel_shlick_fwd': [_T] * 3 + [c_void_p, c_void_p],
+    'nvdr_fresnel_shlick_bwd': [_T] * 4 + [c_void_p] * 3 + [c_void_p],
+    'nvdr_ndf_ggx_fwd': [_T] * 2 + [c_void_p, c_void_p],
+    'nvdr_ndf_ggx_bwd': [_T] * 3 + [c_void_p] * 2 + [c_void_p],
+    'nvdr_lambda_ggx_fwd': [_T] * 2 + [c_void_p, c_void_p],
+    'nvdr_lambda_ggx_bwd': [_T] * 3 + [c_void_p] * 2 + [c_void_p],
+    'nvdr_masking_smith_fwd': [_T] * 3 + [c_void_p, c_void_p],
+    'nvdr_masking_smith_bwd': [_T] * 4 + [c_void_p] * 3 + [c_void_p],
+    'nvdr_pbr_specular_fwd': [_T] * 5 + [c_float, c_void_p, c_void_p],
+    'nvdr_pbr_specular_bwd': [_T] * 5 + [c_float, _T] + [c_void_p] * 5 + [c_void_p],
+    'nvdr_pbr_bsdf_fwd': [_T] * 6 + [c_float, c_int, c_void_p, c_void_p],
+    'nvdr_pbr_bsdf_bwd': [_T] * 6 + [c_float, c_int, _T] + [c_void_p] * 6 + [c_void_p],
+    'nvdr_light_update_pdf': [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    'nvdr_test_detmath': [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+}
+_RESTYPES = {'nvdr_last_error': ctypes.c_char_p, 'nvdr_image_loss_num_partials': c_int64}
+
+EXPORTED_SYMBOLS = sorted(_SIGNATURES)
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load libnvdr_hip.so.  Raises RuntimeError (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "libnvdr_hip.so is not built (%s). Build the HIP extension first: "
+            "python -c 'import __graft_entry__ as g; g.build()'  -- there is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the library is stale: rebuild
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().nvdr_last_error()
+        raise RuntimeError('%s failed (code %d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def require_cuda_f32(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise RuntimeError('%s must reside on the GPU (got %s); this path has no CPU fallback' % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError('%s must have dtype %s (got %s)' % (name, dtype, t.dtype))
+
+
+def tensor_view(t, ndim_to=4, lead=True):
+    """nvdr_tensor for `t`, padded to 4 dims with size-1/stride-0 dims (leading by default)."""
+    v = NvdrTensor()
+    if t is None:
+        v.data = None
+        for i in range(4):
+            v.size[i] = 1
+            v.stride[i] = 0
+        return v
+    sizes, strides = list(t.shape), list(t.stride())
+    assert len(sizes) <= 4
+    pad = 4 - len(sizes)
+    if lead:
+        sizes, strides = [1] * pad + sizes, [0] * pad + strides
+    else:
+        sizes, strides = sizes + [1] * pad, strides + [0] * pad
+    v.data = t.data_ptr()
+    for i in range(4):
+        v.size[i] = sizes[i]
+        v.stride[i] = strides[i]
+    return v

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- MC shadow rays/s and fwd+bwd iterations/s of the direct-lighting hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): bob mesh (10 688 triangles), 512x512, n_samples_x = 8 (64 spp,
+128 shadow rays per covered pixel per pass), 256x256 synthetic "sky + suns" probe, one camera view
+per GPU (weak scaling).  One step = one optimisation iteration of nvdiffrecmc_amd/trainer.py:
+update_pdf + BVH rebuild + shading normal + env-shade fwd + 2x bilateral denoiser + combine +
+log-sRGB L1 image loss + full backward (the env-shade backward RE-TRACES every ray, as the
+reference does) + gradient all-reduce (N > 1) + Adam.  Inputs are resident in HBM before the timed
+region.  `value` = shadow rays actually traced per second, whole job.
+
+Extra objects on the JSON line:
+  roofline     -- forward env-shade kernel: algorithmic bytes per launch (SURVEY 8d formula with the
+                  box/triangle test counts measured by the counting build of the same kernel) over
+                  its average duration measured with HIP events inside the timed steps, vs 8 TB/s.
+  cpu_baseline -- the CPU oracle (plain C, OpenMP over pixels, brute-force visibility) on a 1/16 pixel
+                  subset of the same view, fwd + bwd, on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
+
+
+def algorithmic_bytes_fwd(N, H, W, P, S, probe, n_box, n_tri):
+    """B = B_stream + B_tables + B_trav for one forward launch."""
+    NHW = N * H * W
+    b_stream = 4 * NHW + 60 * P + 24 * NHW
+    m = (probe - 1).bit_length() + 1  # ceil(log2(size-1)) + 1 bisection steps
+    b_tables = P * S * (8 + 4 * (m + 2) + 4 * (m + 2) + 2 * (4 + 12))
+    b_trav = 32 * n_box + 36 * n_tri
+    return b_stream + b_tables + b_trav, b_trav
+
+
+def cpu_baseline(res, n, view, n_views, stride=4):
+    """Oracle fwd+bwd on every stride-th pixel in x and y of the same view; returns the JSON object."""
+    from oracle import oracle as orc, scene_cpu
+    nt = orc.max_threads()
+    inp = scene_cpu.make_inputs('bob', res, res, n, view=view, n_views=n_views, n_threads=nt)
+    m = inp['mesh']
+    sub = torch.zeros_like(inp['mask'])
+    sub[:, ::stride, ::stride] = inp['mask'][:, ::stride, ::stride]
+    inp['mask'] = sub
+    kw = scene_cpu.shade_kwargs(inp)
+    g = torch.Generator().manual_seed(0)
+    dg, sg = torch.rand(1, res, res, 3, generator=g), torch.rand(1, res, res, 3, generator=g)
+    t0 = time.perf_counter()
+    f = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=0, n_threads=nt)
+    orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=0, diff_grad=dg, spec_grad=sg, n_threads=nt)
+    dt = time.perf_counter() - t0
+    rays = 2 * (2 * n * n * f['covered'])
+    return {'value': rays / dt, 'unit': 'rays/s', 'cores': nt, 'kind': 'port',
+            'sample': 'oracle/nvdr_oracle.c env-shade fwd+bwd (brute-force visibility over 10688 triangles), every %dth pixel '
+                      'in x and y of the %dx%d view (%d covered pixels, %d rays), %.1f s' % (stride, res, res, f['covered'], rays, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--res', type=int, default=512)
+    ap.add_argument('--n-samples-x', type=int, default=8)
+    ap.add_argument('--mesh', default='bob')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+
+    from nvdiffrecmc_amd.trainer import DirectLightingStep
+    from nvdiffrecmc_amd import optixutils as ou
+    n_views = max(world, 8)
+    H = W = args.res
+    step = DirectLightingStep(args.mesh, args.res, args.n_samples_x, view=rank, n_views=n_views, device=dev,
+                              pixel_index_offset=rank * H * W, retrace_backward=True)
+
+    # per-launch timing of the forward env-shade op with HIP events on torch's current stream (the stream
+    # the kernels are launched on); recorded inside the timed steps through a light wrapper
+    ev = []
+    orig = ou.ops._optix_env_shade_func.forward
+
+    def timed_forward(ctx, *a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(ctx, *a)
+        e1.record()
+        ev.append((e0, e1))
+        return out
+    ou.ops._optix_env_shade_func.forward = staticmethod(timed_forward)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.step(world)
+    ev.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.step(world)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ou.ops._optix_env_shade_func.forward = staticmethod(orig)
+
+    S = args.n_samples_x ** 2
+    rays_pass = torch.tensor([step.rays_per_pass()], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(rays_pass, op=dist.ReduceOp.SUM)
+    rays_step_total = 2.0 * float(rays_pass.item())  # forward + re-traced backward, all ranks
+    fwd_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+
+    if rank == 0:
+        # counting build of the same forward kernel on this rank's view -> measured traversal work
+        light = step.light
+        with torch.no_grad():
+            from nvdiffrecmc_amd import renderutils as ru
+            m = step.mask[..., None]
+            kd = step.kd_tex[step.texel].view(1, H, W, 3) * m  # same values as the step's kd image
+            ks = step.ks.view(1, 1, 1, 3) * m
+            nrm = ru.prepare_shading_normal(step.gb_pos, step.view_pos, None, step.gb_smooth_nrm, step.gb_tangent, step.gb_geom_nrm)
+            ro = step.gb_pos + nrm * 0.001
+            P, n_box, n_tri = ou.ops.env_shade_traversal_counts(step.ctx, step.mask, ro, step.gb_pos, nrm, step.view_pos, kd, ks,
+                                                               light.base, light._pdf, light.rows[:, 0], light.cols,
+                                                               n_samples_x=args.n_samples_x, rnd_seed=0)
+        probe = light.base.shape[0]
+        bytes_fwd, b_trav = algorithmic_bytes_fwd(1, H, W, P, S, probe, n_box, n_tri)
+        achieved = bytes_fwd / (fwd_ms * 1e-3) / 1e9
+        R = 2 * S * P
+        out = {
+            'metric': 'MC shadow rays/sec (fwd+bwd train iteration, 512x512 64spp bob mesh)',
+            'value': rays_step_total * args.steps / dt,
+            'unit': 'rays/s',
+            'iters_per_sec': args.steps / dt,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'bob.json %dx%d, %d spp (n_samples_x=%d), 1 view per GPU, LBVH + HIP traversal + GGX shading + bilateral denoiser + log-sRGB L1 loss, fwd+bwd+Adam'
+                                   % (H, W, S, args.n_samples_x),
+                       'mesh_triangles': int(step.mesh['t_pos_idx'].shape[0]), 'covered_pixels_rank0': P,
+                       'rays_per_pass_rank0': R, 'views': world, 'probe': '%dx%d E1' % (probe, probe),
+                       'backward': 're-traces all shadow rays', 'parallelism': 'dp%d (one view per GPU)' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'kernel': 'env_shade_kernel<false,false>',
+                         'kernel_ms_hip_events': fwd_ms, 'algorithmic_bytes_per_launch': bytes_fwd,
+                         'traversal_bytes_per_launch': b_trav, 'box_tests_per_ray': n_box / R, 'tri_tests_per_ray': n_tri / R,
+                         'fwd_rays_per_sec': R / (fwd_ms * 1e-3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.res, args.n_samples_x, 0, n_views)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

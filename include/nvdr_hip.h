@@ -110,9 +110,13 @@ typedef struct nvdr_env_shade_args {
     float *gb_kd_grad;
     float *gb_ks_grad;
     float *light_grad;
-    /* optional visibility cache, uint32 [N*H*W, ceil(2S/32)]: written by fwd when non-NULL; when
-       non-NULL in bwd the shadow rays are NOT re-traced (valid only for identical seed/inputs). */
+    /* optional visibility cache, uint32 [N*H*W, 2, ceil(S/32)] (bit i of plane 0 / 1 = the light- /
+       BSDF-sampled shadow ray of stratum i is occluded): written by fwd when non-NULL; when non-NULL in
+       bwd the shadow rays are NOT re-traced (valid only for identical seed and inputs). */
     uint32_t *vis_cache;
+    /* optional device accumulators uint64[2] {box tests, triangle tests} of the shadow-ray traversal
+       (a counting build of the same kernel; feeds the algorithmic-byte roofline figure) */
+    unsigned long long *counters;
 } nvdr_env_shade_args;
 int nvdr_env_shade_fwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
 int nvdr_env_shade_bwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
@@ -136,13 +140,13 @@ int nvdr_bilateral_denoiser_bwd(const nvdr_tensor *col, const nvdr_tensor *nrm, 
 /* image_loss_fwd/bwd (torch_bindings.cpp:727-798, loss.cu:105-228).
  * loss: 0 l1, 1 mse, 2 relmse, 3 smape, 4 n2n;  tonemapper: 0 none, 1 log_srgb.
  * fwd writes ONE partial sum per workgroup into `partials` (n_partials from nvdr_image_loss_num_partials);
- * the caller sums and divides by N*H*W (ops.py:494).  bwd: d_out is the scalar upstream gradient
- * already divided by N*H*W, broadcast to every pixel. */
+ * the caller sums and divides by N*H*W (ops.py:494).  bwd: d_partials f32[n_partials] is the gradient
+ * w.r.t. each partial (autograd hands back one value per partial; a pixel uses its own partial's). */
 int64_t nvdr_image_loss_num_partials(int64_t n, int64_t h, int64_t w);
 int nvdr_image_loss_fwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper, float *partials,
                         void *stream);
-int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper, float d_out,
-                        float *img_grad, float *target_grad, void *stream);
+int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper,
+                        const float *d_partials, float *img_grad, float *target_grad, void *stream);
 
 /* prepare_shading_normal_fwd/bwd (torch_bindings.cpp:148-219, normal.cu:95-179) */
 int nvdr_prepare_shading_normal_fwd(const nvdr_tensor *pos, const nvdr_tensor *view_pos, const nvdr_tensor *perturbed_nrm,

@@ -32,7 +32,7 @@ class NvdrEnvShadeArgs(ctypes.Structure):
         ('diff', c_void_p), ('spec', c_void_p),
         ('diff_grad', NvdrTensor), ('spec_grad', NvdrTensor),
         ('gb_pos_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_kd_grad', c_void_p), ('gb_ks_grad', c_void_p),
-        ('light_grad', c_void_p), ('vis_cache', c_void_p)]
+        ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p)]
 
 
 _T = ctypes.POINTER(NvdrTensor)
@@ -55,7 +55,7 @@ _SIGNATURES = {
     'nvdr_bilateral_denoiser_bwd': [_T, _T, _T, c_float, _T, c_void_p, c_void_p],
     'nvdr_image_loss_num_partials': [c_int64, c_int64, c_int64],
     'nvdr_image_loss_fwd': [_T, _T, c_int, c_int, c_void_p, c_void_p],
-    'nvdr_image_loss_bwd': [_T, _T, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    'nvdr_image_loss_bwd': [_T, _T, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_prepare_shading_normal_fwd': [_T] * 6 + [c_int, c_int, c_void_p, c_void_p],
     'nvdr_prepare_shading_normal_bwd': [_T] * 7 + [c_int, c_int] + [c_void_p] * 6 + [c_void_p],
     'nvdr_xfm_fwd': [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p],

@@ -1,0 +1,720 @@
+// env_shade.hip -- the fused Monte-Carlo direct-lighting kernel (forward and backward).
+//
+// Replaces the OptiX raygen program __raygen__rg (render/optixutils/c_src/envsampling/kernel.cu:463-542,
+// helpers :30-461) and its host launchers env_shade_fwd / env_shade_bwd
+// (render/optixutils/c_src/torch_bindings.cpp:123-272).
+//
+// MI355X design (the reference runs ONE thread per pixel with a serial 2*S-ray loop):
+//   * covered pixels are compacted into a work list first (bob covers ~20 % of the frame);
+//   * PERSISTENT wavefronts stride over the list; a pixel is owned by L = min(64, pow2ceil(S)) lanes
+//     and every lane owns whole strata: it jumps the pixel's LCG stream ahead to its stratum
+//     (5 draws per stratum, kernel.cu:513-524), so the random sequence is bit-identical to the serial loop;
+//   * a lane generates its light-sampled and its BSDF-sampled direction, then walks BOTH shadow rays
+//     through the BVH in one loop (a finished lane starts its next ray instead of idling);
+//     the traversal stack lives in LDS, one bank per lane;
+//   * contributions / gradients are reduced across the L lanes with DPP/permute butterflies; only
+//     the light gradient needs global atomics (kernel.cu:208-210).
+// The sampling math mirrors the evaluation order and the fp32/fp64 promotions of the reference
+// source and uses include/nvdr_detmath.h for sin/cos/acos/atan2, which makes every
+// discrete decision (texel, lobe, visibility) bit-identical to the CPU oracle.
+#include "bvh.h"
+#include "bsdf_device.h"
+
+#define NVDR_PI_DBL 3.14159265358979323846
+
+int bvh_stack_depth(nvdr_ctx *c, hipStream_t stream, int *depth); // bvh.hip
+
+struct Tab {          // small strided table (light, pdf, rows, cols)
+    const float *p;
+    int s0, s1, s2;
+    int n0, n1, n2;
+};
+
+struct ShadeParams {
+    View4 ro, pos, nrm, view_pos, kd, ks, dgrad, sgrad;
+    const float *mask; int64_t ms0, ms1, ms2;
+    Tab light, pdf, rows, cols;
+    const int *perms; int perm_s0, perm_s1; unsigned n_perms;
+    int N, H, W;
+    unsigned bsdf, n, S, seed, pix_offset;
+    float shadow_scale;
+    int L, log2L;             // lanes per pixel
+    float *diff, *spec;
+    float *g_pos, *g_nrm, *g_kd, *g_ks, *g_light;
+    uint32_t *vis_cache; int vis_words; // per plane
+    const int *pix_list;
+    const unsigned *pix_count;
+    int stack_depth;
+    unsigned long long *counters;
+};
+
+// ---------------------------------------------------------------------------------------------
+// work-list compaction: covered pixels (mask > 0, kernel.cu:478) in raster order per wave
+
+__global__ void compact_pixels_kernel(const float *__restrict__ mask, int64_t ms0, int64_t ms1, int64_t ms2, int N, int H,
+                                      int W, int *__restrict__ list, unsigned *count)
+{
+    const int64_t total = (int64_t)N * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool on = false;
+    if (i < total) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((int64_t)W * H));
+        on = mask[z * ms0 + y * ms1 + x * ms2] > 0.0f;
+    }
+    const unsigned long long b = __ballot(on);
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0 && b) base = atomicAdd(count, (unsigned)__popcll(b));
+    base = __shfl(base, 0);
+    if (on) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)i;
+}
+
+__global__ void zero_count_kernel(unsigned *count) { *count = 0; }
+
+// ---------------------------------------------------------------------------------------------
+// RNG (kernel.cu:30-45)
+
+__device__ __forceinline__ unsigned rand_pcg(unsigned &s)
+{
+    const unsigned st = s;
+    const unsigned word = ((st >> ((st >> 28u) + 4u)) ^ st) * 277803737u;
+    s = st * 747796405u + 2891336453u;
+    return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ float uniform_pcg(unsigned &s) { return (float)(rand_pcg(s) & 0xFFFFFF) / (float)0x1000000; }
+// advance the LCG by k steps in O(log k)
+__device__ __forceinline__ unsigned lcg_skip(unsigned s, unsigned k)
+{
+    unsigned am = 1u, ap = 0u, cm = 747796405u, cp = 2891336453u;
+    while (k) {
+        if (k & 1u) { am *= cm; ap = ap * cm + cp; }
+        cp = (cm + 1u) * cp;
+        cm *= cm;
+        k >>= 1;
+    }
+    return am * s + ap;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampling helpers (device transcription of kernel.cu:47-397; same order of operations as the oracle)
+
+__device__ __forceinline__ void branchless_onb(F3 n, F3 &b1, F3 &b2)
+{
+    const float sign = copysignf(1.0f, n.z);
+    const float a = -1.0f / (sign + n.z);
+    const float b = n.x * n.y * a;
+    b1 = f3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+    b2 = f3(b, sign + n.y * n.y * a, -n.y);
+}
+__device__ __forceinline__ F3 tolocal(F3 a, F3 u, F3 v, F3 w) { return f3(dot3(a, u), dot3(a, v), dot3(a, w)); }
+__device__ __forceinline__ F3 toworld(F3 a, F3 u, F3 v, F3 w) { return (u * a.x + v * a.y) + w * a.z; }
+
+__device__ __forceinline__ F3 cosine_sample(F3 N, float u, float v, float &pdf)
+{
+    N = safe_normalize(N);
+    F3 dx, dy;
+    branchless_onb(N, dx, dy);
+    const float phi = (float)(2.0 * NVDR_PI_DBL * (double)u);
+    const float costheta = sqrtf(v);
+    const float sintheta = (float)sqrt(1.0 - (double)v);
+    float sp, cp;
+    nvdr_sincosf(phi, &sp, &cp);
+    const float x = cp * sintheta, y = sp * sintheta, z = costheta;
+    pdf = (float)fmax((double)0.000001f, (double)costheta / NVDR_PI_DBL);
+    const F3 vec = (dx * x + dy * y) + N * z;
+    return safe_normalize(vec);
+}
+__device__ __forceinline__ float albedo(F3 baseColor, F3 wo, F3 N)
+{
+    const F3 W = safe_normalize(N);
+    F3 U, V;
+    branchless_onb(W, U, V);
+    const F3 wo_l = safe_normalize(tolocal(wo, U, V, W));
+    const float cosNO = wo_l.z;
+    if (!(cosNO > 0)) return 0.0f;
+    return luminance(fwd_fresnel3(baseColor, f3(1.0f), cosNO));
+}
+__device__ __forceinline__ void dir_to_tc(F3 dir, float &u, float &v)
+{
+    u = (float)((double)nvdr_atan2f(dir.x, -dir.z) / (2.0 * NVDR_PI_DBL) + 0.5);
+    v = (float)((double)nvdr_acosf(clampf(dir.y, -1.0f, 1.0f)) / NVDR_PI_DBL);
+}
+__device__ __forceinline__ F3 tc_to_dir(float u, float v)
+{
+    float sinphi, cosphi, sintheta, costheta;
+    nvdr_sincosf((float)((double)(u * 2.0f - 1.0f) * NVDR_PI_DBL), &sinphi, &cosphi);
+    nvdr_sincosf((float)((double)v * NVDR_PI_DBL), &sintheta, &costheta);
+    return f3(sintheta * sinphi, costheta, -sintheta * cosphi);
+}
+__device__ __forceinline__ unsigned cdf_iterations(unsigned hi)
+{
+    // int(ceil(log2(float(hi)))) + 1  (kernel.cu:147), in integers
+    return hi >= 2u ? (unsigned)(32 - __clz((int)(hi - 1u))) + 1u : hi;
+}
+__device__ __forceinline__ float sample_cdf(const float *__restrict__ cdf, int stride, int size, float x, unsigned &idx)
+{
+    x = fminf(x, 0.99999994f);
+    unsigned lo = 0, hi = (unsigned)(size - 1);
+    const unsigned m = cdf_iterations(hi);
+    for (unsigned i = 0; i < m; ++i) {
+        const unsigned mid = (lo + hi) >> 1;
+        const float c = cdf[mid * stride];
+        lo = x >= c ? mid : lo;
+        hi = x < c ? mid : hi;
+    }
+    idx = hi;
+    float pdf, sample;
+    if (hi == 0) {
+        pdf = cdf[0];
+        sample = x;
+    } else {
+        const float d0 = cdf[hi * stride], d1 = cdf[(hi - 1) * stride];
+        pdf = d0 - d1;
+        sample = x - d1;
+    }
+    return fminf(sample / pdf, 0.99999994f);
+}
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
+
+__device__ __forceinline__ float light_pdf(const ShadeParams &p, F3 dir, int &tx, int &ty)
+{
+    float cu, cv;
+    dir_to_tc(dir, cu, cv);
+    const int Wl = p.pdf.n1, Hl = p.pdf.n0;
+    const int x = clampi((int)(cu * (float)Wl), 0, Wl - 1);
+    const int y = clampi((int)(cv * (float)Hl), 0, Hl - 1);
+    // the radiance texel (eval_light_fwd, kernel.cu:195-199): same mapping at the light's own resolution
+    tx = clampi((int)(cu * (float)p.light.n1), 0, p.light.n1 - 1);
+    ty = clampi((int)(cv * (float)p.light.n0), 0, p.light.n0 - 1);
+    float s, c;
+    nvdr_sincosf((float)((double)cv * NVDR_PI_DBL), &s, &c);
+    const float pdf_weight = (float)((double)(Hl * Wl) / (2.0 * NVDR_PI_DBL * NVDR_PI_DBL * (double)fmaxf(s, 0.0001f)));
+    return p.pdf.p[y * p.pdf.s0 + x * p.pdf.s1] * pdf_weight;
+}
+__device__ __forceinline__ F3 light_sample(const ShadeParams &p, float u, float v, float &pdf, int &tx, int &ty)
+{
+    unsigned x, y;
+    const float ry = sample_cdf(p.rows.p, p.rows.s0, p.rows.n0, v, y);
+    const float rx = sample_cdf(p.cols.p + (int64_t)y * p.cols.s0, p.cols.s1, p.cols.n1, u, x);
+    const F3 d = tc_to_dir(((float)x + rx) / (float)p.pdf.n1, ((float)y + ry) / (float)p.pdf.n0);
+    pdf = light_pdf(p, d, tx, ty);
+    return d;
+}
+__device__ __forceinline__ float eval_ndf_ggx(float alpha, float cosTheta)
+{
+    const float a2 = alpha * alpha;
+    const float d = ((cosTheta * a2 - cosTheta) * cosTheta + 1);
+    return (float)((double)a2 / ((double)(d * d) * NVDR_PI_DBL));
+}
+__device__ __forceinline__ float eval_g1_ggx(float alphaSqr, float cosTheta)
+{
+    if (cosTheta <= 0) return 0;
+    const float c2 = cosTheta * cosTheta;
+    const float tan2 = fmaxf(1.0f - c2, 0.0f) / c2;
+    return 2 / (1 + sqrtf(1 + alphaSqr * tan2));
+}
+__device__ __forceinline__ float eval_pdf_ggx_vndf(float alpha, F3 wo, F3 h)
+{
+    const float G1 = eval_g1_ggx(alpha * alpha, wo.z);
+    const float D = eval_ndf_ggx(alpha, h.z);
+    return G1 * D * fmaxf(0.f, dot3(wo, h)) / wo.z;
+}
+__device__ __forceinline__ F3 sample_ggx_vndf(float alpha, F3 wo, float ux, float uy, float &pdf)
+{
+    const F3 Vh = safe_normalize(f3(alpha * wo.x, alpha * wo.y, wo.z));
+    const F3 T1 = (Vh.z < 0.9999f) ? safe_normalize(cross3(f3(0.f, 0.f, 1.f), Vh)) : f3(1.f, 0.f, 0.f);
+    const F3 T2 = cross3(Vh, T1);
+    const float r = sqrtf(ux);
+    const float phi = (2.f * NVDR_PI_FLT) * uy;
+    float sp, cp;
+    nvdr_sincosf(phi, &sp, &cp);
+    const float t1 = r * cp;
+    float t2 = r * sp;
+    const float s = 0.5f * (1.f + Vh.z);
+    t2 = (1.f - s) * sqrtf(1.f - t1 * t1) + s * t2;
+    const F3 Nh = (T1 * t1 + T2 * t2) + Vh * sqrtf(fmaxf(0.f, 1.f - t1 * t1 - t2 * t2));
+    const F3 h = safe_normalize(f3(alpha * Nh.x, alpha * Nh.y, fmaxf(0.f, Nh.z)));
+    pdf = eval_pdf_ggx_vndf(alpha, wo, h);
+    return h;
+}
+__device__ __forceinline__ F3 ggx_sample(F3 N, F3 wo, float u, float v, float alpha, float &pdf)
+{
+    const F3 W = safe_normalize(N);
+    F3 U, V;
+    branchless_onb(W, U, V);
+    const F3 wo_l = safe_normalize(tolocal(wo, U, V, W));
+    const float cosNO = wo_l.z;
+    if (!(cosNO > 0)) {
+        pdf = 0.f;
+        return f3(0.f);
+    }
+    const F3 h = sample_ggx_vndf(alpha, wo_l, u, v, pdf);
+    const float woDotH = dot3(wo_l, h);
+    const F3 wi_l = (h * woDotH) * 2.0f - wo_l;
+    pdf /= (4.0f * woDotH);
+    return safe_normalize(toworld(wi_l, U, V, W));
+}
+__device__ __forceinline__ float ggx_pdf(F3 N, F3 wo, F3 wi, float alpha)
+{
+    const F3 W = safe_normalize(N);
+    F3 U, V;
+    branchless_onb(W, U, V);
+    const F3 wo_l = tolocal(wo, U, V, W);
+    const F3 wi_l = tolocal(wi, U, V, W);
+    float pdf = 0.0f;
+    if (wo_l.z > 0 && wi_l.z > 0) {
+        const F3 m = safe_normalize(wi_l + wo_l);
+        const float woDotH = dot3(m, wo_l);
+        const float D = eval_ndf_ggx(alpha, m.z);
+        const float G1 = eval_g1_ggx(alpha * alpha, wo_l.z);
+        pdf = G1 * D * fmaxf(0.f, dot3(wo_l, m)) / wo_l.z;
+        pdf /= (4 * woDotH);
+    }
+    return pdf;
+}
+__device__ __forceinline__ void update_pdf(float &pdf, float opdf, float b)
+{
+    if (b > 0.000001f) {
+        opdf *= b;
+        pdf += opdf;
+    }
+}
+__device__ __forceinline__ F3 bsdf_sample(float pDiffuse, float pSpecular, F3 N, F3 wo, float sx, float sy, float sz,
+                                          float alpha, float &pdf)
+{
+    pdf = 0.0f;
+    F3 wi_o;
+    if (sz < pDiffuse) {
+        if (pDiffuse < 0.0001f) {
+            pdf = 1.0f;
+            return N;
+        }
+        wi_o = cosine_sample(N, sx, sy, pdf);
+        pdf *= pDiffuse;
+        if (pSpecular > 0) update_pdf(pdf, ggx_pdf(N, wo, wi_o, alpha), 1.0f - pDiffuse);
+    } else {
+        wi_o = ggx_sample(N, wo, sx, sy, alpha, pdf);
+        pdf *= 1.f - pDiffuse;
+        if (pDiffuse > 0) update_pdf(pdf, (float)(fmax((double)dot3(N, wi_o), 0.0) / NVDR_PI_DBL), pDiffuse);
+    }
+    return wi_o;
+}
+__device__ __forceinline__ float bsdf_pdf(float pDiffuse, float pSpecular, F3 N, F3 wo, F3 wi, float alpha)
+{
+    const float NdotL = dot3(N, wi), NdotV = dot3(N, wo);
+    float pdf = 0.0f;
+    if (fminf(NdotV, NdotL) < 1e-6f) return 1.0f;
+    if (pDiffuse > 0) update_pdf(pdf, (float)(fmax((double)dot3(N, wi), 0.0) / NVDR_PI_DBL), pDiffuse);
+    if (pSpecular > 0) update_pdf(pdf, ggx_pdf(N, wo, wi, alpha), 1.0f - pDiffuse);
+    return pdf;
+}
+
+// ---------------------------------------------------------------------------------------------
+// two shadow rays per lane in ONE traversal loop.  Bit 0 / bit 1 of the result = ray A / ray B is
+// OCCLUDED.  A lane that finishes ray A immediately restarts at the root with ray B.
+
+template <bool COUNT>
+__device__ __forceinline__ unsigned trace_two(const BvhView &bvh, F3 o, F3 da, F3 db, unsigned todo, int *stack,
+                                              unsigned &n_box, unsigned &n_tri)
+{
+    unsigned occluded = 0;
+    if (bvh.n_tris == 1) {
+        if (COUNT) n_tri += (todo & 1u) + ((todo >> 1) & 1u);
+        if ((todo & 1u) && tri_any_hit(bvh.tris, 0, o.x, o.y, o.z, da.x, da.y, da.z)) occluded |= 1u;
+        if ((todo & 2u) && tri_any_hit(bvh.tris, 0, o.x, o.y, o.z, db.x, db.y, db.z)) occluded |= 2u;
+        return occluded;
+    }
+    int ray = (todo & 1u) ? 0 : ((todo & 2u) ? 1 : 2);
+    F3 d = ray == 0 ? da : db;
+    float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    int sp = 0, cur = 0;
+    while (ray < 2) {
+        const float4 q0 = bvh.nodes[4 * cur + 0], q1 = bvh.nodes[4 * cur + 1];
+        const float4 q2 = bvh.nodes[4 * cur + 2], q3 = bvh.nodes[4 * cur + 3];
+        float tl, tr;
+        bool hl = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o.x, o.y, o.z, ix, iy, iz, NVDR_RAY_TMAX, tl);
+        bool hr = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o.x, o.y, o.z, ix, iy, iz, NVDR_RAY_TMAX, tr);
+        const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
+        bool done = false;
+        if (COUNT) {
+            n_box += 2;
+            n_tri += (hl && cl < 0) ? 1u : 0u;
+        }
+        if (hl && cl < 0) {
+            if (tri_any_hit(bvh.tris, ~cl, o.x, o.y, o.z, d.x, d.y, d.z)) { occluded |= 1u << ray; done = true; }
+            hl = false;
+        }
+        if (!done && hr && cr < 0) {
+            if (COUNT) n_tri++;
+            if (tri_any_hit(bvh.tris, ~cr, o.x, o.y, o.z, d.x, d.y, d.z)) { occluded |= 1u << ray; done = true; }
+            hr = false;
+        }
+        if (!done) {
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                stack[sp * 64] = left_first ? cr : cl;
+                sp++;
+                cur = left_first ? cl : cr;
+            } else if (hl) {
+                cur = cl;
+            } else if (hr) {
+                cur = cr;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack[sp * 64];
+            } else {
+                done = true;
+            }
+        }
+        if (done) {
+            ray = (ray == 0 && (todo & 2u)) ? 1 : 2;
+            d = db;
+            ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
+            sp = 0;
+            cur = 0;
+        }
+    }
+    return occluded;
+}
+
+// butterfly sum over the L lanes that share a pixel (L a power of two <= 64)
+__device__ __forceinline__ float group_sum(float v, int L)
+{
+    for (int o = L >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ F3 group_sum3(F3 v, int L) { return f3(group_sum(v.x, L), group_sum(v.y, L), group_sum(v.z, L)); }
+
+__device__ __forceinline__ F3 fetch_light(const Tab &t, int y, int x)
+{
+    const float *q = t.p + (int64_t)y * t.s0 + (int64_t)x * t.s1;
+    return t.n2 == 1 ? f3(q[0]) : f3(q[0], q[t.s2], q[2 * t.s2]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+
+template <bool BACKWARD, bool COUNT>
+__global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p, BvhView bvh)
+{
+    unsigned n_box = 0, n_tri = 0;
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *stack = smem + wave * p.stack_depth * 64 + lane;
+    const int L = p.L, G = 64 >> p.log2L;
+    const int slot = lane >> p.log2L, sub = lane & (L - 1);
+    const unsigned P = *p.pix_count;
+    const unsigned n_groups = (P + G - 1) / G;
+    const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
+    const unsigned S = p.S, n = p.n;
+    const float strata_frac = 1.0f / (float)n;
+    const float sample_frac = 1.0f / (float)(n * n);
+
+    for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
+        const unsigned pi = grp * G + slot;
+        const bool valid = pi < P;
+        const int lin = p.pix_list[valid ? pi : 0];
+        const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
+        const F3 ro = fetch3(p.ro, z, y, x), pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
+        const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
+        F3 dgrad = f3(0.0f), sgrad = f3(0.0f);
+        if (BACKWARD) {
+            dgrad = fetch3(p.dgrad, z, y, x);
+            sgrad = fetch3(p.sgrad, z, y, x);
+        }
+        // per-pixel set-up (kernel.cu:490-505)
+        const float alpha = ks.y * ks.y;
+        const F3 wo = safe_normalize(view_pos - pos);
+        const float metallic = ks.z;
+        const F3 specColor = f3(0.04f) * (1.0f - metallic) + kd * metallic;
+        const float diffuseWeight = (1.f - metallic) * luminance(kd);
+        const float specularWeight = albedo(specColor, wo, nrm);
+        const float pDiffuse = (diffuseWeight + specularWeight) > 0.f ? diffuseWeight / (diffuseWeight + specularWeight) : 1.f;
+        const float pSpecular = 1.0f - pDiffuse;
+        unsigned a_seed = p.seed, b_seed = (unsigned)lin + p.pix_offset;
+        unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
+        const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
+        const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
+
+        F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
+        F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
+
+        for (unsigned base = 0; base < S; base += L) {
+            const unsigned i = base + sub;
+            const bool active = valid && i < S;
+            const unsigned ii = active ? i : 0;
+            unsigned rng = lcg_skip(rng0, 5u * ii);
+            // light importance sample (kernel.cu:513-516)
+            const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
+            float sx = ((float)(pl % n) + uniform_pcg(rng)) * strata_frac;
+            float sy = ((float)(pl / n) + uniform_pcg(rng)) * strata_frac;
+            float pdfA_light, pdfB_bsdf;
+            int txA, tyA, txB, tyB;
+            const F3 dirA = light_sample(p, sx, sy, pdfA_light, txA, tyA);
+            const float pdfA_bsdf = bsdf_pdf(pDiffuse, pSpecular, nrm, wo, dirA, alpha);
+            // BSDF importance sample (kernel.cu:522-526)
+            const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
+            sx = ((float)(pb % n) + uniform_pcg(rng)) * strata_frac;
+            sy = ((float)(pb / n) + uniform_pcg(rng)) * strata_frac;
+            const float sz = uniform_pcg(rng);
+            const F3 dirB = bsdf_sample(pDiffuse, pSpecular, nrm, wo, sx, sy, sz, alpha, pdfB_bsdf);
+            const float pdfB_light = light_pdf(p, dirB, txB, tyB);
+
+            // visibility: trace both rays, or replay the bits saved by the forward pass
+            unsigned occ;
+            const int chunk = (int)(base >> 6); // only L == 64 has more than one chunk
+            if (BACKWARD && p.vis_cache) {
+                const uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
+                const unsigned bit = i & 31u, word = i >> 5;
+                occ = 0;
+                if (active) {
+                    occ |= ((vc[word] >> bit) & 1u);
+                    occ |= ((vc[p.vis_words + word] >> bit) & 1u) << 1;
+                }
+            } else {
+                occ = trace_two<COUNT>(bvh, ro, dirA, dirB, active ? 3u : 0u, stack, n_box, n_tri);
+                if (!BACKWARD && p.vis_cache) {
+                    const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
+                    if (sub == 0 && valid) {
+                        uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
+                        if (L == 64) {
+                            const int w0 = 2 * chunk;
+                            vc[w0] = (uint32_t)ba;
+                            vc[p.vis_words + w0] = (uint32_t)bb;
+                            if (w0 + 1 < p.vis_words) {
+                                vc[w0 + 1] = (uint32_t)(ba >> 32);
+                                vc[p.vis_words + w0 + 1] = (uint32_t)(bb >> 32);
+                            }
+                        } else {
+                            const unsigned long long m = (1ull << L) - 1ull;
+                            vc[0] = (uint32_t)((ba >> (slot * L)) & m);
+                            vc[p.vis_words] = (uint32_t)((bb >> (slot * L)) & m);
+                        }
+                    }
+                }
+            }
+
+            // shade both samples (process_sample, kernel.cu:403-461)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const F3 dir = r == 0 ? dirA : dirB;
+                const float pdfSum = r == 0 ? (pdfA_light + pdfA_bsdf) : (pdfB_light + pdfB_bsdf);
+                const int tx = r == 0 ? txA : txB, ty = r == 0 ? tyA : tyB;
+                const F3 light_col = fetch_light(p.light, ty, tx);
+                const float mis_weight = (float)(1.0 / (double)fmaxf(pdfSum, 0.0001f));
+                F3 _diff = f3(0.0f), _spec = f3(0.0f);
+                if (p.bsdf == 1 || p.bsdf == 2)
+                    _diff = f3(fwd_lambert(nrm, dir));
+                else
+                    fwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, _diff, _spec);
+                const float vis = ((occ >> r) & 1u) ? 0.0f : 1.0f;
+                const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
+                if (active) {
+                    if (BACKWARD) {
+                        const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
+                        float *g = p.g_light + ((int64_t)ty * p.light.n1 + tx) * 3;
+                        atomicAdd(g + 0, lg.x);
+                        atomicAdd(g + 1, lg.y);
+                        atomicAdd(g + 2, lg.z);
+                        const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
+                        const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
+                        if (p.bsdf == 1 || p.bsdf == 2) {
+                            F3 d_wi = f3(0.0f);
+                            bwd_lambert(nrm, dir, g_nrm, d_wi, sum3(_dg));
+                        } else {
+                            bwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
+                        }
+                    } else {
+                        diffAccum += (((_diff * light_col) * V) * mis_weight) * sample_frac;
+                        specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
+                    }
+                }
+            }
+        }
+
+        if (!BACKWARD) {
+            diffAccum = group_sum3(diffAccum, L);
+            specAccum = group_sum3(specAccum, L);
+            if (valid && sub == 0) {
+                float *o = p.diff + (int64_t)lin * 3;
+                o[0] = diffAccum.x; o[1] = diffAccum.y; o[2] = diffAccum.z;
+                o = p.spec + (int64_t)lin * 3;
+                o[0] = specAccum.x; o[1] = specAccum.y; o[2] = specAccum.z;
+            }
+        } else {
+            g_pos = group_sum3(g_pos, L);
+            g_nrm = group_sum3(g_nrm, L);
+            g_kd = group_sum3(g_kd, L);
+            g_ks = group_sum3(g_ks, L);
+            if (valid && sub == 0) {
+                float *o = p.g_pos + (int64_t)lin * 3;
+                o[0] = g_pos.x; o[1] = g_pos.y; o[2] = g_pos.z;
+                o = p.g_nrm + (int64_t)lin * 3;
+                o[0] = g_nrm.x; o[1] = g_nrm.y; o[2] = g_nrm.z;
+                o = p.g_kd + (int64_t)lin * 3;
+                o[0] = g_kd.x; o[1] = g_kd.y; o[2] = g_kd.z;
+                o = p.g_ks + (int64_t)lin * 3;
+                o[0] = g_ks.x; o[1] = g_ks.y; o[2] = g_ks.z;
+            }
+        }
+    }
+    if (COUNT) {
+        for (int o = 32; o >= 1; o >>= 1) {
+            n_box += __shfl_xor(n_box, o);
+            n_tri += __shfl_xor(n_tri, o);
+        }
+        if (lane == 0) {
+            atomicAdd(&p.counters[0], (unsigned long long)n_box);
+            atomicAdd(&p.counters[1], (unsigned long long)n_tri);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+
+static int make_tab(Tab &t, const nvdr_tensor &v, int ndim, const char *name)
+{
+    NVDR_REQUIRE(v.data != nullptr, "env_shade: %s is NULL", name);
+    t.p = (const float *)v.data;
+    t.n0 = (int)v.size[0]; t.n1 = ndim > 1 ? (int)v.size[1] : 1; t.n2 = ndim > 2 ? (int)v.size[2] : 1;
+    t.s0 = (int)v.stride[0]; t.s1 = ndim > 1 ? (int)v.stride[1] : 0; t.s2 = ndim > 2 ? (int)v.stride[2] : 0;
+    return 0;
+}
+
+static int check_gb(const nvdr_tensor &t, int64_t N, int64_t H, int64_t W, const char *name)
+{
+    NVDR_REQUIRE(t.data != nullptr, "env_shade: %s is NULL", name);
+    NVDR_REQUIRE((t.size[0] == N || t.size[0] == 1) && (t.size[1] == H || t.size[1] == 1) &&
+                     (t.size[2] == W || t.size[2] == 1) && (t.size[3] == 3 || t.size[3] == 1),
+                 "env_shade: %s has shape [%lld,%lld,%lld,%lld], expected [%lld,%lld,%lld,3] or a broadcastable shape",
+                 name, (long long)t.size[0], (long long)t.size[1], (long long)t.size[2], (long long)t.size[3],
+                 (long long)N, (long long)H, (long long)W);
+    return 0;
+}
+
+static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool backward, hipStream_t stream)
+{
+    NVDR_REQUIRE(c && a, "env_shade: NULL argument");
+    NVDR_REQUIRE(c->n_tris > 0, "env_shade: no BVH built on this context (call optix_build_bvh first)");
+    NVDR_REQUIRE(a->bsdf <= 2, "env_shade: BSDF index %u out of range", a->bsdf);
+    NVDR_REQUIRE(a->n_samples_x >= 1 && a->n_samples_x <= 256, "env_shade: n_samples_x %u out of range", a->n_samples_x);
+    const int64_t N = a->ro.size[0], H = a->ro.size[1], W = a->ro.size[2];
+    NVDR_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), "env_shade: bad launch extent");
+    int r;
+    if ((r = check_gb(a->ro, N, H, W, "ro"))) return r;
+    if ((r = check_gb(a->gb_pos, N, H, W, "gb_pos"))) return r;
+    if ((r = check_gb(a->gb_normal, N, H, W, "gb_normal"))) return r;
+    if ((r = check_gb(a->gb_view_pos, N, H, W, "gb_view_pos"))) return r;
+    if ((r = check_gb(a->gb_kd, N, H, W, "gb_kd"))) return r;
+    if ((r = check_gb(a->gb_ks, N, H, W, "gb_ks"))) return r;
+    NVDR_REQUIRE(a->mask.data && a->mask.size[0] == N && a->mask.size[1] == H && a->mask.size[2] == W,
+                 "env_shade: mask must be [N,H,W]");
+    const unsigned S = a->n_samples_x * a->n_samples_x;
+    NVDR_REQUIRE(a->perms.data && a->perms.size[1] == (int64_t)S && a->perms.size[0] > 0,
+                 "env_shade: perms must be int32 [NP, %u]", S);
+    NVDR_REQUIRE(a->light.size[2] == 3 || a->light.size[2] == 1, "env_shade: light must be [Hl,Wl,3]");
+    NVDR_REQUIRE(a->pdf.size[0] == a->cols.size[0] && a->pdf.size[1] == a->cols.size[1] && a->rows.size[0] == a->pdf.size[0],
+                 "env_shade: pdf/rows/cols shapes disagree");
+    NVDR_HIP_TRY(hipSetDevice(c->device));
+
+    ShadeParams p;
+    memset(&p, 0, sizeof(p));
+    p.ro = make_view4(a->ro); p.pos = make_view4(a->gb_pos); p.nrm = make_view4(a->gb_normal);
+    p.view_pos = make_view4(a->gb_view_pos); p.kd = make_view4(a->gb_kd); p.ks = make_view4(a->gb_ks);
+    p.mask = (const float *)a->mask.data;
+    p.ms0 = a->mask.stride[0]; p.ms1 = a->mask.stride[1]; p.ms2 = a->mask.stride[2];
+    if ((r = make_tab(p.light, a->light, 3, "light"))) return r;
+    if ((r = make_tab(p.pdf, a->pdf, 2, "pdf"))) return r;
+    if ((r = make_tab(p.rows, a->rows, 1, "rows"))) return r;
+    if ((r = make_tab(p.cols, a->cols, 2, "cols"))) return r;
+    p.perms = (const int *)a->perms.data;
+    p.perm_s0 = (int)a->perms.stride[0]; p.perm_s1 = (int)a->perms.stride[1];
+    p.n_perms = (unsigned)a->perms.size[0];
+    p.N = (int)N; p.H = (int)H; p.W = (int)W;
+    p.bsdf = a->bsdf; p.n = a->n_samples_x; p.S = S; p.seed = a->rnd_seed; p.pix_offset = a->pixel_index_offset;
+    p.shadow_scale = a->shadow_scale;
+    int L = 1, lg = 0;
+    while (L < (int)S && L < 64) { L <<= 1; lg++; }
+    p.L = L; p.log2L = lg;
+    p.vis_cache = a->vis_cache;
+    p.vis_words = (int)((S + 31) / 32);
+    const int64_t npix = N * H * W;
+    if (!backward) {
+        NVDR_REQUIRE(a->diff && a->spec, "env_shade_fwd: NULL output");
+        p.diff = a->diff; p.spec = a->spec;
+        NVDR_HIP_TRY(hipMemsetAsync(p.diff, 0, sizeof(float) * 3 * npix, stream)); // torch::zeros, torch_bindings.cpp:148-149
+        NVDR_HIP_TRY(hipMemsetAsync(p.spec, 0, sizeof(float) * 3 * npix, stream));
+    } else {
+        NVDR_REQUIRE(a->gb_pos_grad && a->gb_normal_grad && a->gb_kd_grad && a->gb_ks_grad && a->light_grad,
+                     "env_shade_bwd: NULL output");
+        if ((r = check_gb(a->diff_grad, N, H, W, "diff_grad"))) return r;
+        if ((r = check_gb(a->spec_grad, N, H, W, "spec_grad"))) return r;
+        p.dgrad = make_view4(a->diff_grad); p.sgrad = make_view4(a->spec_grad);
+        p.g_pos = a->gb_pos_grad; p.g_nrm = a->gb_normal_grad; p.g_kd = a->gb_kd_grad; p.g_ks = a->gb_ks_grad;
+        p.g_light = a->light_grad;
+        NVDR_HIP_TRY(hipMemsetAsync(p.g_pos, 0, sizeof(float) * 3 * npix, stream));
+        NVDR_HIP_TRY(hipMemsetAsync(p.g_nrm, 0, sizeof(float) * 3 * npix, stream));
+        NVDR_HIP_TRY(hipMemsetAsync(p.g_kd, 0, sizeof(float) * 3 * npix, stream));
+        NVDR_HIP_TRY(hipMemsetAsync(p.g_ks, 0, sizeof(float) * 3 * npix, stream));
+        NVDR_HIP_TRY(hipMemsetAsync(p.g_light, 0, sizeof(float) * 3 * a->light.size[0] * a->light.size[1], stream));
+    }
+    // work list
+    if (c->pix_cap < npix) {
+        NVDR_HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(c->pix_list);
+        c->pix_list = nullptr;
+        NVDR_HIP_TRY(hipMalloc((void **)&c->pix_list, sizeof(int) * npix));
+        c->pix_cap = npix;
+    }
+    zero_count_kernel<<<1, 1, 0, stream>>>(&c->dinfo->pix_count);
+    compact_pixels_kernel<<<div_up(npix, 256), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
+                                                                  &c->dinfo->pix_count);
+    p.pix_list = c->pix_list;
+    p.pix_count = &c->dinfo->pix_count;
+    int depth;
+    if ((r = bvh_stack_depth(c, stream, &depth))) return r;
+    p.stack_depth = depth;
+    const int waves_per_block = 4;
+    const size_t lds = (size_t)waves_per_block * depth * 64 * sizeof(int);
+    // persistent grid: enough workgroups to fill every CU at the occupancy the LDS stack allows
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    int blocks_per_cu = (int)((size_t)(160 * 1024) / (lds > 0 ? lds : 1));
+    if (blocks_per_cu > 4) blocks_per_cu = 4;
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const int64_t max_groups = (npix + (64 / L) - 1) / (64 / L);
+    int64_t blocks = (int64_t)dev_cus * blocks_per_cu;
+    if (blocks * waves_per_block > max_groups) blocks = (max_groups + waves_per_block - 1) / waves_per_block;
+    if (blocks < 1) blocks = 1;
+    p.counters = a->counters;
+    const dim3 grid((unsigned)blocks), block(64 * waves_per_block);
+    if (a->counters) {
+        if (backward) env_shade_kernel<true, true><<<grid, block, lds, stream>>>(p, bvh_view(c));
+        else env_shade_kernel<false, true><<<grid, block, lds, stream>>>(p, bvh_view(c));
+    } else {
+        if (backward) env_shade_kernel<true, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
+        else env_shade_kernel<false, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
+    }
+    NVDR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nvdr_env_shade_fwd(nvdr_ctx *c, const nvdr_env_shade_args *a, void *stream)
+{
+    return env_shade_launch(c, a, false, (hipStream_t)stream);
+}
+extern "C" int nvdr_env_shade_bwd(nvdr_ctx *c, const nvdr_env_shade_args *a, void *stream)
+{
+    return env_shade_launch(c, a, true, (hipStream_t)stream);
+}
+extern "C" int nvdr_env_shade_last_pixel_count(nvdr_ctx *c, int64_t *out, void *stream_)
+{
+    NVDR_REQUIRE(c && out, "nvdr_env_shade_last_pixel_count: NULL argument");
+    unsigned v = 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    NVDR_HIP_TRY(hipMemcpyAsync(&v, &c->dinfo->pix_count, sizeof(v), hipMemcpyDeviceToHost, stream));
+    NVDR_HIP_TRY(hipStreamSynchronize(stream));
+    *out = (int64_t)v;
+    return 0;
+}

@@ -1,0 +1,163 @@
+"""Minimal optimisation step around the direct-lighting hot path (SURVEY 8 f1 + f2).
+
+One iteration mirrors what optimize_mesh does per step in the reference (train.py:385-476), reduced to
+the parts that touch the hot path:
+
+    lgt.update_pdf()                                     train.py:422      -> csrc/light.hip
+    optix_build_bvh(rebuild=1)                           dlmesh.py:50      -> csrc/bvh.hip
+    prepare_shading_normal                               render.py:99      -> csrc/renderutils.hip
+    optix_env_shade (fwd)                                render.py:113     -> csrc/env_shade.hip
+    BilateralDenoiser x2 on cat(light, normal, depth)    render.py:120-121 -> csrc/denoise.hip
+    shaded = diffuse * kd * (1 - metal) + specular       render.py:126-127
+    image_loss('l1', 'log_srgb')                         train.py:51-66    -> csrc/renderutils.hip
+    backward through all of it (env-shade re-traces)     train.py:438
+    gradient all-reduce (new: one view per GPU)          --                -> parallel.py
+    Adam on kd texture, ks, light                        train.py:452-461
+
+What replaces the parts that do not exist on ROCm: the G-buffer comes from primary rays traced
+through the same BVH (closest-hit kernel) instead of nvdiffrast, so it is NOT differentiable
+w.r.t. geometry; kd is a nearest-texel lookup into a trainable texture instead of dr.texture.
+"""
+import math
+
+import torch
+
+from . import optixutils as ou
+from . import renderutils as ru
+from . import scene as sc
+from .denoiser import BilateralDenoiser
+from .light import EnvironmentLight
+from .parallel import allreduce_gradients
+
+
+class _gather_rows(torch.autograd.Function):
+    """tex[idx] with an index_add_ (atomic) backward.  torch's generic advanced-indexing backward sorts the
+    indices and serialises on duplicates: 57 ms per iteration here, 20x the whole hot path."""
+
+    @staticmethod
+    def forward(ctx, tex, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = tex.shape[0]
+        return tex.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        out = torch.zeros(ctx.n, g.shape[1], dtype=g.dtype, device=g.device)
+        out.index_add_(0, idx, g.contiguous())
+        return out, None
+
+
+class DirectLightingStep:
+    def __init__(self, mesh_name='bob', res=512, n_samples_x=8, view=0, n_views=8, device='cuda', env='E1',
+                 probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01):
+        self.dev = torch.device(device)
+        self.res, self.n, self.view = res, n_samples_x, view
+        self.pixel_index_offset = pixel_index_offset
+        self.retrace_backward = retrace_backward
+        mesh = sc.load_mesh(mesh_name, device='cpu')
+        if subdiv:
+            mesh['v_pos'], mesh['t_pos_idx'] = sc.subdivide(mesh['v_pos'], mesh['t_pos_idx'], subdiv)
+            mesh['v_nrm'] = sc.auto_normals(mesh['v_pos'], mesh['t_pos_idx'])
+            mesh['t_tex_idx'] = torch.zeros_like(mesh['t_pos_idx'])
+        self.mesh = {k: (v.to(self.dev) if isinstance(v, torch.Tensor) else v) for k, v in mesh.items()}
+        self.ctx = ou.OptiXContext()
+        ou.optix_build_bvh(self.ctx, self.mesh['v_pos'], self.mesh['t_pos_idx'], rebuild=1)
+
+        # ---- G-buffer from primary rays (stands in for rasterize + interpolate, render.py:208-234)
+        mv, mvp, campos = sc.camera(view, n_views)
+        ro, rd = sc.primary_rays(mv, res, res)
+        ro, rd = ro.to(self.dev), rd.to(self.dev)
+        t, tri, uv = ou.trace_closest(self.ctx, ro, rd)
+        H = W = res
+        t, tri, uv = t.view(H, W), tri.view(H, W), uv.view(H, W, 2)
+        gb = sc.gbuffer_from_hits(self.mesh, t, tri, uv, ro, rd, kd_mode='texture' if not subdiv else 'flat')
+        self.mask = gb['mask']                                  # [1,H,W]
+        self.gb_pos = gb['gb_pos']
+        self.gb_geom_nrm = gb['gb_geometric_normal']
+        self.gb_smooth_nrm = gb['gb_normal']
+        up = torch.tensor([0.0, 1.0, 0.0], device=self.dev)
+        tng = torch.cross(up.expand_as(self.gb_smooth_nrm), self.gb_smooth_nrm, dim=-1)
+        self.gb_tangent = (torch.nn.functional.normalize(tng, dim=-1) * self.mask[..., None]).contiguous()
+        self.view_pos = campos.to(self.dev)[None, None, None, :].contiguous()
+        z = gb['depth']
+        dz = torch.zeros_like(z)
+        dz[:, 1:-1, 1:-1] = 0.5 * ((z[:, 1:-1, 2:] - z[:, 1:-1, :-2]).abs() + (z[:, 2:, 1:-1] - z[:, :-2, 1:-1]).abs())
+        self.gb_depth = torch.cat((z, dz.clamp(max=0.1)), dim=-1).contiguous()  # (z, |dz|), render.py:228-234
+        # texel addresses of the kd lookup (fixed: geometry is locked, configs/bob.json:14)
+        if not subdiv:
+            tidx = self.mesh['t_tex_idx'].long()[tri.clamp(min=0).long()]
+            vt = self.mesh['v_tex']
+            w0 = 1.0 - uv[..., 0:1] - uv[..., 1:2]
+            tc = w0 * vt[tidx[..., 0]] + uv[..., 0:1] * vt[tidx[..., 1]] + uv[..., 1:2] * vt[tidx[..., 2]]
+            R = self.mesh['kd_tex'].shape[0]
+            ix = (tc[..., 0] * R).long().clamp(0, R - 1)
+            iy = ((1.0 - tc[..., 1]) * R).long().clamp(0, R - 1)
+            self.texel = (iy * R + ix).view(-1)
+            kd_true = self.mesh['kd_tex'].reshape(-1, 3)
+        else:
+            R = 64
+            self.texel = torch.zeros(H * W, dtype=torch.long, device=self.dev)
+            kd_true = torch.full((R * R, 3), 0.5, device=self.dev)
+        self.tex_res = R
+        # only covered pixels look the texture up (the background would pile ~200k duplicates on one texel)
+        self.cov = self.mask.view(-1).nonzero().view(-1)
+        self.texel_cov = self.texel[self.cov].contiguous()
+
+        # ---- reference ("true") parameters -> target image; trainable parameters start elsewhere
+        self.denoiser = BilateralDenoiser(influence=1.0) if denoise else None
+        light_true = EnvironmentLight(sc.env_map(env, probe_res).to(self.dev))
+        ks_true = self.mesh['ks'].clone()
+        self.seed = 0
+        with torch.no_grad():
+            self.target = self._render(kd_true, ks_true, light_true).detach()
+        self.kd_tex = torch.nn.Parameter(torch.full_like(kd_true, 0.5))
+        self.ks = torch.nn.Parameter(torch.tensor([0.0, 0.5, 0.0], device=self.dev))
+        self.light = EnvironmentLight(torch.full((probe_res, probe_res, 3), 0.5, device=self.dev).requires_grad_(True))
+        self._ks_min = torch.tensor([0.0, 0.08, 0.0], device=self.dev)
+        self.params = [self.kd_tex, self.ks, self.light.base]
+        self.opt = torch.optim.Adam(self.params, lr=lr)
+        self.covered = int(self.mask.sum().item())
+
+    # rays per pass counted from the actual mask: 2 per stratum per covered pixel
+    def rays_per_pass(self):
+        return 2 * self.n * self.n * self.covered
+
+    def _render(self, kd_tex, ks_vec, light):
+        m = self.mask[..., None]
+        kd = torch.zeros(self.res * self.res, 3, device=self.dev).index_copy(0, self.cov, _gather_rows.apply(kd_tex, self.texel_cov))
+        kd = kd.view(1, self.res, self.res, 3)
+        ks = (ks_vec.view(1, 1, 1, 3) * m)
+        nrm = ru.prepare_shading_normal(self.gb_pos, self.view_pos, None, self.gb_smooth_nrm, self.gb_tangent,
+                                        self.gb_geom_nrm, two_sided_shading=True, opengl=True)
+        ro = self.gb_pos + nrm * 0.001
+        ou.ops.set_pixel_index_offset(self.pixel_index_offset)
+        ou.ops._optix_env_shade_func.cache_visibility = not self.retrace_backward
+        diff, spec = ou.optix_env_shade(self.ctx, self.mask, ro, self.gb_pos, nrm, self.view_pos, kd, ks, light.base,
+                                        light._pdf, light.rows[:, 0], light.cols, BSDF='pbr', n_samples_x=self.n,
+                                        rnd_seed=self.seed, shadow_scale=1.0)
+        self.seed += 1
+        if self.denoiser is not None:
+            diff = self.denoiser.forward(torch.cat((diff, nrm, self.gb_depth), dim=-1))
+            spec = self.denoiser.forward(torch.cat((spec, nrm, self.gb_depth), dim=-1))
+        return diff * (kd * (1.0 - ks[..., 2:3])) + spec
+
+    def forward_backward(self):
+        """The differentiable part of the iteration; returns the loss tensor (grads are in .grad)."""
+        self.light.update_pdf()
+        ou.optix_build_bvh(self.ctx, self.mesh['v_pos'], self.mesh['t_pos_idx'], rebuild=1)
+        self.opt.zero_grad(set_to_none=True)
+        img = self._render(self.kd_tex, self.ks, self.light)
+        loss = ru.image_loss(img, self.target, loss='l1', tonemapper='log_srgb')
+        loss.backward()
+        return loss
+
+    def step(self, world_size=1):
+        loss = self.forward_backward()
+        self.allreduce_bytes = allreduce_gradients(self.params, world_size)
+        self.opt.step()
+        with torch.no_grad():
+            self.kd_tex.clamp_(0.0, 1.0)
+            self.ks.copy_(torch.maximum(self.ks.clamp(max=1.0), self._ks_min))  # ks_min of configs/bob.json: roughness >= 0.08
+            self.light.base.clamp_(min=0.0)
+        return loss

@@ -870,3 +870,18 @@ int oracle_max_threads(void)
     return 1;
 #endif
 }
+
+/* include/nvdr_detmath.h evaluated on the host: op 0 sin, 1 cos, 2 acos, 3 atan2(x, y) -- same
+ * numbering as the device hook nvdr_test_detmath. */
+void oracle_detmath(int op, const float *x, const float *y, long n, float *out)
+{
+    for (long i = 0; i < n; ++i) {
+        float s, c;
+        switch (op) {
+        case 0: nvdr_sincosf(x[i], &s, &c); out[i] = s; break;
+        case 1: nvdr_sincosf(x[i], &s, &c); out[i] = c; break;
+        case 2: out[i] = nvdr_acosf(x[i]); break;
+        default: out[i] = nvdr_atan2f(x[i], y[i]); break;
+        }
+    }
+}

@@ -41,7 +41,7 @@ class EnvShadeArgs(ctypes.Structure):  # mirrors nvdr_env_shade_args
         ('diff', c_void_p), ('spec', c_void_p),
         ('diff_grad', Tensor), ('spec_grad', Tensor),
         ('gb_pos_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_kd_grad', c_void_p), ('gb_ks_grad', c_void_p),
-        ('light_grad', c_void_p), ('vis_cache', c_void_p)]
+        ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p)]
 
 
 def build(force=False):
@@ -238,3 +238,13 @@ def light_update_pdf(base):
     _load(LIB).oracle_light_update_pdf(c_void_p(base.data_ptr()), c_long(H), c_long(W), c_void_p(pdf.data_ptr()),
                                        c_void_p(cols.data_ptr()), c_void_p(rows.data_ptr()))
     return pdf, cols, rows
+
+
+def detmath(op, x, y=None):
+    """include/nvdr_detmath.h on the host: op in ('sin', 'cos', 'acos', 'atan2'); atan2 computes atan2(x, y)."""
+    x = _cpu(x).contiguous()
+    y = x if y is None else _cpu(y).contiguous()
+    out = torch.empty_like(x)
+    _load(LIB).oracle_detmath(c_int(['sin', 'cos', 'acos', 'atan2'].index(op)), c_void_p(x.data_ptr()), c_void_p(y.data_ptr()),
+                              c_long(x.numel()), c_void_p(out.data_ptr()))
+    return out

@@ -1,0 +1,63 @@
+"""The drop-in boundary: libnvdr_hip.so loads on a machine without a GPU and exports every symbol that
+include/nvdr_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from nvdiffrecmc_amd import _build, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'nvdr_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(nvdr_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_all_exported():
+    assert os.path.exists(_build.LIB), 'build the HIP library first (__graft_entry__.build())'
+    lib = ctypes.CDLL(_build.LIB)
+    names = _declared()
+    assert len(names) >= 39
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_the_header():
+    assert sorted(_lib.EXPORTED_SYMBOLS) == _declared()
+    lib = _lib.load()
+    assert lib.nvdr_version() >= 100
+    assert lib.nvdr_image_loss_num_partials(1, 512, 512) == 1024
+    assert lib.nvdr_image_loss_num_partials(1, 8, 8) == 1
+
+
+def test_struct_layouts_match_the_header():
+    # nvdr_tensor: pointer + 4 sizes + 4 strides; the env-shade block: 12 tensors, 5 scalars (+pad), 2 ptrs, 2 tensors, 6 ptrs
+    assert ctypes.sizeof(_lib.NvdrTensor) == 8 + 4 * 8 + 4 * 8
+    assert ctypes.sizeof(_lib.NvdrEnvShadeArgs) == 12 * 72 + 24 + 2 * 8 + 2 * 72 + 7 * 8
+    from oracle import oracle as orc
+    assert ctypes.sizeof(orc.EnvShadeArgs) == ctypes.sizeof(_lib.NvdrEnvShadeArgs)
+
+
+def test_no_cpu_fallback_errors_are_loud(monkeypatch):
+    import nvdiffrecmc_amd.renderutils as ru
+    import nvdiffrecmc_amd.optixutils as ou
+    x = torch.rand(1, 4, 4, 3)
+    with pytest.raises(RuntimeError, match='GPU'):
+        ru.lambert(x, x)
+    with pytest.raises(RuntimeError, match='GPU'):
+        ru.image_loss(x, x)
+    with pytest.raises(RuntimeError, match='GPU'):
+        ou.bilateral_denoiser(x, x, x[..., :2], 2.0)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            ou.OptiXContext()
+    # a missing library is an error, never a silent fallback
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_build, 'LIB', '/nonexistent/libnvdr_hip.so')
+    with pytest.raises(RuntimeError, match='not built'):
+        _lib.load()

@@ -107,7 +107,13 @@ def tonemap_srgb(f):                # loss.py:15
     return torch.where(f > 0.0031308, torch.pow(torch.clamp(f, min=0.0031308), 1.0 / 2.4) * 1.055 - 0.055, 12.92 * f)
 
 
-def image_loss(img, target, loss='l1', tonemapper='none'):      # loss.py:33-47
+def image_loss(img, target, loss='l1', tonemapper='none', kernel_semantics=False):      # loss.py:33-47
+    """kernel_semantics=True adds what the reference's CUDA kernel does and its python path does not: BOTH images are
+    clamped to [0, 65535] for every tonemapper (render/renderutils/c_src/loss.cu:113-114), so out-of-range HDR values
+    contribute a clamped value and get zero gradient (loss.cu:221-226).  In range the two paths agree."""
+    if kernel_semantics:
+        img = torch.clamp(img, min=0, max=65535)
+        target = torch.clamp(target, min=0, max=65535)
     if tonemapper == 'log_srgb':
         img = tonemap_srgb(torch.log(torch.clamp(img, min=0, max=65535) + 1))
         target = tonemap_srgb(torch.log(torch.clamp(target, min=0, max=65535) + 1))

@@ -1,0 +1,81 @@
+"""The N > 1 path on the CPU: world_size-2 gloo processes, one view per rank, ONE flat all-reduce of the shared-parameter
+gradients (nvdiffrecmc_amd/parallel.py).  The renderer inside is the CPU oracle (the HIP kernels need a GPU); what is
+checked is the sharding + reduction logic the GPU job uses unchanged."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nvdiffrecmc_amd.parallel import shard_views, allreduce_gradients
+
+
+def test_shard_views():
+    assert shard_views(8, 3, 8) == [3]
+    assert shard_views(8, 1, 2) == [4, 5, 6, 7]
+    assert shard_views(5, 1, 2) == [3, 4] and shard_views(5, 0, 2) == [0, 1, 2]
+    assert sorted(sum((shard_views(7, r, 4) for r in range(4)), [])) == list(range(7))
+    assert allreduce_gradients([torch.nn.Parameter(torch.ones(3))]) == 0      # no process group: no-op
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _light_grad_of_view(view, offset, res=20, n=2):
+    """d(sum diff + sum spec) / d light for one view through the oracle (stands in for the HIP backward)."""
+    from oracle import oracle as orc, scene_cpu
+    inp = scene_cpu.make_inputs('bob', res, res, n, view=view, n_views=2, probe_res=16, n_threads=2)
+    kw = scene_cpu.shade_kwargs(inp)
+    m = inp['mesh']
+    ones = torch.ones(1, res, res, 3)
+    b = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, n_samples_x=n, rnd_seed=3, diff_grad=ones, spec_grad=ones,
+                      pixel_index_offset=offset, n_threads=1)
+    return b['light_grad'], b['gb_ks_grad'].sum(dim=(0, 1, 2))
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    res = 20
+    view = shard_views(world, rank, world)[0]
+    lg, ksg = _light_grad_of_view(view, rank * res * res)
+    light = torch.nn.Parameter(torch.zeros(16, 16, 3))
+    ks = torch.nn.Parameter(torch.zeros(3))
+    unused = torch.nn.Parameter(torch.zeros(5))             # a parameter without gradient must not break the bucket layout
+    light.grad, ks.grad = lg.clone(), ksg.clone()
+    nbytes = allreduce_gradients([light, ks, unused], world)
+    q.put((rank, light.grad.clone(), ks.grad.clone(), unused.grad.clone(), nbytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_batch_mean():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: mean over the two views, each seeded as slice r of the batch launch
+    l0, k0 = _light_grad_of_view(0, 0)
+    l1, k1 = _light_grad_of_view(1, 20 * 20)
+    for rank, lg, ksg, ug, nbytes in got:
+        assert torch.allclose(lg, (l0 + l1) / 2, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(ksg, (k0 + k1) / 2, rtol=1e-5, atol=1e-6)
+        assert torch.equal(ug, torch.zeros(5))
+        assert nbytes == (16 * 16 * 3 + 3 + 5) * 4
+    assert not torch.equal(got[0][1], torch.zeros_like(got[0][1]))

@@ -1,0 +1,126 @@
+"""renderutils operators (HIP) vs the outputs/gradients of the reference's own PyTorch module (tests/golden) and vs the
+oracle at larger, broadcast and strided shapes.  Mirrors render/renderutils/tests/test_{bsdf,loss,mesh}.py, asserting."""
+import pytest
+import torch
+
+from oracle import renderutils_ref as rr
+from tests.util import load_npz, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _api():
+    import nvdiffrecmc_amd.renderutils as ru
+    return {
+        'fresnel_shlick': ru._fresnel_shlick, 'ndf_ggx': ru._ndf_ggx, 'lambda_ggx': ru._lambda_ggx, 'masking_smith': ru._masking_smith,
+        'lambert': ru.lambert, 'frostbite': ru.frostbite_diffuse, 'pbr_specular': ru.pbr_specular,
+        'pbr_bsdf_lambert': lambda *a: ru.pbr_bsdf(*a, bsdf='lambert'), 'pbr_bsdf_frostbite': lambda *a: ru.pbr_bsdf(*a, bsdf='frostbite'),
+        'prepare_shading_normal_11': lambda *a: ru.prepare_shading_normal(*a, two_sided_shading=True, opengl=True),
+        'prepare_shading_normal_00': lambda *a: ru.prepare_shading_normal(*a, two_sided_shading=False, opengl=False),
+        'prepare_shading_normal_bcast': lambda *a: ru.prepare_shading_normal(*a),
+        'xfm_points': ru.xfm_points, 'xfm_vectors': ru.xfm_vectors, 'xfm_points_b': ru.xfm_points,
+    }
+
+
+NAMES = ['fresnel_shlick', 'ndf_ggx', 'lambda_ggx', 'masking_smith', 'lambert', 'frostbite', 'pbr_specular', 'pbr_bsdf_lambert',
+         'pbr_bsdf_frostbite', 'prepare_shading_normal_11', 'prepare_shading_normal_00', 'prepare_shading_normal_bcast',
+         'xfm_points', 'xfm_vectors', 'xfm_points_b']
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_op_vs_reference_module_vectors(name, dev):
+    c = load_npz('renderutils_reference.npz')[name]
+    ins = [torch.from_numpy(c['in%d' % i]).to(dev).requires_grad_(True) for i in range(int(c['n_in']))]
+    out = _api()[name](*ins)
+    assert_close(out.detach(), c['out'], 1e-5, floor=1e-4, what=name)           # reference tests print the same metric
+    torch.nn.functional.mse_loss(out, torch.from_numpy(c['target']).to(dev)).backward()
+    for i, t in enumerate(ins):
+        if name.startswith('xfm') and i == 1:
+            assert t.grad is None            # the plugin returns no matrix gradient (ops.py:514: (points_grad, None, ...))
+            continue
+        assert t.grad.shape == t.shape                                      # broadcast inputs get reduced gradients
+        assert_close(t.grad, c['grad%d' % i], 2e-4, floor=1e-5, what='%s grad%d' % (name, i))
+
+
+@pytest.mark.parametrize('loss,tm', [('l1', 'none'), ('l1', 'log_srgb'), ('mse', 'log_srgb'), ('smape', 'none'), ('relmse', 'none'),
+                                     ('mse', 'none'), ('n2n', 'none')])
+def test_image_loss_vs_reference_module_vectors(loss, tm, dev):
+    import nvdiffrecmc_amd.renderutils as ru
+    c = load_npz('renderutils_reference.npz')['image_loss_%s_%s' % (loss, tm)]
+    ins = [torch.from_numpy(c['in%d' % i]).to(dev).requires_grad_(True) for i in range(2)]
+    out = ru.image_loss(ins[0], ins[1], loss=loss, tonemapper=tm)
+    out.backward()
+    assert_close(out.detach(), c['out'], 1e-5)
+    for i in range(2):
+        assert_close(ins[i].grad, c['grad%d' % i], 1e-4, floor=1e-6)
+
+
+def test_image_loss_full_size_and_hdr_range(dev):
+    """512x512 (more pixels than partial sums: grid-stride path), HDR values incl. out-of-range ones that must be clamped
+    and get zero gradient (loss.cu:113-114,221-226)."""
+    import nvdiffrecmc_amd.renderutils as ru
+    g = torch.Generator().manual_seed(0)
+    img = (torch.rand(2, 512, 512, 3, generator=g) * 3 - 0.5)
+    img[0, 0, 0] = torch.tensor([70000.0, -2.0, 1.0])
+    tgt = torch.rand(2, 512, 512, 3, generator=g) * 2
+    for loss, tm in (('l1', 'log_srgb'), ('relmse', 'none'), ('mse', 'none')):
+        a = img.clone().requires_grad_(True)
+        ref = rr.image_loss(a, tgt, loss, tm, kernel_semantics=True)
+        ref.backward()
+        ad = img.to(dev).requires_grad_(True)
+        out = ru.image_loss(ad, tgt.to(dev), loss=loss, tonemapper=tm)
+        out.backward()
+        assert_close(out.detach(), ref.detach(), 2e-5)
+        inside = (img > 0) & (img < 65535)
+        assert_close(ad.grad.cpu()[inside], a.grad[inside], 2e-4, floor=1e-9)
+        assert ad.grad.cpu()[~inside].abs().max().item() == 0.0
+
+
+def test_ops_broadcast_strided_and_errors(dev):
+    import nvdiffrecmc_amd.renderutils as ru
+    g = torch.Generator().manual_seed(2)
+    R = lambda *s: torch.rand(*s, generator=g)
+    # pbr_bsdf with broadcast view/light positions and a strided kd view
+    big = R(2, 16, 12, 6)
+    kd, arm = big[..., 0:3], big[..., 3:6]
+    pos, nrm = R(2, 16, 12, 3), torch.nn.functional.normalize(R(2, 16, 12, 3), dim=-1)
+    vp, lp = R(2, 1, 1, 3) + 2, R(1, 1, 1, 3) + 3
+    ins = [kd, arm, pos, nrm, vp, lp]
+    cpu = [t.clone().requires_grad_(True) for t in ins]
+    ref = rr.pbr_bsdf(*cpu)
+    ref.sum().backward()
+    bigd = big.to(dev).requires_grad_(True)
+    gpu = [bigd[..., 0:3], bigd[..., 3:6]] + [t.to(dev).requires_grad_(True) for t in ins[2:]]
+    out = ru.pbr_bsdf(*gpu)
+    out.sum().backward()
+    assert_close(out.detach(), ref.detach(), 2e-4, floor=1e-3)   # GGX D near its peak is ill-conditioned in fp32
+    assert_close(bigd.grad[..., 0:3], cpu[0].grad, 5e-4, floor=1e-3)
+    assert gpu[4].grad.shape == (2, 1, 1, 3) and gpu[5].grad.shape == (1, 1, 1, 3)
+    assert_close(gpu[5].grad, cpu[5].grad, 5e-4, floor=1e-3)
+    # use_python switch exists and agrees
+    assert_close(ru.lambert(gpu[3].detach(), gpu[2].detach(), use_python=True), ru.lambert(gpu[3].detach(), gpu[2].detach()), 1e-6)
+    # argument errors (CHECK_TENSOR, torch_bindings.cpp:24-28)
+    with pytest.raises(RuntimeError):
+        ru.lambert(torch.rand(4, 4, 3, device=dev), torch.rand(4, 4, 3, device=dev))
+    with pytest.raises(RuntimeError):
+        ru.xfm_points(torch.rand(1, 10, 2, device=dev), torch.rand(1, 4, 4, device=dev))
+    with pytest.raises(RuntimeError):
+        ru.image_loss(torch.rand(1, 4, 4, 3, device=dev).double(), torch.rand(1, 4, 4, 3, device=dev).double())
+    # anomaly mode finite check is kept (ops.py:107-108)
+    with torch.autograd.set_detect_anomaly(True):
+        with pytest.raises(AssertionError, match='inf or NaN'):
+            ru._ndf_ggx(torch.full((1, 2, 2, 1), float('nan'), device=dev), torch.rand(1, 2, 2, 1, device=dev))
+
+
+def test_light_update_pdf_vs_oracle(dev):
+    from nvdiffrecmc_amd.light import EnvironmentLight
+    from nvdiffrecmc_amd import scene as sc
+    from oracle import oracle as orc
+    for res in (256, 48):
+        base = sc.env_map('E1', res)
+        L = EnvironmentLight(base.to(dev))
+        pdf, cols, rows = orc.light_update_pdf(base)
+        assert_close(L._pdf, pdf, 1e-5, floor=1e-9)
+        assert_close(L.cols, cols, 1e-5, floor=1e-6)
+        assert_close(L.rows[:, 0], rows, 1e-5, floor=1e-6)
+        assert L.rows.shape == (res, res)

@@ -1,0 +1,104 @@
+"""Host-side logic that needs no GPU: scene generators, API surface parity with the reference modules, the
+opt-in torch formulations behind use_python=True."""
+import inspect
+import math
+
+import pytest
+import torch
+
+from nvdiffrecmc_amd import scene as sc
+from oracle import renderutils_ref as rr
+from tests.util import assert_close
+
+
+def test_camera_matches_dataset_mesh_convention():
+    mv, mvp, campos = sc.camera(2, 8)
+    assert abs(campos.norm().item() - 3.0) < 1e-5                  # radius 3 orbit (train.py:42)
+    p = sc.perspective()
+    assert p[1, 1].item() == pytest.approx(-1 / math.tan(math.radians(45) / 2))
+    assert torch.allclose(mvp, p @ mv)
+    ro, rd = sc.primary_rays(mv, 8, 8)
+    assert torch.allclose(ro[0, 0], campos, atol=1e-6) and torch.allclose(rd.norm(dim=-1), torch.ones(8, 8), atol=1e-6)
+    # the central ray looks at the origin
+    c = sc.primary_rays(mv, 1, 1)[1][0, 0]
+    assert torch.allclose(c, -campos / campos.norm(), atol=1e-6)
+
+
+def test_perms_table_rows_are_permutations_and_seeded():
+    p = sc.perms_table(3, seed=0, n_perms=64)
+    assert p.dtype == torch.int32 and p.shape == (64, 9)
+    assert torch.equal(torch.sort(p, dim=-1)[0], torch.arange(9, dtype=torch.int32).expand(64, 9))
+    assert torch.equal(p, sc.perms_table(3, seed=0, n_perms=64)) and not torch.equal(p, sc.perms_table(3, seed=1, n_perms=64))
+
+
+def test_meshes_and_subdivision():
+    m = sc.load_mesh('bob')
+    assert m['v_pos'].shape == (5344, 3) and m['t_pos_idx'].shape == (10688, 3) and m['t_pos_idx'].dtype == torch.int32
+    assert torch.allclose(m['v_nrm'].norm(dim=-1), torch.ones(5344), atol=1e-5)
+    v, t = sc.subdivide(m['v_pos'], m['t_pos_idx'], 1)
+    assert t.shape[0] == 4 * 10688 and v.shape[0] == 5344 + 16032     # V + E for a closed genus-1... (E = 3T/2)
+    assert int(t.max()) == v.shape[0] - 1
+    s = sc.load_mesh('spot')
+    assert s['t_pos_idx'].shape == (5856, 3) and tuple(s['ks'].tolist()) == pytest.approx((0.0, 0.2, 1.0))
+
+
+def test_env_maps_and_tables():
+    assert torch.equal(sc.env_map('E0', 16), torch.full((16, 16, 3), 0.5))
+    e = sc.env_map('E1', 64)
+    assert e.min().item() >= 1e-4 and e.max().item() > 100 and torch.equal(e, sc.env_map('E1', 64))
+    pdf, rows, cols = sc.light_tables(e)
+    assert rows.shape == (64, 64) and torch.equal(rows[:, 0], rows[:, 5])
+
+
+def test_public_api_surface_matches_reference_modules():
+    import nvdiffrecmc_amd.optixutils as ou
+    import nvdiffrecmc_amd.renderutils as ru
+    assert ou.__all__ == ["OptiXContext", "optix_build_bvh", "optix_env_shade", "bilateral_denoiser"]
+    assert list(inspect.signature(ou.optix_env_shade).parameters) == [
+        'optix_ctx', 'mask', 'ro', 'gb_pos', 'gb_normal', 'gb_view_pos', 'gb_kd', 'gb_ks', 'light', 'pdf', 'rows', 'cols',
+        'BSDF', 'n_samples_x', 'rnd_seed', 'shadow_scale']
+    d = {k: v.default for k, v in inspect.signature(ou.optix_env_shade).parameters.items()}
+    assert (d['BSDF'], d['n_samples_x'], d['rnd_seed'], d['shadow_scale']) == ('pbr', 8, None, 1.0)
+    assert list(inspect.signature(ou.optix_build_bvh).parameters) == ['optix_ctx', 'verts', 'tris', 'rebuild']
+    assert list(inspect.signature(ou.bilateral_denoiser).parameters) == ['col', 'nrm', 'zdz', 'sigma']
+    assert sorted(ru.__all__) == sorted(["xfm_vectors", "xfm_points", "image_loss", "prepare_shading_normal", "lambert",
+                                         "frostbite_diffuse", "pbr_specular", "pbr_bsdf", "_fresnel_shlick", "_ndf_ggx",
+                                         "_lambda_ggx", "_masking_smith"])
+    sig = inspect.signature(ru.pbr_bsdf).parameters
+    assert list(sig) == ['kd', 'arm', 'pos', 'nrm', 'view_pos', 'light_pos', 'min_roughness', 'bsdf', 'use_python']
+    assert sig['min_roughness'].default == 0.08 and sig['bsdf'].default == 'lambert'
+    sig = inspect.signature(ru.image_loss).parameters
+    assert (sig['loss'].default, sig['tonemapper'].default, sig['use_python'].default) == ('l1', 'none', False)
+    sig = inspect.signature(ru.prepare_shading_normal).parameters
+    assert (sig['two_sided_shading'].default, sig['opengl'].default) == (True, True)
+    from nvdiffrecmc_amd.denoiser import BilateralDenoiser
+    d = BilateralDenoiser(0.5)
+    assert d.sigma == 1.0 and d.N == 2 * math.ceil(2.5) + 1
+
+
+def test_use_python_formulations_agree_with_oracle():
+    """The opt-in torch path of the API (use_python=True) against the oracle restatement, on the CPU."""
+    import nvdiffrecmc_amd.renderutils as ru
+    g = torch.Generator().manual_seed(0)
+    R = lambda *s: torch.rand(*s, generator=g)
+    n = lambda: torch.nn.functional.normalize(R(1, 6, 5, 3), dim=-1)
+    a = [R(1, 6, 5, 3), R(1, 6, 5, 3), R(1, 6, 5, 3), n(), R(1, 1, 1, 3) + 2, R(1, 1, 1, 3) + 2]
+    for b in ('lambert', 'frostbite'):
+        assert_close(ru.pbr_bsdf(*a, bsdf=b, use_python=True), rr.pbr_bsdf(*a, bsdf=b), 5e-5)
+    assert_close(ru.prepare_shading_normal(a[0], a[4], None, a[3], n(), n(), use_python=True).shape, (1, 6, 5, 3), 0)
+    pn = R(1, 6, 5, 3)
+    args = (a[0], a[4], pn, a[3], n(), n())
+    assert_close(ru.prepare_shading_normal(*args, use_python=True), rr.prepare_shading_normal(*args), 2e-5)
+    for loss in ('l1', 'mse', 'smape', 'relmse', 'n2n'):
+        for tm in ('none', 'log_srgb'):
+            assert_close(ru.image_loss(a[0], a[1], loss, tm, use_python=True), rr.image_loss(a[0], a[1], loss, tm), 1e-5)
+    p, m = R(1, 7, 3), R(2, 4, 4)
+    assert_close(ru.xfm_points(p, m, use_python=True), rr.xfm_points(p, m), 1e-6)
+    assert ru.xfm_vectors(p, m, use_python=True).shape == (2, 7, 3)
+
+
+def test_bench_algorithmic_byte_formula():
+    import bench
+    total, trav = bench.algorithmic_bytes_fwd(1, 512, 512, 1000, 64, 256, n_box=10, n_tri=2)
+    assert trav == 32 * 10 + 36 * 2
+    assert total == trav + (4 * 512 * 512 + 60 * 1000 + 24 * 512 * 512) + 1000 * 64 * 128   # 128 B per stratum at 256^2

@@ -61,7 +61,8 @@ typedef struct nvdr_bvh_info {
     float   aabb_max[3];
 } nvdr_bvh_info;
 int nvdr_bvh_info_get(nvdr_ctx *ctx, nvdr_bvh_info *out_host, void *stream); /* synchronises `stream` */
-/* copy the device BVH to host buffers: nodes = n_nodes*16 floats (layout in DESIGN.md),
+/* copy the device BVH to host buffers: nodes = n_nodes * 8 uint32 (32-B records: six words of 16-bit
+ * quantised child boxes + two child indices, layout in nvdiffrecmc_amd/csrc/bvh.h and DESIGN.md),
  * tri_records = n_tris*12 floats (v0, e1, e2, {orig index bits, 0, 0}) */
 int nvdr_bvh_export(nvdr_ctx *ctx, float *nodes_host, float *tri_records_host, void *stream);
 

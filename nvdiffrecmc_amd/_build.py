@@ -29,7 +29,7 @@ SOURCES = [
 # -ffp-contract=off: the sampling math must round exactly like the CPU oracle
 # (see include/nvdr_detmath.h); fused operations are written as explicit fmaf.
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
-         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-Wno-unused-result', '-Wno-unused-value']
+         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-Wno-unused-result', '-Wno-unused-value'] + os.environ.get('NVDR_EXTRA_FLAGS', '').split()
 
 
 def _hipcc():

@@ -1,55 +1,79 @@
-// bvh.h -- device BVH layout, context object, and the wave-level traversal routines.
+// bvh.h -- device BVH layout, context object, and the per-lane traversal routines.
 //
 // Replaces the OptiX GAS + optixTrace of the reference (optixAccelBuild at
 // render/optixutils/c_src/torch_bindings.cpp:97-110, shadow_test at envsampling/kernel.cu:101-118).
 //
-// Layout in HBM (all float4-aligned, see DESIGN.md "Data layout"):
-//   nodes[n]  : 4 x float4 = 64 B per internal node, one cache line:
-//       q0 = (lmin.x, lmin.y, lmin.z, lmax.x)   q1 = (lmax.y, lmax.z, rmin.x, rmin.y)
-//       q2 = (rmin.z, rmax.x, rmax.y, rmax.z)   q3 = (left, right, hleft, hright) as int bits
-//     the boxes of BOTH children live in the parent, so one 64-B fetch feeds two slab tests;
-//     child >= 0: internal node index; child < 0: ~child = leaf slot (one triangle per leaf).
-//   tris[k]   : 3 x float4 = 48 B per triangle in Morton order:
-//       (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, orig_index_bits, 0, 0)
+// Layout in HBM (see DESIGN.md "Data layout"):
+//   nodes[n]  : 2 x uint4 = 32 B per internal node, two nodes per 64-B line.  The boxes of BOTH children
+//       live in the parent, quantised to a 16-bit grid spanned over the (padded) scene AABB:
+//         w0 = lmin.x | lmin.y << 16   w1 = lmin.z | lmax.x << 16   w2 = lmax.y | lmax.z << 16
+//         w3 = rmin.x | rmin.y << 16   w4 = rmin.z | rmax.x << 16   w5 = rmax.y | rmax.z << 16
+//         w6 = left child              w7 = right child
+//       child >= 0: internal node index; child < 0: ~child = leaf slot (one triangle per leaf).
+//       Minima are rounded down and maxima up (plus one grid cell of slack), so a quantised box always
+//       contains the exact one: culling stays conservative and visibility stays bit-identical to the
+//       brute-force oracle.  WHY 32 B: a divergent traversal step is bound by the vector-L1 lookup rate
+//       (one 16-B piece per lane per lookup), not by bytes: measured on MI355X, re-touching the same
+//       lines twice as often costs +65 %.  Two lookups per node instead of four is the lever.
+//       The ray is transformed into grid space once (o' = (o - g_lo) * g_scale, d' = d * g_scale), which
+//       leaves the ray parameter t unchanged, so the slab test runs directly on the decoded integers.
+//   tris[k]   : 3 x float4 = 48 B per triangle in Morton order, world space, full precision:
+//       (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, orig_index_bits, 0, 0) -- the hit predicate itself
+//       (include/nvdr_raytri.h) never sees quantised data.
 #pragma once
 
 #include "common.h"
 #include "nvdr_raytri.h"
 
-#define NVDR_STACK_DEPTH 32   // LDS traversal-stack entries per lane (one 4-B entry per level)
-#define NVDR_STACK_DEPTH_DEEP 64
+// Traversal stack: the first NVDR_STACK_LDS entries of every lane live in LDS (entry k of lane l at
+// word k*64 + l: one bank per lane, conflict-free); deeper entries -- rare: a Karras tree over 30-bit
+// Morton codes + index tie-break can be up to ~64 levels deep, typical meshes use < 24 -- spill to a
+// per-lane column of an HBM scratch buffer owned by the context.  Sizing for the worst case this way
+// needs no read-back of the tree height, so nothing on the query path synchronises the host.
+#define NVDR_STACK_LDS 16
+#define NVDR_STACK_MAX 72
+#define NVDR_QUERY_BLOCK 256                 // threads per workgroup of every traversal kernel
+#define NVDR_QUERY_MAX_BLOCKS 2048           // persistent / grid-stride launches never exceed this
+#define NVDR_GRID_MAX 65531.0f               // usable span of the 16-bit box grid (2 cells of slack on both ends)
 
 struct BvhDeviceInfo {
-    int bounds[6];      // vertex AABB as order-preserving ints (min xyz, max xyz)
-    int height;         // tree height in internal nodes
-    int root;           // root node index (Karras numbering: 0)
+    int bounds[6];          // vertex AABB as order-preserving ints (min xyz, max xyz)
+    int height;             // tree height in internal nodes
+    int root;               // root node index (Karras numbering: 0)
     unsigned int pix_count; // env-shade: number of covered pixels appended to the work list
-    unsigned int pad[7];
+    float pad;              // world-space padding applied to every leaf box
+    float g_lo[3];          // quantisation grid: world -> grid is (x - g_lo) * g_scale + 2
+    float g_scale[3];
 };
 
 struct nvdr_ctx {
     int device = 0;
+    int n_cus = 256;
     int64_t cap_tris = 0;
     int64_t n_tris = 0;
     int64_t n_verts = 0;
-    int height_host = -1;          // cached after nvdr_bvh_info_get
-    float4 *nodes = nullptr;
-    float4 *tris = nullptr;
+    uint4 *nodes = nullptr;        // [2 * cap]
+    float4 *tris = nullptr;        // [3 * cap]
     uint32_t *keys[2] = {nullptr, nullptr};
     uint32_t *vals[2] = {nullptr, nullptr};
     int *parent = nullptr;         // [2T]: parents of internal nodes [0,T-1) then of leaves [T, 2T)
     int *flags = nullptr;          // [T] arrival counters of the bottom-up pass
+    int *heights = nullptr;        // [2T] subtree heights of the (left, right) child of every node
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     BvhDeviceInfo *dinfo = nullptr;
+    int *spill = nullptr;          // [(NVDR_STACK_MAX - NVDR_STACK_LDS), NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK]
     // env-shade scratch
     int *pix_list = nullptr;
     int64_t pix_cap = 0;
+    uint32_t *vis_scratch = nullptr; // visibility bits of a re-tracing backward pass
+    size_t vis_cap = 0;
 };
 
 struct BvhView {
-    const float4 *nodes;
+    const uint4 *nodes;
     const float4 *tris;
+    const BvhDeviceInfo *info;
     int n_tris;
 };
 
@@ -58,12 +82,45 @@ static inline BvhView bvh_view(const nvdr_ctx *c)
     BvhView v;
     v.nodes = c->nodes;
     v.tris = c->tris;
+    v.info = c->dinfo;
     v.n_tris = (int)c->n_tris;
     return v;
 }
 
 // ---------------------------------------------------------------------------------------------
 // device side
+
+// explicit address spaces: keeps the compiler from emitting flat (generic) accesses with aperture checks
+typedef __attribute__((address_space(3))) int lds_int_t;
+typedef __attribute__((address_space(1))) int glb_int_t;
+
+struct TravStack {
+    lds_int_t *lds; // this lane's LDS column (stride 64 words)
+    glb_int_t *glb; // this lane's HBM spill column
+    int gstride;    // spill stride = total threads of the launch
+    __device__ __forceinline__ void push(int sp, int v) const
+    {
+        if (sp < NVDR_STACK_LDS) lds[sp * 64] = v;
+        else if (sp < NVDR_STACK_MAX) glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v;
+    }
+    __device__ __forceinline__ int pop(int sp) const
+    {
+        return sp < NVDR_STACK_LDS ? lds[sp * 64]
+                                   : glb[(int64_t)(min(sp, NVDR_STACK_MAX - 1) - NVDR_STACK_LDS) * gstride];
+    }
+};
+
+// the lane's stack view inside a kernel: `smem` is the dynamic LDS base (blockDim.x * NVDR_STACK_LDS ints)
+__device__ __forceinline__ TravStack make_stack(int *smem, int *spill)
+{
+    TravStack s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s.lds = (lds_int_t *)smem + wave * NVDR_STACK_LDS * 64 + lane;
+    s.gstride = gridDim.x * blockDim.x;
+    s.glb = (glb_int_t *)spill + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    return s;
+}
+#define NVDR_STACK_LDS_BYTES(threads) ((size_t)(threads) * NVDR_STACK_LDS * sizeof(int))
 
 __device__ __forceinline__ bool tri_any_hit(const float4 *__restrict__ tris, int slot, float ox, float oy, float oz,
                                             float dx, float dy, float dz)
@@ -73,66 +130,131 @@ __device__ __forceinline__ bool tri_any_hit(const float4 *__restrict__ tris, int
     return nvdr_ray_tri(ox, oy, oz, dx, dy, dz, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, &t, &u, &v, &det) != 0;
 }
 
+// A ray in grid space (for the box tests only).
+struct GridRay {
+    float ox, oy, oz, ix, iy, iz;
+};
+__device__ __forceinline__ GridRay make_grid_ray(const BvhDeviceInfo *__restrict__ info, float ox, float oy, float oz,
+                                                 float dx, float dy, float dz)
+{
+    GridRay g;
+    const float sx = info->g_scale[0], sy = info->g_scale[1], sz = info->g_scale[2];
+    g.ox = (ox - info->g_lo[0]) * sx + 2.0f;
+    g.oy = (oy - info->g_lo[1]) * sy + 2.0f;
+    g.oz = (oz - info->g_lo[2]) * sz + 2.0f;
+    g.ix = 1.0f / (dx * sx);
+    g.iy = 1.0f / (dy * sy);
+    g.iz = 1.0f / (dz * sz);
+    return g;
+}
+
 // slab test of one child box against the ray interval [0, tmax]; IEEE inf/NaN semantics make
 // axis-parallel rays conservative (fminf/fmaxf drop NaNs).
 __device__ __forceinline__ bool box_hit(float minx, float miny, float minz, float maxx, float maxy, float maxz,
-                                        float ox, float oy, float oz, float ix, float iy, float iz, float tmax,
-                                        float &tnear)
+                                        const GridRay &r, float tmax, float &tnear)
 {
-    const float x0 = (minx - ox) * ix, x1 = (maxx - ox) * ix;
-    const float y0 = (miny - oy) * iy, y1 = (maxy - oy) * iy;
-    const float z0 = (minz - oz) * iz, z1 = (maxz - oz) * iz;
+    const float x0 = (minx - r.ox) * r.ix, x1 = (maxx - r.ox) * r.ix;
+    const float y0 = (miny - r.oy) * r.iy, y1 = (maxy - r.oy) * r.iy;
+    const float z0 = (minz - r.oz) * r.iz, z1 = (maxz - r.oz) * r.iz;
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
     tnear = tn;
     return tn <= tf;
 }
 
-// Any-hit traversal for ONE lane's ray.  `stack` points at this lane's column of the wave's LDS
-// stack: entry k lives at stack[k * 64] (bank = lane, conflict-free).  Returns true when the ray
-// is OCCLUDED.  COUNT adds per-lane tallies of box and triangle tests.
+__device__ __forceinline__ float lo16(unsigned w) { return (float)(w & 0xffffu); }
+__device__ __forceinline__ float hi16(unsigned w) { return (float)(w >> 16); }
+
+// one traversal step's worth of node data: fetch (two 16-B lookups), decode, test both children
+struct NodeHit {
+    bool hl, hr;
+    float tl, tr;
+    int cl, cr;
+};
+__device__ __forceinline__ NodeHit visit_node(const uint4 *__restrict__ nodes, int cur, const GridRay &r, float tmax)
+{
+    const uint4 a = nodes[2 * cur + 0], b = nodes[2 * cur + 1];
+    NodeHit h;
+    h.hl = box_hit(lo16(a.x), hi16(a.x), lo16(a.y), hi16(a.y), lo16(a.z), hi16(a.z), r, tmax, h.tl);
+    h.hr = box_hit(lo16(a.w), hi16(a.w), lo16(b.x), hi16(b.x), lo16(b.y), hi16(b.y), r, tmax, h.tr);
+    h.cl = (int)b.z;
+    h.cr = (int)b.w;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Any-hit traversal of up to TWO rays per lane that share an origin (a light-sampled and a BSDF-sampled
+// shadow ray of one stratum; `todo` bit r = ray r exists).  Returns a mask: bit r = ray r is OCCLUDED.
+// One loop for both rays: a lane whose first ray ends restarts at the root with its second ray instead of
+// idling until the slowest lane of the wave is done.  The kernel is VALU-issue bound (rocprofv3: VALU busy
+// ~90 % at ~40 % active lanes), so the loop body is kept short: node step and triangle step are the two arms
+// of one branch.  (A "while-while" variant that parks leaves and runs the triangle test once per batch of
+// node steps was measured 1.7x SLOWER: the extra divergence of the nested loops costs more than it saves.)
+template <bool COUNT>
+__device__ __forceinline__ unsigned bvh_any_hit2(const BvhView &bvh, float ox, float oy, float oz, float ax, float ay,
+                                                 float az, float bx, float by, float bz, unsigned todo,
+                                                 const TravStack &stack, unsigned &n_box, unsigned &n_tri)
+{
+    unsigned occluded = 0;
+    if (bvh.n_tris == 1) {
+        if (COUNT) n_tri += (todo & 1u) + ((todo >> 1) & 1u);
+        if ((todo & 1u) && tri_any_hit(bvh.tris, 0, ox, oy, oz, ax, ay, az)) occluded |= 1u;
+        if ((todo & 2u) && tri_any_hit(bvh.tris, 0, ox, oy, oz, bx, by, bz)) occluded |= 2u;
+        return occluded;
+    }
+    int ray = (todo & 1u) ? 0 : ((todo & 2u) ? 1 : 2);
+    float dx = ray == 0 ? ax : bx, dy = ray == 0 ? ay : by, dz = ray == 0 ? az : bz;
+    GridRay g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
+    int sp = 0, cur = 0;
+    // `cur` >= 0: internal node, < 0: a leaf (~cur = triangle slot), NVDR_TRAV_DONE: nothing left.  Leaves travel
+    // through the same variable / stack as nodes, so the loop body holds ONE copy of the triangle test.
+    while (ray < 2) {
+        bool finished = false;
+        if (cur >= 0) {
+            const NodeHit h = visit_node(bvh.nodes, cur, g, NVDR_RAY_TMAX);
+            if (COUNT) n_box += 2;
+            if (h.hl && h.hr) {
+                const bool left_first = h.tl <= h.tr;
+                stack.push(sp, left_first ? h.cr : h.cl);
+                sp++;
+                cur = left_first ? h.cl : h.cr;
+            } else if (h.hl) {
+                cur = h.cl;
+            } else if (h.hr) {
+                cur = h.cr;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack.pop(sp);
+            } else {
+                finished = true;
+            }
+        } else {
+            if (COUNT) n_tri++;
+            if (tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz)) {
+                occluded |= 1u << ray;
+                finished = true;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack.pop(sp);
+            } else {
+                finished = true;
+            }
+        }
+        if (finished) {
+            ray = (ray == 0 && (todo & 2u)) ? 1 : 2;
+            dx = bx; dy = by; dz = bz;
+            g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
+            sp = 0;
+            cur = 0;
+        }
+    }
+    return occluded;
+}
+
+// one ray per lane
 template <bool COUNT>
 __device__ __forceinline__ bool bvh_any_hit(const BvhView &bvh, float ox, float oy, float oz, float dx, float dy,
-                                            float dz, int *stack, unsigned &n_box, unsigned &n_tri)
+                                            float dz, const TravStack &stack, unsigned &n_box, unsigned &n_tri)
 {
-    if (bvh.n_tris == 1) {
-        if (COUNT) n_tri++;
-        return tri_any_hit(bvh.tris, 0, ox, oy, oz, dx, dy, dz);
-    }
-    const float ix = (1.0f / dx), iy = (1.0f / dy), iz = (1.0f / dz);
-    int sp = 0;
-    int cur = 0;
-    while (true) {
-        const float4 q0 = bvh.nodes[4 * cur + 0], q1 = bvh.nodes[4 * cur + 1];
-        const float4 q2 = bvh.nodes[4 * cur + 2], q3 = bvh.nodes[4 * cur + 3];
-        float tl, tr;
-        bool hl = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, NVDR_RAY_TMAX, tl);
-        bool hr = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, NVDR_RAY_TMAX, tr);
-        const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-        if (COUNT) n_box += 2;
-        if (hl && cl < 0) {
-            if (COUNT) n_tri++;
-            if (tri_any_hit(bvh.tris, ~cl, ox, oy, oz, dx, dy, dz)) return true;
-            hl = false;
-        }
-        if (hr && cr < 0) {
-            if (COUNT) n_tri++;
-            if (tri_any_hit(bvh.tris, ~cr, ox, oy, oz, dx, dy, dz)) return true;
-            hr = false;
-        }
-        if (hl && hr) {
-            const bool left_first = tl <= tr;
-            stack[sp * 64] = left_first ? cr : cl;
-            sp++;
-            cur = left_first ? cl : cr;
-        } else if (hl) {
-            cur = cl;
-        } else if (hr) {
-            cur = cr;
-        } else {
-            if (sp == 0) return false;
-            sp--;
-            cur = stack[sp * 64];
-        }
-    }
+    return bvh_any_hit2<COUNT>(bvh, ox, oy, oz, dx, dy, dz, dx, dy, dz, 1u, stack, n_box, n_tri) != 0;
 }

@@ -8,7 +8,8 @@
 //   3. device radix sort (rocPRIM, 30 key bits) of (code, triangle) pairs
 //   4. Karras-2012 hierarchy, one thread per internal node
 //   5. bottom-up bounds: one thread per leaf climbs, the second arriver at a node continues;
-//      the child boxes are written INTO the parent's 64-B record (layout: bvh.h)
+//      the child boxes are written INTO the parent's 32-B record as 16-bit grid coordinates (layout:
+//      bvh.h); unions are taken on the integers, so quantisation slack does not grow up the tree
 // Buffers live in the context and are reused across iterations; rebuild == 0 re-runs only 1 + 5
 // (OPTIX_BUILD_OPERATION_UPDATE).  Nothing synchronises the host.
 #include "bvh.h"
@@ -42,6 +43,27 @@ __global__ void bvh_init_info_kernel(BvhDeviceInfo *info)
         info->bounds[3] = info->bounds[4] = info->bounds[5] = (int)0x80000000;
         info->height = 0;
         info->root = 0;
+    }
+}
+
+// quantisation grid + leaf padding from the vertex AABB (one thread)
+__global__ void bvh_grid_kernel(BvhDeviceInfo *info)
+{
+    float scale = 0.0f, lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = ordered_to_float(info->bounds[a]);
+        hi[a] = ordered_to_float(info->bounds[3 + a]);
+        scale = fmaxf(scale, fmaxf(hi[a] - lo[a], fmaxf(fabsf(lo[a]), fabsf(hi[a]))));
+    }
+    // conservative padding: the slab test must never cull a triangle the fp32 Moeller-Trumbore
+    // predicate would accept (its acceptance band is a few ulp of the scene scale wide)
+    const float pad = 1e-5f * scale;
+    info->pad = pad;
+    for (int a = 0; a < 3; ++a) {
+        const float g0 = lo[a] - 2.0f * pad, g1 = hi[a] + 2.0f * pad;
+        const float ext = fmaxf(g1 - g0, 1e-6f * scale + 1e-30f);
+        info->g_lo[a] = g0;
+        info->g_scale[a] = NVDR_GRID_MAX / ext;
     }
 }
 
@@ -110,7 +132,7 @@ __device__ __forceinline__ int lbvh_delta(const uint32_t *__restrict__ keys, int
     return a == b ? 32 + __clz(i ^ j) : __clz(a ^ b);
 }
 
-__global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, float4 *__restrict__ nodes,
+__global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, uint4 *__restrict__ nodes,
                                      int *__restrict__ parent)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,7 +156,9 @@ __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, f
     const int lo = min(i, j), hi = max(i, j);
     const int left = (lo == gamma) ? ~gamma : gamma;
     const int right = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
-    nodes[4 * i + 3] = make_float4(__int_as_float(left), __int_as_float(right), __int_as_float(0), __int_as_float(0));
+    unsigned *rec = (unsigned *)(nodes + 2 * i);
+    rec[6] = (unsigned)left;
+    rec[7] = (unsigned)right;
     if (left < 0) parent[n + gamma] = i; else parent[left] = i;
     if (right < 0) parent[n + gamma + 1] = i; else parent[right] = i;
     if (i == 0) parent[0] = -1;
@@ -145,8 +169,8 @@ __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, f
 // plain stores -> release fence -> drained vmcnt -> device-scope atomic; the second arriver does
 // one acquire fence and then plain loads.
 __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *__restrict__ tris,
-                               const uint32_t *__restrict__ order, int n, float4 *__restrict__ tri_rec,
-                               float4 *nodes, const int *__restrict__ parent, int *flags, BvhDeviceInfo *info)
+                               const uint32_t *__restrict__ order, int n, float4 *__restrict__ tri_rec, uint4 *nodes,
+                               const int *__restrict__ parent, int *flags, int *heights, BvhDeviceInfo *info)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -162,37 +186,41 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
     tri_rec[3 * k + 2] = make_float4(e2z, __int_as_float((int)orig), 0.0f, 0.0f);
     if (n == 1) return;
 
-    // conservative padding: the slab test must never cull a triangle the fp32 Moeller-Trumbore
-    // predicate would accept (its acceptance band is a few ulp of the scene scale wide)
-    float scale = 0.0f;
+    // leaf box: exact min/max of the vertices, padded, then snapped OUTWARD to the 16-bit grid with one
+    // extra cell of slack (covers the rounding of the ray's own transform into grid space)
+    const float pad = info->pad;
+    const float mn[3] = {fminf(ax, fminf(bx, cx)) - pad, fminf(ay, fminf(by, cy)) - pad, fminf(az, fminf(bz, cz)) - pad};
+    const float mx[3] = {fmaxf(ax, fmaxf(bx, cx)) + pad, fmaxf(ay, fmaxf(by, cy)) + pad, fmaxf(az, fmaxf(bz, cz)) + pad};
+    int qmn[3], qmx[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float lo = ordered_to_float(info->bounds[a]), hi = ordered_to_float(info->bounds[3 + a]);
-        scale = fmaxf(scale, fmaxf(hi - lo, fmaxf(fabsf(lo), fabsf(hi))));
+        const float lo = (mn[a] - info->g_lo[a]) * info->g_scale[a] + 2.0f;
+        const float hi = (mx[a] - info->g_lo[a]) * info->g_scale[a] + 2.0f;
+        qmn[a] = min(max((int)floorf(lo) - 1, 0), 65535);
+        qmx[a] = min(max((int)ceilf(hi) + 1, 0), 65535);
     }
-    const float pad = 1e-5f * scale;
-    float mnx = fminf(ax, fminf(bx, cx)) - pad, mny = fminf(ay, fminf(by, cy)) - pad, mnz = fminf(az, fminf(bz, cz)) - pad;
-    float mxx = fmaxf(ax, fmaxf(bx, cx)) + pad, mxy = fmaxf(ay, fmaxf(by, cy)) + pad, mxz = fmaxf(az, fmaxf(bz, cz)) + pad;
     int height = 0;
     int me = ~k;
     int node = parent[n + k];
-    float *nf = (float *)nodes;
     while (true) {
-        float *rec = nf + 16 * (int64_t)node;
-        const int cl = __float_as_int(rec[12]);
+        unsigned *rec = (unsigned *)(nodes + 2 * (int64_t)node);
+        const int cl = (int)rec[6];
         const int slot = (cl == me) ? 0 : 1;
-        float *dst = rec + 6 * slot;
-        dst[0] = mnx; dst[1] = mny; dst[2] = mnz; dst[3] = mxx; dst[4] = mxy; dst[5] = mxz;
-        rec[14 + slot] = __int_as_float(height);
+        unsigned *dst = rec + 3 * slot;
+        dst[0] = (unsigned)qmn[0] | ((unsigned)qmn[1] << 16);
+        dst[1] = (unsigned)qmn[2] | ((unsigned)qmx[0] << 16);
+        dst[2] = (unsigned)qmx[1] | ((unsigned)qmx[2] << 16);
+        heights[2 * node + slot] = height;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int old = atomicAdd(&flags[node], 1);
         if (old == 0) return; // first arriver: the sibling subtree finishes this node
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const float *src = rec + 6 * (1 - slot);
-        mnx = fminf(mnx, src[0]); mny = fminf(mny, src[1]); mnz = fminf(mnz, src[2]);
-        mxx = fmaxf(mxx, src[3]); mxy = fmaxf(mxy, src[4]); mxz = fmaxf(mxz, src[5]);
-        height = 1 + max(height, __float_as_int(rec[14 + (1 - slot)]));
+        const unsigned *src = rec + 3 * (1 - slot);
+        const unsigned s0 = src[0], s1 = src[1], s2 = src[2];
+        qmn[0] = min(qmn[0], (int)(s0 & 0xffffu)); qmn[1] = min(qmn[1], (int)(s0 >> 16)); qmn[2] = min(qmn[2], (int)(s1 & 0xffffu));
+        qmx[0] = max(qmx[0], (int)(s1 >> 16)); qmx[1] = max(qmx[1], (int)(s2 & 0xffffu)); qmx[2] = max(qmx[2], (int)(s2 >> 16));
+        height = 1 + max(height, heights[2 * node + (1 - slot)]);
         if (node == 0) {
             info->height = height;
             return;
@@ -206,17 +234,15 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
 // ray-query hooks
 
 template <bool COUNT>
-__global__ void __launch_bounds__(256) trace_visibility_kernel(BvhView bvh, const float *__restrict__ ro,
-                                                                const float *__restrict__ rd, int64_t n_rays,
-                                                                uint8_t *__restrict__ out, unsigned long long *counters,
-                                                                int stack_depth)
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_visibility_kernel(BvhView bvh, const float *__restrict__ ro,
+                                                                             const float *__restrict__ rd, int64_t n_rays,
+                                                                             uint8_t *__restrict__ out,
+                                                                             unsigned long long *counters, int *spill)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *stack = smem + wave * stack_depth * 64 + lane;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const TravStack stack = make_stack(smem, spill);
     unsigned nb = 0, nt = 0;
-    if (r < n_rays) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
         const bool occ = bvh_any_hit<COUNT>(bvh, ro[3 * r], ro[3 * r + 1], ro[3 * r + 2], rd[3 * r], rd[3 * r + 1],
                                             rd[3 * r + 2], stack, nb, nt);
         out[r] = occ ? 0 : 1;
@@ -226,7 +252,7 @@ __global__ void __launch_bounds__(256) trace_visibility_kernel(BvhView bvh, cons
             nb += __shfl_xor(nb, o);
             nt += __shfl_xor(nt, o);
         }
-        if (lane == 0) {
+        if ((threadIdx.x & 63) == 0) {
             atomicAdd(&counters[0], (unsigned long long)nb);
             atomicAdd(&counters[1], (unsigned long long)nt);
         }
@@ -234,67 +260,62 @@ __global__ void __launch_bounds__(256) trace_visibility_kernel(BvhView bvh, cons
 }
 
 // closest hit (ordered traversal, shrinking tmax); used by the G-buffer producer
-__global__ void __launch_bounds__(256) trace_closest_kernel(BvhView bvh, const float *__restrict__ ro,
-                                                             const float *__restrict__ rd, int64_t n_rays,
-                                                             float *__restrict__ out_t, int32_t *__restrict__ out_tri,
-                                                             float *__restrict__ out_uv, int stack_depth)
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_closest_kernel(BvhView bvh, const float *__restrict__ ro,
+                                                                          const float *__restrict__ rd, int64_t n_rays,
+                                                                          float *__restrict__ out_t,
+                                                                          int32_t *__restrict__ out_tri,
+                                                                          float *__restrict__ out_uv, int *spill)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *stack = smem + wave * stack_depth * 64 + lane;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rays) return;
-    const float ox = ro[3 * r], oy = ro[3 * r + 1], oz = ro[3 * r + 2];
-    const float dx = rd[3 * r], dy = rd[3 * r + 1], dz = rd[3 * r + 2];
-    float best_t = NVDR_RAY_TMAX, best_u = 0.0f, best_v = 0.0f;
-    int best = -1;
-    auto test_leaf = [&](int slot) {
-        const float4 a = bvh.tris[3 * slot + 0], b = bvh.tris[3 * slot + 1], c = bvh.tris[3 * slot + 2];
-        float t, u, v, det;
-        if (nvdr_ray_tri(ox, oy, oz, dx, dy, dz, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, &t, &u, &v, &det)) {
-            const float tt = (t / det);
-            if (tt < best_t) {
-                best_t = tt;
-                best_u = (u / det);
-                best_v = (v / det);
-                best = __float_as_int(c.y);
+    const TravStack stack = make_stack(smem, spill);
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
+        const float ox = ro[3 * r], oy = ro[3 * r + 1], oz = ro[3 * r + 2];
+        const float dx = rd[3 * r], dy = rd[3 * r + 1], dz = rd[3 * r + 2];
+        float best_t = NVDR_RAY_TMAX, best_u = 0.0f, best_v = 0.0f;
+        int best = -1;
+        auto test_leaf = [&](int slot) {
+            const float4 a = bvh.tris[3 * slot + 0], b = bvh.tris[3 * slot + 1], c = bvh.tris[3 * slot + 2];
+            float t, u, v, det;
+            if (nvdr_ray_tri(ox, oy, oz, dx, dy, dz, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, &t, &u, &v, &det)) {
+                const float tt = t / det;
+                if (tt < best_t) {
+                    best_t = tt;
+                    best_u = u / det;
+                    best_v = v / det;
+                    best = __float_as_int(c.y);
+                }
+            }
+        };
+        if (bvh.n_tris == 1) {
+            test_leaf(0);
+        } else {
+            const GridRay g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
+            int sp = 0, cur = 0;
+            while (true) {
+                NodeHit h = visit_node(bvh.nodes, cur, g, best_t);
+                if (h.hl && h.cl < 0) { test_leaf(~h.cl); h.hl = false; }
+                if (h.hr && h.cr < 0) { test_leaf(~h.cr); h.hr = false; }
+                if (h.hl && h.hr) {
+                    const bool left_first = h.tl <= h.tr;
+                    stack.push(sp, left_first ? h.cr : h.cl);
+                    sp++;
+                    cur = left_first ? h.cl : h.cr;
+                } else if (h.hl) {
+                    cur = h.cl;
+                } else if (h.hr) {
+                    cur = h.cr;
+                } else {
+                    if (sp == 0) break;
+                    sp--;
+                    cur = stack.pop(sp);
+                }
             }
         }
-    };
-    if (bvh.n_tris == 1) {
-        test_leaf(0);
-    } else {
-        const float ix = (1.0f / dx), iy = (1.0f / dy), iz = (1.0f / dz);
-        int sp = 0, cur = 0;
-        while (true) {
-            const float4 q0 = bvh.nodes[4 * cur + 0], q1 = bvh.nodes[4 * cur + 1];
-            const float4 q2 = bvh.nodes[4 * cur + 2], q3 = bvh.nodes[4 * cur + 3];
-            float tl, tr;
-            bool hl = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ox, oy, oz, ix, iy, iz, best_t, tl);
-            bool hr = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ox, oy, oz, ix, iy, iz, best_t, tr);
-            const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-            if (hl && cl < 0) { test_leaf(~cl); hl = false; }
-            if (hr && cr < 0) { test_leaf(~cr); hr = false; }
-            if (hl && hr) {
-                const bool left_first = tl <= tr;
-                stack[sp * 64] = left_first ? cr : cl;
-                sp++;
-                cur = left_first ? cl : cr;
-            } else if (hl) {
-                cur = cl;
-            } else if (hr) {
-                cur = cr;
-            } else {
-                if (sp == 0) break;
-                sp--;
-                cur = stack[sp * 64];
-            }
-        }
+        out_t[r] = best >= 0 ? best_t : -1.0f;
+        out_tri[r] = best;
+        out_uv[2 * r] = best_u;
+        out_uv[2 * r + 1] = best_v;
     }
-    out_t[r] = best >= 0 ? best_t : -1.0f;
-    out_tri[r] = best;
-    out_uv[2 * r] = best_u;
-    out_uv[2 * r + 1] = best_v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,10 +325,11 @@ static int ctx_free_bvh(nvdr_ctx *c)
 {
     hipFree(c->nodes); hipFree(c->tris);
     hipFree(c->keys[0]); hipFree(c->keys[1]); hipFree(c->vals[0]); hipFree(c->vals[1]);
-    hipFree(c->parent); hipFree(c->flags); hipFree(c->sort_tmp);
-    c->nodes = c->tris = nullptr;
+    hipFree(c->parent); hipFree(c->flags); hipFree(c->heights); hipFree(c->sort_tmp);
+    c->nodes = nullptr;
+    c->tris = nullptr;
     c->keys[0] = c->keys[1] = c->vals[0] = c->vals[1] = nullptr;
-    c->parent = c->flags = nullptr;
+    c->parent = c->flags = c->heights = nullptr;
     c->sort_tmp = nullptr;
     c->sort_tmp_bytes = 0;
     c->cap_tris = 0;
@@ -327,6 +349,15 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         return (int)e;
     }
     hipMemset(c->dinfo, 0, sizeof(BvhDeviceInfo));
+    e = hipMalloc((void **)&c->spill, sizeof(int) * (size_t)(NVDR_STACK_MAX - NVDR_STACK_LDS) * NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK);
+    if (e != hipSuccess) {
+        hipFree(c->dinfo);
+        delete c;
+        nvdr_set_error("nvdr_ctx_create: hipMalloc(spill) failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (c->n_cus <= 0) c->n_cus = 256;
     *out = c;
     return 0;
 }
@@ -337,7 +368,9 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     hipSetDevice(c->device);
     ctx_free_bvh(c);
     hipFree(c->dinfo);
+    hipFree(c->spill);
     hipFree(c->pix_list);
+    hipFree(c->vis_scratch);
     delete c;
     return 0;
 }
@@ -350,7 +383,7 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     NVDR_HIP_TRY(hipDeviceSynchronize());
     ctx_free_bvh(c);
     const int64_t cap = n_tris + n_tris / 2 + 64;
-    NVDR_HIP_TRY(hipMalloc((void **)&c->nodes, sizeof(float4) * 4 * cap));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->nodes, sizeof(uint4) * 2 * cap));
     NVDR_HIP_TRY(hipMalloc((void **)&c->tris, sizeof(float4) * 3 * cap));
     for (int i = 0; i < 2; ++i) {
         NVDR_HIP_TRY(hipMalloc((void **)&c->keys[i], sizeof(uint32_t) * cap));
@@ -358,6 +391,7 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     }
     NVDR_HIP_TRY(hipMalloc((void **)&c->parent, sizeof(int) * 2 * cap));
     NVDR_HIP_TRY(hipMalloc((void **)&c->flags, sizeof(int) * cap));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->heights, sizeof(int) * 2 * cap));
     size_t bytes = 0;
     NVDR_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1], (size_t)cap, 0, 30));
     NVDR_HIP_TRY(hipMalloc(&c->sort_tmp, bytes + 256));
@@ -388,6 +422,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     const int n = (int)n_tris;
     bvh_init_info_kernel<<<1, 64, 0, stream>>>(c->dinfo);
     bvh_bounds_kernel<<<min(div_up(n_verts, 256), 1024u), 256, 0, stream>>>(verts, n_verts, c->dinfo);
+    bvh_grid_kernel<<<1, 1, 0, stream>>>(c->dinfo);
     if (rebuild != 0) {
         bvh_morton_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, n, c->dinfo, c->keys[0], c->vals[0]);
         size_t bytes = c->sort_tmp_bytes;
@@ -398,29 +433,20 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     }
     NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
     bvh_fit_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->parent,
-                                                        c->flags, c->dinfo);
+                                                        c->flags, c->heights, c->dinfo);
     NVDR_LAUNCH_CHECK();
     c->n_tris = n_tris;
     c->n_verts = n_verts;
-    c->height_host = -1;
     return 0;
 }
 
-// The traversal kernels size their LDS stack from the tree height, which is produced on the
-// device; the first query after a build reads it back (one 4-byte copy on the query's stream).
-int bvh_stack_depth(nvdr_ctx *c, hipStream_t stream, int *depth)
+// grid of a grid-stride traversal launch over `items` work items
+unsigned query_grid(const nvdr_ctx *c, int64_t items)
 {
-    if (c->height_host < 0) {
-        int h = 0;
-        NVDR_HIP_TRY(hipMemcpyAsync(&h, &c->dinfo->height, sizeof(int), hipMemcpyDeviceToHost, stream));
-        NVDR_HIP_TRY(hipStreamSynchronize(stream));
-        c->height_host = h;
-    }
-    int d = ((c->height_host + 1 + 7) / 8) * 8;
-    if (d < 8) d = 8;
-    NVDR_REQUIRE(d <= 96, "BVH too deep for the LDS traversal stack (height %d)", c->height_host);
-    *depth = d;
-    return 0;
+    int64_t b = (items + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
+    const int64_t cap = (int64_t)c->n_cus * 8 < NVDR_QUERY_MAX_BLOCKS ? (int64_t)c->n_cus * 8 : NVDR_QUERY_MAX_BLOCKS;
+    if (b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
 }
 
 extern "C" int nvdr_bvh_info_get(nvdr_ctx *c, nvdr_bvh_info *out, void *stream_)
@@ -439,7 +465,6 @@ extern "C" int nvdr_bvh_info_get(nvdr_ctx *c, nvdr_bvh_info *out, void *stream_)
         out->aabb_min[a] = ordered_to_float(h.bounds[a]);
         out->aabb_max[a] = ordered_to_float(h.bounds[3 + a]);
     }
-    c->height_host = h.height;
     return 0;
 }
 
@@ -448,7 +473,7 @@ extern "C" int nvdr_bvh_export(nvdr_ctx *c, float *nodes_host, float *tri_host, 
     NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_bvh_export: no BVH built");
     hipStream_t stream = (hipStream_t)stream_;
     if (nodes_host && c->n_tris > 1)
-        NVDR_HIP_TRY(hipMemcpyAsync(nodes_host, c->nodes, sizeof(float) * 16 * (c->n_tris - 1), hipMemcpyDeviceToHost, stream));
+        NVDR_HIP_TRY(hipMemcpyAsync(nodes_host, c->nodes, sizeof(uint32_t) * 8 * (c->n_tris - 1), hipMemcpyDeviceToHost, stream));
     if (tri_host)
         NVDR_HIP_TRY(hipMemcpyAsync(tri_host, c->tris, sizeof(float) * 12 * c->n_tris, hipMemcpyDeviceToHost, stream));
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
@@ -461,14 +486,12 @@ extern "C" int nvdr_trace_visibility(nvdr_ctx *c, const float *ro, const float *
     NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_trace_visibility: no BVH built");
     if (n_rays <= 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
-    int depth;
-    int r = bvh_stack_depth(c, stream, &depth);
-    if (r) return r;
-    const size_t lds = (size_t)4 * depth * 64 * sizeof(int);
+    const size_t lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
+    const unsigned grid = query_grid(c, n_rays);
     if (counters)
-        trace_visibility_kernel<true><<<div_up(n_rays, 256), 256, lds, stream>>>(bvh_view(c), ro, rd, n_rays, out_vis, counters, depth);
+        trace_visibility_kernel<true><<<grid, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), ro, rd, n_rays, out_vis, counters, c->spill);
     else
-        trace_visibility_kernel<false><<<div_up(n_rays, 256), 256, lds, stream>>>(bvh_view(c), ro, rd, n_rays, out_vis, nullptr, depth);
+        trace_visibility_kernel<false><<<grid, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), ro, rd, n_rays, out_vis, nullptr, c->spill);
     NVDR_LAUNCH_CHECK();
     return 0;
 }
@@ -479,11 +502,8 @@ extern "C" int nvdr_trace_closest(nvdr_ctx *c, const float *ro, const float *rd,
     NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_trace_closest: no BVH built");
     if (n_rays <= 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
-    int depth;
-    int r = bvh_stack_depth(c, stream, &depth);
-    if (r) return r;
-    const size_t lds = (size_t)4 * depth * 64 * sizeof(int);
-    trace_closest_kernel<<<div_up(n_rays, 256), 256, lds, stream>>>(bvh_view(c), ro, rd, n_rays, out_t, out_tri, out_uv, depth);
+    trace_closest_kernel<<<query_grid(c, n_rays), NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream>>>(
+        bvh_view(c), ro, rd, n_rays, out_t, out_tri, out_uv, c->spill);
     NVDR_LAUNCH_CHECK();
     return 0;
 }

@@ -22,7 +22,6 @@
 
 #define NVDR_PI_DBL 3.14159265358979323846
 
-int bvh_stack_depth(nvdr_ctx *c, hipStream_t stream, int *depth); // bvh.hip
 
 struct Tab {          // small strided table (light, pdf, rows, cols)
     const float *p;
@@ -44,7 +43,8 @@ struct ShadeParams {
     uint32_t *vis_cache; int vis_words; // per plane
     const int *pix_list;
     const unsigned *pix_count;
-    int stack_depth;
+    int *spill;
+    unsigned debug;           // NVDR_DEBUG bits: 1 skip tracing, 2 skip light-gradient atomics, 8 single-launch re-tracing backward
     unsigned long long *counters;
 };
 
@@ -309,74 +309,6 @@ __device__ __forceinline__ float bsdf_pdf(float pDiffuse, float pSpecular, F3 N,
     return pdf;
 }
 
-// ---------------------------------------------------------------------------------------------
-// two shadow rays per lane in ONE traversal loop.  Bit 0 / bit 1 of the result = ray A / ray B is
-// OCCLUDED.  A lane that finishes ray A immediately restarts at the root with ray B.
-
-template <bool COUNT>
-__device__ __forceinline__ unsigned trace_two(const BvhView &bvh, F3 o, F3 da, F3 db, unsigned todo, int *stack,
-                                              unsigned &n_box, unsigned &n_tri)
-{
-    unsigned occluded = 0;
-    if (bvh.n_tris == 1) {
-        if (COUNT) n_tri += (todo & 1u) + ((todo >> 1) & 1u);
-        if ((todo & 1u) && tri_any_hit(bvh.tris, 0, o.x, o.y, o.z, da.x, da.y, da.z)) occluded |= 1u;
-        if ((todo & 2u) && tri_any_hit(bvh.tris, 0, o.x, o.y, o.z, db.x, db.y, db.z)) occluded |= 2u;
-        return occluded;
-    }
-    int ray = (todo & 1u) ? 0 : ((todo & 2u) ? 1 : 2);
-    F3 d = ray == 0 ? da : db;
-    float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-    int sp = 0, cur = 0;
-    while (ray < 2) {
-        const float4 q0 = bvh.nodes[4 * cur + 0], q1 = bvh.nodes[4 * cur + 1];
-        const float4 q2 = bvh.nodes[4 * cur + 2], q3 = bvh.nodes[4 * cur + 3];
-        float tl, tr;
-        bool hl = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o.x, o.y, o.z, ix, iy, iz, NVDR_RAY_TMAX, tl);
-        bool hr = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o.x, o.y, o.z, ix, iy, iz, NVDR_RAY_TMAX, tr);
-        const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-        bool done = false;
-        if (COUNT) {
-            n_box += 2;
-            n_tri += (hl && cl < 0) ? 1u : 0u;
-        }
-        if (hl && cl < 0) {
-            if (tri_any_hit(bvh.tris, ~cl, o.x, o.y, o.z, d.x, d.y, d.z)) { occluded |= 1u << ray; done = true; }
-            hl = false;
-        }
-        if (!done && hr && cr < 0) {
-            if (COUNT) n_tri++;
-            if (tri_any_hit(bvh.tris, ~cr, o.x, o.y, o.z, d.x, d.y, d.z)) { occluded |= 1u << ray; done = true; }
-            hr = false;
-        }
-        if (!done) {
-            if (hl && hr) {
-                const bool left_first = tl <= tr;
-                stack[sp * 64] = left_first ? cr : cl;
-                sp++;
-                cur = left_first ? cl : cr;
-            } else if (hl) {
-                cur = cl;
-            } else if (hr) {
-                cur = cr;
-            } else if (sp > 0) {
-                sp--;
-                cur = stack[sp * 64];
-            } else {
-                done = true;
-            }
-        }
-        if (done) {
-            ray = (ray == 0 && (todo & 2u)) ? 1 : 2;
-            d = db;
-            ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
-            sp = 0;
-            cur = 0;
-        }
-    }
-    return occluded;
-}
-
 // butterfly sum over the L lanes that share a pixel (L a power of two <= 64)
 __device__ __forceinline__ float group_sum(float v, int L)
 {
@@ -394,13 +326,26 @@ __device__ __forceinline__ F3 fetch_light(const Tab &t, int y, int x)
 // ---------------------------------------------------------------------------------------------
 // the kernel
 
-template <bool BACKWARD, bool COUNT>
-__global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p, BvhView bvh)
+// VISONLY: generate the samples and trace them, record the visibility bits, skip all shading (first half of a
+// re-tracing backward pass)
+#ifndef NVDR_OCC_FWD
+#define NVDR_OCC_FWD 4   // min waves per SIMD the register allocator must leave room for (forward / visibility-only)
+#endif
+#ifndef NVDR_OCC_VIS
+#define NVDR_OCC_VIS 6   // ... visibility-only pass (lean: sampling + traversal)
+#endif
+#ifndef NVDR_OCC_BWD
+#define NVDR_OCC_BWD 3   // ... gradient kernel
+#endif
+// measured on the benchmark view (bob 512^2, 64 spp), forward ms at FWD = 3/4/5/6: 2.30 / 2.17 / 2.49 / 2.34;
+// visibility-only pass at 4/5/6: 1.70 / 1.61 / 1.56
+template <bool BACKWARD, bool COUNT, bool VISONLY>
+__global__ void __launch_bounds__(256, BACKWARD ? NVDR_OCC_BWD : (VISONLY ? NVDR_OCC_VIS : NVDR_OCC_FWD)) env_shade_kernel(ShadeParams p, BvhView bvh)
 {
     unsigned n_box = 0, n_tri = 0;
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *stack = smem + wave * p.stack_depth * 64 + lane;
+    const TravStack stack = make_stack(smem, p.spill);
     const int L = p.L, G = 64 >> p.log2L;
     const int slot = lane >> p.log2L, sub = lane & (L - 1);
     const unsigned P = *p.pix_count;
@@ -472,7 +417,8 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p, BvhView b
                     occ |= ((vc[p.vis_words + word] >> bit) & 1u) << 1;
                 }
             } else {
-                occ = trace_two<COUNT>(bvh, ro, dirA, dirB, active ? 3u : 0u, stack, n_box, n_tri);
+                occ = bvh_any_hit2<COUNT>(bvh, ro.x, ro.y, ro.z, dirA.x, dirA.y, dirA.z, dirB.x, dirB.y, dirB.z,
+                                          (active && !(p.debug & 1u)) ? 3u : 0u, stack, n_box, n_tri);
                 if (!BACKWARD && p.vis_cache) {
                     const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
                     if (sub == 0 && valid) {
@@ -496,7 +442,7 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p, BvhView b
 
             // shade both samples (process_sample, kernel.cu:403-461)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < (VISONLY ? 0 : 2); ++r) {
                 const F3 dir = r == 0 ? dirA : dirB;
                 const float pdfSum = r == 0 ? (pdfA_light + pdfA_bsdf) : (pdfB_light + pdfB_bsdf);
                 const int tx = r == 0 ? txA : txB, ty = r == 0 ? tyA : tyB;
@@ -513,9 +459,11 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p, BvhView b
                     if (BACKWARD) {
                         const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
                         float *g = p.g_light + ((int64_t)ty * p.light.n1 + tx) * 3;
-                        atomicAdd(g + 0, lg.x);
-                        atomicAdd(g + 1, lg.y);
-                        atomicAdd(g + 2, lg.z);
+                        if (!(p.debug & 2u)) {
+                            atomicAdd(g + 0, lg.x);
+                            atomicAdd(g + 1, lg.y);
+                            atomicAdd(g + 2, lg.z);
+                        }
                         const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
                         const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
                         if (p.bsdf == 1 || p.bsdf == 2) {
@@ -532,7 +480,8 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p, BvhView b
             }
         }
 
-        if (!BACKWARD) {
+        if (VISONLY) {
+        } else if (!BACKWARD) {
             diffAccum = group_sum3(diffAccum, L);
             specAccum = group_sum3(specAccum, L);
             if (valid && sub == 0) {
@@ -672,29 +621,45 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
                                                                   &c->dinfo->pix_count);
     p.pix_list = c->pix_list;
     p.pix_count = &c->dinfo->pix_count;
-    int depth;
-    if ((r = bvh_stack_depth(c, stream, &depth))) return r;
-    p.stack_depth = depth;
-    const int waves_per_block = 4;
-    const size_t lds = (size_t)waves_per_block * depth * 64 * sizeof(int);
-    // persistent grid: enough workgroups to fill every CU at the occupancy the LDS stack allows
-    int dev_cus = 256;
-    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c->device);
-    int blocks_per_cu = (int)((size_t)(160 * 1024) / (lds > 0 ? lds : 1));
-    if (blocks_per_cu > 4) blocks_per_cu = 4;
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    p.spill = c->spill;
+    const char *dbg = getenv("NVDR_DEBUG");
+    p.debug = dbg ? (unsigned)atoi(dbg) : 0u;
+    const int waves_per_block = NVDR_QUERY_BLOCK / 64;
+    const size_t lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
+    // persistent grid: a few workgroups per CU, each wavefront strides over the covered-pixel list
     const int64_t max_groups = (npix + (64 / L) - 1) / (64 / L);
-    int64_t blocks = (int64_t)dev_cus * blocks_per_cu;
+    int64_t blocks = (int64_t)c->n_cus * (backward ? NVDR_OCC_BWD : NVDR_OCC_FWD);
+    if (blocks > NVDR_QUERY_MAX_BLOCKS) blocks = NVDR_QUERY_MAX_BLOCKS;
     if (blocks * waves_per_block > max_groups) blocks = (max_groups + waves_per_block - 1) / waves_per_block;
     if (blocks < 1) blocks = 1;
     p.counters = a->counters;
     const dim3 grid((unsigned)blocks), block(64 * waves_per_block);
-    if (a->counters) {
-        if (backward) env_shade_kernel<true, true><<<grid, block, lds, stream>>>(p, bvh_view(c));
-        else env_shade_kernel<false, true><<<grid, block, lds, stream>>>(p, bvh_view(c));
+    if (backward && !p.vis_cache && !a->counters && !(p.debug & 8u)) {
+        // Re-tracing backward (the reference launches the whole raygen program again, torch_bindings.cpp:238,266) as
+        // TWO launches: the sampling + traversal half runs in the lean forward configuration (96 VGPRs, 5 waves
+        // per SIMD) and leaves one bit per ray; the gradient half (132 VGPRs) then replays the bits.  Tracing at
+        // the backward kernel's occupancy costs 3.7 ms on the benchmark view, this way 2.4 ms.
+        const size_t need = sizeof(uint32_t) * (size_t)npix * 2 * p.vis_words;
+        if (c->vis_cap < need) {
+            NVDR_HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(c->vis_scratch);
+            c->vis_scratch = nullptr;
+            NVDR_HIP_TRY(hipMalloc((void **)&c->vis_scratch, need));
+            c->vis_cap = need;
+        }
+        p.vis_cache = c->vis_scratch;
+        int64_t fblocks = (int64_t)c->n_cus * NVDR_OCC_VIS;
+        if (fblocks > NVDR_QUERY_MAX_BLOCKS) fblocks = NVDR_QUERY_MAX_BLOCKS;
+        if (fblocks * waves_per_block > max_groups) fblocks = (max_groups + waves_per_block - 1) / waves_per_block;
+        if (fblocks < 1) fblocks = 1;
+        env_shade_kernel<false, false, true><<<dim3((unsigned)fblocks), block, lds, stream>>>(p, bvh_view(c));
+        env_shade_kernel<true, false, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
+    } else if (a->counters) {
+        if (backward) env_shade_kernel<true, true, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
+        else env_shade_kernel<false, true, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
     } else {
-        if (backward) env_shade_kernel<true, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
-        else env_shade_kernel<false, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
+        if (backward) env_shade_kernel<true, false, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
+        else env_shade_kernel<false, false, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
     }
     NVDR_LAUNCH_CHECK();
     return 0;

@@ -17,7 +17,7 @@ Extra objects on the JSON line:
   roofline     -- forward env-shade kernel: algorithmic bytes per launch (SURVEY 8d formula with the
                   box/triangle test counts measured by the counting build of the same kernel) over
                   its average duration measured with HIP events inside the timed steps, vs 8 TB/s.
-  cpu_baseline -- the CPU oracle (plain C, OpenMP over pixels, brute-force visibility) on a 1/16 pixel
+  cpu_baseline -- the CPU oracle (plain C, OpenMP over pixels, brute-force visibility) on a 1/4 pixel
                   subset of the same view, fwd + bwd, on this box's host cores (rank 0, N = 1 only).
 """
 import argparse
@@ -44,7 +44,7 @@ def algorithmic_bytes_fwd(N, H, W, P, S, probe, n_box, n_tri):
     return b_stream + b_tables + b_trav, b_trav
 
 
-def cpu_baseline(res, n, view, n_views, stride=4):
+def cpu_baseline(res, n, view, n_views, stride=2):
     """Oracle fwd+bwd on every stride-th pixel in x and y of the same view; returns the JSON object."""
     from oracle import oracle as orc, scene_cpu
     nt = orc.max_threads()
@@ -82,13 +82,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # one process per GPU; the modulo only matters for 1-GPU dry runs
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
+        backend = os.environ.get('NVDR_BENCH_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; gloo only for dry runs
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device('cuda', dev_index)
 
     from nvdiffrecmc_amd.trainer import DirectLightingStep
     from nvdiffrecmc_amd import optixutils as ou
@@ -132,6 +137,24 @@ def main():
         dt = float(tt.item())
     ou.ops._optix_env_shade_func.forward = staticmethod(orig)
 
+    # second, shorter timed loop: the same iteration with the forward pass's visibility bits replayed in backward
+    # (identical gradients, no second traversal) -- reported as an extra, never as `value`
+    step.retrace_backward = False
+    k2 = max(5, args.steps // 2)
+    for _ in range(2):
+        step.step(world)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(k2):
+        step.step(world)
+    barrier()
+    dt2 = time.perf_counter() - t1
+    if dist is not None:
+        tt = torch.tensor([dt2], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt2 = float(tt.item())
+    step.retrace_backward = True
+
     S = args.n_samples_x ** 2
     rays_pass = torch.tensor([step.rays_per_pass()], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -155,12 +178,21 @@ def main():
         probe = light.base.shape[0]
         bytes_fwd, b_trav = algorithmic_bytes_fwd(1, H, W, P, S, probe, n_box, n_tri)
         achieved = bytes_fwd / (fwd_ms * 1e-3) / 1e9
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (counters cannot be read in-process)
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
+            traffic = (2.0 * pm['FETCH_SIZE_KB_per_launch'] + pm['WRITE_SIZE_KB_per_launch']) * 1024.0
+            traffic_src = pm['source']
+        except Exception:
+            pass
         R = 2 * S * P
         out = {
             'metric': 'MC shadow rays/sec (fwd+bwd train iteration, 512x512 64spp bob mesh)',
             'value': rays_step_total * args.steps / dt,
             'unit': 'rays/s',
             'iters_per_sec': args.steps / dt,
+            'iters_per_sec_cached_visibility': k2 / dt2,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -171,7 +203,7 @@ def main():
                        'rays_per_pass_rank0': R, 'views': world, 'probe': '%dx%d E1' % (probe, probe),
                        'backward': 're-traces all shadow rays', 'parallelism': 'dp%d (one view per GPU)' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'env_shade_kernel<false,false>',
+                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'env_shade_kernel<false,false,false>',
                          'kernel_ms_hip_events': fwd_ms, 'algorithmic_bytes_per_launch': bytes_fwd,
                          'traversal_bytes_per_launch': b_trav, 'box_tests_per_ray': n_box / R, 'tri_tests_per_ray': n_tri / R,
                          'fwd_rays_per_sec': R / (fwd_ms * 1e-3)},

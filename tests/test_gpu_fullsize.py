@@ -1,0 +1,127 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through size-independent properties (the oracle's
+brute force cannot run 512x512 x 64..256 spp in seconds) plus an oracle comparison on a sparse pixel subset."""
+import pytest
+import torch
+
+from oracle import oracle as orc
+from nvdiffrecmc_amd import scene as sc
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+NT = orc.max_threads()
+
+
+def _gpu_scene(mesh_name, res, n, dev, view=0, env='E1', subdiv=0):
+    """Full-size inputs built on the GPU with the product's own G-buffer producer (trace_closest)."""
+    from nvdiffrecmc_amd import optixutils as ou
+    mesh = sc.load_mesh(mesh_name)
+    if subdiv:
+        mesh['v_pos'], mesh['t_pos_idx'] = sc.subdivide(mesh['v_pos'], mesh['t_pos_idx'], subdiv)
+        mesh['v_nrm'] = sc.auto_normals(mesh['v_pos'], mesh['t_pos_idx'])
+    md = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in mesh.items()}
+    ctx = ou.OptiXContext()
+    ou.optix_build_bvh(ctx, md['v_pos'], md['t_pos_idx'], 1)
+    mv, _, campos = sc.camera(view, 8)
+    ro, rd = sc.primary_rays(mv, res, res)
+    t, tri, uv = ou.trace_closest(ctx, ro.to(dev), rd.to(dev))
+    gb = sc.gbuffer_from_hits(md, t.view(res, res), tri.view(res, res), uv.view(res, res, 2), ro, rd,
+                              kd_mode='flat' if subdiv else 'texture')
+    base = sc.env_map(env, 256).to(dev)
+    pdf, rows, cols = sc.light_tables(base)
+    kw = {'mask': gb['mask'], 'gb_pos': gb['gb_pos'], 'gb_normal': gb['gb_normal'],
+          'gb_view_pos': campos.to(dev)[None, None, None, :].contiguous(), 'gb_kd': gb['kd'], 'gb_ks': gb['ks'],
+          'light': base, 'pdf': pdf, 'rows': rows[:, 0], 'cols': cols}
+    kw['ro'] = (kw['gb_pos'] + kw['gb_normal'] * 0.001).contiguous()
+    perms = sc.perms_table(n)
+    ou.ops.set_permutation_table(n, perms.to(dev))
+    return mesh, ctx, kw, perms
+
+
+def _shade(ctx, kw, n, seed, bsdf='pbr', shadow_scale=1.0, light=None):
+    from nvdiffrecmc_amd import optixutils as ou
+    return ou.optix_env_shade(ctx, kw['mask'], kw['ro'], kw['gb_pos'], kw['gb_normal'], kw['gb_view_pos'], kw['gb_kd'], kw['gb_ks'],
+                              kw['light'] if light is None else light, kw['pdf'], kw['rows'], kw['cols'], BSDF=bsdf,
+                              n_samples_x=n, rnd_seed=seed, shadow_scale=shadow_scale)
+
+
+@pytest.mark.parametrize('mesh_name,n', [('bob', 8), ('spot', 16)])   # configs[1] and configs[2]: 512x512, 64 / 256 spp
+def test_fullsize_properties(mesh_name, n, dev):
+    res = 512
+    mesh, ctx, kw, perms = _gpu_scene(mesh_name, res, n, dev)
+    d1, s1 = _shade(ctx, kw, n, 11)
+    d2, s2 = _shade(ctx, kw, n, 11)
+    assert torch.equal(d1, d2) and torch.equal(s1, s2)                       # deterministic for a fixed seed
+    assert torch.isfinite(d1).all() and torch.isfinite(s1).all()
+    assert (d1[kw['mask'] <= 0] == 0).all() and (d1 >= 0).all() and (s1 >= 0).all()
+    # linearity in the radiance with the sampling tables held fixed: x2 is exact in fp32
+    d3, s3 = _shade(ctx, kw, n, 11, light=kw['light'] * 2.0)
+    assert torch.equal(d3, d1 * 2.0) and torch.equal(s3, s1 * 2.0)
+    # shadows only remove light: unshadowed >= half-shadowed >= shadowed, per pixel and channel
+    du, su = _shade(ctx, kw, n, 11, shadow_scale=0.0)
+    dh, sh = _shade(ctx, kw, n, 11, shadow_scale=0.5)
+    eps = 1e-5 * (1 + du.abs())
+    assert (du + eps >= dh).all() and (dh + eps >= d1).all() and (su + 1e-5 * (1 + su.abs()) >= s1).all()
+    assert_close(dh, 0.5 * (du + d1), 1e-4, floor=1e-3)                     # V = vis*ss + (1-ss) is affine in ss
+    # another seed gives a different but statistically equal image
+    d4, _ = _shade(ctx, kw, n, 12)
+    assert not torch.equal(d4, d1)
+    m = kw['mask'] > 0
+    assert abs(d4[m].mean().item() - d1[m].mean().item()) < 0.01 * d1[m].mean().item()
+
+
+def test_fullsize_sparse_subset_vs_oracle(dev):
+    """bob 512x512, 64 spp: every 24th pixel in x and y (the same launch geometry, linear pixel indices and seeds as the
+    full frame) against the oracle's brute force, forward and backward."""
+    res, n, seed = 512, 8, 3
+    mesh, ctx, kw, perms = _gpu_scene('bob', res, n, dev)
+    sub = torch.zeros_like(kw['mask'])
+    sub[:, 7::24, 5::24] = kw['mask'][:, 7::24, 5::24]
+    kws = dict(kw, mask=sub)
+    g = torch.Generator().manual_seed(1)
+    dg, sg = torch.rand(1, res, res, 3, generator=g), torch.rand(1, res, res, 3, generator=g)
+    leaves = {k: kws[k].clone().requires_grad_(True) for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')}
+    kq = dict(kws, **leaves)
+    d, s = _shade(ctx, kq, n, seed)
+    ((d * dg.to(dev)).sum() + (s * sg.to(dev)).sum()).backward()
+    cpu = {k: v.detach().cpu().contiguous() for k, v in kws.items()}
+    f = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT)
+    b = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, diff_grad=dg, spec_grad=sg, n_threads=NT)
+    assert 50 < f['covered'] < 200
+    assert_close(d, f['diff'], 2e-6)
+    assert_close(s, f['spec'], 2e-6)
+    assert_close(leaves['gb_normal'].grad, b['gb_normal_grad'], 2e-4, floor=1e-3 * b['gb_normal_grad'].abs().max().item())
+    assert_close(leaves['gb_ks'].grad, b['gb_ks_grad'], 2e-4, floor=1e-3 * b['gb_ks_grad'].abs().max().item())
+    assert_close(leaves['light'].grad, b['light_grad'], 1e-4, floor=1e-3 * b['light_grad'].abs().max().item())
+
+
+def test_dmtet_sized_mesh_800(dev):
+    """configs[3] stand-in: 800x800, n_samples_x = 8 on a 171k-triangle mesh (bob subdivided twice): finite, deterministic,
+    and identical visibility-driven result after a refit to the same vertices."""
+    from nvdiffrecmc_amd import optixutils as ou
+    res, n = 800, 8
+    mesh, ctx, kw, perms = _gpu_scene('bob', res, n, dev, view=5, subdiv=2)
+    assert ctx.bvh_info()['n_tris'] == 171008
+    d1, s1 = _shade(ctx, kw, n, 2)
+    assert torch.isfinite(d1).all() and d1.sum().item() > 0
+    ou.optix_build_bvh(ctx, mesh['v_pos'].to(dev), mesh['t_pos_idx'].to(dev), 0)
+    d2, s2 = _shade(ctx, kw, n, 2)
+    assert torch.equal(d1, d2) and torch.equal(s1, s2)
+
+
+def test_training_step_reduces_loss(dev):
+    """The iteration the benchmark times (trainer.py) actually optimises: the image loss goes down."""
+    from nvdiffrecmc_amd.trainer import DirectLightingStep
+    st = DirectLightingStep('bob', 128, 4, view=1, device=dev, lr=0.03)
+    losses = [st.step().item() for _ in range(25)]
+    assert all(map(lambda v: v == v, losses))
+    assert sum(losses[-5:]) / 5 < 0.8 * sum(losses[:3]) / 3
+    # cached-visibility backward gives the gradients of the re-tracing backward
+    st.retrace_backward = True
+    st.seed = 100
+    st.forward_backward()
+    g1 = [p.grad.clone() for p in st.params]
+    st.retrace_backward = False
+    st.seed = 100
+    st.forward_backward()
+    for a, b in zip(g1, [p.grad for p in st.params]):
+        assert_close(b, a, 1e-4, floor=1e-3 * a.abs().max().item())

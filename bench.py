@@ -14,9 +14,10 @@ reference does) + gradient all-reduce (N > 1) + Adam.  Inputs are resident in HB
 region.  `value` = shadow rays actually traced per second, whole job.
 
 Extra objects on the JSON line:
-  roofline     -- forward env-shade kernel: algorithmic bytes per launch (SURVEY 8d formula with the
-                  box/triangle test counts measured by the counting build of the same kernel) over
-                  its average duration measured with HIP events inside the timed steps, vs 8 TB/s.
+  roofline     -- the dominant kernel, env_trace_kernel (persistent-wavefront shadow-ray traversal): algorithmic
+                  bytes per launch (32 B per box test + 36 B per triangle test, counts measured by the
+                  counting build of the same kernel, + its 17 B/ray stream) over its average duration from HIP
+                  events the library records on the launch stream inside the timed steps, vs 8 TB/s.
   cpu_baseline -- the CPU oracle (plain C, OpenMP over pixels, brute-force visibility) on a 1/4 pixel
                   subset of the same view, fwd + bwd, on this box's host cores (rank 0, N = 1 only).
 """
@@ -34,14 +35,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
 
 
-def algorithmic_bytes_fwd(N, H, W, P, S, probe, n_box, n_tri):
-    """B = B_stream + B_tables + B_trav for one forward launch."""
+def algorithmic_bytes(N, H, W, P, S, probe, n_box, n_tri):
+    """B = B_stream + B_tables + B_trav for one forward pass, and the share the traversal kernel
+    (env_trace_kernel) moves: B_trav + its ray stream (16 B direction+pdf in, 1 B visibility out per ray, 16 B origin per pixel)."""
     NHW = N * H * W
+    R = 2 * S * P
     b_stream = 4 * NHW + 60 * P + 24 * NHW
     m = (probe - 1).bit_length() + 1  # ceil(log2(size-1)) + 1 bisection steps
     b_tables = P * S * (8 + 4 * (m + 2) + 4 * (m + 2) + 2 * (4 + 12))
     b_trav = 32 * n_box + 36 * n_tri
-    return b_stream + b_tables + b_trav, b_trav
+    b_trace_kernel = b_trav + 17 * R + 16 * P
+    return b_stream + b_tables + b_trav, b_trace_kernel, b_trav
 
 
 def cpu_baseline(res, n, view, n_views, stride=2):
@@ -102,19 +106,8 @@ def main():
     step = DirectLightingStep(args.mesh, args.res, args.n_samples_x, view=rank, n_views=n_views, device=dev,
                               pixel_index_offset=rank * H * W, retrace_backward=True)
 
-    # per-launch timing of the forward env-shade op with HIP events on torch's current stream (the stream
-    # the kernels are launched on); recorded inside the timed steps through a light wrapper
-    ev = []
-    orig = ou.ops._optix_env_shade_func.forward
-
-    def timed_forward(ctx, *a):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig(ctx, *a)
-        e1.record()
-        ev.append((e0, e1))
-        return out
-    ou.ops._optix_env_shade_func.forward = staticmethod(timed_forward)
+    # per-stage HIP-event timing recorded by the library on the launch stream itself (ring of the last 128 launches)
+    step.ctx.set_profiling(True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -124,7 +117,7 @@ def main():
 
     for _ in range(args.warmup):
         step.step(world)
-    ev.clear()
+    step.ctx.set_profiling(True)   # clears the ring
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -135,7 +128,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    ou.ops._optix_env_shade_func.forward = staticmethod(orig)
+    n_f, (gen_ms, trace_ms, shade_ms) = step.ctx.stage_times(backward=False)
+    n_b, (bgen_ms, btrace_ms, bshade_ms) = step.ctx.stage_times(backward=True)
+    step.ctx.set_profiling(False)
 
     # second, shorter timed loop: the same iteration with the forward pass's visibility bits replayed in backward
     # (identical gradients, no second traversal) -- reported as an extra, never as `value`
@@ -160,7 +155,7 @@ def main():
     if dist is not None:
         dist.all_reduce(rays_pass, op=dist.ReduceOp.SUM)
     rays_step_total = 2.0 * float(rays_pass.item())  # forward + re-traced backward, all ranks
-    fwd_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    fwd_ms = gen_ms + trace_ms + shade_ms
 
     if rank == 0:
         # counting build of the same forward kernel on this rank's view -> measured traversal work
@@ -176,8 +171,8 @@ def main():
                                                                light.base, light._pdf, light.rows[:, 0], light.cols,
                                                                n_samples_x=args.n_samples_x, rnd_seed=0)
         probe = light.base.shape[0]
-        bytes_fwd, b_trav = algorithmic_bytes_fwd(1, H, W, P, S, probe, n_box, n_tri)
-        achieved = bytes_fwd / (fwd_ms * 1e-3) / 1e9
+        bytes_fwd, bytes_trace, b_trav = algorithmic_bytes(1, H, W, P, S, probe, n_box, n_tri)
+        achieved = bytes_trace / (trace_ms * 1e-3) / 1e9
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (counters cannot be read in-process)
         traffic, traffic_src = None, None
         try:
@@ -203,10 +198,15 @@ def main():
                        'rays_per_pass_rank0': R, 'views': world, 'probe': '%dx%d E1' % (probe, probe),
                        'backward': 're-traces all shadow rays', 'parallelism': 'dp%d (one view per GPU)' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'env_shade_kernel<false,false,false>',
-                         'kernel_ms_hip_events': fwd_ms, 'algorithmic_bytes_per_launch': bytes_fwd,
-                         'traversal_bytes_per_launch': b_trav, 'box_tests_per_ray': n_box / R, 'tri_tests_per_ray': n_tri / R,
-                         'fwd_rays_per_sec': R / (fwd_ms * 1e-3)},
+                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'env_trace_kernel<false>',
+                         'kernel_ms_hip_events': trace_ms, 'launches_timed': n_f,
+                         'algorithmic_bytes_per_launch': bytes_trace, 'traversal_bytes_per_launch': b_trav,
+                         'box_tests_per_ray': n_box / R, 'tri_tests_per_ray': n_tri / R,
+                         'rays_per_launch': R, 'kernel_rays_per_sec': R / (trace_ms * 1e-3),
+                         'forward_pass': {'gen_ms': gen_ms, 'trace_ms': trace_ms, 'shade_ms': shade_ms,
+                                          'algorithmic_bytes': bytes_fwd, 'achieved_GBs': bytes_fwd / (fwd_ms * 1e-3) / 1e9,
+                                          'rays_per_sec': R / (fwd_ms * 1e-3)},
+                         'backward_pass': {'gen_ms': bgen_ms, 'trace_ms': btrace_ms, 'shade_ms': bshade_ms, 'launches_timed': n_b}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.res, args.n_samples_x, 0, n_views)

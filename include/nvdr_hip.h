@@ -125,6 +125,13 @@ int nvdr_env_shade_bwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *str
  * synchronises `stream`).  rays per pass = 2 * S * this. */
 int nvdr_env_shade_last_pixel_count(nvdr_ctx *ctx, int64_t *out_host, void *stream);
 
+/* Per-stage HIP-event timing of the env-shade launches (sample generation, traversal, shading), recorded on the launch
+ * stream itself into a ring of 128 launches; used by bench.py for the roofline figure of the traversal kernel.
+ * nvdr_env_shade_stage_times sums the recorded launches of one kind (backward = 0 | 1) into ms[3], returns their
+ * number in *count, and clears the ring; it synchronises on the last recorded event. */
+int nvdr_ctx_set_profiling(nvdr_ctx *ctx, int enable);
+int nvdr_env_shade_stage_times(nvdr_ctx *ctx, int backward, double *ms, int64_t *count);
+
 /* ---- bilateral_denoiser_fwd/bwd (torch_bindings.cpp:274-319; kernels denoising.cu:14-130).
  * col [N,H,W,3], nrm [N,H,W,3], zdz [N,H,W,2] strided views; out f32 [N,H,W,4] contiguous
  * (rgb*w sum, max(sum w, 1e-4)); out_grad [N,H,W,4] strided; col_grad f32 [N,H,W,3] contiguous. */

@@ -51,6 +51,8 @@ _SIGNATURES = {
     'nvdr_env_shade_fwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_bwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_last_pixel_count': [c_void_p, ctypes.POINTER(c_int64), c_void_p],
+    'nvdr_ctx_set_profiling': [c_void_p, c_int],
+    'nvdr_env_shade_stage_times': [c_void_p, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)],
     'nvdr_bilateral_denoiser_fwd': [_T, _T, _T, c_float, c_void_p, c_void_p],
     'nvdr_bilateral_denoiser_bwd': [_T, _T, _T, c_float, _T, c_void_p, c_void_p],
     'nvdr_image_loss_num_partials': [c_int64, c_int64, c_int64],

@@ -66,8 +66,19 @@ struct nvdr_ctx {
     // env-shade scratch
     int *pix_list = nullptr;
     int64_t pix_cap = 0;
-    uint32_t *vis_scratch = nullptr; // visibility bits of a re-tracing backward pass
-    size_t vis_cap = 0;
+    // ray stream of the three-stage env-shade (csrc/env_shade.hip)
+    float4 *rays = nullptr;
+    int *texel = nullptr;
+    uint8_t *vis = nullptr;
+    float4 *pix_origin = nullptr;
+    size_t stream_cap_rays = 0;
+    float *lg_xcd = nullptr;       // 8 per-XCD light-gradient accumulators
+    size_t lg_cap = 0;
+    // optional per-stage timing ring (nvdr_ctx_set_profiling)
+    bool profiling = false;
+    hipEvent_t prof_ev[128][4] = {};
+    int prof_kind[128] = {};
+    int64_t prof_n = 0;
 };
 
 struct BvhView {

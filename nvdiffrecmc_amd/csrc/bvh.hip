@@ -367,10 +367,13 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     if (!c) return 0;
     hipSetDevice(c->device);
     ctx_free_bvh(c);
+    if (c->prof_ev[0][0])
+        for (int i = 0; i < 128; ++i)
+            for (int k = 0; k < 4; ++k) hipEventDestroy(c->prof_ev[i][k]);
     hipFree(c->dinfo);
     hipFree(c->spill);
     hipFree(c->pix_list);
-    hipFree(c->vis_scratch);
+    hipFree(c->rays); hipFree(c->texel); hipFree(c->vis); hipFree(c->pix_origin); hipFree(c->lg_xcd);
     delete c;
     return 0;
 }

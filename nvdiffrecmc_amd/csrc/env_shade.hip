@@ -4,16 +4,23 @@
 // helpers :30-461) and its host launchers env_shade_fwd / env_shade_bwd
 // (render/optixutils/c_src/torch_bindings.cpp:123-272).
 //
-// MI355X design (the reference runs ONE thread per pixel with a serial 2*S-ray loop):
+// MI355X design (the reference runs ONE thread per pixel with a serial 2*S-ray loop inside one OptiX program):
 //   * covered pixels are compacted into a work list first (bob covers ~20 % of the frame);
-//   * PERSISTENT wavefronts stride over the list; a pixel is owned by L = min(64, pow2ceil(S)) lanes
-//     and every lane owns whole strata: it jumps the pixel's LCG stream ahead to its stratum
-//     (5 draws per stratum, kernel.cu:513-524), so the random sequence is bit-identical to the serial loop;
-//   * a lane generates its light-sampled and its BSDF-sampled direction, then walks BOTH shadow rays
-//     through the BVH in one loop (a finished lane starts its next ray instead of idling);
-//     the traversal stack lives in LDS, one bank per lane;
-//   * contributions / gradients are reduced across the L lanes with DPP/permute butterflies; only
-//     the light gradient needs global atomics (kernel.cu:208-210).
+//   * the raygen program is cut at its two natural seams into THREE lean kernels that hand a ray stream
+//     through HBM (16 B + 4 B + 1 B per ray -- ~170 MB per pass at 512^2 x 64 spp, ~0.1 ms of bandwidth):
+//       1. env_gen_kernel    sample generation: a pixel is owned by L = min(64, pow2ceil(S)) lanes, every lane
+//                            owns whole strata and jumps the pixel's LCG stream ahead to its stratum (5 draws per
+//                            stratum, kernel.cu:513-524): bit-identical random sequence to the serial loop;
+//       2. env_trace_kernel  PERSISTENT wavefronts over the ray stream: each wave owns a contiguous range of rays,
+//                            a lane that finishes its ray immediately takes the next one of the range (wave-local
+//                            counter, no atomics), so lanes never idle behind the slowest ray of a pixel; the
+//                            traversal stack lives in LDS, one bank per lane; nothing but traversal state in registers;
+//       3. env_shade_kernel  BSDF evaluation (forward) or hand-derived gradients (backward) per sample, reduced
+//                            across the L lanes with shuffle butterflies; only the light gradient needs global
+//                            atomics (kernel.cu:208-210).
+//     Why not one fused kernel (the first version, 2.1 ms forward): rocprofv3 showed the traversal VALU-bound at ~40 %
+//     active lanes and the fused kernel spilling 67 VGPRs + 146 SGPRs; the split keeps each stage in registers and
+//     lets the traversal refill lanes across pixel boundaries.
 // The sampling math mirrors the evaluation order and the fp32/fp64 promotions of the reference
 // source and uses include/nvdr_detmath.h for sin/cos/acos/atan2, which makes every
 // discrete decision (texel, lobe, visibility) bit-identical to the CPU oracle.
@@ -40,12 +47,17 @@ struct ShadeParams {
     int L, log2L;             // lanes per pixel
     float *diff, *spec;
     float *g_pos, *g_nrm, *g_kd, *g_ks, *g_light;
-    uint32_t *vis_cache; int vis_words; // per plane
+    uint32_t *vis_cache; int vis_words; // caller's bit planes (optional)
     const int *pix_list;
     const unsigned *pix_count;
-    int *spill;
-    unsigned debug;           // NVDR_DEBUG bits: 1 skip tracing, 2 skip light-gradient atomics, 8 single-launch re-tracing backward
-    unsigned long long *counters;
+    // ray stream between the three stages (context scratch, indexed by compacted pixel * 2S + 2*stratum + r)
+    float4 *rays;             // (dir.xyz, pdf_light + pdf_bsdf)
+    int *texel;               // ty * Wl + tx of the radiance lookup
+    float4 *pix_origin;       // shadow-ray origin per compacted pixel
+    uint8_t *vis;             // 1 = unoccluded
+    float *g_light_xcd;       // [8][Hl*Wl*3] per-XCD private light-gradient accumulators (backward)
+    int light_elems;          // Hl*Wl*3
+    unsigned debug;           // NVDR_DEBUG bits: 1 skip tracing, 2 skip light-gradient atomics
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -317,35 +329,19 @@ __device__ __forceinline__ float group_sum(float v, int L)
 }
 __device__ __forceinline__ F3 group_sum3(F3 v, int L) { return f3(group_sum(v.x, L), group_sum(v.y, L), group_sum(v.z, L)); }
 
-__device__ __forceinline__ F3 fetch_light(const Tab &t, int y, int x)
+__device__ __forceinline__ F3 fetch_light_texel(const Tab &t, int texel)
 {
+    const int y = texel / t.n1, x = texel - y * t.n1;
     const float *q = t.p + (int64_t)y * t.s0 + (int64_t)x * t.s1;
     return t.n2 == 1 ? f3(q[0]) : f3(q[0], q[t.s2], q[2 * t.s2]);
 }
 
 // ---------------------------------------------------------------------------------------------
-// the kernel
+// stage 1: sample generation (kernel.cu:463-526 minus process_sample)
 
-// VISONLY: generate the samples and trace them, record the visibility bits, skip all shading (first half of a
-// re-tracing backward pass)
-#ifndef NVDR_OCC_FWD
-#define NVDR_OCC_FWD 4   // min waves per SIMD the register allocator must leave room for (forward / visibility-only)
-#endif
-#ifndef NVDR_OCC_VIS
-#define NVDR_OCC_VIS 6   // ... visibility-only pass (lean: sampling + traversal)
-#endif
-#ifndef NVDR_OCC_BWD
-#define NVDR_OCC_BWD 3   // ... gradient kernel
-#endif
-// measured on the benchmark view (bob 512^2, 64 spp), forward ms at FWD = 3/4/5/6: 2.30 / 2.17 / 2.49 / 2.34;
-// visibility-only pass at 4/5/6: 1.70 / 1.61 / 1.56
-template <bool BACKWARD, bool COUNT, bool VISONLY>
-__global__ void __launch_bounds__(256, BACKWARD ? NVDR_OCC_BWD : (VISONLY ? NVDR_OCC_VIS : NVDR_OCC_FWD)) env_shade_kernel(ShadeParams p, BvhView bvh)
+__global__ void __launch_bounds__(256) env_gen_kernel(ShadeParams p)
 {
-    unsigned n_box = 0, n_tri = 0;
-    extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const TravStack stack = make_stack(smem, p.spill);
     const int L = p.L, G = 64 >> p.log2L;
     const int slot = lane >> p.log2L, sub = lane & (L - 1);
     const unsigned P = *p.pix_count;
@@ -353,19 +349,17 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_OCC_BWD : (VISONLY ? NVDR
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
     const unsigned S = p.S, n = p.n;
     const float strata_frac = 1.0f / (float)n;
-    const float sample_frac = 1.0f / (float)(n * n);
 
     for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
         const unsigned pi = grp * G + slot;
-        const bool valid = pi < P;
-        const int lin = p.pix_list[valid ? pi : 0];
+        if (pi >= P) continue;
+        const int lin = p.pix_list[pi];
         const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
-        const F3 ro = fetch3(p.ro, z, y, x), pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
+        const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
         const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
-        F3 dgrad = f3(0.0f), sgrad = f3(0.0f);
-        if (BACKWARD) {
-            dgrad = fetch3(p.dgrad, z, y, x);
-            sgrad = fetch3(p.sgrad, z, y, x);
+        if (sub == 0) {
+            const F3 ro = fetch3(p.ro, z, y, x);
+            p.pix_origin[pi] = make_float4(ro.x, ro.y, ro.z, 0.0f);
         }
         // per-pixel set-up (kernel.cu:490-505)
         const float alpha = ks.y * ks.y;
@@ -381,16 +375,10 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_OCC_BWD : (VISONLY ? NVDR
         const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
         const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
 
-        F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
-        F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
-
-        for (unsigned base = 0; base < S; base += L) {
-            const unsigned i = base + sub;
-            const bool active = valid && i < S;
-            const unsigned ii = active ? i : 0;
-            unsigned rng = lcg_skip(rng0, 5u * ii);
+        for (unsigned i = sub; i < S; i += L) {
+            unsigned rng = lcg_skip(rng0, 5u * i);
             // light importance sample (kernel.cu:513-516)
-            const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
+            const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
             float sx = ((float)(pl % n) + uniform_pcg(rng)) * strata_frac;
             float sy = ((float)(pl / n) + uniform_pcg(rng)) * strata_frac;
             float pdfA_light, pdfB_bsdf;
@@ -398,55 +386,195 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_OCC_BWD : (VISONLY ? NVDR
             const F3 dirA = light_sample(p, sx, sy, pdfA_light, txA, tyA);
             const float pdfA_bsdf = bsdf_pdf(pDiffuse, pSpecular, nrm, wo, dirA, alpha);
             // BSDF importance sample (kernel.cu:522-526)
-            const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
+            const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
             sx = ((float)(pb % n) + uniform_pcg(rng)) * strata_frac;
             sy = ((float)(pb / n) + uniform_pcg(rng)) * strata_frac;
             const float sz = uniform_pcg(rng);
             const F3 dirB = bsdf_sample(pDiffuse, pSpecular, nrm, wo, sx, sy, sz, alpha, pdfB_bsdf);
             const float pdfB_light = light_pdf(p, dirB, txB, tyB);
+            const int64_t r = ((int64_t)pi * S + i) * 2;
+            p.rays[r] = make_float4(dirA.x, dirA.y, dirA.z, pdfA_light + pdfA_bsdf);
+            p.rays[r + 1] = make_float4(dirB.x, dirB.y, dirB.z, pdfB_light + pdfB_bsdf);
+            p.texel[r] = tyA * p.light.n1 + txA;
+            p.texel[r + 1] = tyB * p.light.n1 + txB;
+        }
+    }
+}
 
-            // visibility: trace both rays, or replay the bits saved by the forward pass
-            unsigned occ;
-            const int chunk = (int)(base >> 6); // only L == 64 has more than one chunk
-            if (BACKWARD && p.vis_cache) {
-                const uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
-                const unsigned bit = i & 31u, word = i >> 5;
-                occ = 0;
-                if (active) {
-                    occ |= ((vc[word] >> bit) & 1u);
-                    occ |= ((vc[p.vis_words + word] >> bit) & 1u) << 1;
+// ---------------------------------------------------------------------------------------------
+// stage 2: persistent-wavefront any-hit traversal of the ray stream
+
+template <bool COUNT>
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView bvh, const float4 *__restrict__ rays,
+                                                                          const float4 *__restrict__ pix_origin,
+                                                                          const unsigned *__restrict__ pix_count,
+                                                                          unsigned rays_per_pixel,
+                                                                          uint8_t *__restrict__ vis, int *spill,
+                                                                          unsigned long long *counters)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const TravStack stack = make_stack(smem, spill);
+    const int lane = threadIdx.x & 63;
+    const unsigned total = *pix_count * rays_per_pixel;
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // contiguous range per wave, a multiple of 64 rays so that the ranges tile the stream
+    unsigned per = (total + n_waves - 1) / n_waves;
+    per = (per + 63u) & ~63u;
+    unsigned next = min(wid * per, total);                 // wave-uniform cursor
+    const unsigned end = min(next + per, total);
+    unsigned n_box = 0, n_tri = 0;
+    const bool single = bvh.n_tris == 1;
+
+    int ray = -1, cur = 0, sp = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+    GridRay g;
+    g.ox = g.oy = g.oz = g.ix = g.iy = g.iz = 0.0f;
+    while (true) {
+        const unsigned long long idle = __ballot(ray < 0);
+        if (idle && next < end) {
+            // refill every idle lane from the wave's range (no atomics: the cursor is wave-uniform)
+            const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+            if (ray < 0 && take < end) {
+                ray = (int)take;
+                const float4 rd = rays[take];
+                const float4 ro = pix_origin[take / rays_per_pixel];
+                ox = ro.x; oy = ro.y; oz = ro.z;
+                dx = rd.x; dy = rd.y; dz = rd.z;
+                g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
+                cur = single ? ~0 : 0;
+                sp = 0;
+            }
+            next += (unsigned)__popcll(idle);
+        } else if (idle == ~0ull) {
+            break;
+        }
+        if (ray >= 0) {
+            bool finished = false, occluded = false;
+            if (cur >= 0) {
+                const NodeHit h = visit_node(bvh.nodes, cur, g, NVDR_RAY_TMAX);
+                if (COUNT) n_box += 2;
+                if (h.hl && h.hr) {
+                    const bool left_first = h.tl <= h.tr;
+                    stack.push(sp, left_first ? h.cr : h.cl);
+                    sp++;
+                    cur = left_first ? h.cl : h.cr;
+                } else if (h.hl) {
+                    cur = h.cl;
+                } else if (h.hr) {
+                    cur = h.cr;
+                } else if (sp > 0) {
+                    sp--;
+                    cur = stack.pop(sp);
+                } else {
+                    finished = true;
                 }
             } else {
-                occ = bvh_any_hit2<COUNT>(bvh, ro.x, ro.y, ro.z, dirA.x, dirA.y, dirA.z, dirB.x, dirB.y, dirB.z,
-                                          (active && !(p.debug & 1u)) ? 3u : 0u, stack, n_box, n_tri);
-                if (!BACKWARD && p.vis_cache) {
-                    const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
-                    if (sub == 0 && valid) {
-                        uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
-                        if (L == 64) {
-                            const int w0 = 2 * chunk;
-                            vc[w0] = (uint32_t)ba;
-                            vc[p.vis_words + w0] = (uint32_t)bb;
-                            if (w0 + 1 < p.vis_words) {
-                                vc[w0 + 1] = (uint32_t)(ba >> 32);
-                                vc[p.vis_words + w0 + 1] = (uint32_t)(bb >> 32);
-                            }
-                        } else {
-                            const unsigned long long m = (1ull << L) - 1ull;
-                            vc[0] = (uint32_t)((ba >> (slot * L)) & m);
-                            vc[p.vis_words] = (uint32_t)((bb >> (slot * L)) & m);
+                if (COUNT) n_tri++;
+                if (tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz)) {
+                    occluded = true;
+                    finished = true;
+                } else if (sp > 0) {
+                    sp--;
+                    cur = stack.pop(sp);
+                } else {
+                    finished = true;
+                }
+            }
+            if (finished) {
+                vis[ray] = occluded ? 0 : 1;
+                ray = -1;
+            }
+        }
+    }
+    if (COUNT) {
+        for (int o = 32; o >= 1; o >>= 1) {
+            n_box += __shfl_xor(n_box, o);
+            n_tri += __shfl_xor(n_tri, o);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], (unsigned long long)n_box);
+            atomicAdd(&counters[1], (unsigned long long)n_tri);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
+
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = p.L, G = 64 >> p.log2L;
+    const int slot = lane >> p.log2L, sub = lane & (L - 1);
+    const unsigned P = *p.pix_count;
+    const unsigned n_groups = (P + G - 1) / G;
+    const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
+    const unsigned S = p.S, n = p.n;
+    const float sample_frac = 1.0f / (float)(n * n);
+    // HW_REG_XCC_ID (hwreg 20), bits [3:0]: the XCD this wave runs on
+    const unsigned xcc = BACKWARD ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0u;
+    float *xcd_light = BACKWARD ? p.g_light_xcd + (int64_t)xcc * p.light_elems : nullptr;
+    const bool use_bits = BACKWARD && p.vis_cache != nullptr;    // replay the caller's cached forward bits
+    const bool save_bits = !BACKWARD && p.vis_cache != nullptr;
+
+    for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
+        const unsigned pi = grp * G + slot;
+        const bool valid = pi < P;
+        const int lin = p.pix_list[valid ? pi : 0];
+        const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
+        const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
+        const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
+        F3 dgrad = f3(0.0f), sgrad = f3(0.0f);
+        if (BACKWARD) {
+            dgrad = fetch3(p.dgrad, z, y, x);
+            sgrad = fetch3(p.sgrad, z, y, x);
+        }
+        F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
+        F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
+
+        for (unsigned base = 0; base < S; base += L) {
+            const unsigned i = base + sub;
+            const bool active = valid && i < S;
+            const int64_t r0 = ((int64_t)(valid ? pi : 0) * S + (active ? i : 0)) * 2;
+            unsigned occ = 0;
+            if (use_bits) {
+                const uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
+                if (active) {
+                    occ |= ((vc[i >> 5] >> (i & 31u)) & 1u);
+                    occ |= ((vc[p.vis_words + (i >> 5)] >> (i & 31u)) & 1u) << 1;
+                }
+            } else if (active) {
+                occ = (p.vis[r0] ? 0u : 1u) | (p.vis[r0 + 1] ? 0u : 2u);
+            }
+            if (save_bits) {
+                const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
+                if (sub == 0 && valid) {
+                    uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
+                    if (L == 64) {
+                        const int w0 = 2 * (int)(base >> 6);
+                        vc[w0] = (uint32_t)ba;
+                        vc[p.vis_words + w0] = (uint32_t)bb;
+                        if (w0 + 1 < p.vis_words) {
+                            vc[w0 + 1] = (uint32_t)(ba >> 32);
+                            vc[p.vis_words + w0 + 1] = (uint32_t)(bb >> 32);
                         }
+                    } else {
+                        const unsigned long long m = (1ull << L) - 1ull;
+                        vc[0] = (uint32_t)((ba >> (slot * L)) & m);
+                        vc[p.vis_words] = (uint32_t)((bb >> (slot * L)) & m);
                     }
                 }
             }
-
-            // shade both samples (process_sample, kernel.cu:403-461)
+            if (!active) continue;
 #pragma unroll
-            for (int r = 0; r < (VISONLY ? 0 : 2); ++r) {
-                const F3 dir = r == 0 ? dirA : dirB;
-                const float pdfSum = r == 0 ? (pdfA_light + pdfA_bsdf) : (pdfB_light + pdfB_bsdf);
-                const int tx = r == 0 ? txA : txB, ty = r == 0 ? tyA : tyB;
-                const F3 light_col = fetch_light(p.light, ty, tx);
+            for (int r = 0; r < 2; ++r) {
+                const float4 rd = p.rays[r0 + r];
+                const int texel = p.texel[r0 + r];
+                const F3 dir = f3(rd.x, rd.y, rd.z);
+                const float pdfSum = rd.w;
+                const F3 light_col = fetch_light_texel(p.light, texel);
                 const float mis_weight = (float)(1.0 / (double)fmaxf(pdfSum, 0.0001f));
                 F3 _diff = f3(0.0f), _spec = f3(0.0f);
                 if (p.bsdf == 1 || p.bsdf == 2)
@@ -455,33 +583,35 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_OCC_BWD : (VISONLY ? NVDR
                     fwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, _diff, _spec);
                 const float vis = ((occ >> r) & 1u) ? 0.0f : 1.0f;
                 const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
-                if (active) {
-                    if (BACKWARD) {
-                        const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
-                        float *g = p.g_light + ((int64_t)ty * p.light.n1 + tx) * 3;
-                        if (!(p.debug & 2u)) {
-                            atomicAdd(g + 0, lg.x);
-                            atomicAdd(g + 1, lg.y);
-                            atomicAdd(g + 2, lg.z);
-                        }
-                        const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
-                        const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
-                        if (p.bsdf == 1 || p.bsdf == 2) {
-                            F3 d_wi = f3(0.0f);
-                            bwd_lambert(nrm, dir, g_nrm, d_wi, sum3(_dg));
-                        } else {
-                            bwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
-                        }
-                    } else {
-                        diffAccum += (((_diff * light_col) * V) * mis_weight) * sample_frac;
-                        specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
+                if (BACKWARD) {
+                    const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
+                    // light gradient (eval_light_bwd, kernel.cu:203-211).  A device-scope atomic is a fabric transaction on
+                    // MI355X (the 8 XCD L2s are not coherent with each other): 24 M of them cost 0.9 ms.  Each XCD
+                    // therefore accumulates into ITS OWN copy with L2-resident (workgroup-scope encoding) atomics -- all
+                    // CUs of an XCD share that L2, and the copy is picked by the XCC id the wave actually runs on, so
+                    // the result does not depend on workgroup placement -- and a tiny kernel sums the 8 copies.
+                    float *g = xcd_light + (int64_t)texel * 3;
+                    if (!(p.debug & 2u)) {
+                        __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                    const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
+                    const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
+                    if (p.bsdf == 1 || p.bsdf == 2) {
+                        F3 d_wi = f3(0.0f);
+                        bwd_lambert(nrm, dir, g_nrm, d_wi, sum3(_dg));
+                    } else {
+                        bwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
+                    }
+                } else {
+                    diffAccum += (((_diff * light_col) * V) * mis_weight) * sample_frac;
+                    specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
                 }
             }
         }
 
-        if (VISONLY) {
-        } else if (!BACKWARD) {
+        if (!BACKWARD) {
             diffAccum = group_sum3(diffAccum, L);
             specAccum = group_sum3(specAccum, L);
             if (valid && sub == 0) {
@@ -507,16 +637,18 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_OCC_BWD : (VISONLY ? NVDR
             }
         }
     }
-    if (COUNT) {
-        for (int o = 32; o >= 1; o >>= 1) {
-            n_box += __shfl_xor(n_box, o);
-            n_tri += __shfl_xor(n_tri, o);
-        }
-        if (lane == 0) {
-            atomicAdd(&p.counters[0], (unsigned long long)n_box);
-            atomicAdd(&p.counters[1], (unsigned long long)n_tri);
-        }
-    }
+}
+
+// light_grad = sum over the 8 per-XCD copies (runs after the gradient kernel: the kernel boundary makes every XCD's
+// L2 contents visible)
+__global__ void __launch_bounds__(256) light_grad_reduce_kernel(const float *__restrict__ xcd, int n, float *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += xcd[(int64_t)k * n + i];
+    out[i] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -539,6 +671,34 @@ static int check_gb(const nvdr_tensor &t, int64_t N, int64_t H, int64_t W, const
                  "env_shade: %s has shape [%lld,%lld,%lld,%lld], expected [%lld,%lld,%lld,3] or a broadcastable shape",
                  name, (long long)t.size[0], (long long)t.size[1], (long long)t.size[2], (long long)t.size[3],
                  (long long)N, (long long)H, (long long)W);
+    return 0;
+}
+
+// grow-only scratch for the ray stream (sized for the worst case: every pixel covered)
+static int reserve_stream(nvdr_ctx *c, int64_t npix, unsigned S, hipStream_t stream)
+{
+    const size_t rays = (size_t)npix * 2 * S;
+    if (c->stream_cap_rays >= rays && c->pix_cap >= npix) return 0;
+    NVDR_HIP_TRY(hipStreamSynchronize(stream));
+    if (c->pix_cap < npix) {
+        (void)hipFree(c->pix_list);
+        (void)hipFree(c->pix_origin);
+        c->pix_list = nullptr;
+        c->pix_origin = nullptr;
+        NVDR_HIP_TRY(hipMalloc((void **)&c->pix_list, sizeof(int) * npix));
+        NVDR_HIP_TRY(hipMalloc((void **)&c->pix_origin, sizeof(float4) * npix));
+        c->pix_cap = npix;
+    }
+    if (c->stream_cap_rays < rays) {
+        (void)hipFree(c->rays);
+        (void)hipFree(c->texel);
+        (void)hipFree(c->vis);
+        c->rays = nullptr; c->texel = nullptr; c->vis = nullptr;
+        NVDR_HIP_TRY(hipMalloc((void **)&c->rays, sizeof(float4) * rays));
+        NVDR_HIP_TRY(hipMalloc((void **)&c->texel, sizeof(int) * rays));
+        NVDR_HIP_TRY(hipMalloc((void **)&c->vis, rays));
+        c->stream_cap_rays = rays;
+    }
     return 0;
 }
 
@@ -565,6 +725,9 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     NVDR_REQUIRE(a->light.size[2] == 3 || a->light.size[2] == 1, "env_shade: light must be [Hl,Wl,3]");
     NVDR_REQUIRE(a->pdf.size[0] == a->cols.size[0] && a->pdf.size[1] == a->cols.size[1] && a->rows.size[0] == a->pdf.size[0],
                  "env_shade: pdf/rows/cols shapes disagree");
+    const int64_t npix = N * H * W;
+    NVDR_REQUIRE((double)npix * 2.0 * S < 4.0e9, "env_shade: %lld pixels x %u rays exceed the 32-bit ray index; split the batch",
+                 (long long)npix, 2 * S);
     NVDR_HIP_TRY(hipSetDevice(c->device));
 
     ShadeParams p;
@@ -588,7 +751,6 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     p.L = L; p.log2L = lg;
     p.vis_cache = a->vis_cache;
     p.vis_words = (int)((S + 31) / 32);
-    const int64_t npix = N * H * W;
     if (!backward) {
         NVDR_REQUIRE(a->diff && a->spec, "env_shade_fwd: NULL output");
         p.diff = a->diff; p.spec = a->spec;
@@ -606,62 +768,104 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         NVDR_HIP_TRY(hipMemsetAsync(p.g_nrm, 0, sizeof(float) * 3 * npix, stream));
         NVDR_HIP_TRY(hipMemsetAsync(p.g_kd, 0, sizeof(float) * 3 * npix, stream));
         NVDR_HIP_TRY(hipMemsetAsync(p.g_ks, 0, sizeof(float) * 3 * npix, stream));
-        NVDR_HIP_TRY(hipMemsetAsync(p.g_light, 0, sizeof(float) * 3 * a->light.size[0] * a->light.size[1], stream));
+        p.light_elems = (int)(3 * a->light.size[0] * a->light.size[1]);
+        if (c->lg_cap < (size_t)p.light_elems * 8) {
+            NVDR_HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(c->lg_xcd);
+            c->lg_xcd = nullptr;
+            NVDR_HIP_TRY(hipMalloc((void **)&c->lg_xcd, sizeof(float) * (size_t)p.light_elems * 8));
+            c->lg_cap = (size_t)p.light_elems * 8;
+        }
+        p.g_light_xcd = c->lg_xcd;
+        NVDR_HIP_TRY(hipMemsetAsync(c->lg_xcd, 0, sizeof(float) * (size_t)p.light_elems * 8, stream));
     }
+    if ((r = reserve_stream(c, npix, S, stream))) return r;
+    p.pix_list = c->pix_list;
+    p.pix_count = &c->dinfo->pix_count;
+    p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.vis = c->vis;
+    const char *dbg = getenv("NVDR_DEBUG");
+    p.debug = dbg ? (unsigned)atoi(dbg) : 0u;
+
     // work list
-    if (c->pix_cap < npix) {
-        NVDR_HIP_TRY(hipStreamSynchronize(stream));
-        (void)hipFree(c->pix_list);
-        c->pix_list = nullptr;
-        NVDR_HIP_TRY(hipMalloc((void **)&c->pix_list, sizeof(int) * npix));
-        c->pix_cap = npix;
-    }
     zero_count_kernel<<<1, 1, 0, stream>>>(&c->dinfo->pix_count);
     compact_pixels_kernel<<<div_up(npix, 256), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
                                                                   &c->dinfo->pix_count);
-    p.pix_list = c->pix_list;
-    p.pix_count = &c->dinfo->pix_count;
-    p.spill = c->spill;
-    const char *dbg = getenv("NVDR_DEBUG");
-    p.debug = dbg ? (unsigned)atoi(dbg) : 0u;
-    const int waves_per_block = NVDR_QUERY_BLOCK / 64;
-    const size_t lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
-    // persistent grid: a few workgroups per CU, each wavefront strides over the covered-pixel list
+    // persistent grids (the covered-pixel count lives on the device)
+    const int waves_per_block = 4;
     const int64_t max_groups = (npix + (64 / L) - 1) / (64 / L);
-    int64_t blocks = (int64_t)c->n_cus * (backward ? NVDR_OCC_BWD : NVDR_OCC_FWD);
-    if (blocks > NVDR_QUERY_MAX_BLOCKS) blocks = NVDR_QUERY_MAX_BLOCKS;
-    if (blocks * waves_per_block > max_groups) blocks = (max_groups + waves_per_block - 1) / waves_per_block;
-    if (blocks < 1) blocks = 1;
-    p.counters = a->counters;
-    const dim3 grid((unsigned)blocks), block(64 * waves_per_block);
-    if (backward && !p.vis_cache && !a->counters && !(p.debug & 8u)) {
-        // Re-tracing backward (the reference launches the whole raygen program again, torch_bindings.cpp:238,266) as
-        // TWO launches: the sampling + traversal half runs in the lean forward configuration (96 VGPRs, 5 waves
-        // per SIMD) and leaves one bit per ray; the gradient half (132 VGPRs) then replays the bits.  Tracing at
-        // the backward kernel's occupancy costs 3.7 ms on the benchmark view, this way 2.4 ms.
-        const size_t need = sizeof(uint32_t) * (size_t)npix * 2 * p.vis_words;
-        if (c->vis_cap < need) {
-            NVDR_HIP_TRY(hipStreamSynchronize(stream));
-            (void)hipFree(c->vis_scratch);
-            c->vis_scratch = nullptr;
-            NVDR_HIP_TRY(hipMalloc((void **)&c->vis_scratch, need));
-            c->vis_cap = need;
-        }
-        p.vis_cache = c->vis_scratch;
-        int64_t fblocks = (int64_t)c->n_cus * NVDR_OCC_VIS;
-        if (fblocks > NVDR_QUERY_MAX_BLOCKS) fblocks = NVDR_QUERY_MAX_BLOCKS;
-        if (fblocks * waves_per_block > max_groups) fblocks = (max_groups + waves_per_block - 1) / waves_per_block;
-        if (fblocks < 1) fblocks = 1;
-        env_shade_kernel<false, false, true><<<dim3((unsigned)fblocks), block, lds, stream>>>(p, bvh_view(c));
-        env_shade_kernel<true, false, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
-    } else if (a->counters) {
-        if (backward) env_shade_kernel<true, true, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
-        else env_shade_kernel<false, true, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
-    } else {
-        if (backward) env_shade_kernel<true, false, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
-        else env_shade_kernel<false, false, false><<<grid, block, lds, stream>>>(p, bvh_view(c));
+    int64_t pblocks = (int64_t)c->n_cus * 4;
+    if (pblocks * waves_per_block > max_groups) pblocks = (max_groups + waves_per_block - 1) / waves_per_block;
+    if (pblocks < 1) pblocks = 1;
+    hipEvent_t *pe = nullptr;
+    if (c->profiling) {
+        const int slot = (int)(c->prof_n % 128);
+        pe = c->prof_ev[slot];
+        c->prof_kind[slot] = backward ? 1 : 0;
+        c->prof_n++;
+        NVDR_HIP_TRY(hipEventRecord(pe[0], stream));
     }
+    env_gen_kernel<<<(unsigned)pblocks, 256, 0, stream>>>(p);
+    if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
+    const bool replay = backward && p.vis_cache != nullptr;   // forward bits handed back by the caller: no traversal
+    if (!replay) {
+        if (p.debug & 1u) {
+            NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)npix * 2 * S, stream));
+        } else {
+            int64_t tblocks = (int64_t)c->n_cus * 8;
+            if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
+            const int64_t need = (npix * 2 * S + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
+            if (tblocks > need) tblocks = need < 1 ? 1 : need;
+            const size_t lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
+            if (a->counters)
+                env_trace_kernel<true><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin,
+                                                                                             p.pix_count, 2 * S, c->vis, c->spill, a->counters);
+            else
+                env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin,
+                                                                                              p.pix_count, 2 * S, c->vis, c->spill, nullptr);
+        }
+    }
+    if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
+    if (backward) {
+        env_shade_kernel<true><<<(unsigned)pblocks, 256, 0, stream>>>(p);
+        light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_xcd, p.light_elems, p.g_light);
+    } else {
+        env_shade_kernel<false><<<(unsigned)pblocks, 256, 0, stream>>>(p);
+    }
+    if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));
     NVDR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nvdr_ctx_set_profiling(nvdr_ctx *c, int enable)
+{
+    NVDR_REQUIRE(c, "nvdr_ctx_set_profiling: NULL ctx");
+    NVDR_HIP_TRY(hipSetDevice(c->device));
+    if (enable && !c->prof_ev[0][0]) {
+        for (int i = 0; i < 128; ++i)
+            for (int k = 0; k < 4; ++k) NVDR_HIP_TRY(hipEventCreate(&c->prof_ev[i][k]));
+    }
+    c->profiling = enable != 0;
+    c->prof_n = 0;
+    return 0;
+}
+
+extern "C" int nvdr_env_shade_stage_times(nvdr_ctx *c, int backward, double *ms, int64_t *count)
+{
+    NVDR_REQUIRE(c && ms && count, "nvdr_env_shade_stage_times: NULL argument");
+    ms[0] = ms[1] = ms[2] = 0.0;
+    *count = 0;
+    const int64_t n = c->prof_n < 128 ? c->prof_n : 128;
+    if (n == 0) return 0;
+    NVDR_HIP_TRY(hipEventSynchronize(c->prof_ev[(c->prof_n - 1) % 128][3]));
+    for (int64_t i = 0; i < n; ++i) {
+        if (c->prof_kind[i] != (backward ? 1 : 0)) continue;
+        for (int k = 0; k < 3; ++k) {
+            float t = 0.0f;
+            NVDR_HIP_TRY(hipEventElapsedTime(&t, c->prof_ev[i][k], c->prof_ev[i][k + 1]));
+            ms[k] += t;
+        }
+        (*count)++;
+    }
     return 0;
 }
 

@@ -52,6 +52,20 @@ class OptiXContext:
     def __init__(self, device=None):
         self.cpp_wrapper = _HipContext(device)
 
+    def set_profiling(self, enable=True):
+        """Record HIP events around the three env-shade stages of every launch on this context (bench.py)."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_ctx_set_profiling(w.handle, int(bool(enable))), 'nvdr_ctx_set_profiling')
+
+    def stage_times(self, backward=False):
+        """(launches, [gen_ms, trace_ms, shade_ms] averaged) over the recorded forward or backward launches."""
+        w = self.cpp_wrapper
+        ms = (ctypes.c_double * 3)()
+        n = ctypes.c_int64()
+        _lib.check(w.lib.nvdr_env_shade_stage_times(w.handle, int(bool(backward)), ms, ctypes.byref(n)), 'stage_times')
+        k = max(int(n.value), 1)
+        return int(n.value), [ms[0] / k, ms[1] / k, ms[2] / k]
+
     def bvh_info(self):
         w = self.cpp_wrapper
         info = _lib.NvdrBvhInfo()

@@ -99,6 +99,7 @@ def test_use_python_formulations_agree_with_oracle():
 
 def test_bench_algorithmic_byte_formula():
     import bench
-    total, trav = bench.algorithmic_bytes_fwd(1, 512, 512, 1000, 64, 256, n_box=10, n_tri=2)
+    total, trace, trav = bench.algorithmic_bytes(1, 512, 512, 1000, 64, 256, n_box=10, n_tri=2)
     assert trav == 32 * 10 + 36 * 2
     assert total == trav + (4 * 512 * 512 + 60 * 1000 + 24 * 512 * 512) + 1000 * 64 * 128   # 128 B per stratum at 256^2
+    assert trace == trav + 17 * (2 * 64 * 1000) + 16 * 1000

@@ -118,12 +118,18 @@ typedef struct nvdr_env_shade_args {
     /* optional device accumulators uint64[2] {box tests, triangle tests} of the shadow-ray traversal
        (a counting build of the same kernel; feeds the algorithmic-byte roofline figure) */
     unsigned long long *counters;
+    /* backward only: id (nvdr_env_shade_stream_id) of the forward launch whose inputs and seed this backward pass
+       repeats.  When it is still the most recent ray stream generated on the context, sample generation is skipped
+       and the stored rays are traced again (or, with vis_cache, only re-shaded).  0 = always regenerate. */
+    uint64_t reuse_stream_id;
 } nvdr_env_shade_args;
 int nvdr_env_shade_fwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
 int nvdr_env_shade_bwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
 /* number of covered pixels seen by the last env-shade launch on this ctx (device counter read back;
  * synchronises `stream`).  rays per pass = 2 * S * this. */
 int nvdr_env_shade_last_pixel_count(nvdr_ctx *ctx, int64_t *out_host, void *stream);
+/* id of the ray stream written by the most recent env-shade launch on this ctx (host-side counter, no sync) */
+int nvdr_env_shade_stream_id(nvdr_ctx *ctx, uint64_t *out_host);
 
 /* Per-stage HIP-event timing of the env-shade launches (sample generation, traversal, shading), recorded on the launch
  * stream itself into a ring of 128 launches; used by bench.py for the roofline figure of the traversal kernel.

@@ -32,7 +32,7 @@ class NvdrEnvShadeArgs(ctypes.Structure):
         ('diff', c_void_p), ('spec', c_void_p),
         ('diff_grad', NvdrTensor), ('spec_grad', NvdrTensor),
         ('gb_pos_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_kd_grad', c_void_p), ('gb_ks_grad', c_void_p),
-        ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p)]
+        ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p), ('reuse_stream_id', ctypes.c_uint64)]
 
 
 _T = ctypes.POINTER(NvdrTensor)
@@ -51,6 +51,7 @@ _SIGNATURES = {
     'nvdr_env_shade_fwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_bwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_last_pixel_count': [c_void_p, ctypes.POINTER(c_int64), c_void_p],
+    'nvdr_env_shade_stream_id': [c_void_p, ctypes.POINTER(ctypes.c_uint64)],
     'nvdr_ctx_set_profiling': [c_void_p, c_int],
     'nvdr_env_shade_stage_times': [c_void_p, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)],
     'nvdr_bilateral_denoiser_fwd': [_T, _T, _T, c_float, c_void_p, c_void_p],

@@ -72,6 +72,8 @@ struct nvdr_ctx {
     uint8_t *vis = nullptr;
     float4 *pix_origin = nullptr;
     size_t stream_cap_rays = 0;
+    uint64_t stream_id = 0;        // id of the ray stream currently held in rays/texel/pix_origin/pix_list
+    uint64_t stream_seq = 0;
     float *lg_xcd = nullptr;       // 8 per-XCD light-gradient accumulators
     size_t lg_cap = 0;
     // optional per-stage timing ring (nvdr_ctx_set_profiling)

@@ -440,6 +440,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     NVDR_LAUNCH_CHECK();
     c->n_tris = n_tris;
     c->n_verts = n_verts;
+    c->stream_id = 0; // a ray stream traced against the old geometry must not be reused
     return 0;
 }
 

@@ -786,10 +786,8 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     const char *dbg = getenv("NVDR_DEBUG");
     p.debug = dbg ? (unsigned)atoi(dbg) : 0u;
 
-    // work list
-    zero_count_kernel<<<1, 1, 0, stream>>>(&c->dinfo->pix_count);
-    compact_pixels_kernel<<<div_up(npix, 256), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
-                                                                  &c->dinfo->pix_count);
+    // backward pass of a forward launch whose ray stream is still in the context: no need to rebuild it
+    const bool reuse = backward && a->reuse_stream_id != 0 && a->reuse_stream_id == c->stream_id;
     // persistent grids (the covered-pixel count lives on the device)
     const int waves_per_block = 4;
     const int64_t max_groups = (npix + (64 / L) - 1) / (64 / L);
@@ -804,7 +802,14 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         c->prof_n++;
         NVDR_HIP_TRY(hipEventRecord(pe[0], stream));
     }
-    env_gen_kernel<<<(unsigned)pblocks, 256, 0, stream>>>(p);
+    if (!reuse) {
+        c->stream_id = 0; // invalid while being rewritten
+        zero_count_kernel<<<1, 1, 0, stream>>>(&c->dinfo->pix_count);
+        compact_pixels_kernel<<<div_up(npix, 256), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
+                                                                      &c->dinfo->pix_count);
+        env_gen_kernel<<<(unsigned)pblocks, 256, 0, stream>>>(p);
+        c->stream_id = ++c->stream_seq;
+    }
     if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
     const bool replay = backward && p.vis_cache != nullptr;   // forward bits handed back by the caller: no traversal
     if (!replay) {
@@ -876,6 +881,12 @@ extern "C" int nvdr_env_shade_fwd(nvdr_ctx *c, const nvdr_env_shade_args *a, voi
 extern "C" int nvdr_env_shade_bwd(nvdr_ctx *c, const nvdr_env_shade_args *a, void *stream)
 {
     return env_shade_launch(c, a, true, (hipStream_t)stream);
+}
+extern "C" int nvdr_env_shade_stream_id(nvdr_ctx *c, uint64_t *out)
+{
+    NVDR_REQUIRE(c && out, "nvdr_env_shade_stream_id: NULL argument");
+    *out = c->stream_id;
+    return 0;
 }
 extern "C" int nvdr_env_shade_last_pixel_count(nvdr_ctx *c, int64_t *out, void *stream_)
 {

@@ -141,6 +141,9 @@ class _optix_env_shade_func(torch.autograd.Function):
             vis = torch.empty(N * H * W * 2 * words, dtype=torch.int32, device=ro.device)
             a.vis_cache = vis.data_ptr()
         _lib.check(w.lib.nvdr_env_shade_fwd(w.handle, ctypes.byref(a), _lib.stream_ptr()), 'env_shade_fwd')
+        sid = ctypes.c_uint64()
+        _lib.check(w.lib.nvdr_env_shade_stream_id(w.handle, ctypes.byref(sid)), 'env_shade_stream_id')
+        ctx.stream_id = int(sid.value) if rnd_seed is not None else 0   # a decorrelated backward draws new samples
         ctx.save_for_backward(mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols)
         ctx.optix_ctx = optix_ctx
         ctx.BSDF = BSDF
@@ -173,9 +176,12 @@ class _optix_env_shade_func(torch.autograd.Function):
         light_grad = torch.empty(light.shape[0], light.shape[1], 3, dtype=torch.float32, device=dev)
         a.gb_pos_grad, a.gb_normal_grad = gb_pos_grad.data_ptr(), gb_normal_grad.data_ptr()
         a.gb_kd_grad, a.gb_ks_grad, a.light_grad = gb_kd_grad.data_ptr(), gb_ks_grad.data_ptr(), light_grad.data_ptr()
-        # the cached bits are only valid while the context still holds the geometry of the forward pass
-        if ctx.vis is not None and ctx.bvh_geom is w._geom:
-            a.vis_cache = ctx.vis.data_ptr()
+        # the cached bits / the stored ray stream are only valid while the context still holds the geometry of the
+        # forward pass (the library additionally checks that no other launch has overwritten the stream)
+        if ctx.bvh_geom is w._geom:
+            a.reuse_stream_id = ctx.stream_id
+            if ctx.vis is not None:
+                a.vis_cache = ctx.vis.data_ptr()
         _lib.check(w.lib.nvdr_env_shade_bwd(w.handle, ctypes.byref(a), _lib.stream_ptr()), 'env_shade_bwd')
         if light.shape[-1] == 1:
             light_grad = light_grad.sum(-1, keepdim=True)

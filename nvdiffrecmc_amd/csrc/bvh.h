@@ -34,6 +34,7 @@
 #define NVDR_STACK_MAX 72
 #define NVDR_QUERY_BLOCK 256                 // threads per workgroup of every traversal kernel
 #define NVDR_QUERY_MAX_BLOCKS 2048           // persistent / grid-stride launches never exceed this
+#define NVDR_TRAV_DONE 0x7fffffff            // traversal marker: nothing left (never a valid node / leaf id)
 #define NVDR_GRID_MAX 65531.0f               // usable span of the 16-bit box grid (2 cells of slack on both ends)
 
 struct BvhDeviceInfo {
@@ -116,6 +117,20 @@ struct TravStack {
         if (sp < NVDR_STACK_LDS) lds[sp * 64] = v;
         else if (sp < NVDR_STACK_MAX) glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v;
     }
+    // speculative forms for branch-free traversal loops: the push always writes the LDS slot (row NVDR_STACK_LDS is a
+    // scratch row for sp beyond the LDS part) and `keep` only matters for the rare HBM spill; peek returns what a pop
+    // at depth sp would yield without changing anything.
+    __device__ __forceinline__ void push_spec(int sp, int v, bool keep) const
+    {
+        lds[min(sp, NVDR_STACK_LDS) * 64] = v;
+        if (keep && sp >= NVDR_STACK_LDS && sp < NVDR_STACK_MAX) glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v;
+    }
+    __device__ __forceinline__ int peek(int sp) const
+    {
+        int v = lds[max(min(sp - 1, NVDR_STACK_LDS - 1), 0) * 64];
+        if (sp - 1 >= NVDR_STACK_LDS) v = glb[(int64_t)(min(sp - 1, NVDR_STACK_MAX - 1) - NVDR_STACK_LDS) * gstride];
+        return v;
+    }
     __device__ __forceinline__ int pop(int sp) const
     {
         return sp < NVDR_STACK_LDS ? lds[sp * 64]
@@ -128,12 +143,12 @@ __device__ __forceinline__ TravStack make_stack(int *smem, int *spill)
 {
     TravStack s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    s.lds = (lds_int_t *)smem + wave * NVDR_STACK_LDS * 64 + lane;
+    s.lds = (lds_int_t *)smem + wave * (NVDR_STACK_LDS + 1) * 64 + lane;
     s.gstride = gridDim.x * blockDim.x;
     s.glb = (glb_int_t *)spill + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     return s;
 }
-#define NVDR_STACK_LDS_BYTES(threads) ((size_t)(threads) * NVDR_STACK_LDS * sizeof(int))
+#define NVDR_STACK_LDS_BYTES(threads) ((size_t)(threads) * (NVDR_STACK_LDS + 1) * sizeof(int))   // + the scratch row
 
 __device__ __forceinline__ bool tri_any_hit(const float4 *__restrict__ tris, int slot, float ox, float oy, float oz,
                                             float dx, float dy, float dz)
@@ -143,32 +158,40 @@ __device__ __forceinline__ bool tri_any_hit(const float4 *__restrict__ tris, int
     return nvdr_ray_tri(ox, oy, oz, dx, dy, dz, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, &t, &u, &v, &det) != 0;
 }
 
-// A ray in grid space (for the box tests only).
+// A ray in grid space (for the box tests only): t(b) = b * inv + noi with noi = -o * inv, one fused op per plane.
 struct GridRay {
-    float ox, oy, oz, ix, iy, iz;
+    float nx, ny, nz, ix, iy, iz;
 };
 __device__ __forceinline__ GridRay make_grid_ray(const BvhDeviceInfo *__restrict__ info, float ox, float oy, float oz,
                                                  float dx, float dy, float dz)
 {
     GridRay g;
     const float sx = info->g_scale[0], sy = info->g_scale[1], sz = info->g_scale[2];
-    g.ox = (ox - info->g_lo[0]) * sx + 2.0f;
-    g.oy = (oy - info->g_lo[1]) * sy + 2.0f;
-    g.oz = (oz - info->g_lo[2]) * sz + 2.0f;
     g.ix = 1.0f / (dx * sx);
     g.iy = 1.0f / (dy * sy);
     g.iz = 1.0f / (dz * sz);
+    g.nx = -((ox - info->g_lo[0]) * sx + 2.0f) * g.ix;
+    g.ny = -((oy - info->g_lo[1]) * sy + 2.0f) * g.iy;
+    g.nz = -((oz - info->g_lo[2]) * sz + 2.0f) * g.iz;
     return g;
 }
 
-// slab test of one child box against the ray interval [0, tmax]; IEEE inf/NaN semantics make
-// axis-parallel rays conservative (fminf/fmaxf drop NaNs).
+// Slab test of one child box against the ray interval [0, tmax].  The traversal is VALU-issue bound, so every plane
+// distance is ONE fma (pairs of them pack into v_pk_fma_f32).  An axis-parallel ray gives inv = +-inf and NaN plane
+// distances; fminf/fmaxf drop NaNs, i.e. that axis simply stops culling: conservative.  The fma rounds differently
+// from (b - o) * inv by < 0.01 grid cells, far inside the one-cell slack every box carries.
 __device__ __forceinline__ bool box_hit(float minx, float miny, float minz, float maxx, float maxy, float maxz,
                                         const GridRay &r, float tmax, float &tnear)
 {
-    const float x0 = (minx - r.ox) * r.ix, x1 = (maxx - r.ox) * r.ix;
-    const float y0 = (miny - r.oy) * r.iy, y1 = (maxy - r.oy) * r.iy;
-    const float z0 = (minz - r.oz) * r.iz, z1 = (maxz - r.oz) * r.iz;
+#ifndef NVDR_SLAB_MULADD
+    const float x0 = fmaf(minx, r.ix, r.nx), x1 = fmaf(maxx, r.ix, r.nx);
+    const float y0 = fmaf(miny, r.iy, r.ny), y1 = fmaf(maxy, r.iy, r.ny);
+    const float z0 = fmaf(minz, r.iz, r.nz), z1 = fmaf(maxz, r.iz, r.nz);
+#else
+    const float x0 = minx * r.ix + r.nx, x1 = maxx * r.ix + r.nx;
+    const float y0 = miny * r.iy + r.ny, y1 = maxy * r.iy + r.ny;
+    const float z0 = minz * r.iz + r.nz, z1 = maxz * r.iz + r.nz;
+#endif
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
     tnear = tn;

@@ -392,11 +392,15 @@ __global__ void __launch_bounds__(256) env_gen_kernel(ShadeParams p)
             const float sz = uniform_pcg(rng);
             const F3 dirB = bsdf_sample(pDiffuse, pSpecular, nrm, wo, sx, sy, sz, alpha, pdfB_bsdf);
             const float pdfB_light = light_pdf(p, dirB, txB, tyB);
-            const int64_t r = ((int64_t)pi * S + i) * 2;
-            p.rays[r] = make_float4(dirA.x, dirA.y, dirA.z, pdfA_light + pdfA_bsdf);
-            p.rays[r + 1] = make_float4(dirB.x, dirB.y, dirB.z, pdfB_light + pdfB_bsdf);
-            p.texel[r] = tyA * p.light.n1 + txA;
-            p.texel[r + 1] = tyB * p.light.n1 + txB;
+            // Stream order inside a pixel: the S light-sampled rays by THEIR STRATUM (pl), then the S BSDF-sampled rays by
+            // theirs (pb).  The permutation tables scramble which sample draws which stratum; ordering by stratum puts
+            // neighbouring cells of the CDF / hemisphere grid -- i.e. nearby directions -- into neighbouring lanes of the
+            // traversal kernel, which keeps its wavefronts coherent (both rows are permutations of 0..S-1: a bijection).
+            const int64_t rA = (int64_t)pi * 2 * S + pl, rB = (int64_t)pi * 2 * S + S + pb;
+            p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, pdfA_light + pdfA_bsdf);
+            p.rays[rB] = make_float4(dirB.x, dirB.y, dirB.z, pdfB_light + pdfB_bsdf);
+            p.texel[rA] = tyA * p.light.n1 + txA;
+            p.texel[rB] = tyB * p.light.n1 + txB;
         }
     }
 }
@@ -429,7 +433,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     int ray = -1, cur = 0, sp = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
     GridRay g;
-    g.ox = g.oy = g.oz = g.ix = g.iy = g.iz = 0.0f;
+    g.nx = g.ny = g.nz = g.ix = g.iy = g.iz = 0.0f;
     while (true) {
         const unsigned long long idle = __ballot(ray < 0);
         if (idle && next < end) {
@@ -450,39 +454,31 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
             break;
         }
         if (ray >= 0) {
-            bool finished = false, occluded = false;
+            // One step.  Everything except "node or leaf" is written branch-free (selects + a speculative LDS push/pop):
+            // the kernel is VALU-issue bound, and every divergent if/else costs a handful of exec-mask instructions
+            // on top of both arms.
+            const int popv = stack.peek(sp);            // value a pop would return (garbage when sp == 0: unused then)
+            int next;                                   // next node / leaf, or one of the two markers below
+            const int POP = NVDR_TRAV_DONE, HIT = NVDR_TRAV_DONE - 1;
             if (cur >= 0) {
                 const NodeHit h = visit_node(bvh.nodes, cur, g, NVDR_RAY_TMAX);
                 if (COUNT) n_box += 2;
-                if (h.hl && h.hr) {
-                    const bool left_first = h.tl <= h.tr;
-                    stack.push(sp, left_first ? h.cr : h.cl);
-                    sp++;
-                    cur = left_first ? h.cl : h.cr;
-                } else if (h.hl) {
-                    cur = h.cl;
-                } else if (h.hr) {
-                    cur = h.cr;
-                } else if (sp > 0) {
-                    sp--;
-                    cur = stack.pop(sp);
-                } else {
-                    finished = true;
-                }
+                const bool both = h.hl & h.hr, any = h.hl | h.hr;
+                const bool left_first = h.tl <= h.tr;
+                const int nearc = h.hl ? ((h.hr & !left_first) ? h.cr : h.cl) : h.cr;
+                stack.push_spec(sp, left_first ? h.cr : h.cl, both);   // stored always, kept only if both were hit
+                sp += both ? 1 : 0;
+                next = any ? nearc : POP;
             } else {
                 if (COUNT) n_tri++;
-                if (tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz)) {
-                    occluded = true;
-                    finished = true;
-                } else if (sp > 0) {
-                    sp--;
-                    cur = stack.pop(sp);
-                } else {
-                    finished = true;
-                }
+                next = tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz) ? HIT : POP;
             }
+            const bool pop = next == POP;
+            const bool finished = (next == HIT) | (pop & (sp == 0));
+            sp -= (pop & (sp > 0)) ? 1 : 0;
+            cur = pop ? popv : next;
             if (finished) {
-                vis[ray] = occluded ? 0 : 1;
+                vis[ray] = next == HIT ? 0 : 1;
                 ray = -1;
             }
         }
@@ -533,11 +529,20 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
         }
         F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
         F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
+        // the two permutation rows of this pixel (kernel.cu:504-505) give the stream slot of every sample
+        unsigned a_seed = p.seed, b_seed = (unsigned)lin + p.pix_offset;
+        unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
+        const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
+        const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
 
         for (unsigned base = 0; base < S; base += L) {
             const unsigned i = base + sub;
             const bool active = valid && i < S;
-            const int64_t r0 = ((int64_t)(valid ? pi : 0) * S + (active ? i : 0)) * 2;
+            const unsigned ii = active ? i : 0;
+            const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
+            const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
+            const int64_t rbase = (int64_t)(valid ? pi : 0) * 2 * S;
+            const int64_t rA = rbase + pl, rB = rbase + S + pb;
             unsigned occ = 0;
             if (use_bits) {
                 const uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
@@ -546,7 +551,7 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
                     occ |= ((vc[p.vis_words + (i >> 5)] >> (i & 31u)) & 1u) << 1;
                 }
             } else if (active) {
-                occ = (p.vis[r0] ? 0u : 1u) | (p.vis[r0 + 1] ? 0u : 2u);
+                occ = (p.vis[rA] ? 0u : 1u) | (p.vis[rB] ? 0u : 2u);
             }
             if (save_bits) {
                 const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
@@ -570,8 +575,9 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
             if (!active) continue;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const float4 rd = p.rays[r0 + r];
-                const int texel = p.texel[r0 + r];
+                const int64_t ri = r == 0 ? rA : rB;
+                const float4 rd = p.rays[ri];
+                const int texel = p.texel[ri];
                 const F3 dir = f3(rd.x, rd.y, rd.z);
                 const float pdfSum = rd.w;
                 const F3 light_col = fetch_light_texel(p.light, texel);

@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
                     // therefore accumulates into ITS OWN copy with L2-resident (workgroup-scope encoding) atomics -- all
                     // CUs of an XCD share that L2, and the copy is picked by the XCC id the wave actually runs on, so
                     // the result does not depend on workgroup placement -- and a tiny kernel sums the 8 copies.
-                    float *g = xcd_light + (int64_t)texel * 3;
+                    float *g = xcd_light + (int64_t)((p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel) * 3;   // bit 4: contention experiment
                     if (!(p.debug & 2u)) {
                         __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -60,14 +60,18 @@ def cpu_baseline(res, n, view, n_views, stride=2):
     kw = scene_cpu.shade_kwargs(inp)
     g = torch.Generator().manual_seed(0)
     dg, sg = torch.rand(1, res, res, 3, generator=g), torch.rand(1, res, res, 3, generator=g)
+    # the REFERENCE's own raygen program compiled for the CPU (oracle/_ref, prebuilt where /root/reference exists) when
+    # it travelled with the repo, otherwise our plain-C restatement of it; visibility is a brute-force loop in both
+    impl, kind, what = ('ref', 'reference', 'oracle/_ref: the reference envsampling/kernel.cu built for the CPU') if orc.have_ref() \
+        else ('oracle', 'port', 'oracle/nvdr_oracle.c')
     t0 = time.perf_counter()
-    f = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=0, n_threads=nt)
-    orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=0, diff_grad=dg, spec_grad=sg, n_threads=nt)
+    f = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=0, n_threads=nt, impl=impl)
+    orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=0, diff_grad=dg, spec_grad=sg, n_threads=nt, impl=impl)
     dt = time.perf_counter() - t0
     rays = 2 * (2 * n * n * f['covered'])
-    return {'value': rays / dt, 'unit': 'rays/s', 'cores': nt, 'kind': 'port',
-            'sample': 'oracle/nvdr_oracle.c env-shade fwd+bwd (brute-force visibility over 10688 triangles), every %dth pixel '
-                      'in x and y of the %dx%d view (%d covered pixels, %d rays), %.1f s' % (stride, res, res, f['covered'], rays, dt)}
+    return {'value': rays / dt, 'unit': 'rays/s', 'cores': nt, 'kind': kind,
+            'sample': '%s, env-shade fwd+bwd (OpenMP over pixels, brute-force visibility over 10688 triangles), every %dth pixel '
+                      'in x and y of the %dx%d view (%d covered pixels, %d rays), %.1f s' % (what, stride, res, res, f['covered'], rays, dt)}
 
 
 def main():

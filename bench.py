@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
 
 
-def algorithmic_bytes(N, H, W, P, S, probe, n_box, n_tri):
+def algorithmic_bytes(N, H, W, P, S, probe, n_box, n_tri, n_traced=None):
     """B = B_stream + B_tables + B_trav for one forward pass, and the share the traversal kernel
     (env_trace_kernel) moves: B_trav + its ray stream (16 B direction+pdf in, 1 B visibility out per ray, 16 B origin per pixel)."""
     NHW = N * H * W
@@ -44,7 +44,9 @@ def algorithmic_bytes(N, H, W, P, S, probe, n_box, n_tri):
     m = (probe - 1).bit_length() + 1  # ceil(log2(size-1)) + 1 bisection steps
     b_tables = P * S * (8 + 4 * (m + 2) + 4 * (m + 2) + 2 * (4 + 12))
     b_trav = 32 * n_box + 36 * n_tri
-    b_trace_kernel = b_trav + 17 * R + 16 * P
+    # every slot of the stream is read (16 B: direction + pdf sum, the sign bit flags a dead sample); only traversed
+    # rays fetch their pixel's origin and write a visibility byte
+    b_trace_kernel = b_trav + 16 * R + 1 * (R if n_traced is None else n_traced) + 16 * P
     return b_stream + b_tables + b_trav, b_trace_kernel, b_trav
 
 
@@ -155,27 +157,29 @@ def main():
     step.retrace_backward = True
 
     S = args.n_samples_x ** 2
-    rays_pass = torch.tensor([step.rays_per_pass()], dtype=torch.float64, device=dev)
+    # counting build of the same forward kernel on this rank's view -> measured traversal work and the number of rays
+    # actually traversed (dead samples -- dot(n, wi) <= 0, zero through the BSDF's own gates -- are never traced)
+    light = step.light
+    with torch.no_grad():
+        from nvdiffrecmc_amd import renderutils as ru
+        m = step.mask[..., None]
+        kd = step.kd_tex[step.texel].view(1, H, W, 3) * m  # same values as the step's kd image
+        ks = step.ks.view(1, 1, 1, 3) * m
+        nrm = ru.prepare_shading_normal(step.gb_pos, step.view_pos, None, step.gb_smooth_nrm, step.gb_tangent, step.gb_geom_nrm)
+        ro = step.gb_pos + nrm * 0.001
+        P, n_box, n_tri, n_traced = ou.ops.env_shade_traversal_counts(step.ctx, step.mask, ro, step.gb_pos, nrm, step.view_pos, kd, ks,
+                                                                     light.base, light._pdf, light.rows[:, 0], light.cols,
+                                                                     n_samples_x=args.n_samples_x, rnd_seed=0)
+    rays_pass = torch.tensor([step.rays_per_pass(), n_traced], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(rays_pass, op=dist.ReduceOp.SUM)
-    rays_step_total = 2.0 * float(rays_pass.item())  # forward + re-traced backward, all ranks
+    queries_step_total = 2.0 * float(rays_pass[0].item())  # forward + backward shadow-ray queries (2*S per covered pixel), all ranks
+    rays_step_total = 2.0 * float(rays_pass[1].item())     # of which traversed: forward + re-traced backward, all ranks
     fwd_ms = gen_ms + trace_ms + shade_ms
 
     if rank == 0:
-        # counting build of the same forward kernel on this rank's view -> measured traversal work
-        light = step.light
-        with torch.no_grad():
-            from nvdiffrecmc_amd import renderutils as ru
-            m = step.mask[..., None]
-            kd = step.kd_tex[step.texel].view(1, H, W, 3) * m  # same values as the step's kd image
-            ks = step.ks.view(1, 1, 1, 3) * m
-            nrm = ru.prepare_shading_normal(step.gb_pos, step.view_pos, None, step.gb_smooth_nrm, step.gb_tangent, step.gb_geom_nrm)
-            ro = step.gb_pos + nrm * 0.001
-            P, n_box, n_tri = ou.ops.env_shade_traversal_counts(step.ctx, step.mask, ro, step.gb_pos, nrm, step.view_pos, kd, ks,
-                                                               light.base, light._pdf, light.rows[:, 0], light.cols,
-                                                               n_samples_x=args.n_samples_x, rnd_seed=0)
         probe = light.base.shape[0]
-        bytes_fwd, bytes_trace, b_trav = algorithmic_bytes(1, H, W, P, S, probe, n_box, n_tri)
+        bytes_fwd, bytes_trace, b_trav = algorithmic_bytes(1, H, W, P, S, probe, n_box, n_tri, n_traced)
         achieved = bytes_trace / (trace_ms * 1e-3) / 1e9
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (counters cannot be read in-process)
         traffic, traffic_src = None, None
@@ -188,8 +192,9 @@ def main():
         R = 2 * S * P
         out = {
             'metric': 'MC shadow rays/sec (fwd+bwd train iteration, 512x512 64spp bob mesh)',
-            'value': rays_step_total * args.steps / dt,
+            'value': rays_step_total * args.steps / dt,       # TRAVERSED rays only
             'unit': 'rays/s',
+            'shadow_ray_queries_per_sec': queries_step_total * args.steps / dt,   # 2*S per covered pixel per pass, traversed or not
             'iters_per_sec': args.steps / dt,
             'iters_per_sec_cached_visibility': k2 / dt2,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -199,17 +204,19 @@ def main():
             'config': {'workload': 'bob.json %dx%d, %d spp (n_samples_x=%d), 1 view per GPU, LBVH + HIP traversal + GGX shading + bilateral denoiser + log-sRGB L1 loss, fwd+bwd+Adam'
                                    % (H, W, S, args.n_samples_x),
                        'mesh_triangles': int(step.mesh['t_pos_idx'].shape[0]), 'covered_pixels_rank0': P,
-                       'rays_per_pass_rank0': R, 'views': world, 'probe': '%dx%d E1' % (probe, probe),
+                       'shadow_ray_queries_per_pass_rank0': R, 'rays_traversed_per_pass_rank0': n_traced,
+                       'dead_samples': '%.1f%% of the queries have dot(n,wi)<=0, are zero through the BSDF gates whatever their visibility and are answered without traversal (outputs bit-identical; NVDR_DEBUG=8 traces them); value counts traversed rays only' % (100.0 * (1.0 - n_traced / R)),
+                       'views': world, 'probe': '%dx%d E1' % (probe, probe),
                        'backward': 're-traces all shadow rays', 'parallelism': 'dp%d (one view per GPU)' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'env_trace_kernel<false>',
                          'kernel_ms_hip_events': trace_ms, 'launches_timed': n_f,
                          'algorithmic_bytes_per_launch': bytes_trace, 'traversal_bytes_per_launch': b_trav,
-                         'box_tests_per_ray': n_box / R, 'tri_tests_per_ray': n_tri / R,
-                         'rays_per_launch': R, 'kernel_rays_per_sec': R / (trace_ms * 1e-3),
+                         'box_tests_per_ray': n_box / n_traced, 'tri_tests_per_ray': n_tri / n_traced,
+                         'rays_per_launch': n_traced, 'kernel_rays_per_sec': n_traced / (trace_ms * 1e-3),
                          'forward_pass': {'gen_ms': gen_ms, 'trace_ms': trace_ms, 'shade_ms': shade_ms,
                                           'algorithmic_bytes': bytes_fwd, 'achieved_GBs': bytes_fwd / (fwd_ms * 1e-3) / 1e9,
-                                          'rays_per_sec': R / (fwd_ms * 1e-3)},
+                                          'rays_per_sec': n_traced / (fwd_ms * 1e-3)},
                          'backward_pass': {'gen_ms': bgen_ms, 'trace_ms': btrace_ms, 'shade_ms': bshade_ms, 'launches_timed': n_b}},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -115,8 +115,11 @@ typedef struct nvdr_env_shade_args {
        BSDF-sampled shadow ray of stratum i is occluded): written by fwd when non-NULL; when non-NULL in
        bwd the shadow rays are NOT re-traced (valid only for identical seed and inputs). */
     uint32_t *vis_cache;
-    /* optional device accumulators uint64[2] {box tests, triangle tests} of the shadow-ray traversal
-       (a counting build of the same kernel; feeds the algorithmic-byte roofline figure) */
+    /* optional device accumulators uint64[8 + 2*8192] {box tests, triangle tests, rays traversed, sum and max of the
+       per-wavefront busy time in 100 MHz ticks, wavefronts, 2 reserved, then (begin, end) ticks of every wavefront} of the shadow-ray
+       traversal (a counting build of the same kernel; feeds the algorithmic-byte roofline figure).
+       Rays traversed < 2*S*pixels: samples with dot(n, wi) <= 0 contribute exactly zero through the BSDF's own
+       gates whatever their visibility and are not traced (env var NVDR_DEBUG bit 8 traces them anyway). */
     unsigned long long *counters;
     /* backward only: id (nvdr_env_shade_stream_id) of the forward launch whose inputs and seed this backward pass
        repeats.  When it is still the most recent ray stream generated on the context, sample generation is skipped

@@ -45,6 +45,7 @@ struct BvhDeviceInfo {
     float pad;              // world-space padding applied to every leaf box
     float g_lo[3];          // quantisation grid: world -> grid is (x - g_lo) * g_scale + 2
     float g_scale[3];
+    unsigned int ray_count; // env-shade: number of live shadow rays appended to the traversal list
 };
 
 struct nvdr_ctx {
@@ -71,6 +72,7 @@ struct nvdr_ctx {
     float4 *rays = nullptr;
     int *texel = nullptr;
     uint8_t *vis = nullptr;
+    uint32_t *live = nullptr;      // stream slots of the rays that need traversal (dead samples left out)
     float4 *pix_origin = nullptr;
     size_t stream_cap_rays = 0;
     uint64_t stream_id = 0;        // id of the ray stream currently held in rays/texel/pix_origin/pix_list

@@ -373,7 +373,7 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     hipFree(c->dinfo);
     hipFree(c->spill);
     hipFree(c->pix_list);
-    hipFree(c->rays); hipFree(c->texel); hipFree(c->vis); hipFree(c->pix_origin); hipFree(c->lg_xcd);
+    hipFree(c->rays); hipFree(c->texel); hipFree(c->vis); hipFree(c->live); hipFree(c->pix_origin); hipFree(c->lg_xcd);
     delete c;
     return 0;
 }

@@ -9,6 +9,12 @@
 // conflict-free ds_read_b128 (half-wave = one row of 32 consecutive pixels).  Taps that fall
 // outside the image are zero-filled: a zero normal gives clamp(dot,1e-4,1)^128 == 0 exactly, which
 // reproduces the reference's `continue` (denoising.cu:39-40).
+// The same identity gives the background early-out: a centre pixel whose normal is exactly zero (every pixel the
+// rasteriser did not cover, render.py:99-104) has w == 0 on all taps, forward and backward, so its result is
+// (0,0,0,1e-4) / (0,0,0) without looking at a single tap.  Workgroups and wavefronts made only of such pixels skip the
+// tile load / the tap loop (bob covers 23 % of the frame).  (Only non-finite colours would tell the difference: 0*inf.)
+// The per-tap constants exp(-d^2/2s^2) and d are wave-uniform; gfx950 has no scalar float unit, so they are tabulated
+// once per workgroup in LDS and fetched as broadcast reads instead of being recomputed (v_sqrt + v_exp per tap).
 //   forward : w = w_xy * w_n * exp(-|z_t - z_c| / max(dz_c * dist, 1e-4)),  out = (sum w*col_t, max(sum w, 1e-4))
 //   backward: the transposed gather with the TAP's dz in the denominator (denoising.cu:118).
 #include "common.h"
@@ -35,9 +41,35 @@ __global__ void __launch_bounds__(DN_BX * DN_BY) bilateral_kernel(DnView v, floa
     extern __shared__ __attribute__((aligned(16))) float4 tile[];
     const int TW = DN_BX + 2 * rad, TH = DN_BY + 2 * rad;
     float4 *tA = tile, *tB = tile + (TILED ? TW * TH : 0);
+    float2 *tap_tab = (float2 *)(tile + (TILED ? 2 * TW * TH : 0));   // (w_xy, dist) per tap
     const int n = blockIdx.z;
     const int x0 = blockIdx.x * DN_BX, y0 = blockIdx.y * DN_BY;
     const int lx = threadIdx.x & (DN_BX - 1), ly = threadIdx.x / DN_BX;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool inside = x < v.W && y < v.H;
+    const int64_t o = ((int64_t)n * v.H + y) * v.W + x;
+    // background early-out, workgroup level (before the tile is staged)
+    F3 cn = f3(0.0f);
+    if (inside) cn = fetch3(v.nrm, n, y, x);
+    const bool live = cn.x != 0.0f || cn.y != 0.0f || cn.z != 0.0f;
+    if (!__syncthreads_or(live)) {
+        if (inside) {
+            if (BACKWARD) {
+                out[3 * o + 0] = 0.f; out[3 * o + 1] = 0.f; out[3 * o + 2] = 0.f;
+            } else {
+                out[4 * o + 0] = 0.f; out[4 * o + 1] = 0.f; out[4 * o + 2] = 0.f; out[4 * o + 3] = DN_EPS;
+            }
+        }
+        return;
+    }
+    const float inv2var = 1.0f / (2.0f * sigma * sigma);
+    const int side = 2 * rad + 1;
+    for (int t = threadIdx.x; t < side * side; t += DN_BX * DN_BY) {
+        const int fx = t % side - rad, fy = t / side - rad;
+        const float dist_sqr = (float)(fx * fx + fy * fy);
+        tap_tab[t] = make_float2(__expf(-dist_sqr * inv2var), sqrtf(dist_sqr));
+    }
+    if (!TILED) __syncthreads();
     if (TILED) {
         for (int t = threadIdx.x; t < TW * TH; t += DN_BX * DN_BY) {
             const int tx = t % TW, ty = t / TW;
@@ -54,8 +86,16 @@ __global__ void __launch_bounds__(DN_BX * DN_BY) bilateral_kernel(DnView v, floa
         }
         __syncthreads();
     }
-    const int x = x0 + lx, y = y0 + ly;
-    if (x >= v.W || y >= v.H) return;
+    if (!inside) return;
+    // wavefront-level early-out (two rows of 32 pixels)
+    if (__ballot(live) == 0ull) {
+        if (BACKWARD) {
+            out[3 * o + 0] = 0.f; out[3 * o + 1] = 0.f; out[3 * o + 2] = 0.f;
+        } else {
+            out[4 * o + 0] = 0.f; out[4 * o + 1] = 0.f; out[4 * o + 2] = 0.f; out[4 * o + 3] = DN_EPS;
+        }
+        return;
+    }
     float4 cA, cB;
     if (TILED) {
         cA = tA[(ly + rad) * TW + lx + rad];
@@ -66,10 +106,10 @@ __global__ void __launch_bounds__(DN_BX * DN_BY) bilateral_kernel(DnView v, floa
         cA = make_float4(c.x, c.y, c.z, zp[0]);
         cB = make_float4(nn.x, nn.y, nn.z, zp[v.zdz.s3]);
     }
-    const float inv2var = 1.0f / (2.0f * sigma * sigma);
     float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
     for (int fy = -rad; fy <= rad; ++fy) {
         for (int fx = -rad; fx <= rad; ++fx) {
+            const float2 tt = tap_tab[(fy + rad) * side + fx + rad];
             float4 tAv, tBv;
             if (TILED) {
                 const int t = (ly + rad + fy) * TW + lx + rad + fx;
@@ -83,9 +123,7 @@ __global__ void __launch_bounds__(DN_BX * DN_BY) bilateral_kernel(DnView v, floa
                 tAv = make_float4(c.x, c.y, c.z, zp[0]);
                 tBv = make_float4(nn.x, nn.y, nn.z, zp[v.zdz.s3]);
             }
-            const float dist_sqr = (float)(fx * fx + fy * fy);
-            const float dist = sqrtf(dist_sqr);
-            const float w_xy = __expf(-dist_sqr * inv2var);
+            const float w_xy = tt.x, dist = tt.y;
             const float d = tBv.x * cB.x + tBv.y * cB.y + tBv.z * cB.z;
             const float w_normal = pow128(fminf(fmaxf(d, DN_EPS), 1.0f));
             const float dz = BACKWARD ? tBv.w : cB.w;
@@ -97,7 +135,6 @@ __global__ void __launch_bounds__(DN_BX * DN_BY) bilateral_kernel(DnView v, floa
             aw += w;
         }
     }
-    const int64_t o = ((int64_t)n * v.H + y) * v.W + x;
     if (BACKWARD) {
         out[3 * o + 0] = ax; out[3 * o + 1] = ay; out[3 * o + 2] = az;
     } else {
@@ -134,15 +171,18 @@ static int launch_bilateral(const nvdr_tensor *col_or_grad, const nvdr_tensor *c
     v.zdz = make_view4(*zdz);
     v.N = (int)N; v.H = (int)H; v.W = (int)W;
     const int rad = 2 * (int)ceil((double)sigma * 2.5) + 1; // denoising.cu:27
-    const size_t lds = (size_t)(DN_BX + 2 * rad) * (DN_BY + 2 * rad) * 2 * sizeof(float4);
+    const size_t lds_tab = (size_t)(2 * rad + 1) * (2 * rad + 1) * sizeof(float2);
+    const size_t lds_tile = (size_t)(DN_BX + 2 * rad) * (DN_BY + 2 * rad) * 2 * sizeof(float4);
     dim3 grid(div_up(W, DN_BX), div_up(H, DN_BY), (unsigned)N);
-    const bool tiled = lds <= 64 * 1024;
+    const bool tiled = lds_tile + lds_tab <= 64 * 1024;
+    NVDR_REQUIRE(lds_tab <= 64 * 1024, "%s: sigma %g needs a %d-wide window, more than fits", op, (double)sigma, 2 * rad + 1);
+    const size_t lds = (tiled ? lds_tile : 0) + lds_tab;
     if (backward) {
         if (tiled) bilateral_kernel<true, true><<<grid, DN_BX * DN_BY, lds, stream>>>(v, sigma, rad, out);
-        else bilateral_kernel<true, false><<<grid, DN_BX * DN_BY, 0, stream>>>(v, sigma, rad, out);
+        else bilateral_kernel<true, false><<<grid, DN_BX * DN_BY, lds, stream>>>(v, sigma, rad, out);
     } else {
         if (tiled) bilateral_kernel<false, true><<<grid, DN_BX * DN_BY, lds, stream>>>(v, sigma, rad, out);
-        else bilateral_kernel<false, false><<<grid, DN_BX * DN_BY, 0, stream>>>(v, sigma, rad, out);
+        else bilateral_kernel<false, false><<<grid, DN_BX * DN_BY, lds, stream>>>(v, sigma, rad, out);
     }
     NVDR_LAUNCH_CHECK();
     return 0;

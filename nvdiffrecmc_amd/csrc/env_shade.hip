@@ -55,6 +55,8 @@ struct ShadeParams {
     int *texel;               // ty * Wl + tx of the radiance lookup
     float4 *pix_origin;       // shadow-ray origin per compacted pixel
     uint8_t *vis;             // 1 = unoccluded
+    uint32_t *live;           // compacted list of the stream slots stage 2 has to traverse
+    unsigned *ray_count;      // its length (device counter)
     float *g_light_xcd;       // [8][Hl*Wl*3] per-XCD private light-gradient accumulators (backward)
     int light_elems;          // Hl*Wl*3
     unsigned debug;           // NVDR_DEBUG bits: 1 skip tracing, 2 skip light-gradient atomics
@@ -81,7 +83,7 @@ __global__ void compact_pixels_kernel(const float *__restrict__ mask, int64_t ms
     if (on) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)i;
 }
 
-__global__ void zero_count_kernel(unsigned *count) { *count = 0; }
+__global__ void zero_count_kernel(unsigned *a, unsigned *b) { *a = 0; *b = 0; }
 
 // ---------------------------------------------------------------------------------------------
 // RNG (kernel.cu:30-45)
@@ -339,6 +341,21 @@ __device__ __forceinline__ F3 fetch_light_texel(const Tab &t, int texel)
 // ---------------------------------------------------------------------------------------------
 // stage 1: sample generation (kernel.cu:463-526 minus process_sample)
 
+#define NVDR_GEN_STAGE 1024u
+
+// one list-space claim for `staged` slots of a wavefront, then a coalesced copy out of LDS; returns the new fill (0)
+__device__ __forceinline__ unsigned flush_live(const unsigned *stage, unsigned staged, int lane, const ShadeParams &p)
+{
+    if (staged == 0) return 0;
+    __builtin_amdgcn_wave_barrier();        // the staged entries were written by other lanes of this wavefront
+    unsigned at = 0;
+    if (lane == 0) at = atomicAdd(p.ray_count, staged);
+    at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+    for (unsigned k = lane; k < staged; k += 64) p.live[at + k] = stage[k];
+    __builtin_amdgcn_wave_barrier();
+    return 0;
+}
+
 __global__ void __launch_bounds__(256) env_gen_kernel(ShadeParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -349,15 +366,20 @@ __global__ void __launch_bounds__(256) env_gen_kernel(ShadeParams p)
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
     const unsigned S = p.S, n = p.n;
     const float strata_frac = 1.0f / (float)n;
+    // Live-ray list: a device-scope atomic per wavefront and round serialises on its one address (61 k of them cost
+    // 0.4 ms); each wavefront therefore stages slots in LDS and claims list space once per NVDR_GEN_STAGE-128 entries.
+    __shared__ unsigned stage_all[4][NVDR_GEN_STAGE];
+    unsigned *stage = stage_all[wave];
+    unsigned staged = 0;
 
     for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
         const unsigned pi = grp * G + slot;
-        if (pi >= P) continue;
-        const int lin = p.pix_list[pi];
+        const bool valid = pi < P;
+        const int lin = p.pix_list[valid ? pi : 0];
         const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
         const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
         const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
-        if (sub == 0) {
+        if (sub == 0 && valid) {
             const F3 ro = fetch3(p.ro, z, y, x);
             p.pix_origin[pi] = make_float4(ro.x, ro.y, ro.z, 0.0f);
         }
@@ -375,34 +397,59 @@ __global__ void __launch_bounds__(256) env_gen_kernel(ShadeParams p)
         const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
         const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
 
-        for (unsigned i = sub; i < S; i += L) {
-            unsigned rng = lcg_skip(rng0, 5u * i);
-            // light importance sample (kernel.cu:513-516)
-            const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
-            float sx = ((float)(pl % n) + uniform_pcg(rng)) * strata_frac;
-            float sy = ((float)(pl / n) + uniform_pcg(rng)) * strata_frac;
-            float pdfA_light, pdfB_bsdf;
-            int txA, tyA, txB, tyB;
-            const F3 dirA = light_sample(p, sx, sy, pdfA_light, txA, tyA);
-            const float pdfA_bsdf = bsdf_pdf(pDiffuse, pSpecular, nrm, wo, dirA, alpha);
-            // BSDF importance sample (kernel.cu:522-526)
-            const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
-            sx = ((float)(pb % n) + uniform_pcg(rng)) * strata_frac;
-            sy = ((float)(pb / n) + uniform_pcg(rng)) * strata_frac;
-            const float sz = uniform_pcg(rng);
-            const F3 dirB = bsdf_sample(pDiffuse, pSpecular, nrm, wo, sx, sy, sz, alpha, pdfB_bsdf);
-            const float pdfB_light = light_pdf(p, dirB, txB, tyB);
-            // Stream order inside a pixel: the S light-sampled rays by THEIR STRATUM (pl), then the S BSDF-sampled rays by
-            // theirs (pb).  The permutation tables scramble which sample draws which stratum; ordering by stratum puts
-            // neighbouring cells of the CDF / hemisphere grid -- i.e. nearby directions -- into neighbouring lanes of the
-            // traversal kernel, which keeps its wavefronts coherent (both rows are permutations of 0..S-1: a bijection).
-            const int64_t rA = (int64_t)pi * 2 * S + pl, rB = (int64_t)pi * 2 * S + S + pb;
-            p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, pdfA_light + pdfA_bsdf);
-            p.rays[rB] = make_float4(dirB.x, dirB.y, dirB.z, pdfB_light + pdfB_bsdf);
-            p.texel[rA] = tyA * p.light.n1 + txA;
-            p.texel[rB] = tyB * p.light.n1 + txB;
+        for (unsigned base = 0; base < S; base += L) {
+            const unsigned i = base + sub;
+            unsigned deadA = 0x80000000u, deadB = 0x80000000u;   // lanes without a sample stage nothing
+            int64_t rA = 0, rB = 0;
+            if (valid && i < S) {
+                unsigned rng = lcg_skip(rng0, 5u * i);
+                // light importance sample (kernel.cu:513-516)
+                const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
+                float sx = ((float)(pl % n) + uniform_pcg(rng)) * strata_frac;
+                float sy = ((float)(pl / n) + uniform_pcg(rng)) * strata_frac;
+                float pdfA_light, pdfB_bsdf;
+                int txA, tyA, txB, tyB;
+                const F3 dirA = light_sample(p, sx, sy, pdfA_light, txA, tyA);
+                const float pdfA_bsdf = bsdf_pdf(pDiffuse, pSpecular, nrm, wo, dirA, alpha);
+                // BSDF importance sample (kernel.cu:522-526)
+                const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
+                sx = ((float)(pb % n) + uniform_pcg(rng)) * strata_frac;
+                sy = ((float)(pb / n) + uniform_pcg(rng)) * strata_frac;
+                const float sz = uniform_pcg(rng);
+                const F3 dirB = bsdf_sample(pDiffuse, pSpecular, nrm, wo, sx, sy, sz, alpha, pdfB_bsdf);
+                const float pdfB_light = light_pdf(p, dirB, txB, tyB);
+                // Stream order inside a pixel: the S light-sampled rays by THEIR STRATUM (pl), then the S BSDF-sampled rays by
+                // theirs (pb).  The permutation tables scramble which sample draws which stratum; ordering by stratum puts
+                // neighbouring cells of the CDF / hemisphere grid -- i.e. nearby directions -- into neighbouring lanes of the
+                // traversal kernel, which keeps its wavefronts coherent (both rows are permutations of 0..S-1: a bijection).
+                rA = (int64_t)pi * 2 * S + pl;
+                rB = (int64_t)pi * 2 * S + S + pb;
+                // Dead samples: with dot(n, wi) <= 0 the Lambert term is max(.,0) = 0 and the GGX lobe fails its front-facing
+                // gate (bsdf.h:121,165 -- the same dot product), forward AND backward, so the sample contributes exactly
+                // zero whatever its visibility.  Such rays (about half of the light-sampled ones: the probe covers the whole
+                // sphere) are flagged in the sign bit of the pdf sum (never negative) for stage 3, which skips them, and are
+                // left out of the list of stream slots stage 2 traverses (appended per wavefront: one atomic per wave and
+                // round; the list order varies from run to run, the visibility of a slot does not).
+                // NVDR_DEBUG bit 8 switches the culling off (traces every ray like the reference).
+                const bool cull = !(p.debug & 8u);
+                deadA = (cull && !(dot3(nrm, dirA) > 0.0f)) ? 0x80000000u : 0u;
+                deadB = (cull && !(dot3(nrm, dirB) > 0.0f)) ? 0x80000000u : 0u;
+                p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(__float_as_uint(pdfA_light + pdfA_bsdf) | deadA));
+                p.rays[rB] = make_float4(dirB.x, dirB.y, dirB.z, __uint_as_float(__float_as_uint(pdfB_light + pdfB_bsdf) | deadB));
+                p.texel[rA] = tyA * p.light.n1 + txA;
+                p.texel[rB] = tyB * p.light.n1 + txB;
+            }
+            // append the live slots to this wavefront's LDS staging buffer (ballot ranks; `staged` is wave-uniform)
+            const unsigned long long mA = __ballot(deadA == 0u), mB = __ballot(deadB == 0u);
+            const unsigned nA = (unsigned)__popcll(mA), nB = (unsigned)__popcll(mB);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (!deadA) stage[staged + (unsigned)__popcll(mA & below)] = (unsigned)rA;
+            if (!deadB) stage[staged + nA + (unsigned)__popcll(mB & below)] = (unsigned)rB;
+            staged += nA + nB;
+            if (staged > NVDR_GEN_STAGE - 128u) staged = flush_live(stage, staged, lane, p);
         }
     }
+    flush_live(stage, staged, lane, p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -414,10 +461,14 @@ __global__ void __launch_bounds__(256) env_gen_kernel(ShadeParams p)
 #ifndef NVDR_LEAF_MIN
 #define NVDR_LEAF_MIN 8
 #endif
+#ifndef NVDR_TRACE_CHUNK_LOG2
+#define NVDR_TRACE_CHUNK_LOG2 6
+#endif
 template <bool COUNT>
 __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView bvh, const float4 *__restrict__ rays,
                                                                           const float4 *__restrict__ pix_origin,
-                                                                          const unsigned *__restrict__ pix_count,
+                                                                          const uint32_t *__restrict__ live,
+                                                                          const unsigned *__restrict__ ray_count,
                                                                           unsigned rays_per_pixel,
                                                                           uint8_t *__restrict__ vis, int *spill,
                                                                           unsigned long long *counters)
@@ -425,16 +476,22 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const TravStack stack = make_stack(smem, spill);
     const int lane = threadIdx.x & 63;
-    const unsigned total = *pix_count * rays_per_pixel;
+    const unsigned total = *ray_count;
     const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
     const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    // contiguous range per wave, a multiple of 64 rays so that the ranges tile the stream
-    unsigned per = (total + n_waves - 1) / n_waves;
-    per = (per + 63u) & ~63u;
-    unsigned next = min(wid * per, total);                 // wave-uniform cursor
-    const unsigned end = min(next + per, total);
-    unsigned n_box = 0, n_tri = 0;
+    // Round-robin chunks: the list is cut into chunks of 64 rays and wave w walks chunks w, w + n_waves, w + 2 n_waves ...
+    // (virtual cursor v -> list position ((v >> 6) * n_waves + w) * 64 + (v & 63)): every wave gets the same mix of cheap
+    // and expensive pixels with no communication (0.82 -> 0.77 ms against one contiguous range per wave; chunks of
+    // 16 rays the same, 256 slower).  Claiming chunks from a device counter was far worse (same-address device-scope
+    // atomics: 1.4 ms with 1024-ray chunks, 2.5 ms with 256) and is not needed: per-wave clocks of the counting build
+    // show all waves starting together and finishing evenly spread over [T/8, T] for ANY chunk size down to 2 rays --
+    // the signature of oldest-first issue among the 8 waves of a SIMD that is busy to the end, not of imbalance.
+    unsigned next = 0;                                      // wave-uniform virtual cursor
+    const unsigned CL = NVDR_TRACE_CHUNK_LOG2, CS = 1u << CL;
+    const unsigned end = ((total + CS - 1u) / CS + n_waves - 1) / n_waves * CS;
+    unsigned n_box = 0, n_tri = 0, n_ray = 0;
     const bool single = bvh.n_tris == 1;
+    const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
 
     int ray = -1, cur = 0, sp = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
@@ -446,19 +503,21 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     //   leaf   : when >= NVDR_LEAF_MIN lanes are parked on a leaf, or no lane has a node to visit;
     //   node   : whenever some lane has one.
     // Measured (same GPU session, bob 512^2 x 64 spp): ungated 1.36 ms, (16, 8) 1.23-1.31 ms, one-arm-per-iteration
-    // (16, 16) 1.30 ms, (32, 16) 1.68 ms.
+    // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
+    // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
     while (true) {
         const unsigned long long idle = __ballot(ray < 0);
-        const unsigned long long on_leaf = __ballot(ray >= 0 && cur < 0);
-        const int n_idle = __popcll(idle), n_leaf = __popcll(on_leaf);
-        const int n_node = 64 - n_idle - n_leaf;
-        if (next < end && (n_idle >= NVDR_REFILL_MIN || n_idle == 64 || (n_node == 0 && n_leaf == 0))) {
+        const int n_idle = __popcll(idle);
+        if (next < end && n_idle >= NVDR_REFILL_MIN) {
             // refill every idle lane from the wave's range (no atomics: the cursor is wave-uniform)
             const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-            if (ray < 0 && take < end) {
-                ray = (int)take;
-                const float4 rd = rays[take];
-                const float4 ro = pix_origin[take / rays_per_pixel];
+            const unsigned at = (((take >> CL) * n_waves + wid) << CL) | (take & (CS - 1u));
+            if (ray < 0 && take < end && at < total) {
+                const unsigned slot = live[at];
+                ray = (int)slot;
+                if (COUNT) n_ray++;
+                const float4 rd = rays[slot];
+                const float4 ro = pix_origin[slot / rays_per_pixel];
                 ox = ro.x; oy = ro.y; oz = ro.z;
                 dx = rd.x; dy = rd.y; dz = rd.z;
                 g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
@@ -466,9 +525,12 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
                 sp = 0;
             }
             next += (unsigned)n_idle;
-            continue;
+        } else if (n_idle == 64) {
+            break;
         }
-        if (n_idle == 64) break;
+        const unsigned long long on_leaf = __ballot(ray >= 0 && cur < 0);
+        const int n_leaf = __popcll(on_leaf);
+        const int n_node = __popcll(__ballot(ray >= 0 && cur >= 0));
         const int POP = NVDR_TRAV_DONE, HIT = NVDR_TRAV_DONE - 1, WAIT = NVDR_TRAV_DONE - 2;
 #ifdef NVDR_TRAV_ONE_ARM
         const bool leaf_turn = n_leaf >= NVDR_LEAF_MIN || n_node == 0;
@@ -493,25 +555,35 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
             sp += both ? 1 : 0;
             nxt = any ? nearc : POP;
         }
+        bool finished = false;
         if (nxt != WAIT) {
             const bool pop = nxt == POP;
-            const bool finished = (nxt == HIT) | (pop & (sp == 0));
+            finished = (nxt == HIT) | (pop & (sp == 0));
             sp -= (pop & (sp > 0)) ? 1 : 0;
             cur = pop ? popv : nxt;
-            if (finished) {
-                vis[ray] = nxt == HIT ? 0 : 1;
-                ray = -1;
-            }
+        }
+        if (finished) {
+            vis[ray] = nxt == HIT ? 0 : 1;
+            ray = -1;
         }
     }
     if (COUNT) {
         for (int o = 32; o >= 1; o >>= 1) {
             n_box += __shfl_xor(n_box, o);
             n_tri += __shfl_xor(n_tri, o);
+            n_ray += __shfl_xor(n_ray, o);
         }
         if (lane == 0) {
             atomicAdd(&counters[0], (unsigned long long)n_box);
             atomicAdd(&counters[1], (unsigned long long)n_tri);
+            atomicAdd(&counters[2], (unsigned long long)n_ray);
+            // load balance of the static ranges: sum and maximum of the per-wave busy time (100 MHz ticks), wave count
+            const unsigned long long dt = wall_clock64() - t_begin;
+            atomicAdd(&counters[3], dt);
+            atomicMax(&counters[4], dt);
+            atomicAdd(&counters[5], 1ull);
+            counters[8 + 2 * wid] = t_begin;                 // per-wave begin / end ticks (wid < 8192)
+            counters[9 + 2 * wid] = t_begin + dt;
         }
     }
 }
@@ -564,6 +636,9 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
             const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
             const int64_t rbase = (int64_t)(valid ? pi : 0) * 2 * S;
             const int64_t rA = rbase + pl, rB = rbase + S + pb;
+            // the two rays of this stratum; a set sign bit on the pdf sum marks a dead sample (stage 1)
+            const float4 rdA = p.rays[rA], rdB = p.rays[rB];
+            const unsigned dead = active ? ((__float_as_uint(rdA.w) >> 31) | ((__float_as_uint(rdB.w) >> 31) << 1)) : 3u;
             unsigned occ = 0;
             if (use_bits) {
                 const uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
@@ -571,8 +646,9 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
                     occ |= ((vc[i >> 5] >> (i & 31u)) & 1u);
                     occ |= ((vc[p.vis_words + (i >> 5)] >> (i & 31u)) & 1u) << 1;
                 }
-            } else if (active) {
-                occ = (p.vis[rA] ? 0u : 1u) | (p.vis[rB] ? 0u : 2u);
+            } else {
+                if (!(dead & 1u)) occ |= p.vis[rA] ? 0u : 1u;
+                if (!(dead & 2u)) occ |= p.vis[rB] ? 0u : 2u;
             }
             if (save_bits) {
                 const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
@@ -596,8 +672,9 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
             if (!active) continue;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
+                if ((dead >> r) & 1u) continue;         // contributes exactly zero to every output
                 const int64_t ri = r == 0 ? rA : rB;
-                const float4 rd = p.rays[ri];
+                const float4 rd = r == 0 ? rdA : rdB;
                 const int texel = p.texel[ri];
                 const F3 dir = f3(rd.x, rd.y, rd.z);
                 const float pdfSum = rd.w;
@@ -618,7 +695,8 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
                     // CUs of an XCD share that L2, and the copy is picked by the XCC id the wave actually runs on, so
                     // the result does not depend on workgroup placement -- and a tiny kernel sums the 8 copies.
                     float *g = xcd_light + (int64_t)((p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel) * 3;   // bit 4: contention experiment
-                    if (!(p.debug & 2u)) {
+                    // adding +-0 never changes an accumulator that started at +0: occluded samples are skipped
+                    if (!(p.debug & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f)) {
                         __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -720,10 +798,12 @@ static int reserve_stream(nvdr_ctx *c, int64_t npix, unsigned S, hipStream_t str
         (void)hipFree(c->rays);
         (void)hipFree(c->texel);
         (void)hipFree(c->vis);
-        c->rays = nullptr; c->texel = nullptr; c->vis = nullptr;
+        (void)hipFree(c->live);
+        c->rays = nullptr; c->texel = nullptr; c->vis = nullptr; c->live = nullptr;
         NVDR_HIP_TRY(hipMalloc((void **)&c->rays, sizeof(float4) * rays));
         NVDR_HIP_TRY(hipMalloc((void **)&c->texel, sizeof(int) * rays));
         NVDR_HIP_TRY(hipMalloc((void **)&c->vis, rays));
+        NVDR_HIP_TRY(hipMalloc((void **)&c->live, sizeof(uint32_t) * rays));
         c->stream_cap_rays = rays;
     }
     return 0;
@@ -753,7 +833,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     NVDR_REQUIRE(a->pdf.size[0] == a->cols.size[0] && a->pdf.size[1] == a->cols.size[1] && a->rows.size[0] == a->pdf.size[0],
                  "env_shade: pdf/rows/cols shapes disagree");
     const int64_t npix = N * H * W;
-    NVDR_REQUIRE((double)npix * 2.0 * S < 4.0e9, "env_shade: %lld pixels x %u rays exceed the 32-bit ray index; split the batch",
+    NVDR_REQUIRE((double)npix * 2.0 * S < 2147483647.0, "env_shade: %lld pixels x %u rays exceed the 31-bit ray index; split the batch",
                  (long long)npix, 2 * S);
     NVDR_HIP_TRY(hipSetDevice(c->device));
 
@@ -810,6 +890,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     p.pix_list = c->pix_list;
     p.pix_count = &c->dinfo->pix_count;
     p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.vis = c->vis;
+    p.live = c->live; p.ray_count = &c->dinfo->ray_count;
     const char *dbg = getenv("NVDR_DEBUG");
     p.debug = dbg ? (unsigned)atoi(dbg) : 0u;
 
@@ -818,9 +899,16 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     // persistent grids (the covered-pixel count lives on the device)
     const int waves_per_block = 4;
     const int64_t max_groups = (npix + (64 / L) - 1) / (64 / L);
-    int64_t pblocks = (int64_t)c->n_cus * 4;
-    if (pblocks * waves_per_block > max_groups) pblocks = (max_groups + waves_per_block - 1) / waves_per_block;
-    if (pblocks < 1) pblocks = 1;
+    // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading); NVDR_PBLOCKS="g,f,b"
+    // overrides them for tuning
+    int per_cu[3] = {6, 6, 4};   // measured (bob 512^2 x 64 spp): gen 0.40 -> 0.365 ms, fwd shade 0.164 -> 0.145 ms, bwd shade best at 4
+    if (const char *e = getenv("NVDR_PBLOCKS")) sscanf(e, "%d,%d,%d", &per_cu[0], &per_cu[1], &per_cu[2]);
+    int64_t pb[3];
+    for (int k = 0; k < 3; ++k) {
+        pb[k] = (int64_t)c->n_cus * (per_cu[k] < 1 ? 1 : per_cu[k]);
+        if (pb[k] * waves_per_block > max_groups) pb[k] = (max_groups + waves_per_block - 1) / waves_per_block;
+        if (pb[k] < 1) pb[k] = 1;
+    }
     hipEvent_t *pe = nullptr;
     if (c->profiling) {
         const int slot = (int)(c->prof_n % 128);
@@ -831,10 +919,10 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     }
     if (!reuse) {
         c->stream_id = 0; // invalid while being rewritten
-        zero_count_kernel<<<1, 1, 0, stream>>>(&c->dinfo->pix_count);
+        zero_count_kernel<<<1, 1, 0, stream>>>(&c->dinfo->pix_count, &c->dinfo->ray_count);
         compact_pixels_kernel<<<div_up(npix, 256), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
                                                                       &c->dinfo->pix_count);
-        env_gen_kernel<<<(unsigned)pblocks, 256, 0, stream>>>(p);
+        env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
         c->stream_id = ++c->stream_seq;
     }
     if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
@@ -849,19 +937,19 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             if (tblocks > need) tblocks = need < 1 ? 1 : need;
             const size_t lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
             if (a->counters)
-                env_trace_kernel<true><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin,
-                                                                                             p.pix_count, 2 * S, c->vis, c->spill, a->counters);
+                env_trace_kernel<true><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
+                                                                                             p.ray_count, 2 * S, c->vis, c->spill, a->counters);
             else
-                env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin,
-                                                                                              p.pix_count, 2 * S, c->vis, c->spill, nullptr);
+                env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
+                                                                                              p.ray_count, 2 * S, c->vis, c->spill, nullptr);
         }
     }
     if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
     if (backward) {
-        env_shade_kernel<true><<<(unsigned)pblocks, 256, 0, stream>>>(p);
+        env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
         light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_xcd, p.light_elems, p.g_light);
     } else {
-        env_shade_kernel<false><<<(unsigned)pblocks, 256, 0, stream>>>(p);
+        env_shade_kernel<false><<<(unsigned)pb[1], 256, 0, stream>>>(p);
     }
     if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));
     NVDR_LAUNCH_CHECK();

@@ -253,7 +253,7 @@ def trace_visibility(optix_ctx, ro, rd, count=False):
     ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
     R = ro.shape[0]
     vis = torch.empty(R, dtype=torch.uint8, device=ro.device)
-    cnt = torch.zeros(2, dtype=torch.int64, device=ro.device) if count else None
+    cnt = torch.zeros(8 + 2 * 8192, dtype=torch.int64, device=ro.device) if count else None
     _lib.check(w.lib.nvdr_trace_visibility(w.handle, _lib.ptr(ro), _lib.ptr(rd), R, _lib.ptr(vis), _lib.ptr(cnt),
                                            _lib.stream_ptr()), 'trace_visibility')
     return (vis, cnt) if count else vis
@@ -276,7 +276,8 @@ def trace_closest(optix_ctx, ro, rd):
 
 def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols,
                                BSDF='pbr', n_samples_x=8, rnd_seed=0, shadow_scale=1.0):
-    """Run the COUNTING build of the forward kernel once: returns (covered pixels, box tests, triangle tests)."""
+    """Run the COUNTING build of the forward kernel once: returns (covered pixels, box tests, triangle tests,
+    rays traversed).  Rays traversed is below 2*S*pixels: samples under the shading horizon are never traced."""
     if n_samples_x not in _optix_env_shade_func._random_perm:
         _optix_env_shade_func._random_perm[n_samples_x] = torch.argsort(
             torch.rand(32768, n_samples_x * n_samples_x, device=ro.device), dim=-1).int()
@@ -288,10 +289,12 @@ def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_p
     N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
     diff = torch.empty(N, H, W, 3, dtype=torch.float32, device=ro.device)
     spec = torch.empty_like(diff)
-    cnt = torch.zeros(2, dtype=torch.int64, device=ro.device)
+    cnt = torch.zeros(8 + 2 * 8192, dtype=torch.int64, device=ro.device)
     a.diff, a.spec, a.counters = diff.data_ptr(), spec.data_ptr(), cnt.data_ptr()
     _lib.check(w.lib.nvdr_env_shade_fwd(w.handle, ctypes.byref(a), _lib.stream_ptr()), 'env_shade_fwd(count)')
     npx = ctypes.c_int64()
     _lib.check(w.lib.nvdr_env_shade_last_pixel_count(w.handle, ctypes.byref(npx), _lib.stream_ptr()), 'pixel_count')
     c = cnt.cpu()
-    return int(npx.value), int(c[0]), int(c[1])
+    env_shade_traversal_counts.balance = (int(c[3]), int(c[4]), int(c[5]))   # sum, max of per-wave ticks (100 MHz), waves
+    env_shade_traversal_counts.wave_ticks = c[8:8 + 2 * int(c[5])].view(-1, 2)   # (begin, end) per wavefront
+    return int(npx.value), int(c[0]), int(c[1]), int(c[2])

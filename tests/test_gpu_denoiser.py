@@ -82,3 +82,28 @@ def test_denoiser_full_size_properties(dev):
     out.backward(gr)
     rhs = (c.detach() * c.grad).sum().double()
     assert abs(lhs.item() - rhs.item()) < 1e-4 * abs(lhs.item())
+
+
+@pytest.mark.parametrize('sigma', [2.0, 6.0])
+def test_denoiser_background_early_out(sigma, dev):
+    """Pixels with an exactly-zero normal (everything the rasteriser did not cover) have zero weight on every tap; the
+    kernel skips whole workgroups / wavefronts of them.  Mixed, fully empty and fully covered tiles vs the oracle."""
+    from nvdiffrecmc_amd import optixutils as ou
+    N, H, W = 1, 96, 160
+    x, col, nrm, zdz, og = mg.denoiser_inputs(N, H, W, 17)
+    nrm = nrm.clone()
+    nrm[:, :, 70:] = 0.0          # columns 70.. : whole 32x8 workgroups empty from x = 96 on, mixed ones before
+    nrm[:, 40:50, :] = 0.0        # an empty band: wavefront-level skips inside covered workgroups
+    nrm[:, 3, 5] = 0.0            # a single hole
+    zdz = zdz.contiguous()
+    ref = orc.bilateral_fwd(col, nrm, zdz, sigma, n_threads=NT)
+    refg = orc.bilateral_bwd(col, nrm, zdz, sigma, og, n_threads=NT)
+    cd = col.to(dev).requires_grad_(True)
+    out = ou.ops._bilateral_denoiser_func.apply(cd, nrm.to(dev), zdz.to(dev), sigma)
+    assert_close(out.detach(), ref, RTOL, floor=1e-4)
+    out.backward(og.to(dev))
+    assert_close(cd.grad, refg, RTOL, floor=1e-4)
+    empty = (nrm == 0).all(-1)
+    assert torch.equal(out.detach().cpu()[empty][:, :3], torch.zeros(int(empty.sum()), 3))
+    assert torch.equal(out.detach().cpu()[empty][:, 3], torch.full((int(empty.sum()),), 1e-4))
+    assert torch.equal(cd.grad.cpu()[empty], torch.zeros(int(empty.sum()), 3))

@@ -131,3 +131,34 @@ def test_env_shade_api_contract(dev):
     z, _ = ou.optix_env_shade(ctx, torch.zeros_like(g['mask']), g['ro'], g['gb_pos'], g['gb_normal'], g['gb_view_pos'], g['gb_kd'],
                               g['gb_ks'], g['light'], g['pdf'], g['rows'], g['cols'], n_samples_x=2, rnd_seed=1)
     assert z.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize('mesh,n,bsdf', [('bob', 8, 'pbr'), ('spot', 4, 'pbr'), ('bob', 3, 'diffuse')])
+def test_dead_samples_are_exactly_zero(mesh, n, bsdf, dev, monkeypatch):
+    """Samples under the shading horizon (dot(n, wi) <= 0) are not traced and not shaded; tracing and shading them all
+    (NVDR_DEBUG=8, what the reference does) must give bit-identical images and per-pixel gradients."""
+    H = W = 64
+    inp = scene_cpu.make_inputs(mesh, H, W, n, view=3, probe_res=128, n_threads=NT)
+    kw = scene_cpu.shade_kwargs(inp)
+    g = torch.Generator().manual_seed(11)
+    dg, sg = torch.rand(1, H, W, 3, generator=g), torch.rand(1, H, W, 3, generator=g)
+    ctx = make_ctx(inp['mesh'], dev)
+    fast = gpu_env_shade(ctx, kw, dev, bsdf, n, 9, dg, sg)
+    monkeypatch.setenv('NVDR_DEBUG', '8')
+    full = gpu_env_shade(ctx, kw, dev, bsdf, n, 9, dg, sg)
+    monkeypatch.delenv('NVDR_DEBUG')
+    for k in ('diff', 'spec', 'gb_pos_grad', 'gb_normal_grad', 'gb_kd_grad', 'gb_ks_grad'):
+        assert torch.equal(fast[k], full[k]), k
+    # atomics: same addends (the skipped ones are zeros), different order
+    assert_close(fast['light_grad'], full['light_grad'], 1e-4, floor=1e-3 * max(1.0, full['light_grad'].abs().max().item()))
+    # and the traversal really is shorter
+    from nvdiffrecmc_amd import optixutils as ou
+    d = {k: v.to(dev) for k, v in kw.items()}
+    ou.ops.set_permutation_table(n, d['perms'])
+    args = (ctx, d['mask'], d['ro'], d['gb_pos'], d['gb_normal'], d['gb_view_pos'], d['gb_kd'], d['gb_ks'], d['light'], d['pdf'], d['rows'], d['cols'])
+    P, _, _, traced = ou.ops.env_shade_traversal_counts(*args, BSDF=bsdf, n_samples_x=n, rnd_seed=9)
+    monkeypatch.setenv('NVDR_DEBUG', '8')
+    P2, _, _, traced_all = ou.ops.env_shade_traversal_counts(*args, BSDF=bsdf, n_samples_x=n, rnd_seed=9)
+    monkeypatch.delenv('NVDR_DEBUG')
+    assert P == P2 and traced_all == 2 * n * n * P
+    assert 0.5 * traced_all < traced < 0.95 * traced_all

@@ -1,0 +1,14 @@
+#!/bin/bash
+# time every library variant under nvdiffrecmc_amd/csrc/build/variants/ in ONE gpurun call
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+B=nvdiffrecmc_amd/csrc/build
+cp $B/libnvdr_hip.so /tmp/libnvdr_hip.so.orig
+for f in $B/variants/libnvdr_hip.so.*; do
+  tag=${f##*.so.}
+  cp $f $B/libnvdr_hip.so
+  echo "== $tag"
+  timeout 300 python tools/stage_probe.py ${PROBE_CFGS:-6,6,4} 2>&1 | tail -n +3
+  if [ -n "$AB_TEST" ]; then timeout 600 python -m pytest tests/test_gpu_env_shade.py tests/test_gpu_fullsize.py -q -m gpu -x 2>&1 | tail -2; fi
+done
+cp /tmp/libnvdr_hip.so.orig $B/libnvdr_hip.so

@@ -1,0 +1,56 @@
+"""Per-stage HIP-event times of the env-shade op (gen / trace / shade, forward and backward) on the benchmark workload,
+for a list of NVDR_PBLOCKS / NVDR_DEBUG settings given as argv: e.g.  stage_probe.py 4,4,4 6,4,5 'dbg=8'"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nvdiffrecmc_amd.trainer import DirectLightingStep
+from nvdiffrecmc_amd import optixutils as ou, renderutils as ru
+
+n = int(os.environ.get('PROBE_N', '8'))
+res = int(os.environ.get('PROBE_RES', '512'))
+mesh = os.environ.get('PROBE_MESH', 'bob')
+st = DirectLightingStep(mesh, res, n, view=0, n_views=8, device='cuda:0')
+m = st.mask[..., None]
+with torch.no_grad():
+    kd = (st.kd_tex[st.texel].view(1, res, res, 3) * m).contiguous()
+    ks = (st.ks.view(1, 1, 1, 3) * m).contiguous()
+    nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)
+    ro = st.gb_pos + nrm * 0.001
+L = st.light
+ou.ops._optix_env_shade_func.cache_visibility = False
+
+def run(iters=12):
+    st.ctx.set_profiling(True)
+    for it in range(iters):
+        if it == 2: st.ctx.set_profiling(True)
+        g = [t.clone().requires_grad_(True) for t in (st.gb_pos, nrm, kd, ks, L.base.detach())]
+        d, s = ou.optix_env_shade(st.ctx, st.mask, ro, g[0], g[1], st.view_pos, g[2], g[3], g[4], L._pdf, L.rows[:, 0], L.cols,
+                                  n_samples_x=n, rnd_seed=it, shadow_scale=1.0)
+        torch.autograd.backward([d, s], [torch.ones_like(d), torch.ones_like(s)])
+    torch.cuda.synchronize()
+    nf, f = st.ctx.stage_times(backward=False)
+    nb, b = st.ctx.stage_times(backward=True)
+    st.ctx.set_profiling(False)
+    return f, b
+
+print('workload: %s %dx%d n=%d covered=%d' % (mesh, res, res, n, st.covered))
+for cfg in sys.argv[1:] or ['4,4,4']:
+    os.environ.pop('NVDR_PBLOCKS', None); os.environ['NVDR_DEBUG'] = '0'
+    for tok in cfg.split(';'):
+        if tok.startswith('dbg='): os.environ['NVDR_DEBUG'] = tok[4:]
+        elif tok: os.environ['NVDR_PBLOCKS'] = tok
+    f, b = run()
+    print('%-16s fwd gen %.3f trace %.3f shade %.3f | bwd gen %.3f trace %.3f shade %.3f  (ms)' % ((cfg,) + tuple(f) + tuple(b)))
+os.environ.pop('NVDR_PBLOCKS', None); os.environ['NVDR_DEBUG'] = '0'
+P, nb, nt, nr = ou.ops.env_shade_traversal_counts(st.ctx, st.mask, ro, st.gb_pos, nrm, st.view_pos, kd, ks, L.base.detach(), L._pdf, L.rows[:, 0], L.cols,
+                                                  n_samples_x=n, rnd_seed=0)
+tot, mx, nw = ou.ops.env_shade_traversal_counts.balance
+print('counting build: %d rays traversed of %d, %.1f box %.2f tri tests/ray; per-wave busy time mean %.1f us max %.1f us over %d waves'
+      % (nr, 2 * n * n * P, nb / nr, nt / nr, tot / max(nw, 1) / 100.0, mx / 100.0, nw))
+wt = ou.ops.env_shade_traversal_counts.wave_ticks.double()
+t0 = wt[:, 0].min()
+b, e = (wt[:, 0] - t0) / 100.0, (wt[:, 1] - t0) / 100.0
+q = torch.tensor([0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0], dtype=torch.float64)
+print('wave begin (us) quantiles', [round(x, 1) for x in torch.quantile(b, q).tolist()])
+print('wave end   (us) quantiles', [round(x, 1) for x in torch.quantile(e, q).tolist()])
+print('wave busy  (us) quantiles', [round(x, 1) for x in torch.quantile(e - b, q).tolist()])

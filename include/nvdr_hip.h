@@ -221,6 +221,17 @@ int nvdr_pbr_bsdf_bwd(const nvdr_tensor *kd, const nvdr_tensor *arm, const nvdr_
                       const nvdr_tensor *d_out, float *kd_grad, float *arm_grad, float *pos_grad, float *nrm_grad,
                       float *view_pos_grad, float *light_pos_grad, void *stream);
 
+/* ---- fused shading composite (additive; replaces the torch expressions of render/render.py:119-127 and the division of
+ * render/optixutils/ops.py:139-141):  out = (diff.rgb / diff.w) * kd * (1 - ks.z) + spec.rgb / spec.w  for bsdf 0 ('pbr'),
+ * (diff.rgb / diff.w) * kd for bsdf 1 ('diffuse' / 'white').  diff, spec: f32 [N,H,W,4] (colour sum, weight: the raw
+ * bilateral_denoiser_fwd output) or [N,H,W,3] (already normalised, weight 1); kd, ks [N,H,W,3] broadcastable.
+ * Gradients are contiguous at the full extent with the channel count of their input. */
+int nvdr_shade_composite_fwd(const nvdr_tensor *diff, const nvdr_tensor *spec, const nvdr_tensor *kd, const nvdr_tensor *ks,
+                             int bsdf, float *out, void *stream);
+int nvdr_shade_composite_bwd(const nvdr_tensor *diff, const nvdr_tensor *spec, const nvdr_tensor *kd, const nvdr_tensor *ks,
+                             int bsdf, const nvdr_tensor *d_out, float *diff_grad, float *spec_grad, float *kd_grad,
+                             float *ks_grad, void *stream);
+
 /* ---- EnvironmentLight.update_pdf (render/light.py:46-59) fused on device: base f32 [Hl,Wl,3] contiguous ->
  * pdf [Hl,Wl], cols [Hl,Wl], rows [Hl] (the reference materialises rows as [Hl,Wl] with identical
  * columns and passes rows[:,0], render.py:114). */

@@ -29,6 +29,14 @@
 
 #define NVDR_PI_DBL 3.14159265358979323846
 
+// minimum workgroups per CU the per-pixel kernels are compiled for (register budget = 512 / (4 waves * this / 4 SIMDs))
+#ifndef NVDR_SHADE_OCC
+#define NVDR_SHADE_OCC 1
+#endif
+#ifndef NVDR_GEN_OCC
+#define NVDR_GEN_OCC 1
+#endif
+
 
 struct Tab {          // small strided table (light, pdf, rows, cols)
     const float *p;
@@ -356,7 +364,7 @@ __device__ __forceinline__ unsigned flush_live(const unsigned *stage, unsigned s
     return 0;
 }
 
-__global__ void __launch_bounds__(256) env_gen_kernel(ShadeParams p)
+__global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = p.L, G = 64 >> p.log2L;
@@ -464,6 +472,12 @@ __global__ void __launch_bounds__(256) env_gen_kernel(ShadeParams p)
 #ifndef NVDR_TRACE_CHUNK_LOG2
 #define NVDR_TRACE_CHUNK_LOG2 6
 #endif
+#ifndef NVDR_TRACE_ALIGN
+#define NVDR_TRACE_ALIGN 6
+#endif
+#ifndef NVDR_TRACE_PAD
+#define NVDR_TRACE_PAD 10
+#endif
 template <bool COUNT>
 __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView bvh, const float4 *__restrict__ rays,
                                                                           const float4 *__restrict__ pix_origin,
@@ -505,6 +519,13 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     // Measured (same GPU session, bob 512^2 x 64 spp): ungated 1.36 ms, (16, 8) 1.23-1.31 ms, one-arm-per-iteration
     // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
     // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
+    // CODE PLACEMENT MATTERS HERE.  The same loop body runs at 0.76-0.83 ms or at 1.27-1.33 ms depending only on where
+    // it falls relative to 64-byte instruction-cache lines (measured for all 16 four-byte offsets: 12, 32, 36 and 48
+    // bytes are the slow ones; found because adding an unrelated kernel to this file moved the loop).  The preheader
+    // is therefore pinned to a 64-byte boundary plus NVDR_TRACE_PAD s_nops.  Re-measure the offsets (tools/
+    // build_variants.sh + tools/ab_run.sh) whenever the loop body changes.
+    asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
+    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
     while (true) {
         const unsigned long long idle = __ballot(ray < 0);
         const int n_idle = __popcll(idle);
@@ -592,7 +613,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
 // stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
 
 template <bool BACKWARD>
-__global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
+__global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_kernel(ShadeParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = p.L, G = 64 >> p.log2L;
@@ -670,6 +691,8 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
                 }
             }
             if (!active) continue;
+            F3 lg_add[2] = {f3(0.0f), f3(0.0f)};
+            int lg_at[2] = {0, 0};
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if ((dead >> r) & 1u) continue;         // contributes exactly zero to every output
@@ -694,13 +717,11 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
                     // therefore accumulates into ITS OWN copy with L2-resident (workgroup-scope encoding) atomics -- all
                     // CUs of an XCD share that L2, and the copy is picked by the XCC id the wave actually runs on, so
                     // the result does not depend on workgroup placement -- and a tiny kernel sums the 8 copies.
-                    float *g = xcd_light + (int64_t)((p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel) * 3;   // bit 4: contention experiment
-                    // adding +-0 never changes an accumulator that started at +0: occluded samples are skipped
-                    if (!(p.debug & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f)) {
-                        __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                    // The atomics of both samples are issued together after the loop over r: gfx950 counts loads, stores and
+                    // atomics in ONE in-order counter, so an atomic issued between the two samples would sit in front of
+                    // the second sample's texel / radiance loads and the wave would wait for its round trip.
+                    lg_add[r] = lg;
+                    lg_at[r] = (p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel;   // bit 4: contention experiment
                     const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
                     const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
                     if (p.bsdf == 1 || p.bsdf == 2) {
@@ -712,6 +733,19 @@ __global__ void __launch_bounds__(256) env_shade_kernel(ShadeParams p)
                 } else {
                     diffAccum += (((_diff * light_col) * V) * mis_weight) * sample_frac;
                     specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
+                }
+            }
+            if (BACKWARD && !(p.debug & 2u)) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    // adding +-0 never changes an accumulator that started at +0: occluded and dead samples are skipped
+                    const F3 lg = lg_add[r];
+                    if (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f) {
+                        float *g = xcd_light + (int64_t)lg_at[r] * 3;
+                        __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }

@@ -666,3 +666,75 @@ extern "C" int nvdr_pbr_bsdf_bwd(const nvdr_tensor *kd, const nvdr_tensor *arm, 
         store3(light_pos_grad, i, dlp);
     });
 }
+
+// ---- shade composite (render/render.py:119-127 + the division of optixutils/ops.py:139-141) ------------------------
+// The reference composes the final colour with ~10 small torch kernels per direction:
+//     diffuse  = diff_w.rgb / diff_w.w          (bilateral_denoiser's Python epilogue; skipped for 3-channel inputs)
+//     specular = spec_w.rgb / spec_w.w
+//     shaded   = diffuse * kd * (1 - ks.z) + specular         ('pbr')       or   diffuse * kd   ('diffuse', 'white')
+// Fused here into one streaming kernel per direction.  Additive API: nothing in the reference's plugin.
+__device__ __forceinline__ F3 fetch_rgb_over_w(const View4 &v, int n, int h, int w, float &inv_w)
+{
+    const float *q = v.p + n * v.s0 + h * v.s1 + w * v.s2;
+    const float wt = v.c == 4 ? q[3 * v.s3] : 1.0f;
+    inv_w = 1.0f / wt;
+    return f3(q[0] / wt, q[v.s3] / wt, q[2 * v.s3] / wt);   // true division, as torch does
+}
+static int check_accum(const nvdr_tensor *t, const Extent &e, const char *op, const char *name)
+{
+    NVDR_REQUIRE(t && t->data, "%s: %s is NULL", op, name);
+    NVDR_REQUIRE(t->size[0] == e.N && t->size[1] == e.H && t->size[2] == e.W && (t->size[3] == 3 || t->size[3] == 4),
+                 "%s: %s must be [%d,%d,%d,3] or [%d,%d,%d,4] (colour sum and weight), got [%lld,%lld,%lld,%lld]", op, name,
+                 e.N, e.H, e.W, e.N, e.H, e.W, (long long)t->size[0], (long long)t->size[1], (long long)t->size[2],
+                 (long long)t->size[3]);
+    return 0;
+}
+extern "C" int nvdr_shade_composite_fwd(const nvdr_tensor *diff, const nvdr_tensor *spec, const nvdr_tensor *kd,
+                                        const nvdr_tensor *ks, int bsdf, float *out, void *stream)
+{
+    static const char *OP = "shade_composite_fwd";
+    NVDR_REQUIRE(diff && spec && kd && ks && out, "%s: NULL argument", OP);
+    NVDR_REQUIRE(bsdf == 0 || bsdf == 1, "%s: bsdf must be 0 (pbr) or 1 (diffuse only)", OP);
+    const Extent e = make_extent(diff, spec, kd, ks);
+    int r;
+    if ((r = check_accum(diff, e, OP, "diff"))) return r;
+    if ((r = check_accum(spec, e, OP, "spec"))) return r;
+    CHECK_VIEW(kd, 3); CHECK_VIEW(ks, 3);
+    const View4 a = make_view4(*diff), b = make_view4(*spec), c = make_view4(*kd), d = make_view4(*ks);
+    return launch_ew(e, (hipStream_t)stream, [=] __device__(int n, int h, int w, int64_t i) {
+        float iwd, iws;
+        const F3 dn = fetch_rgb_over_w(a, n, h, w, iwd), sn = fetch_rgb_over_w(b, n, h, w, iws);
+        const F3 k = fetch3(c, n, h, w), arm = fetch3(d, n, h, w);
+        store3(out, i, bsdf == 0 ? dn * (k * (1.0f - arm.z)) + sn : dn * k);
+    });
+}
+extern "C" int nvdr_shade_composite_bwd(const nvdr_tensor *diff, const nvdr_tensor *spec, const nvdr_tensor *kd,
+                                        const nvdr_tensor *ks, int bsdf, const nvdr_tensor *d_out, float *diff_grad,
+                                        float *spec_grad, float *kd_grad, float *ks_grad, void *stream)
+{
+    static const char *OP = "shade_composite_bwd";
+    NVDR_REQUIRE(diff && spec && kd && ks && d_out && diff_grad && spec_grad && kd_grad && ks_grad, "%s: NULL argument", OP);
+    NVDR_REQUIRE(bsdf == 0 || bsdf == 1, "%s: bsdf must be 0 (pbr) or 1 (diffuse only)", OP);
+    const Extent e = make_extent(diff, spec, kd, ks);
+    int r;
+    if ((r = check_accum(diff, e, OP, "diff"))) return r;
+    if ((r = check_accum(spec, e, OP, "spec"))) return r;
+    CHECK_VIEW(kd, 3); CHECK_VIEW(ks, 3); CHECK_VIEW(d_out, 3);
+    const View4 a = make_view4(*diff), b = make_view4(*spec), c = make_view4(*kd), d = make_view4(*ks), g = make_view4(*d_out);
+    const int cd = (int)diff->size[3], cs = (int)spec->size[3];
+    return launch_ew(e, (hipStream_t)stream, [=] __device__(int n, int h, int w, int64_t i) {
+        float iwd, iws;
+        const F3 dn = fetch_rgb_over_w(a, n, h, w, iwd), sn = fetch_rgb_over_w(b, n, h, w, iws);
+        const F3 k = fetch3(c, n, h, w), arm = fetch3(d, n, h, w), go = fetch3(g, n, h, w);
+        const float om = bsdf == 0 ? 1.0f - arm.z : 1.0f;
+        const F3 d_dn = go * (k * om);                       // gradient of the normalised diffuse term
+        const F3 d_sn = bsdf == 0 ? go : f3(0.0f);
+        float *pd = diff_grad + i * cd, *ps = spec_grad + i * cs;
+        pd[0] = d_dn.x * iwd; pd[1] = d_dn.y * iwd; pd[2] = d_dn.z * iwd;
+        if (cd == 4) pd[3] = -sum3(d_dn * dn) * iwd;         // d(rgb / w) / dw = -rgb / w^2
+        ps[0] = d_sn.x * iws; ps[1] = d_sn.y * iws; ps[2] = d_sn.z * iws;
+        if (cs == 4) ps[3] = -sum3(d_sn * sn) * iws;
+        store3(kd_grad, i, go * dn * om);
+        store3(ks_grad, i, f3(0.0f, 0.0f, bsdf == 0 ? -sum3(go * dn * k) : 0.0f));
+    });
+}

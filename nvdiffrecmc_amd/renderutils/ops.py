@@ -292,3 +292,54 @@ def xfm_vectors(vectors, matrix, use_python=False):
     else:
         out = _xfm_func.apply(vectors, matrix, False)
     return _finite(out, 'xfm_vectors')
+
+
+# ----------------------------------------------------------------------------------------------
+# fused shading composite (additive: the reference writes this in torch, render/render.py:119-127)
+
+class _shade_composite_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, diff, spec, kd, ks, bsdf):
+        for t, name in ((diff, 'diff'), (spec, 'spec')):
+            _lib.require_cuda_f32(t, name)
+            if t.dim() != 4 or t.shape[3] not in (3, 4):
+                raise RuntimeError("shade_composite: %s must be [N,H,W,3] or [N,H,W,4] (got %s)" % (name, tuple(t.shape)))
+        _check4(kd, 'shade_composite kd', 3)
+        _check4(ks, 'shade_composite ks', 3)
+        N, H, W = _extent(diff, spec, kd, ks)
+        out = torch.empty(N, H, W, 3, dtype=torch.float32, device=diff.device)
+        keep, refs = _views(diff, spec, kd, ks)
+        _lib.check(_lib.load().nvdr_shade_composite_fwd(*refs, bsdf, _lib.ptr(out), _lib.stream_ptr()), 'shade_composite_fwd')
+        ctx.save_for_backward(diff, spec, kd, ks)
+        ctx.bsdf = bsdf
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        diff, spec, kd, ks = ctx.saved_tensors
+        N, H, W = _extent(diff, spec, kd, ks)
+        dout = dout.contiguous()
+        grads = [torch.empty(N, H, W, c, dtype=torch.float32, device=dout.device) for c in (diff.shape[3], spec.shape[3], 3, 3)]
+        keep, refs = _views(diff, spec, kd, ks, dout)
+        _lib.check(_lib.load().nvdr_shade_composite_bwd(*refs[:4], ctx.bsdf, refs[4], *[_lib.ptr(g) for g in grads],
+                                                        _lib.stream_ptr()), 'shade_composite_bwd')
+        # broadcast inputs get their gradient at the full extent: fold it (the caller-sums rule of tensor.h:60-62)
+        out = []
+        for g, t in zip(grads, (diff, spec, kd, ks)):
+            for d in range(4):
+                if t.shape[d] == 1 and g.shape[d] != 1:
+                    g = g.sum(d, keepdim=True)
+            out.append(g)
+        return tuple(out) + (None,)
+
+
+def shade_composite(diffuse_accum, specular_accum, kd, ks, bsdf='pbr', use_python=False):
+    '''Final colour of the direct-lighting pass: (diffuse / w) * kd * (1 - metalness) + specular / w for 'pbr',
+    (diffuse / w) * kd for 'diffuse' / 'white' (render.py:119-127).  diffuse_accum / specular_accum are either the
+    [N,H,W,4] (colour sum, weight) output of the bilateral filter kernel -- the division of ops.py:139-141 is folded
+    in -- or plain [N,H,W,3] images.  One kernel per direction instead of ~10 torch kernels.'''
+    if use_python:
+        out = torch_ref.shade_composite(diffuse_accum, specular_accum, kd, ks, bsdf)
+    else:
+        out = _shade_composite_func.apply(diffuse_accum, specular_accum, kd, ks, 0 if bsdf == 'pbr' else 1)
+    return _finite(out, 'shade_composite')

@@ -104,3 +104,12 @@ def image_loss(img, target, loss, tonemapper):
     if loss == 'n2n':
         return (d * d / (img.detach() ** 2 + 0.01)).mean()
     return d.abs().mean()
+
+
+def shade_composite(diff, spec, kd, ks, bsdf='pbr'):
+    """render/render.py:119-127 with the division of optixutils/ops.py:139-141 in front."""
+    d = diff[..., 0:3] / diff[..., 3:4] if diff.shape[-1] == 4 else diff
+    s = spec[..., 0:3] / spec[..., 3:4] if spec.shape[-1] == 4 else spec
+    if bsdf == 'pbr':
+        return d * (kd * (1.0 - ks[..., 2:3])) + s
+    return d * kd

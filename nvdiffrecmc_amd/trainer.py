@@ -7,8 +7,8 @@ the parts that touch the hot path:
     optix_build_bvh(rebuild=1)                           dlmesh.py:50      -> csrc/bvh.hip
     prepare_shading_normal                               render.py:99      -> csrc/renderutils.hip
     optix_env_shade (fwd)                                render.py:113     -> csrc/env_shade.hip
-    BilateralDenoiser x2 on cat(light, normal, depth)    render.py:120-121 -> csrc/denoise.hip
-    shaded = diffuse * kd * (1 - metal) + specular       render.py:126-127
+    bilateral filter x2 on (light, normal, depth)        render.py:120-121 -> csrc/denoise.hip
+    shaded = diffuse * kd * (1 - metal) + specular       render.py:126-127 -> csrc/renderutils.hip (shade_composite)
     image_loss('l1', 'log_srgb')                         train.py:51-66    -> csrc/renderutils.hip
     backward through all of it (env-shade re-traces)     train.py:438
     gradient all-reduce (new: one view per GPU)          --                -> parallel.py
@@ -25,7 +25,7 @@ import torch
 from . import optixutils as ou
 from . import renderutils as ru
 from . import scene as sc
-from .denoiser import BilateralDenoiser
+from .denoiser import BilateralDenoiser, _safe_normalize
 from .light import EnvironmentLight
 from .parallel import allreduce_gradients
 
@@ -50,11 +50,12 @@ class _gather_rows(torch.autograd.Function):
 
 class DirectLightingStep:
     def __init__(self, mesh_name='bob', res=512, n_samples_x=8, view=0, n_views=8, device='cuda', env='E1',
-                 probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01):
+                 probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view
         self.pixel_index_offset = pixel_index_offset
         self.retrace_backward = retrace_backward
+        self.fused = fused
         mesh = sc.load_mesh(mesh_name, device='cpu')
         if subdiv:
             mesh['v_pos'], mesh['t_pos_idx'] = sc.subdivide(mesh['v_pos'], mesh['t_pos_idx'], subdiv)
@@ -137,7 +138,16 @@ class DirectLightingStep:
                                         light._pdf, light.rows[:, 0], light.cols, BSDF='pbr', n_samples_x=self.n,
                                         rnd_seed=self.seed, shadow_scale=1.0)
         self.seed += 1
-        if self.denoiser is not None:
+        if self.fused:
+            # same arithmetic as the branch below; the normal is normalised once for both filter passes, the filter
+            # kernel is called without the 8-channel cat, and its (colour sum, weight) output goes straight into the
+            # fused composite: ~45 small torch kernels per iteration less
+            if self.denoiser is not None:
+                nn = _safe_normalize(nrm)
+                diff = ou.ops._bilateral_denoiser_func.apply(diff, nn, self.gb_depth, self.denoiser.sigma)
+                spec = ou.ops._bilateral_denoiser_func.apply(spec, nn, self.gb_depth, self.denoiser.sigma)
+            return ru.shade_composite(diff, spec, kd, ks)
+        if self.denoiser is not None:   # the reference's own sequence of calls (render.py:119-127)
             diff = self.denoiser.forward(torch.cat((diff, nrm, self.gb_depth), dim=-1))
             spec = self.denoiser.forward(torch.cat((spec, nrm, self.gb_depth), dim=-1))
         return diff * (kd * (1.0 - ks[..., 2:3])) + spec

@@ -125,3 +125,15 @@ def test_training_step_reduces_loss(dev):
     st.forward_backward()
     for a, b in zip(g1, [p.grad for p in st.params]):
         assert_close(b, a, 1e-4, floor=1e-3 * a.abs().max().item())
+    # the fused composite / direct filter calls give the gradients of the reference's own sequence of torch calls
+    st.retrace_backward = True
+    st.fused = False
+    st.seed = 100
+    l0 = st.forward_backward().item()
+    g0 = [p.grad.clone() for p in st.params]
+    st.fused = True
+    st.seed = 100
+    l1 = st.forward_backward().item()
+    assert abs(l0 - l1) < 1e-5 * abs(l0)
+    for a, b in zip(g0, [p.grad for p in st.params]):
+        assert_close(b, a, 1e-4, floor=1e-3 * a.abs().max().item())

@@ -612,6 +612,10 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
 // ---------------------------------------------------------------------------------------------
 // stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
 
+// Tried on the backward instantiation and dropped (no gain, same GPU session): issuing the light-gradient atomics after both
+// samples / 3-4 waves per SIMD with spills (launch bounds) / fast division + contraction + fp32 islands (-23 % VALU
+// instructions, but gradient errors of 1e-2) -- all 0.87-0.93 ms.  0.37 ms of it is the 8 M float atomics: every one leaves
+// the XCD as a 64-byte write (rocprofv3 WRITE_SIZE = 506 MB per launch).
 template <bool BACKWARD>
 __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_kernel(ShadeParams p)
 {
@@ -895,8 +899,12 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     if (!backward) {
         NVDR_REQUIRE(a->diff && a->spec, "env_shade_fwd: NULL output");
         p.diff = a->diff; p.spec = a->spec;
-        NVDR_HIP_TRY(hipMemsetAsync(p.diff, 0, sizeof(float) * 3 * npix, stream)); // torch::zeros, torch_bindings.cpp:148-149
-        NVDR_HIP_TRY(hipMemsetAsync(p.spec, 0, sizeof(float) * 3 * npix, stream));
+        if (p.spec == p.diff + 3 * npix) {
+            NVDR_HIP_TRY(hipMemsetAsync(p.diff, 0, sizeof(float) * 6 * npix, stream)); // torch::zeros, torch_bindings.cpp:148-149
+        } else {
+            NVDR_HIP_TRY(hipMemsetAsync(p.diff, 0, sizeof(float) * 3 * npix, stream));
+            NVDR_HIP_TRY(hipMemsetAsync(p.spec, 0, sizeof(float) * 3 * npix, stream));
+        }
     } else {
         NVDR_REQUIRE(a->gb_pos_grad && a->gb_normal_grad && a->gb_kd_grad && a->gb_ks_grad && a->light_grad,
                      "env_shade_bwd: NULL output");
@@ -905,10 +913,14 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         p.dgrad = make_view4(a->diff_grad); p.sgrad = make_view4(a->spec_grad);
         p.g_pos = a->gb_pos_grad; p.g_nrm = a->gb_normal_grad; p.g_kd = a->gb_kd_grad; p.g_ks = a->gb_ks_grad;
         p.g_light = a->light_grad;
-        NVDR_HIP_TRY(hipMemsetAsync(p.g_pos, 0, sizeof(float) * 3 * npix, stream));
-        NVDR_HIP_TRY(hipMemsetAsync(p.g_nrm, 0, sizeof(float) * 3 * npix, stream));
-        NVDR_HIP_TRY(hipMemsetAsync(p.g_kd, 0, sizeof(float) * 3 * npix, stream));
-        NVDR_HIP_TRY(hipMemsetAsync(p.g_ks, 0, sizeof(float) * 3 * npix, stream));
+        if (p.g_nrm == p.g_pos + 3 * npix && p.g_kd == p.g_nrm + 3 * npix && p.g_ks == p.g_kd + 3 * npix) {
+            NVDR_HIP_TRY(hipMemsetAsync(p.g_pos, 0, sizeof(float) * 12 * npix, stream));   // caller packed the four outputs
+        } else {
+            NVDR_HIP_TRY(hipMemsetAsync(p.g_pos, 0, sizeof(float) * 3 * npix, stream));
+            NVDR_HIP_TRY(hipMemsetAsync(p.g_nrm, 0, sizeof(float) * 3 * npix, stream));
+            NVDR_HIP_TRY(hipMemsetAsync(p.g_kd, 0, sizeof(float) * 3 * npix, stream));
+            NVDR_HIP_TRY(hipMemsetAsync(p.g_ks, 0, sizeof(float) * 3 * npix, stream));
+        }
         p.light_elems = (int)(3 * a->light.size[0] * a->light.size[1]);
         if (c->lg_cap < (size_t)p.light_elems * 8) {
             NVDR_HIP_TRY(hipStreamSynchronize(stream));

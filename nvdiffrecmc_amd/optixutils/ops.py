@@ -132,8 +132,7 @@ class _optix_env_shade_func(torch.autograd.Function):
         a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
                        BSDF, n_samples_x, _rnd_seed, shadow_scale, off)
         N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
-        diff = torch.empty(N, H, W, 3, dtype=torch.float32, device=ro.device)
-        spec = torch.empty(N, H, W, 3, dtype=torch.float32, device=ro.device)
+        diff, spec = torch.empty(2, N, H, W, 3, dtype=torch.float32, device=ro.device).unbind(0)   # one zero-fill
         a.diff, a.spec = diff.data_ptr(), spec.data_ptr()
         vis = None
         if rnd_seed is not None and _optix_env_shade_func.cache_visibility:
@@ -169,10 +168,8 @@ class _optix_env_shade_func(torch.autograd.Function):
         diff_grad, spec_grad = diff_grad.contiguous(), spec_grad.contiguous()
         a.diff_grad = _lib.tensor_view(diff_grad, lead=False)
         a.spec_grad = _lib.tensor_view(spec_grad, lead=False)
-        gb_pos_grad = torch.empty(N, H, W, 3, dtype=torch.float32, device=dev)
-        gb_normal_grad = torch.empty(N, H, W, 3, dtype=torch.float32, device=dev)
-        gb_kd_grad = torch.empty(N, H, W, 3, dtype=torch.float32, device=dev)
-        gb_ks_grad = torch.empty(N, H, W, 3, dtype=torch.float32, device=dev)
+        # one allocation for the four per-pixel gradients: the library zero-fills contiguous outputs with one memset
+        gb_pos_grad, gb_normal_grad, gb_kd_grad, gb_ks_grad = torch.empty(4, N, H, W, 3, dtype=torch.float32, device=dev).unbind(0)
         light_grad = torch.empty(light.shape[0], light.shape[1], 3, dtype=torch.float32, device=dev)
         a.gb_pos_grad, a.gb_normal_grad = gb_pos_grad.data_ptr(), gb_normal_grad.data_ptr()
         a.gb_kd_grad, a.gb_ks_grad, a.light_grad = gb_kd_grad.data_ptr(), gb_ks_grad.data_ptr(), light_grad.data_ptr()
@@ -253,7 +250,7 @@ def trace_visibility(optix_ctx, ro, rd, count=False):
     ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
     R = ro.shape[0]
     vis = torch.empty(R, dtype=torch.uint8, device=ro.device)
-    cnt = torch.zeros(8 + 2 * 8192, dtype=torch.int64, device=ro.device) if count else None
+    cnt = torch.zeros(2, dtype=torch.int64, device=ro.device) if count else None
     _lib.check(w.lib.nvdr_trace_visibility(w.handle, _lib.ptr(ro), _lib.ptr(rd), R, _lib.ptr(vis), _lib.ptr(cnt),
                                            _lib.stream_ptr()), 'trace_visibility')
     return (vis, cnt) if count else vis

@@ -48,6 +48,22 @@ class _gather_rows(torch.autograd.Function):
         return out, None
 
 
+class _broadcast_pixels(torch.autograd.Function):
+    """x[C] -> [N,H,W,C] stride-0 view, with a column sum as backward that does not go through torch's generic
+    reduction (summing [262144, 3] over its long dimension took 91 us: one wavefront per output column)."""
+
+    @staticmethod
+    def forward(ctx, x, N, H, W):
+        return x.view(1, 1, 1, -1).expand(N, H, W, x.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        C = g.shape[-1]
+        P = g.numel() // C
+        k = 256 if P % 256 == 0 else 1
+        return g.reshape(P // k, k * C).sum(0).view(k, C).sum(0), None, None, None
+
+
 class DirectLightingStep:
     def __init__(self, mesh_name='bob', res=512, n_samples_x=8, view=0, n_views=8, device='cuda', env='E1',
                  probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True):
@@ -128,7 +144,8 @@ class DirectLightingStep:
         m = self.mask[..., None]
         kd = torch.zeros(self.res * self.res, 3, device=self.dev).index_copy(0, self.cov, _gather_rows.apply(kd_tex, self.texel_cov))
         kd = kd.view(1, self.res, self.res, 3)
-        ks = (ks_vec.view(1, 1, 1, 3) * m)
+        # uncovered pixels are skipped by the mask in env-shade and have zero light in the composite: no ks * mask needed
+        ks = _broadcast_pixels.apply(ks_vec, 1, self.res, self.res) if self.fused else (ks_vec.view(1, 1, 1, 3) * m)
         nrm = ru.prepare_shading_normal(self.gb_pos, self.view_pos, None, self.gb_smooth_nrm, self.gb_tangent,
                                         self.gb_geom_nrm, two_sided_shading=True, opengl=True)
         ro = self.gb_pos + nrm * 0.001

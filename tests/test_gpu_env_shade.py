@@ -162,3 +162,70 @@ def test_dead_samples_are_exactly_zero(mesh, n, bsdf, dev, monkeypatch):
     monkeypatch.delenv('NVDR_DEBUG')
     assert P == P2 and traced_all == 2 * n * n * P
     assert 0.5 * traced_all < traced < 0.95 * traced_all
+
+
+def test_backward_after_another_forward_regenerates_the_stream(dev):
+    """The backward pass re-uses the forward's ray stream only while it is still the context's most recent one: a second
+    forward (other seed) in between, or a BVH rebuild, must make backward regenerate the samples -- same gradients."""
+    from nvdiffrecmc_amd import optixutils as ou
+    H = W = 48
+    n = 4
+    inp = scene_cpu.make_inputs('bob', H, W, n, view=2, probe_res=64, n_threads=NT)
+    kw = scene_cpu.shade_kwargs(inp)
+    m = inp['mesh']
+    ctx = make_ctx(m, dev)
+    ou.ops.set_permutation_table(n, kw['perms'].to(dev))
+    d = {k: v.to(dev) for k, v in kw.items() if k != 'perms'}
+    leaves = ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')
+
+    def fwd(seed):
+        g = dict(d)
+        for k in leaves:
+            g[k] = d[k].clone().requires_grad_(True)
+        out = ou.optix_env_shade(ctx, g['mask'], g['ro'], g['gb_pos'], g['gb_normal'], g['gb_view_pos'], g['gb_kd'], g['gb_ks'],
+                                 g['light'], g['pdf'], g['rows'], g['cols'], BSDF='pbr', n_samples_x=n, rnd_seed=seed)
+        return g, out
+
+    def grads(g, out):
+        (out[0].sum() + 2.0 * out[1].sum()).backward()
+        return [g[k].grad.clone() for k in leaves]
+
+    g, out = fwd(7)
+    ref = grads(g, out)                                   # plain forward -> backward (stream re-used)
+    g, out = fwd(7)
+    fwd(8)                                                # another launch overwrites the context's stream
+    got = grads(g, out)
+    for a, b, k in zip(got[:4], ref[:4], leaves):
+        assert torch.equal(a, b), k
+    assert_close(got[4], ref[4], 1e-4, floor=1e-3 * max(1.0, ref[4].abs().max().item()))
+    g, out = fwd(7)
+    ou.optix_build_bvh(ctx, m['v_pos'].to(dev), m['t_pos_idx'].to(dev), rebuild=1)   # same geometry, new build
+    got = grads(g, out)
+    for a, b, k in zip(got[:4], ref[:4], leaves):
+        assert torch.equal(a, b), k
+    # decorrelated seeds (rnd_seed=None, ops.py:83,99): forward and backward draw independent samples; must run and be finite
+    g, out = fwd(None)
+    got = grads(g, out)
+    assert all(torch.isfinite(x).all() for x in got) and got[1].abs().sum().item() > 0 and got[4].abs().sum().item() > 0
+
+
+def test_stage_profiling_hooks(dev):
+    """nvdr_ctx_set_profiling / nvdr_env_shade_stage_times (the HIP-event timing bench.py's roofline uses)."""
+    H = W = 64
+    n = 4
+    inp = scene_cpu.make_inputs('bob', H, W, n, view=1, probe_res=64, n_threads=NT)
+    kw = scene_cpu.shade_kwargs(inp)
+    ctx = make_ctx(inp['mesh'], dev)
+    g = torch.Generator().manual_seed(1)
+    dg, sg = torch.rand(1, H, W, 3, generator=g), torch.rand(1, H, W, 3, generator=g)
+    ctx.set_profiling(True)
+    for seed in range(3):
+        gpu_env_shade(ctx, kw, dev, 'pbr', n, seed, dg, sg)
+    nf, f = ctx.stage_times(backward=False)
+    nb, b = ctx.stage_times(backward=True)
+    ctx.set_profiling(False)
+    assert nf == 3 and nb == 3
+    assert all(t > 0 for t in f) and b[1] > 0 and b[2] > 0
+    assert b[0] < f[0]          # backward re-used the stream: no sample generation
+    nf, f = ctx.stage_times(backward=False)
+    assert nf == 0

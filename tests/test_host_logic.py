@@ -103,3 +103,24 @@ def test_bench_algorithmic_byte_formula():
     assert trav == 32 * 10 + 36 * 2
     assert total == trav + (4 * 512 * 512 + 60 * 1000 + 24 * 512 * 512) + 1000 * 64 * 128   # 128 B per stratum at 256^2
     assert trace == trav + 17 * (2 * 64 * 1000) + 16 * 1000
+
+
+def test_broadcast_pixels_column_sum_and_composite_reference():
+    """Harness helpers that run on any device: the stride-0 broadcast with its two-step column-sum backward, and the
+    torch formulation of the fused composite (render.py:119-127) the HIP op is tested against."""
+    from nvdiffrecmc_amd.trainer import _broadcast_pixels
+    from nvdiffrecmc_amd.renderutils import torch_ref
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(3, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = torch.rand(2, 16, 32, 3, generator=g, dtype=torch.float64)       # 1024 pixels: the k = 256 path
+    (_broadcast_pixels.apply(x, 2, 16, 32) * w).sum().backward()
+    assert torch.allclose(x.grad, w.sum((0, 1, 2)), rtol=1e-12)
+    x.grad = None
+    w = torch.rand(1, 5, 7, 3, generator=g, dtype=torch.float64)         # 35 pixels: the k = 1 path
+    (_broadcast_pixels.apply(x, 1, 5, 7) * w).sum().backward()
+    assert torch.allclose(x.grad, w.sum((0, 1, 2)), rtol=1e-12)
+    d4, s4 = torch.rand(1, 4, 4, 4, generator=g) + 0.1, torch.rand(1, 4, 4, 4, generator=g) + 0.1
+    kd, ks = torch.rand(1, 4, 4, 3, generator=g), torch.rand(1, 4, 4, 3, generator=g)
+    ref = (d4[..., :3] / d4[..., 3:]) * kd * (1 - ks[..., 2:3]) + s4[..., :3] / s4[..., 3:]
+    assert torch.allclose(torch_ref.shade_composite(d4, s4, kd, ks, 'pbr'), ref, rtol=1e-6)
+    assert torch.allclose(torch_ref.shade_composite(d4[..., :3], s4[..., :3], kd, ks, 'diffuse'), d4[..., :3] * kd, rtol=1e-6)

@@ -17,6 +17,11 @@
 //       lines twice as often costs +65 %.  Two lookups per node instead of four is the lever.
 //       The ray is transformed into grid space once (o' = (o - g_lo) * g_scale, d' = d * g_scale), which
 //       leaves the ray parameter t unchanged, so the slab test runs directly on the decoded integers.
+//   wide[n]   : 4 x uint4 = 64 B per internal node: the node's up to four GRANDCHILDREN (both children expanded one
+//       level; a leaf child stays one slot), one uint4 per slot = the slot's quantised box (3 words as above) +
+//       its child reference (>= 0 internal node, < 0 leaf, NVDR_TRAV_EMPTY unused slot).  Derived from nodes[] by
+//       one kernel after the fit; the shadow-ray traversal of env-shade walks THESE (half the dependent steps:
+//       the step's fixed cost -- ballots, stack, loop -- is paid once per four box tests instead of per two).
 //   tris[k]   : 3 x float4 = 48 B per triangle in Morton order, world space, full precision:
 //       (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, orig_index_bits, 0, 0) -- the hit predicate itself
 //       (include/nvdr_raytri.h) never sees quantised data.
@@ -31,10 +36,11 @@
 // per-lane column of an HBM scratch buffer owned by the context.  Sizing for the worst case this way
 // needs no read-back of the tree height, so nothing on the query path synchronises the host.
 #define NVDR_STACK_LDS 16
-#define NVDR_STACK_MAX 72
+#define NVDR_STACK_MAX 104
 #define NVDR_QUERY_BLOCK 256                 // threads per workgroup of every traversal kernel
 #define NVDR_QUERY_MAX_BLOCKS 2048           // persistent / grid-stride launches never exceed this
 #define NVDR_TRAV_DONE 0x7fffffff            // traversal marker: nothing left (never a valid node / leaf id)
+#define NVDR_TRAV_EMPTY 0x7ffffff0           // child reference of an unused slot of a wide node
 #define NVDR_GRID_MAX 65531.0f               // usable span of the 16-bit box grid (2 cells of slack on both ends)
 
 struct BvhDeviceInfo {
@@ -55,6 +61,7 @@ struct nvdr_ctx {
     int64_t n_tris = 0;
     int64_t n_verts = 0;
     uint4 *nodes = nullptr;        // [2 * cap]
+    uint4 *wide = nullptr;         // [4 * cap] four-slot nodes derived from nodes[]
     float4 *tris = nullptr;        // [3 * cap]
     uint32_t *keys[2] = {nullptr, nullptr};
     uint32_t *vals[2] = {nullptr, nullptr};
@@ -88,6 +95,7 @@ struct nvdr_ctx {
 
 struct BvhView {
     const uint4 *nodes;
+    const uint4 *wide;
     const float4 *tris;
     const BvhDeviceInfo *info;
     int n_tris;
@@ -97,6 +105,7 @@ static inline BvhView bvh_view(const nvdr_ctx *c)
 {
     BvhView v;
     v.nodes = c->nodes;
+    v.wide = c->wide;
     v.tris = c->tris;
     v.info = c->dinfo;
     v.n_tris = (int)c->n_tris;
@@ -163,6 +172,7 @@ __device__ __forceinline__ bool tri_any_hit(const float4 *__restrict__ tris, int
 // A ray in grid space (for the box tests only): t(b) = b * inv + noi with noi = -o * inv, one fused op per plane.
 struct GridRay {
     float nx, ny, nz, ix, iy, iz;
+    unsigned px, py, pz;    // v_perm_b32 selectors that order a slot's (lo, hi) pair of an axis as (near, far) for this ray
 };
 __device__ __forceinline__ GridRay make_grid_ray(const BvhDeviceInfo *__restrict__ info, float ox, float oy, float oz,
                                                  float dx, float dy, float dz)
@@ -175,6 +185,12 @@ __device__ __forceinline__ GridRay make_grid_ray(const BvhDeviceInfo *__restrict
     g.nx = -((ox - info->g_lo[0]) * sx + 2.0f) * g.ix;
     g.ny = -((oy - info->g_lo[1]) * sy + 2.0f) * g.iy;
     g.nz = -((oz - info->g_lo[2]) * sz + 2.0f) * g.iz;
+    // slot words: x = lo.x | lo.y << 16, y = lo.z | hi.x << 16, z = hi.y | hi.z << 16.  v_perm_b32(S0, S1, sel) picks each
+    // result byte from S1 (selector 0-3) or S0 (4-7):  X = perm(x, y): lo.x = bytes 4,5 / hi.x = bytes 2,3;
+    // Y = perm(x, z): lo.y = 6,7 / hi.y = 0,1;  Z = perm(y, z): lo.z = 4,5 / hi.z = 2,3.  Result = near | far << 16.
+    g.px = g.ix >= 0.0f ? 0x03020504u : 0x05040302u;
+    g.py = g.iy >= 0.0f ? 0x01000706u : 0x07060100u;
+    g.pz = g.iz >= 0.0f ? 0x03020504u : 0x05040302u;
     return g;
 }
 
@@ -218,6 +234,22 @@ __device__ __forceinline__ NodeHit visit_node(const uint4 *__restrict__ nodes, i
     h.cl = (int)b.z;
     h.cr = (int)b.w;
     return h;
+}
+
+// one slot of a wide node: box (x, y, z words) + child reference (w).  The (lo, hi) pair of every axis is ordered
+// (near, far) for this ray by one byte permute with a per-ray selector, which replaces the min/max pair of the
+// generic slab test: 3 perm + 6 cvt + 6 fma + 4 instead of 6 cvt + 6 fma + 6 min/max + 4.
+__device__ __forceinline__ bool slot_hit(const uint4 &q, const GridRay &r, float tmax, float &tnear)
+{
+    const unsigned X = __builtin_amdgcn_perm(q.x, q.y, r.px), Y = __builtin_amdgcn_perm(q.x, q.z, r.py),
+                   Z = __builtin_amdgcn_perm(q.y, q.z, r.pz);
+    const float nx = fmaf(lo16(X), r.ix, r.nx), fx = fmaf(hi16(X), r.ix, r.nx);
+    const float ny = fmaf(lo16(Y), r.iy, r.ny), fy = fmaf(hi16(Y), r.iy, r.ny);
+    const float nz = fmaf(lo16(Z), r.iz, r.nz), fz = fmaf(hi16(Z), r.iz, r.nz);
+    const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    const float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
+    tnear = tn;
+    return (tn <= tf) & ((int)q.w != NVDR_TRAV_EMPTY);
 }
 
 // ---------------------------------------------------------------------------------------------

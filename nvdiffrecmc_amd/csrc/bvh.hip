@@ -318,15 +318,41 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_closest_kernel(BvhView
     }
 }
 
+// wide[i] = the (up to four) grandchildren of internal node i, see bvh.h
+__global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal, uint4 *__restrict__ wide)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_internal) return;
+    const uint4 a = nodes[2 * i], b = nodes[2 * i + 1];
+    uint4 slot[4];
+    int k = 0;
+    const int child[2] = {(int)b.z, (int)b.w};
+    const uint4 own[2] = {make_uint4(a.x, a.y, a.z, b.z), make_uint4(a.w, b.x, b.y, b.w)};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (child[s] >= 0) {                    // internal child: its two children take a slot each
+            const uint4 ca = nodes[2 * child[s]], cb = nodes[2 * child[s] + 1];
+            slot[k++] = make_uint4(ca.x, ca.y, ca.z, cb.z);
+            slot[k++] = make_uint4(ca.w, cb.x, cb.y, cb.w);
+        } else {
+            slot[k++] = own[s];                 // leaf child: box from this node
+        }
+    }
+    for (; k < 4; ++k) slot[k] = make_uint4(0u, 0u, 0u, (unsigned)NVDR_TRAV_EMPTY);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wide[4 * (int64_t)i + q] = slot[q];
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 
 static int ctx_free_bvh(nvdr_ctx *c)
 {
-    hipFree(c->nodes); hipFree(c->tris);
+    hipFree(c->nodes); hipFree(c->wide); hipFree(c->tris);
     hipFree(c->keys[0]); hipFree(c->keys[1]); hipFree(c->vals[0]); hipFree(c->vals[1]);
     hipFree(c->parent); hipFree(c->flags); hipFree(c->heights); hipFree(c->sort_tmp);
     c->nodes = nullptr;
+    c->wide = nullptr;
     c->tris = nullptr;
     c->keys[0] = c->keys[1] = c->vals[0] = c->vals[1] = nullptr;
     c->parent = c->flags = c->heights = nullptr;
@@ -387,6 +413,7 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     ctx_free_bvh(c);
     const int64_t cap = n_tris + n_tris / 2 + 64;
     NVDR_HIP_TRY(hipMalloc((void **)&c->nodes, sizeof(uint4) * 2 * cap));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->wide, sizeof(uint4) * 4 * cap));
     NVDR_HIP_TRY(hipMalloc((void **)&c->tris, sizeof(float4) * 3 * cap));
     for (int i = 0; i < 2; ++i) {
         NVDR_HIP_TRY(hipMalloc((void **)&c->keys[i], sizeof(uint32_t) * cap));
@@ -437,6 +464,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
     bvh_fit_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->parent,
                                                         c->flags, c->heights, c->dinfo);
+    if (n > 1) bvh_widen_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->nodes, n - 1, c->wide);
     NVDR_LAUNCH_CHECK();
     c->n_tris = n_tris;
     c->n_verts = n_verts;

@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
 #define NVDR_TRACE_ALIGN 6
 #endif
 #ifndef NVDR_TRACE_PAD
-#define NVDR_TRACE_PAD 10
+#define NVDR_TRACE_PAD 6
 #endif
 template <bool COUNT>
 __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView bvh, const float4 *__restrict__ rays,
@@ -511,6 +511,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
     GridRay g;
     g.nx = g.ny = g.nz = g.ix = g.iy = g.iz = 0.0f;
+    g.px = g.py = g.pz = 0u;
     // The three arms of an iteration -- refill, leaf step, node step -- are gated by WAVE-UNIFORM lane counts so that
     // the two expensive rare ones are never issued for a handful of lanes:
     //   refill : when >= NVDR_REFILL_MIN lanes are idle (or nobody can step) and the range still has rays;
@@ -519,11 +520,12 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     // Measured (same GPU session, bob 512^2 x 64 spp): ungated 1.36 ms, (16, 8) 1.23-1.31 ms, one-arm-per-iteration
     // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
     // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
-    // CODE PLACEMENT MATTERS HERE.  The same loop body runs at 0.76-0.83 ms or at 1.27-1.33 ms depending only on where
-    // it falls relative to 64-byte instruction-cache lines (measured for all 16 four-byte offsets: 12, 32, 36 and 48
-    // bytes are the slow ones; found because adding an unrelated kernel to this file moved the loop).  The preheader
-    // is therefore pinned to a 64-byte boundary plus NVDR_TRACE_PAD s_nops.  Re-measure the offsets (tools/
-    // build_variants.sh + tools/ab_run.sh) whenever the loop body changes.
+    // CODE PLACEMENT MATTERS HERE.  The same loop body runs ~1.6x slower for some placements relative to the 64-byte
+    // instruction-cache lines (binary-node version of this loop: 0.76-0.83 ms at 12 of the 16 four-byte offsets,
+    // 1.27-1.33 ms at 12, 32, 36 and 48 bytes; first wide-node version: 0.71 ms vs 1.20 ms at 24 and 32 bytes; found
+    // because adding an unrelated kernel to this file moved the loop).  The preheader is therefore pinned to a 64-byte
+    // boundary plus NVDR_TRACE_PAD s_nops (current body: 0.67-0.68 ms at all even paddings 0..14).  Re-measure
+    // (tools/build_variants.sh + tools/ab_run.sh) whenever the loop body changes.
     asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
     asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
     while (true) {
@@ -567,14 +569,25 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
         }
         const int popv = stack.peek(sp);                // value a pop would return (unused when sp == 0)
         if (node_turn && ray >= 0 && cur >= 0) {
-            const NodeHit h = visit_node(bvh.nodes, cur, g, NVDR_RAY_TMAX);
-            if (COUNT) n_box += 2;
-            const bool both = h.hl & h.hr, any = h.hl | h.hr;
-            const bool left_first = h.tl <= h.tr;
-            const int nearc = h.hl ? ((h.hr & !left_first) ? h.cr : h.cl) : h.cr;
-            stack.push_spec(sp, left_first ? h.cr : h.cl, both);   // stored always, kept only if both were hit
-            sp += both ? 1 : 0;
-            nxt = any ? nearc : POP;
+            // one step = the four grandchildren of `cur` (bvh.h "wide"): test all, continue with the nearest hit, push
+            // the other hits.  Any-hit needs no exact order; nearest-first just finds occluders sooner.
+            const uint4 *w4 = bvh.wide + 4 * (int64_t)cur;
+            const uint4 q0 = w4[0], q1 = w4[1], q2 = w4[2], q3 = w4[3];
+            float t0, t1, t2, t3;
+            const bool h0 = slot_hit(q0, g, NVDR_RAY_TMAX, t0), h1 = slot_hit(q1, g, NVDR_RAY_TMAX, t1);
+            const bool h2 = slot_hit(q2, g, NVDR_RAY_TMAX, t2), h3 = slot_hit(q3, g, NVDR_RAY_TMAX, t3);
+            if (COUNT) n_box += 4;
+            const float BIG = 3.0e38f;
+            const float u0 = h0 ? t0 : BIG, u1 = h1 ? t1 : BIG, u2 = h2 ? t2 : BIG, u3 = h3 ? t3 : BIG;
+            const float um = fminf(fminf(u0, u1), fminf(u2, u3));
+            const int best = (h0 & (u0 == um)) ? 0 : (h1 & (u1 == um)) ? 1 : (h2 & (u2 == um)) ? 2 : 3;
+            const bool any = h0 | h1 | h2 | h3;
+            const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
+            nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
+            if (h0 & (best != 0)) { stack.push(sp, c0); sp++; }
+            if (h1 & (best != 1)) { stack.push(sp, c1); sp++; }
+            if (h2 & (best != 2)) { stack.push(sp, c2); sp++; }
+            if (h3 & (best != 3)) { stack.push(sp, c3); sp++; }
         }
         bool finished = false;
         if (nxt != WAIT) {

@@ -9,10 +9,12 @@ from nvdiffrecmc_amd import optixutils as ou, renderutils as ru
 n = int(os.environ.get('PROBE_N', '8'))
 res = int(os.environ.get('PROBE_RES', '512'))
 mesh = os.environ.get('PROBE_MESH', 'bob')
-st = DirectLightingStep(mesh, res, n, view=0, n_views=8, device='cuda:0')
+subdiv = int(os.environ.get('PROBE_SUBDIV', '0'))
+st = DirectLightingStep(mesh, res, n, view=0, n_views=8, device='cuda:0', subdiv=subdiv)
 m = st.mask[..., None]
 with torch.no_grad():
     kd = (st.kd_tex[st.texel].view(1, res, res, 3) * m).contiguous()
+    import time as _t
     ks = (st.ks.view(1, 1, 1, 3) * m).contiguous()
     nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)
     ro = st.gb_pos + nrm * 0.001
@@ -33,7 +35,14 @@ def run(iters=12):
     st.ctx.set_profiling(False)
     return f, b
 
-print('workload: %s %dx%d n=%d covered=%d' % (mesh, res, res, n, st.covered))
+print('workload: %s %dx%d n=%d covered=%d triangles=%d' % (mesh, res, res, n, st.covered, st.mesh['t_pos_idx'].shape[0]))
+# BVH rebuild time (stream-ordered, no host sync inside)
+for _ in range(3): ou.optix_build_bvh(st.ctx, st.mesh['v_pos'], st.mesh['t_pos_idx'], rebuild=1)
+torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): ou.optix_build_bvh(st.ctx, st.mesh['v_pos'], st.mesh['t_pos_idx'], rebuild=1)
+e1.record(); torch.cuda.synchronize()
+print('bvh rebuild %.3f ms' % (e0.elapsed_time(e1) / 10))
 for cfg in sys.argv[1:] or ['4,4,4']:
     os.environ.pop('NVDR_PBLOCKS', None); os.environ['NVDR_DEBUG'] = '0'
     for tok in cfg.split(';'):

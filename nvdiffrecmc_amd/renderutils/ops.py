@@ -120,6 +120,9 @@ def _masking_smith(alphaSqr, cosThetaI, cosThetaO, use_python=False):
 # ----------------------------------------------------------------------------------------------
 # shading normal setup (ops.py:181-227)
 
+_UNIT_Z = {}   # device -> [1,1,1,3] tangent-space 'no perturbation' normal
+
+
 class _prepare_shading_normal_func(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading, opengl):
@@ -155,7 +158,13 @@ def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng,
     space, flips towards the viewer for two-sided shading, perturbs by the normal map and bends back-facing
     normals (same contract as the reference, ops.py:196-214).  All tensors [N,H,W,3] or broadcastable.'''
     if perturbed_nrm is None:
-        perturbed_nrm = torch.tensor([0, 0, 1], dtype=torch.float32, device=pos.device, requires_grad=False)[None, None, None, ...]
+        # the reference builds this constant with torch.tensor(..., device='cuda') on every call (ops.py:218): a pageable
+        # host-to-device copy that makes the host wait for the stream to drain -- 1 ms per iteration with the GPU kept
+        # busy, and it stops the host from running ahead.  One constant per device instead.
+        perturbed_nrm = _UNIT_Z.get(pos.device)
+        if perturbed_nrm is None:
+            perturbed_nrm = _UNIT_Z[pos.device] = torch.tensor([0, 0, 1], dtype=torch.float32, device=pos.device,
+                                                               requires_grad=False)[None, None, None, ...]
     if use_python:
         out = torch_ref.prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm,
                                                two_sided_shading, opengl)

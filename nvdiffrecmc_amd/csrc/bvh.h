@@ -128,14 +128,7 @@ struct TravStack {
         if (sp < NVDR_STACK_LDS) lds[sp * 64] = v;
         else if (sp < NVDR_STACK_MAX) glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v;
     }
-    // speculative forms for branch-free traversal loops: the push always writes the LDS slot (row NVDR_STACK_LDS is a
-    // scratch row for sp beyond the LDS part) and `keep` only matters for the rare HBM spill; peek returns what a pop
-    // at depth sp would yield without changing anything.
-    __device__ __forceinline__ void push_spec(int sp, int v, bool keep) const
-    {
-        lds[min(sp, NVDR_STACK_LDS) * 64] = v;
-        if (keep && sp >= NVDR_STACK_LDS && sp < NVDR_STACK_MAX) glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v;
-    }
+    // peek returns what a pop at depth sp would yield without changing anything (branch-free loops read it every step)
     __device__ __forceinline__ int peek(int sp) const
     {
         int v = lds[max(min(sp - 1, NVDR_STACK_LDS - 1), 0) * 64];
@@ -154,12 +147,12 @@ __device__ __forceinline__ TravStack make_stack(int *smem, int *spill)
 {
     TravStack s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    s.lds = (lds_int_t *)smem + wave * (NVDR_STACK_LDS + 1) * 64 + lane;
+    s.lds = (lds_int_t *)smem + wave * NVDR_STACK_LDS * 64 + lane;
     s.gstride = gridDim.x * blockDim.x;
     s.glb = (glb_int_t *)spill + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     return s;
 }
-#define NVDR_STACK_LDS_BYTES(threads) ((size_t)(threads) * (NVDR_STACK_LDS + 1) * sizeof(int))   // + the scratch row
+#define NVDR_STACK_LDS_BYTES(threads) ((size_t)(threads) * NVDR_STACK_LDS * sizeof(int))
 
 __device__ __forceinline__ bool tri_any_hit(const float4 *__restrict__ tris, int slot, float ox, float oy, float oz,
                                             float dx, float dy, float dz)
@@ -201,15 +194,9 @@ __device__ __forceinline__ GridRay make_grid_ray(const BvhDeviceInfo *__restrict
 __device__ __forceinline__ bool box_hit(float minx, float miny, float minz, float maxx, float maxy, float maxz,
                                         const GridRay &r, float tmax, float &tnear)
 {
-#ifndef NVDR_SLAB_MULADD
     const float x0 = fmaf(minx, r.ix, r.nx), x1 = fmaf(maxx, r.ix, r.nx);
     const float y0 = fmaf(miny, r.iy, r.ny), y1 = fmaf(maxy, r.iy, r.ny);
     const float z0 = fmaf(minz, r.iz, r.nz), z1 = fmaf(maxz, r.iz, r.nz);
-#else
-    const float x0 = minx * r.ix + r.nx, x1 = maxx * r.ix + r.nx;
-    const float y0 = miny * r.iy + r.ny, y1 = maxy * r.iy + r.ny;
-    const float z0 = minz * r.iz + r.nz, z1 = maxz * r.iz + r.nz;
-#endif
     const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
     tnear = tn;

@@ -555,13 +555,8 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
         const int n_leaf = __popcll(on_leaf);
         const int n_node = __popcll(__ballot(ray >= 0 && cur >= 0));
         const int POP = NVDR_TRAV_DONE, HIT = NVDR_TRAV_DONE - 1, WAIT = NVDR_TRAV_DONE - 2;
-#ifdef NVDR_TRAV_ONE_ARM
-        const bool leaf_turn = n_leaf >= NVDR_LEAF_MIN || n_node == 0;
-        const bool node_turn = !leaf_turn;
-#else
         const bool leaf_turn = n_leaf >= NVDR_LEAF_MIN || n_node == 0;   // parked leaves are tested in batches
         const bool node_turn = n_node > 0;
-#endif
         int nxt = WAIT;                                 // next node / leaf, or one of the markers
         if (leaf_turn && ray >= 0 && cur < 0) {
             if (COUNT) n_tri++;

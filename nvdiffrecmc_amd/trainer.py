@@ -133,7 +133,12 @@ class DirectLightingStep:
         self.light = EnvironmentLight(torch.full((probe_res, probe_res, 3), 0.5, device=self.dev).requires_grad_(True))
         self._ks_min = torch.tensor([0.0, 0.08, 0.0], device=self.dev)
         self.params = [self.kd_tex, self.ks, self.light.base]
-        self.opt = torch.optim.Adam(self.params, lr=lr)
+        # the same Adam as the reference (train.py:452-461); `fused` only selects torch's single-kernel implementation
+        # (8 multi_tensor_apply launches -> 1) where this build of torch has it for the device
+        try:
+            self.opt = torch.optim.Adam(self.params, lr=lr, fused=self.dev.type == 'cuda')
+        except (RuntimeError, TypeError):
+            self.opt = torch.optim.Adam(self.params, lr=lr)
         self.covered = int(self.mask.sum().item())
 
     # rays per pass counted from the actual mask: 2 per stratum per covered pixel

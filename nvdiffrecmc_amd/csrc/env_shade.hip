@@ -623,7 +623,8 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
 // Tried on the backward instantiation and dropped (no gain, same GPU session): issuing the light-gradient atomics after both
 // samples / 3-4 waves per SIMD with spills (launch bounds) / fast division + contraction + fp32 islands (-23 % VALU
 // instructions, but gradient errors of 1e-2) -- all 0.87-0.93 ms.  0.37 ms of it is the 8 M float atomics: every one leaves
-// the XCD as a 64-byte write (rocprofv3 WRITE_SIZE = 506 MB per launch).
+// the XCD as a 64-byte write (rocprofv3 WRITE_SIZE = 506 MB per launch), i.e. it is executed at the memory side whatever the
+// scope bits say; non-temporal loads of the ray stream (to keep the accumulators in L2) change nothing either.
 template <bool BACKWARD>
 __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_kernel(ShadeParams p)
 {

@@ -579,6 +579,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
             const bool any = h0 | h1 | h2 | h3;
             const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
             nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
+            // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs 0.67 ms)
             if (h0 & (best != 0)) { stack.push(sp, c0); sp++; }
             if (h1 & (best != 1)) { stack.push(sp, c1); sp++; }
             if (h2 & (best != 2)) { stack.push(sp, c2); sp++; }

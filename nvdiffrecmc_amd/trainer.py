@@ -68,7 +68,7 @@ class DirectLightingStep:
     def __init__(self, mesh_name='bob', res=512, n_samples_x=8, view=0, n_views=8, device='cuda', env='E1',
                  probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True):
         self.dev = torch.device(device)
-        self.res, self.n, self.view = res, n_samples_x, view
+        self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
         self.retrace_backward = retrace_backward
         self.fused = fused
@@ -81,40 +81,54 @@ class DirectLightingStep:
         self.ctx = ou.OptiXContext()
         ou.optix_build_bvh(self.ctx, self.mesh['v_pos'], self.mesh['t_pos_idx'], rebuild=1)
 
-        # ---- G-buffer from primary rays (stands in for rasterize + interpolate, render.py:208-234)
-        mv, mvp, campos = sc.camera(view, n_views)
-        ro, rd = sc.primary_rays(mv, res, res)
-        ro, rd = ro.to(self.dev), rd.to(self.dev)
-        t, tri, uv = ou.trace_closest(self.ctx, ro, rd)
+        # ---- G-buffers from primary rays, one per view of this rank's batch (stands in for rasterize + interpolate,
+        # render.py:208-234); the views are stacked along N exactly like the reference's batch (configs/bob.json:8)
         H = W = res
-        t, tri, uv = t.view(H, W), tri.view(H, W), uv.view(H, W, 2)
-        gb = sc.gbuffer_from_hits(self.mesh, t, tri, uv, ro, rd, kd_mode='texture' if not subdiv else 'flat')
-        self.mask = gb['mask']                                  # [1,H,W]
-        self.gb_pos = gb['gb_pos']
-        self.gb_geom_nrm = gb['gb_geometric_normal']
-        self.gb_smooth_nrm = gb['gb_normal']
+        views = list(view) if isinstance(view, (list, tuple)) else [view]
+        self.views = views
+        gbs, texels, campos_all = [], [], []
+        for vw in views:
+            mv, mvp, campos = sc.camera(vw, n_views)
+            ro, rd = sc.primary_rays(mv, res, res)
+            ro, rd = ro.to(self.dev), rd.to(self.dev)
+            t, tri, uv = ou.trace_closest(self.ctx, ro, rd)
+            t, tri, uv = t.view(H, W), tri.view(H, W), uv.view(H, W, 2)
+            gb = sc.gbuffer_from_hits(self.mesh, t, tri, uv, ro, rd, kd_mode='texture' if not subdiv else 'flat')
+            z = gb['depth']
+            dz = torch.zeros_like(z)
+            dz[:, 1:-1, 1:-1] = 0.5 * ((z[:, 1:-1, 2:] - z[:, 1:-1, :-2]).abs() + (z[:, 2:, 1:-1] - z[:, :-2, 1:-1]).abs())
+            gb['gb_depth'] = torch.cat((z, dz.clamp(max=0.1)), dim=-1)           # (z, |dz|), render.py:228-234
+            gbs.append(gb)
+            campos_all.append(campos.to(self.dev)[None, None, None, :])
+            # texel addresses of the kd lookup (fixed: geometry is locked, configs/bob.json:14)
+            if not subdiv:
+                tidx = self.mesh['t_tex_idx'].long()[tri.clamp(min=0).long()]
+                vt = self.mesh['v_tex']
+                w0 = 1.0 - uv[..., 0:1] - uv[..., 1:2]
+                tc = w0 * vt[tidx[..., 0]] + uv[..., 0:1] * vt[tidx[..., 1]] + uv[..., 1:2] * vt[tidx[..., 2]]
+                R = self.mesh['kd_tex'].shape[0]
+                ix = (tc[..., 0] * R).long().clamp(0, R - 1)
+                iy = ((1.0 - tc[..., 1]) * R).long().clamp(0, R - 1)
+                texels.append((iy * R + ix).view(-1))
+            else:
+                texels.append(torch.zeros(H * W, dtype=torch.long, device=self.dev))
+        cat = lambda k: torch.cat([g[k] for g in gbs], dim=0).contiguous()
+        self.nv = len(views)
+        self.mask = cat('mask')                                 # [V,H,W]
+        self.gb_pos = cat('gb_pos')
+        self.gb_geom_nrm = cat('gb_geometric_normal')
+        self.gb_smooth_nrm = cat('gb_normal')
         up = torch.tensor([0.0, 1.0, 0.0], device=self.dev)
         tng = torch.cross(up.expand_as(self.gb_smooth_nrm), self.gb_smooth_nrm, dim=-1)
         self.gb_tangent = (torch.nn.functional.normalize(tng, dim=-1) * self.mask[..., None]).contiguous()
-        self.view_pos = campos.to(self.dev)[None, None, None, :].contiguous()
-        z = gb['depth']
-        dz = torch.zeros_like(z)
-        dz[:, 1:-1, 1:-1] = 0.5 * ((z[:, 1:-1, 2:] - z[:, 1:-1, :-2]).abs() + (z[:, 2:, 1:-1] - z[:, :-2, 1:-1]).abs())
-        self.gb_depth = torch.cat((z, dz.clamp(max=0.1)), dim=-1).contiguous()  # (z, |dz|), render.py:228-234
-        # texel addresses of the kd lookup (fixed: geometry is locked, configs/bob.json:14)
+        self.view_pos = torch.cat(campos_all, dim=0).contiguous()            # [V,1,1,3]
+        self.gb_depth = cat('gb_depth')
+        self.texel = torch.cat(texels)
         if not subdiv:
-            tidx = self.mesh['t_tex_idx'].long()[tri.clamp(min=0).long()]
-            vt = self.mesh['v_tex']
-            w0 = 1.0 - uv[..., 0:1] - uv[..., 1:2]
-            tc = w0 * vt[tidx[..., 0]] + uv[..., 0:1] * vt[tidx[..., 1]] + uv[..., 1:2] * vt[tidx[..., 2]]
             R = self.mesh['kd_tex'].shape[0]
-            ix = (tc[..., 0] * R).long().clamp(0, R - 1)
-            iy = ((1.0 - tc[..., 1]) * R).long().clamp(0, R - 1)
-            self.texel = (iy * R + ix).view(-1)
             kd_true = self.mesh['kd_tex'].reshape(-1, 3)
         else:
             R = 64
-            self.texel = torch.zeros(H * W, dtype=torch.long, device=self.dev)
             kd_true = torch.full((R * R, 3), 0.5, device=self.dev)
         self.tex_res = R
         # only covered pixels look the texture up (the background would pile ~200k duplicates on one texel)
@@ -147,10 +161,10 @@ class DirectLightingStep:
 
     def _render(self, kd_tex, ks_vec, light):
         m = self.mask[..., None]
-        kd = torch.zeros(self.res * self.res, 3, device=self.dev).index_copy(0, self.cov, _gather_rows.apply(kd_tex, self.texel_cov))
-        kd = kd.view(1, self.res, self.res, 3)
+        kd = torch.zeros(self.nv * self.res * self.res, 3, device=self.dev).index_copy(0, self.cov, _gather_rows.apply(kd_tex, self.texel_cov))
+        kd = kd.view(self.nv, self.res, self.res, 3)
         # uncovered pixels are skipped by the mask in env-shade and have zero light in the composite: no ks * mask needed
-        ks = _broadcast_pixels.apply(ks_vec, 1, self.res, self.res) if self.fused else (ks_vec.view(1, 1, 1, 3) * m)
+        ks = _broadcast_pixels.apply(ks_vec, self.nv, self.res, self.res) if self.fused else (ks_vec.view(1, 1, 1, 3) * m)
         nrm = ru.prepare_shading_normal(self.gb_pos, self.view_pos, None, self.gb_smooth_nrm, self.gb_tangent,
                                         self.gb_geom_nrm, two_sided_shading=True, opengl=True)
         ro = self.gb_pos + nrm * 0.001

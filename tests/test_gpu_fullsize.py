@@ -108,6 +108,18 @@ def test_dmtet_sized_mesh_800(dev):
     assert torch.equal(d1, d2) and torch.equal(s1, s2)
 
 
+def test_training_step_on_a_batch_of_views(dev):
+    """The harness renders a batch of views per iteration like the reference (configs/bob.json:8); a two-view batch is the
+    concatenation of its views (same RNG streams: the pixel index runs over the batch) and still optimises."""
+    from nvdiffrecmc_amd.trainer import DirectLightingStep
+    both = DirectLightingStep('bob', 96, 4, view=[1, 5], device=dev, lr=0.03)
+    assert both.mask.shape == (2, 96, 96) and both.view_pos.shape == (2, 1, 1, 3)
+    one = DirectLightingStep('bob', 96, 4, view=[5], device=dev, lr=0.03, pixel_index_offset=96 * 96)
+    assert torch.equal(both.target[1], one.target[0])          # second view of the batch == the same view alone, offset seeds
+    losses = [both.step().item() for _ in range(20)]
+    assert sum(losses[-4:]) / 4 < 0.85 * sum(losses[:3]) / 3
+
+
 def test_training_step_reduces_loss(dev):
     """The iteration the benchmark times (trainer.py) actually optimises: the image loss goes down."""
     from nvdiffrecmc_amd.trainer import DirectLightingStep

@@ -10,10 +10,11 @@ n = int(os.environ.get('PROBE_N', '8'))
 res = int(os.environ.get('PROBE_RES', '512'))
 mesh = os.environ.get('PROBE_MESH', 'bob')
 subdiv = int(os.environ.get('PROBE_SUBDIV', '0'))
-st = DirectLightingStep(mesh, res, n, view=0, n_views=8, device='cuda:0', subdiv=subdiv)
+nviews = int(os.environ.get('PROBE_VIEWS', '1'))
+st = DirectLightingStep(mesh, res, n, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
 m = st.mask[..., None]
 with torch.no_grad():
-    kd = (st.kd_tex[st.texel].view(1, res, res, 3) * m).contiguous()
+    kd = (st.kd_tex[st.texel].view(st.nv, res, res, 3) * m).contiguous()
     import time as _t
     ks = (st.ks.view(1, 1, 1, 3) * m).contiguous()
     nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)

@@ -957,7 +957,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     const int64_t max_groups = (npix + (64 / L) - 1) / (64 / L);
     // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading); NVDR_PBLOCKS="g,f,b"
     // overrides them for tuning
-    int per_cu[3] = {6, 6, 4};   // measured (bob 512^2 x 64 spp): gen 0.40 -> 0.365 ms, fwd shade 0.164 -> 0.145 ms, bwd shade best at 4
+    int per_cu[3] = {8, 6, 6};   // measured (bob 512^2 x 64 spp, 1 and 8 views per launch): within 3 % of the best for each kernel
     if (const char *e = getenv("NVDR_PBLOCKS")) sscanf(e, "%d,%d,%d", &per_cu[0], &per_cu[1], &per_cu[2]);
     int64_t pb[3];
     for (int k = 0; k < 3; ++k) {

@@ -84,7 +84,8 @@ def main():
     ap.add_argument('--res', type=int, default=512)
     ap.add_argument('--n-samples-x', type=int, default=8)
     ap.add_argument('--mesh', default='bob')
-    ap.add_argument('--batch', type=int, default=8, help='views per iteration over all GPUs (configs/bob.json:8)')
+    ap.add_argument('--batch', type=int, default=8, help='views per iteration (configs/bob.json:8): per GPU for weak, in total for strong scaling')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -108,11 +109,12 @@ def main():
 
     from nvdiffrecmc_amd.trainer import DirectLightingStep
     from nvdiffrecmc_amd import optixutils as ou
-    # The batch of the reference config (configs/bob.json:8: 8 views per iteration) is sharded over the GPUs: 8 views on
-    # one GPU, 4 + 4 on two, ... one view per GPU on eight (strong scaling of one iteration, what north_star asks for:
-    # "batch=8 views sharded across 8xMI355X").  Every rank seeds its pixels as slice [first_view, ...) of the global batch.
+    # Every GPU renders the batch of the reference config (configs/bob.json:8: 8 views per iteration, stacked along N like
+    # the reference's render()): per-GPU work is fixed, the global batch is 8 * world views ("weak").  --scaling strong
+    # instead shards ONE batch of 8 views over the GPUs (8 on one GPU ... 1 view per GPU on eight: north_star's
+    # "batch=8 views sharded across 8xMI355X").  Every rank seeds its pixels as its slice of the global batch launch.
     from nvdiffrecmc_amd.parallel import shard_views
-    n_views = max(world, args.batch)
+    n_views = args.batch * world if args.scaling == 'weak' else max(world, args.batch)
     H = W = args.res
     my_views = shard_views(n_views, rank, world)
     if not my_views:
@@ -207,10 +209,10 @@ def main():
             'iters_per_sec_cached_visibility': k2 / dt2,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'bob.json %dx%d, %d spp (n_samples_x=%d), batch of %d views per iteration (configs/bob.json:8) sharded over the GPUs, LBVH + HIP traversal + GGX shading + bilateral denoiser + log-sRGB L1 loss, fwd+bwd+Adam'
-                                   % (H, W, S, args.n_samples_x, n_views),
+            'config': {'workload': 'bob.json %dx%d, %d spp (n_samples_x=%d), batch of %d views per iteration (configs/bob.json:8; %s), LBVH + HIP traversal + GGX shading + bilateral denoiser + log-sRGB L1 loss, fwd+bwd+Adam'
+                                   % (H, W, S, args.n_samples_x, n_views, '%d per GPU' % args.batch if args.scaling == 'weak' else 'one batch sharded over the GPUs'),
                        'mesh_triangles': int(step.mesh['t_pos_idx'].shape[0]), 'covered_pixels_rank0': P,
                        'shadow_ray_queries_per_pass_rank0': R, 'rays_traversed_per_pass_rank0': n_traced,
                        'dead_samples': '%.1f%% of the queries have dot(n,wi)<=0, are zero through the BSDF gates whatever their visibility and are answered without traversal (outputs bit-identical; NVDR_DEBUG=8 traces them); value counts traversed rays only' % (100.0 * (1.0 - n_traced / R)),

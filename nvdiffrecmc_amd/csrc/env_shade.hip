@@ -437,6 +437,8 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 // theirs (pb).  The permutation tables scramble which sample draws which stratum; ordering by stratum puts
                 // neighbouring cells of the CDF / hemisphere grid -- i.e. nearby directions -- into neighbouring lanes of the
                 // traversal kernel, which keeps its wavefronts coherent (both rows are permutations of 0..S-1: a bijection).
+            // (The other grouping -- one stratum of 64 neighbouring pixels per wave, i.e. near-parallel rays from spread-out
+            // origins -- was measured 3-12 % slower than this one: shared origins matter more than shared directions.)
                 rA = (int64_t)pi * 2 * S + pl;
                 rB = (int64_t)pi * 2 * S + S + pb;
                 // Dead samples: with dot(n, wi) <= 0 the Lambert term is max(.,0) = 0 and the GGX lobe fails its front-facing

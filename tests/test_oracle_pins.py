@@ -172,3 +172,43 @@ def test_light_tables_oracle_vs_torch_restatement():
     assert_close(rows, tr[:, 0], 1e-5, floor=1e-6)
     assert abs(pdf.sum().item() - 1.0) < 1e-5 and rows[-1].item() == pytest.approx(1.0, abs=1e-6)
     assert (cols[:, 1:] >= cols[:, :-1]).all() and (rows[1:] >= rows[:-1]).all()
+
+
+# ---------------------------------------------------------------------------------------------- dead samples
+@pytest.mark.parametrize('impl', ['oracle', 'ref'])
+@pytest.mark.parametrize('mesh,bsdf', [('bob', 'pbr'), ('spot', 'pbr'), ('bob', 'diffuse')])
+def test_samples_under_the_shading_horizon_never_matter(impl, mesh, bsdf):
+    """The HIP path does not trace shadow rays of samples with dot(n, wi) <= 0.  Justification, checked on the
+    reference's own raygen program compiled for the CPU ('ref') and on the restatement: flipping the visibility of
+    exactly those samples changes NOTHING -- forward images and all five gradients are bit-identical (the Lambert term is
+    max(.,0) = 0 and the GGX lobe fails its front-facing gate, bsdf.h:121,165, forward and backward)."""
+    if impl == 'ref' and not orc.have_ref():
+        pytest.skip('oracle/_ref not built (no /root/reference on this machine)')
+    H = W = 40
+    n = 4
+    S = n * n
+    inp = scene_cpu.make_inputs(mesh, H, W, n, view=4, probe_res=64, n_threads=NT)
+    kw = scene_cpu.shade_kwargs(inp)
+    m = inp['mesh']
+    g = torch.Generator().manual_seed(3)
+    dg, sg = torch.rand(1, H, W, 3, generator=g), torch.rand(1, H, W, 3, generator=g)
+    common = dict(bsdf=bsdf, n_samples_x=n, rnd_seed=5, n_threads=1)
+    base = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, **common, want_vis=True, want_dbg=True)
+    dirs = base['dbg'][..., 0:3].view(1, H, W, 2 * S, 3)
+    cosn = (dirs * kw['gb_normal'][:, :, :, None, :]).sum(-1).view(H * W, 2 * S)
+    dead = cosn < -1e-6                                    # surely under the horizon (margin: torch sums in another order)
+    covered = (kw['mask'].view(-1) > 0)
+    frac = dead[covered].float().mean().item()
+    assert 0.1 < frac < 0.5, frac                          # a quarter of the samples, give or take
+    vis_a = base['vis'].clone()
+    vis_b = torch.where(dead, 1 - vis_a, vis_a).contiguous()
+    assert (vis_a != vis_b)[covered].any()
+    outs = []
+    for vis in (vis_a, vis_b):
+        f = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, **common, vis_in=vis, impl=impl)
+        b = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, **common, vis_in=vis, diff_grad=dg, spec_grad=sg, impl=impl)
+        outs.append({**{k: f[k] for k in ('diff', 'spec')},
+                     **{k: b[k] for k in ('gb_pos_grad', 'gb_normal_grad', 'gb_kd_grad', 'gb_ks_grad', 'light_grad')}})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), '%s: %s depends on the visibility of a sample under the horizon' % (impl, k)
+    assert outs[0]['diff'].abs().sum() > 0

@@ -212,3 +212,23 @@ def test_samples_under_the_shading_horizon_never_matter(impl, mesh, bsdf):
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), '%s: %s depends on the visibility of a sample under the horizon' % (impl, k)
     assert outs[0]['diff'].abs().sum() > 0
+
+
+@pytest.mark.parametrize('impl', ['oracle', 'ref'])
+def test_filter_output_is_empty_where_the_centre_normal_is_zero(impl):
+    """Premise of the HIP filter's background early-out, on the reference's own kernel compiled for the CPU: a pixel whose
+    normal is exactly zero gets (0, 0, 0, 1e-4) forward and a zero colour gradient, whatever its neighbourhood holds."""
+    if impl == 'ref' and not orc.have_ref():
+        pytest.skip('oracle/_ref not built (no /root/reference on this machine)')
+    x, col, nrm, zdz, og = mg.denoiser_inputs(1, 40, 48, 9)
+    nrm = nrm.clone()
+    nrm[:, 10:20, 5:30] = 0.0
+    nrm[:, 33, 40] = 0.0
+    zdz = zdz.contiguous()
+    empty = (nrm == 0).all(-1)
+    out = orc.bilateral_fwd(col, nrm, zdz, 2.0, n_threads=NT, impl=impl)
+    grad = orc.bilateral_bwd(col, nrm, zdz, 2.0, og, n_threads=NT, impl=impl)
+    assert torch.equal(out[empty][:, :3], torch.zeros(int(empty.sum()), 3))
+    assert torch.equal(out[empty][:, 3], torch.full((int(empty.sum()),), 1e-4))
+    assert torch.equal(grad[empty], torch.zeros(int(empty.sum()), 3))
+    assert out[~empty][:, 3].min().item() > 1e-4

@@ -1,4 +1,4 @@
-// env_shade.hip -- the fused Monte-Carlo direct-lighting kernel (forward and backward).
+// env_shade.hip -- Monte-Carlo direct lighting (forward and backward) as three kernels around a ray stream.
 //
 // Replaces the OptiX raygen program __raygen__rg (render/optixutils/c_src/envsampling/kernel.cu:463-542,
 // helpers :30-461) and its host launchers env_shade_fwd / env_shade_bwd
@@ -7,15 +7,17 @@
 // MI355X design (the reference runs ONE thread per pixel with a serial 2*S-ray loop inside one OptiX program):
 //   * covered pixels are compacted into a work list first (bob covers ~20 % of the frame);
 //   * the raygen program is cut at its two natural seams into THREE lean kernels that hand a ray stream
-//     through HBM (16 B + 4 B + 1 B per ray -- ~170 MB per pass at 512^2 x 64 spp, ~0.1 ms of bandwidth):
+//     through HBM (16 B + 4 B + 1 B per slot -- ~170 MB per pass and view at 512^2 x 64 spp):
 //       1. env_gen_kernel    sample generation: a pixel is owned by L = min(64, pow2ceil(S)) lanes, every lane
 //                            owns whole strata and jumps the pixel's LCG stream ahead to its stratum (5 draws per
-//                            stratum, kernel.cu:513-524): bit-identical random sequence to the serial loop;
-//       2. env_trace_kernel  PERSISTENT wavefronts over the ray stream: each wave owns a contiguous range of rays,
-//                            a lane that finishes its ray immediately takes the next one of the range (wave-local
-//                            counter, no atomics), so lanes never idle behind the slowest ray of a pixel; the
-//                            traversal stack lives in LDS, one bank per lane; nothing but traversal state in registers;
-//       3. env_shade_kernel  BSDF evaluation (forward) or hand-derived gradients (backward) per sample, reduced
+//                            stratum, kernel.cu:513-524): bit-identical random sequence to the serial loop.  Samples
+//                            under the shading horizon contribute exactly zero and are left out of the LIVE-RAY LIST
+//                            the next stage walks;
+//       2. env_trace_kernel  PERSISTENT wavefronts over the live-ray list (round-robin chunks of 64): a lane that
+//                            finishes its ray immediately takes the next one of its wave (wave-uniform cursor, no
+//                            atomics), so lanes never idle behind the slowest ray of a pixel; four-slot wide nodes,
+//                            the traversal stack in LDS, one bank per lane;
+//       3. env_shade_kernel  BSDF evaluation (forward) or hand-derived gradients (backward) per live sample, reduced
 //                            across the L lanes with shuffle butterflies; only the light gradient needs global
 //                            atomics (kernel.cu:208-210).
 //     Why not one fused kernel (the first version, 2.1 ms forward): rocprofv3 showed the traversal VALU-bound at ~40 %

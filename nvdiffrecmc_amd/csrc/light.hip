@@ -1,4 +1,4 @@
-// light.hip -- EnvironmentLight.update_pdf fused into two launches.
+// light.hip -- EnvironmentLight.update_pdf fused into three small launches.
 //
 // Replaces the ~10 small torch kernels of render/light.py:46-59 that the reference runs every
 // training iteration (train.py:422): pdf = max_c(base) * sin(pi*(y+0.5)/H), normalised to sum 1;

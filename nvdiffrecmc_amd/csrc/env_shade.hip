@@ -484,10 +484,10 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
 #define NVDR_TRACE_CHUNK_LOG2 6
 #endif
 #ifndef NVDR_TRACE_ALIGN
-#define NVDR_TRACE_ALIGN 6
+#define NVDR_TRACE_ALIGN 8
 #endif
 #ifndef NVDR_TRACE_PAD
-#define NVDR_TRACE_PAD 6
+#define NVDR_TRACE_PAD 10
 #endif
 template <bool COUNT>
 __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView bvh, const float4 *__restrict__ rays,
@@ -531,12 +531,13 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     // Measured (same GPU session, bob 512^2 x 64 spp): ungated 1.36 ms, (16, 8) 1.23-1.31 ms, one-arm-per-iteration
     // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
     // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
-    // CODE PLACEMENT MATTERS HERE.  The same loop body runs ~1.6x slower for some placements relative to the 64-byte
-    // instruction-cache lines (binary-node version of this loop: 0.76-0.83 ms at 12 of the 16 four-byte offsets,
-    // 1.27-1.33 ms at 12, 32, 36 and 48 bytes; first wide-node version: 0.71 ms vs 1.20 ms at 24 and 32 bytes; found
-    // because adding an unrelated kernel to this file moved the loop).  The preheader is therefore pinned to a 64-byte
-    // boundary plus NVDR_TRACE_PAD s_nops (current body: 0.67-0.68 ms at all even paddings 0..14).  Re-measure
-    // (tools/build_variants.sh + tools/ab_run.sh) whenever the loop body changes.
+    // CODE PLACEMENT MATTERS HERE.  The same loop body runs ~1.6x slower for some placements relative to the instruction
+    // cache lines (binary-node version of this loop: 0.76-0.83 ms at 12 of the 16 four-byte offsets within 64 bytes,
+    // 1.27-1.33 ms at 12, 32, 36 and 48; found because adding an unrelated kernel to this file moved the loop).  Pinning
+    // the offset within 64 bytes was NOT enough: editing the sample generator moved this kernel by an odd multiple of
+    // 64 bytes and the traversal went from 0.67 to 0.73 ms (1.15 ms with one more edit).  The preheader is therefore
+    // pinned to a 256-byte boundary plus NVDR_TRACE_PAD s_nops (current body: 0.67-0.69 ms at paddings 2, 6, ... 30).
+    // Re-measure (tools/build_variants.sh + tools/ab_run.sh) whenever the loop body changes.
     asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
     asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
     while (true) {

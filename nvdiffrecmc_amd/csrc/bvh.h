@@ -35,7 +35,13 @@
 // Morton codes + index tie-break can be up to ~64 levels deep, typical meshes use < 24 -- spill to a
 // per-lane column of an HBM scratch buffer owned by the context.  Sizing for the worst case this way
 // needs no read-back of the tree height, so nothing on the query path synchronises the host.
-#define NVDR_STACK_LDS 16
+// 12 entries = 12 KB of LDS per 256-thread workgroup.  NOT 16: the shadow-ray kernel is persistent (8 workgroups per CU, every
+// wave owns a fixed share of the rays), and with 17 KB per workgroup the 8th workgroup did not become resident on some CUs in
+// ~30 % of the processes (10 fresh processes: 3 ran the same launch in 1.16 ms instead of 0.68 ms; with 12 KB: 0 of 10).
+// Deeper entries go to the HBM spill columns; on a 171 k-triangle mesh 12 is even faster than 16 (27.5 vs 30.1 ms).
+#ifndef NVDR_STACK_LDS
+#define NVDR_STACK_LDS 12
+#endif
 #define NVDR_STACK_MAX 104
 #define NVDR_QUERY_BLOCK 256                 // threads per workgroup of every traversal kernel
 #define NVDR_QUERY_MAX_BLOCKS 2048           // persistent / grid-stride launches never exceed this

@@ -531,13 +531,10 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     // Measured (same GPU session, bob 512^2 x 64 spp): ungated 1.36 ms, (16, 8) 1.23-1.31 ms, one-arm-per-iteration
     // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
     // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
-    // CODE PLACEMENT MATTERS HERE.  The same loop body runs ~1.6x slower for some placements relative to the instruction
-    // cache lines (binary-node version of this loop: 0.76-0.83 ms at 12 of the 16 four-byte offsets within 64 bytes,
-    // 1.27-1.33 ms at 12, 32, 36 and 48; found because adding an unrelated kernel to this file moved the loop).  Pinning
-    // the offset within 64 bytes was NOT enough: editing the sample generator moved this kernel by an odd multiple of
-    // 64 bytes and the traversal went from 0.67 to 0.73 ms (1.15 ms with one more edit).  The preheader is therefore
-    // pinned to a 256-byte boundary plus NVDR_TRACE_PAD s_nops (current body: 0.67-0.69 ms at paddings 2, 6, ... 30).
-    // Re-measure (tools/build_variants.sh + tools/ab_run.sh) whenever the loop body changes.
+    // The loop is placed at a fixed offset from a 256-byte boundary so that edits elsewhere in this file cannot move it
+    // relative to the instruction-cache lines.  (History: this kernel showed a ~1.7x "slow mode" that first looked like a
+    // code-placement effect -- it came and went with unrelated edits -- and was finally traced to LDS residency of the
+    // persistent grid, see NVDR_STACK_LDS in bvh.h: the same binary is slow in ~30 % of fresh processes.)
     asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
     asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
     while (true) {

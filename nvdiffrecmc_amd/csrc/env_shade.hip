@@ -735,14 +735,13 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
                 if (BACKWARD) {
                     const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
-                    // light gradient (eval_light_bwd, kernel.cu:203-211).  A device-scope atomic is a fabric transaction on
-                    // MI355X (the 8 XCD L2s are not coherent with each other): 24 M of them cost 0.9 ms.  Each XCD
-                    // therefore accumulates into ITS OWN copy with L2-resident (workgroup-scope encoding) atomics -- all
-                    // CUs of an XCD share that L2, and the copy is picked by the XCC id the wave actually runs on, so
-                    // the result does not depend on workgroup placement -- and a tiny kernel sums the 8 copies.
-                    // The atomics of both samples are issued together after the loop over r: gfx950 counts loads, stores and
-                    // atomics in ONE in-order counter, so an atomic issued between the two samples would sit in front of
-                    // the second sample's texel / radiance loads and the wave would wait for its round trip.
+                    // light gradient (eval_light_bwd, kernel.cu:203-211).  fp32 atomics are executed at the memory side on
+                    // MI355X (rocprofv3: one 64-byte write leaves the XCD per atomic, whatever the scope bits say), ~25 G
+                    // of them per second.  Each XCD accumulates into ITS OWN copy (picked by the XCC id the wave actually
+                    // runs on, so the result does not depend on workgroup placement) and a tiny kernel sums the 8 copies:
+                    // that spreads hot texels over 8 addresses (measured: a few per cent); what really helped was not
+                    // issuing the zero addends.  The atomics of both samples are issued together after the loop over r
+                    // (no effect on time, but it keeps them out of the way of the second sample's loads).
                     lg_add[r] = lg;
                     lg_at[r] = (p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel;   // bit 4: contention experiment
                     const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;

@@ -35,10 +35,8 @@
 // Morton codes + index tie-break can be up to ~64 levels deep, typical meshes use < 24 -- spill to a
 // per-lane column of an HBM scratch buffer owned by the context.  Sizing for the worst case this way
 // needs no read-back of the tree height, so nothing on the query path synchronises the host.
-// 12 entries = 12 KB of LDS per 256-thread workgroup.  NOT 16: the shadow-ray kernel is persistent (8 workgroups per CU, every
-// wave owns a fixed share of the rays), and with 17 KB per workgroup the 8th workgroup did not become resident on some CUs in
-// ~30 % of the processes (10 fresh processes: 3 ran the same launch in 1.16 ms instead of 0.68 ms; with 12 KB: 0 of 10).
-// Deeper entries go to the HBM spill columns; on a 171 k-triangle mesh 12 is even faster than 16 (27.5 vs 30.1 ms).
+// 12 entries = 12 KB of LDS per 256-thread workgroup (8 workgroups per CU leave slack in the 160 KB); deeper entries go to
+// the HBM spill columns.  Same speed as 16 on bob, faster on a 171 k-triangle mesh (27.5 vs 30.1 ms).
 #ifndef NVDR_STACK_LDS
 #define NVDR_STACK_LDS 12
 #endif
@@ -128,7 +126,7 @@ typedef __attribute__((address_space(1))) int glb_int_t;
 struct TravStack {
     lds_int_t *lds; // this lane's LDS column (stride 64 words)
     glb_int_t *glb; // this lane's HBM spill column
-    int gstride;    // spill stride = total threads of the launch
+    int gstride;    // spill stride between two levels of a lane = threads of the workgroup
     __device__ __forceinline__ void push(int sp, int v) const
     {
         if (sp < NVDR_STACK_LDS) lds[sp * 64] = v;
@@ -154,8 +152,10 @@ __device__ __forceinline__ TravStack make_stack(int *smem, int *spill)
     TravStack s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     s.lds = (lds_int_t *)smem + wave * NVDR_STACK_LDS * 64 + lane;
-    s.gstride = gridDim.x * blockDim.x;
-    s.glb = (glb_int_t *)spill + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Every workgroup keeps its spill columns together (level k of lane l at block_base + k * blockDim + l): a lane's levels
+    // are 1 KB apart (the first layout strided them by the whole launch: 2 MB, one large page per level).
+    s.gstride = blockDim.x;
+    s.glb = (glb_int_t *)spill + (int64_t)blockIdx.x * blockDim.x * (NVDR_STACK_MAX - NVDR_STACK_LDS) + threadIdx.x;
     return s;
 }
 #define NVDR_STACK_LDS_BYTES(threads) ((size_t)(threads) * NVDR_STACK_LDS * sizeof(int))

@@ -532,9 +532,10 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
     // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
     // The loop is placed at a fixed offset from a 256-byte boundary so that edits elsewhere in this file cannot move it
-    // relative to the instruction-cache lines.  (History: this kernel showed a ~1.7x "slow mode" that first looked like a
-    // code-placement effect -- it came and went with unrelated edits -- and was finally traced to LDS residency of the
-    // persistent grid, see NVDR_STACK_LDS in bvh.h: the same binary is slow in ~30 % of fresh processes.)
+    // relative to the instruction-cache lines.  OPEN ISSUE: in ~20 % of fresh processes the one-view launch of this kernel
+    // takes 1.16 ms instead of 0.68 ms for the whole life of the process (tools/mode_run.sh; same binary, same inputs; the
+    // other kernels are unaffected).  It first looked like a code-placement effect because it came and went with
+    // unrelated edits; ruled out since: code placement, LDS footprint (17 vs 12 KB per workgroup), spill-buffer layout.
     asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
     asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
     while (true) {

@@ -42,7 +42,9 @@
 #endif
 #define NVDR_STACK_MAX 104
 #define NVDR_QUERY_BLOCK 256                 // threads per workgroup of every traversal kernel
+#ifndef NVDR_QUERY_MAX_BLOCKS
 #define NVDR_QUERY_MAX_BLOCKS 2048           // persistent / grid-stride launches never exceed this
+#endif
 #define NVDR_TRAV_DONE 0x7fffffff            // traversal marker: nothing left (never a valid node / leaf id)
 #define NVDR_TRAV_EMPTY 0x7ffffff0           // child reference of an unused slot of a wide node
 #define NVDR_GRID_MAX 65531.0f               // usable span of the 16-bit box grid (2 cells of slack on both ends)

@@ -535,7 +535,8 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     // relative to the instruction-cache lines.  OPEN ISSUE: in ~20 % of fresh processes the one-view launch of this kernel
     // takes 1.16 ms instead of 0.68 ms for the whole life of the process (tools/mode_run.sh; same binary, same inputs; the
     // other kernels are unaffected).  It first looked like a code-placement effect because it came and went with
-    // unrelated edits; ruled out since: code placement, LDS footprint (17 vs 12 KB per workgroup), spill-buffer layout.
+    // unrelated edits; ruled out since: code placement, LDS footprint (17 vs 12 KB per workgroup), spill-buffer layout,
+    // grid size (8 resident vs 16 workgroups per CU).
     asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
     asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
     while (true) {
@@ -996,7 +997,10 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (p.debug & 1u) {
             NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)npix * 2 * S, stream));
         } else {
-            int64_t tblocks = (int64_t)c->n_cus * 8;
+#ifndef NVDR_TRACE_BLOCKS_PER_CU
+#define NVDR_TRACE_BLOCKS_PER_CU 8
+#endif
+            int64_t tblocks = (int64_t)c->n_cus * NVDR_TRACE_BLOCKS_PER_CU;
             if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
             const int64_t need = (npix * 2 * S + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
             if (tblocks > need) tblocks = need < 1 ? 1 : need;

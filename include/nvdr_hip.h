@@ -116,7 +116,8 @@ typedef struct nvdr_env_shade_args {
        bwd the shadow rays are NOT re-traced (valid only for identical seed and inputs). */
     uint32_t *vis_cache;
     /* optional device accumulators uint64[8 + 2*8192] {box tests, triangle tests, rays traversed, sum and max of the
-       per-wavefront busy time in 100 MHz ticks, wavefronts, 2 reserved, then (begin, end) ticks of every wavefront} of the shadow-ray
+       per-wavefront busy time in 100 MHz ticks, wavefronts, sum of the per-wavefront shader-clock cycles, bit mask of the XCDs that
+       ran wavefronts, then (begin, end) ticks of every wavefront} of the shadow-ray
        traversal (a counting build of the same kernel; feeds the algorithmic-byte roofline figure).
        Rays traversed < 2*S*pixels: samples with dot(n, wi) <= 0 contribute exactly zero through the BSDF's own
        gates whatever their visibility and are not traced (env var NVDR_DEBUG bit 8 traces them anyway). */

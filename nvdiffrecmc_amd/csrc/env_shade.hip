@@ -517,6 +517,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     unsigned n_box = 0, n_tri = 0, n_ray = 0;
     const bool single = bvh.n_tris == 1;
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
+    const unsigned long long c_begin = COUNT ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
 
     int ray = -1, cur = 0, sp = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
@@ -623,6 +624,10 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
             atomicAdd(&counters[3], dt);
             atomicMax(&counters[4], dt);
             atomicAdd(&counters[5], 1ull);
+            // diagnostics for the per-process slow mode: shader-clock cycles spent (sum over waves; / counters[3] = cycles
+            // per 100 MHz tick, i.e. the clock the waves actually ran at) and the set of XCDs that ran waves
+            atomicAdd(&counters[6], (unsigned long long)__builtin_readcyclecounter() - c_begin);
+            atomicOr(&counters[7], 1ull << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
             counters[8 + 2 * wid] = t_begin;                 // per-wave begin / end ticks (wid < 8192)
             counters[9 + 2 * wid] = t_begin + dt;
         }

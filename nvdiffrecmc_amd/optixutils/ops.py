@@ -294,4 +294,6 @@ def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_p
     c = cnt.cpu()
     env_shade_traversal_counts.balance = (int(c[3]), int(c[4]), int(c[5]))   # sum, max of per-wave ticks (100 MHz), waves
     env_shade_traversal_counts.wave_ticks = c[8:8 + 2 * int(c[5])].view(-1, 2)   # (begin, end) per wavefront
+    env_shade_traversal_counts.clock_mhz = 100.0 * int(c[6]) / max(int(c[3]), 1)     # shader clock the waves ran at
+    env_shade_traversal_counts.xcd_mask = int(c[7])
     return int(npx.value), int(c[0]), int(c[1]), int(c[2])

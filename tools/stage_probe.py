@@ -61,6 +61,7 @@ wt = ou.ops.env_shade_traversal_counts.wave_ticks.double()
 t0 = wt[:, 0].min()
 b, e = (wt[:, 0] - t0) / 100.0, (wt[:, 1] - t0) / 100.0
 q = torch.tensor([0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0], dtype=torch.float64)
+print('shader clock during the counting launch: %.0f MHz, XCD mask 0x%x' % (ou.ops.env_shade_traversal_counts.clock_mhz, ou.ops.env_shade_traversal_counts.xcd_mask))
 print('wave begin (us) quantiles', [round(x, 1) for x in torch.quantile(b, q).tolist()])
 print('wave end   (us) quantiles', [round(x, 1) for x in torch.quantile(e, q).tolist()])
 print('wave busy  (us) quantiles', [round(x, 1) for x in torch.quantile(e - b, q).tolist()])

@@ -44,6 +44,16 @@ int nvdr_version(void);
 /* ---- context: owns the BVH buffers, replaces OptiXStateWrapper ctor/dtor (optix_wrapper.cpp:306-348) */
 int nvdr_ctx_create(nvdr_ctx **out, int device);
 int nvdr_ctx_destroy(nvdr_ctx *ctx);
+/* Synchronises `stream` and reports (non-zero + nvdr_last_error) if any traversal launch on this context ever pushed
+ * beyond its stack bound -- the only way a visibility answer could be wrong.  Every other entry point checks the same
+ * (host-mapped) flag without synchronising, so such a failure surfaces at the latest on the next call.  The reference
+ * has no counterpart: OptiX errors are swallowed (render/optixutils/c_src/common.h:37-77). */
+int nvdr_ctx_check(nvdr_ctx *ctx, void *stream);
+/* Bytes of HBM the env-shade ray stream of this context may take (default 2 GiB, or NVDR_STREAM_BUDGET_MB read when the
+ * context is created).  The stream holds one chunk of covered pixels (2*S rays x 25 B each); a launch whose covered pixels
+ * exceed the chunk is processed chunk by chunk with identical results.  The reference needs no scratch (one thread per
+ * pixel keeps its rays in registers); a worst-case allocation would be N*H*W*2S*25 B (16 GB for 8 x 800^2 x 64 spp). */
+int nvdr_ctx_set_stream_budget(nvdr_ctx *ctx, int64_t bytes);
 
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
  * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);
@@ -59,6 +69,9 @@ typedef struct nvdr_bvh_info {
     int32_t root;         /* index of the root node */
     float   aabb_min[3];
     float   aabb_max[3];
+    float   grid_lo[3];   /* quantisation grid of the node boxes: grid = (world - grid_lo) * grid_scale + 2 */
+    float   grid_scale[3];
+    int32_t stack_max;    /* traversal-stack entries per lane the context provides (proven bound, see csrc/bvh.h) */
 } nvdr_bvh_info;
 int nvdr_bvh_info_get(nvdr_ctx *ctx, nvdr_bvh_info *out_host, void *stream); /* synchronises `stream` */
 /* copy the device BVH to host buffers: nodes = n_nodes * 8 uint32 (32-B records: six words of 16-bit
@@ -79,6 +92,8 @@ int nvdr_trace_closest(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t 
                        int32_t *out_tri, float *out_uv, void *stream);
 
 /* ---- env_shade_fwd / env_shade_bwd (torch_bindings.cpp:123-272; raygen program kernel.cu:463-542) */
+#define NVDR_COUNTERS_BVH2 (8 + 2 * 8192)
+#define NVDR_COUNTERS_LEN (NVDR_COUNTERS_BVH2 + 8)
 typedef struct nvdr_env_shade_args {
     nvdr_tensor mask;        /* f32 [N,H,W]    (>0 = covered)                     params.h:17 */
     nvdr_tensor ro;          /* f32 [N,H,W,3]  shadow-ray origins                 params.h:14 */
@@ -115,16 +130,23 @@ typedef struct nvdr_env_shade_args {
        BSDF-sampled shadow ray of stratum i is occluded): written by fwd when non-NULL; when non-NULL in
        bwd the shadow rays are NOT re-traced (valid only for identical seed and inputs). */
     uint32_t *vis_cache;
-    /* optional device accumulators uint64[8 + 2*8192] {box tests, triangle tests, rays traversed, sum and max of the
-       per-wavefront busy time in 100 MHz ticks, wavefronts, sum of the per-wavefront shader-clock cycles, bit mask of the XCDs that
-       ran wavefronts, then (begin, end) ticks of every wavefront} of the shadow-ray
-       traversal (a counting build of the same kernel; feeds the algorithmic-byte roofline figure).
+    /* optional device accumulators uint64[NVDR_COUNTERS_LEN], zeroed by the caller (a COUNTING build of the traversal
+       kernel runs instead of the production one; feeds the roofline figures):
+         [0] box tests of the wide walk (non-empty slots only)   [1] its triangle tests   [2] rays traversed
+         [3] sum and [4] max of the per-wavefront busy time in 100 MHz ticks   [5] wavefronts
+         [6] sum of the per-wavefront shader-clock cycles   [7] bit mask of the XCDs that ran wavefronts
+         [8 .. 8+2*8192) (begin, end) ticks of every wavefront
+         [NVDR_COUNTERS_BVH2 + 0] node visits, [+1] triangle tests, [+2] rays of the CANONICAL binary any-hit walk over
+         the same live rays (reference accounting layout: 32-B BVH2 node, 36-B triangle) -- invariant to how speculative
+         the production walk is, checked against a CPU walk of the exported tree in tests/test_gpu_bvh.py.
        Rays traversed < 2*S*pixels: samples with dot(n, wi) <= 0 contribute exactly zero through the BSDF's own
-       gates whatever their visibility and are not traced (env var NVDR_DEBUG bit 8 traces them anyway). */
+       gates whatever their visibility and are not traced (NVDR_DEBUG bit 8 traces them anyway). */
     unsigned long long *counters;
     /* backward only: id (nvdr_env_shade_stream_id) of the forward launch whose inputs and seed this backward pass
-       repeats.  When it is still the most recent ray stream generated on the context, sample generation is skipped
-       and the stored rays are traced again (or, with vis_cache, only re-shaded).  0 = always regenerate. */
+       repeats.  When it is still the most recent ray stream generated on the context (and the launch's covered pixels
+       fitted one chunk of the stream -- decided on the device), sample generation is skipped and the stored rays are
+       traced again (or, with vis_cache, only re-shaded).  0 = always regenerate.  A backward pass consumes the stream
+       (it leaves light-gradient records in it): a second backward pass with the same id regenerates it. */
     uint64_t reuse_stream_id;
 } nvdr_env_shade_args;
 int nvdr_env_shade_fwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
@@ -135,10 +157,11 @@ int nvdr_env_shade_last_pixel_count(nvdr_ctx *ctx, int64_t *out_host, void *stre
 /* id of the ray stream written by the most recent env-shade launch on this ctx (host-side counter, no sync) */
 int nvdr_env_shade_stream_id(nvdr_ctx *ctx, uint64_t *out_host);
 
-/* Per-stage HIP-event timing of the env-shade launches (sample generation, traversal, shading), recorded on the launch
- * stream itself into a ring of 128 launches; used by bench.py for the roofline figure of the traversal kernel.
- * nvdr_env_shade_stage_times sums the recorded launches of one kind (backward = 0 | 1) into ms[3], returns their
- * number in *count, and clears the ring; it synchronises on the last recorded event. */
+/* Per-stage HIP-event timing of the env-shade launches (sample generation, traversal, shading incl. the light-gradient
+ * gather), recorded on the launch stream itself into a ring of 512 records, one per (launch, chunk of the ray stream);
+ * used by bench.py for the roofline figure of the traversal kernel.  nvdr_env_shade_stage_times sums the recorded
+ * launches of one kind (backward = 0 | 1) into ms[3] and returns their number in *count (launches, not chunks); it
+ * synchronises on the last recorded event. */
 int nvdr_ctx_set_profiling(nvdr_ctx *ctx, int enable);
 int nvdr_env_shade_stage_times(nvdr_ctx *ctx, int backward, double *ms, int64_t *count);
 

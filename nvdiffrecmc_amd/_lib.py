@@ -21,7 +21,11 @@ class NvdrTensor(ctypes.Structure):
 
 class NvdrBvhInfo(ctypes.Structure):
     _fields_ = [('n_tris', c_int64), ('n_nodes', c_int64), ('height', ctypes.c_int32), ('root', ctypes.c_int32),
-                ('aabb_min', c_float * 3), ('aabb_max', c_float * 3)]
+                ('aabb_min', c_float * 3), ('aabb_max', c_float * 3), ('grid_lo', c_float * 3), ('grid_scale', c_float * 3),
+                ('stack_max', ctypes.c_int32)]
+
+COUNTERS_BVH2 = 8 + 2 * 8192   # NVDR_COUNTERS_BVH2
+COUNTERS_LEN = COUNTERS_BVH2 + 8
 
 
 class NvdrEnvShadeArgs(ctypes.Structure):
@@ -43,6 +47,8 @@ _SIGNATURES = {
     'nvdr_version': [],
     'nvdr_ctx_create': [ctypes.POINTER(c_void_p), c_int],
     'nvdr_ctx_destroy': [c_void_p],
+    'nvdr_ctx_check': [c_void_p, c_void_p],
+    'nvdr_ctx_set_stream_budget': [c_void_p, c_int64],
     'nvdr_bvh_build': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
     'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
     'nvdr_bvh_export': [c_void_p, c_void_p, c_void_p, c_void_p],

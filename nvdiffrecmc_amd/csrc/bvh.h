@@ -37,6 +37,16 @@
 // needs no read-back of the tree height, so nothing on the query path synchronises the host.
 // 12 entries = 12 KB of LDS per 256-thread workgroup (8 workgroups per CU leave slack in the 160 KB); deeper entries go to
 // the HBM spill columns.  Same speed as 16 on bob, faster on a 171 k-triangle mesh (27.5 vs 30.1 ms).
+//
+// WHY THE STACK CANNOT OVERFLOW.  A Karras node is identified by the common-prefix length delta of its key range and
+// delta strictly grows from parent to child.  Distinct 30-bit keys give delta = clz(a ^ b) in [2, 31] (30 values), equal
+// keys give delta = 32 + clz(i ^ j) with i, j < n (at most ceil(log2 n) values): a root-to-leaf path holds at most
+// h_max = 30 + ceil(log2 n) <= 60 internal nodes whatever the mesh (100 k triangles on one centroid: a balanced tree over
+// the index bits).  The binary walk holds <= h_max entries; the wide walk pushes <= 3 entries per step and a step
+// descends two levels (or ends in a leaf), so it holds <= 3 * (ceil(h_max / 2) + 1) <= 93 < NVDR_STACK_MAX entries.
+// nvdr_bvh_build sizes the spill columns from this bound (nvdr_stack_bound); a push beyond it -- unreachable unless the
+// bound is wrong -- raises the context's overflow flag (host-mapped memory), which every later call on the context and
+// nvdr_ctx_check() turn into an error instead of a silently wrong visibility (tests/test_gpu_bvh.py feeds degenerate meshes).
 #ifndef NVDR_STACK_LDS
 #define NVDR_STACK_LDS 12
 #endif
@@ -45,6 +55,8 @@
 #ifndef NVDR_QUERY_MAX_BLOCKS
 #define NVDR_QUERY_MAX_BLOCKS 2048           // persistent / grid-stride launches never exceed this
 #endif
+#define NVDR_PROF_RING 512
+#define NVDR_MAX_CHUNKS 1024                 // chunks of the env-shade ray stream one launch may be cut into
 #define NVDR_TRAV_DONE 0x7fffffff            // traversal marker: nothing left (never a valid node / leaf id)
 #define NVDR_TRAV_EMPTY 0x7ffffff0           // child reference of an unused slot of a wide node
 #define NVDR_GRID_MAX 65531.0f               // usable span of the 16-bit box grid (2 cells of slack on both ends)
@@ -57,8 +69,19 @@ struct BvhDeviceInfo {
     float pad;              // world-space padding applied to every leaf box
     float g_lo[3];          // quantisation grid: world -> grid is (x - g_lo) * g_scale + 2
     float g_scale[3];
-    unsigned int ray_count; // env-shade: number of live shadow rays appended to the traversal list
+    unsigned int ray_count; // (unused since the chunked ray stream: the per-chunk counters live in nvdr_ctx::chunk_counts)
 };
+
+// upper bound of the traversal stack depth for a tree over n triangles (see the note at NVDR_STACK_MAX)
+static inline int nvdr_stack_bound(int64_t n_tris)
+{
+    int lg = 0;
+    while ((1ll << lg) < n_tris) ++lg;
+    const int h_max = 30 + lg;
+    const int wide = 3 * ((h_max + 1) / 2 + 1);
+    const int b = wide > h_max ? wide : h_max;
+    return b < NVDR_STACK_MAX ? b : NVDR_STACK_MAX;
+}
 
 struct nvdr_ctx {
     int device = 0;
@@ -77,10 +100,18 @@ struct nvdr_ctx {
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     BvhDeviceInfo *dinfo = nullptr;
-    int *spill = nullptr;          // [(NVDR_STACK_MAX - NVDR_STACK_LDS), NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK]
+    int *spill = nullptr;          // [NVDR_QUERY_MAX_BLOCKS][stack_max - NVDR_STACK_LDS][NVDR_QUERY_BLOCK]
+    int stack_max = 0;             // entries per lane the current spill allocation supports (LDS part included)
+    int spill_cap = 0;             // stack_max the spill buffer was allocated for (grow-only)
+    int *ovf_host = nullptr;       // host-mapped overflow flag (a push beyond stack_max sets it)
+    int *ovf_dev = nullptr;        // its device address
+    unsigned debug = 0;            // NVDR_DEBUG, read ONCE when the context is created
     // env-shade scratch
-    int *pix_list = nullptr;
+    int *pix_list = nullptr;       // [N*H*W] compacted indices of the covered pixels of the whole launch
     int64_t pix_cap = 0;
+    unsigned *chunk_counts = nullptr; // [NVDR_MAX_CHUNKS] live-ray count of every chunk of the ray stream
+    int64_t stream_cap_pixels = 0; // pixels one chunk of the ray stream holds (x 2S rays)
+    int64_t stream_budget = 2048ll << 20;   // bytes the ray stream may take (nvdr_ctx_set_stream_budget)
     // ray stream of the three-stage env-shade (csrc/env_shade.hip)
     float4 *rays = nullptr;
     int *texel = nullptr;
@@ -90,12 +121,12 @@ struct nvdr_ctx {
     size_t stream_cap_rays = 0;
     uint64_t stream_id = 0;        // id of the ray stream currently held in rays/texel/pix_origin/pix_list
     uint64_t stream_seq = 0;
-    float *lg_xcd = nullptr;       // 8 per-XCD light-gradient accumulators
+    float *lg_part = nullptr;      // light-gradient partials: [chunks][Hl*Wl*3] of the band gather, or 8 per-XCD copies
     size_t lg_cap = 0;
     // optional per-stage timing ring (nvdr_ctx_set_profiling)
     bool profiling = false;
-    hipEvent_t prof_ev[128][4] = {};
-    int prof_kind[128] = {};
+    hipEvent_t prof_ev[NVDR_PROF_RING][4] = {};   // one record per (launch, chunk of the ray stream)
+    int prof_kind[NVDR_PROF_RING] = {};           // bit 0: backward, bit 1: first chunk of its launch
     int64_t prof_n = 0;
 };
 
@@ -105,7 +136,11 @@ struct BvhView {
     const float4 *tris;
     const BvhDeviceInfo *info;
     int n_tris;
+    int stack_max;      // entries per lane (LDS + spill) the context's spill buffer holds
+    int *overflow;      // host-mapped flag, set by a push beyond stack_max
 };
+
+int ctx_check_overflow(nvdr_ctx *c, const char *who);   // bvh.hip
 
 static inline BvhView bvh_view(const nvdr_ctx *c)
 {
@@ -115,6 +150,8 @@ static inline BvhView bvh_view(const nvdr_ctx *c)
     v.tris = c->tris;
     v.info = c->dinfo;
     v.n_tris = (int)c->n_tris;
+    v.stack_max = c->stack_max;
+    v.overflow = c->ovf_dev;
     return v;
 }
 
@@ -129,27 +166,30 @@ struct TravStack {
     lds_int_t *lds; // this lane's LDS column (stride 64 words)
     glb_int_t *glb; // this lane's HBM spill column
     int gstride;    // spill stride between two levels of a lane = threads of the workgroup
+    int smax;       // entries this lane may hold (LDS + spill); see the note at NVDR_STACK_MAX
+    int *ovf;       // host-mapped overflow flag of the context
     __device__ __forceinline__ void push(int sp, int v) const
     {
         if (sp < NVDR_STACK_LDS) lds[sp * 64] = v;
-        else if (sp < NVDR_STACK_MAX) glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v;
+        else if (sp < smax) glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v;
+        else *ovf = 1;   // never silently: the launcher of the NEXT call on this context (and nvdr_ctx_check) reports it
     }
     // peek returns what a pop at depth sp would yield without changing anything (branch-free loops read it every step)
     __device__ __forceinline__ int peek(int sp) const
     {
         int v = lds[max(min(sp - 1, NVDR_STACK_LDS - 1), 0) * 64];
-        if (sp - 1 >= NVDR_STACK_LDS) v = glb[(int64_t)(min(sp - 1, NVDR_STACK_MAX - 1) - NVDR_STACK_LDS) * gstride];
+        if (sp - 1 >= NVDR_STACK_LDS) v = glb[(int64_t)(min(sp - 1, smax - 1) - NVDR_STACK_LDS) * gstride];
         return v;
     }
     __device__ __forceinline__ int pop(int sp) const
     {
         return sp < NVDR_STACK_LDS ? lds[sp * 64]
-                                   : glb[(int64_t)(min(sp, NVDR_STACK_MAX - 1) - NVDR_STACK_LDS) * gstride];
+                                   : glb[(int64_t)(min(sp, smax - 1) - NVDR_STACK_LDS) * gstride];
     }
 };
 
 // the lane's stack view inside a kernel: `smem` is the dynamic LDS base (blockDim.x * NVDR_STACK_LDS ints)
-__device__ __forceinline__ TravStack make_stack(int *smem, int *spill)
+__device__ __forceinline__ TravStack make_stack(int *smem, int *spill, int stack_max, int *overflow)
 {
     TravStack s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -157,7 +197,9 @@ __device__ __forceinline__ TravStack make_stack(int *smem, int *spill)
     // Every workgroup keeps its spill columns together (level k of lane l at block_base + k * blockDim + l): a lane's levels
     // are 1 KB apart (the first layout strided them by the whole launch: 2 MB, one large page per level).
     s.gstride = blockDim.x;
-    s.glb = (glb_int_t *)spill + (int64_t)blockIdx.x * blockDim.x * (NVDR_STACK_MAX - NVDR_STACK_LDS) + threadIdx.x;
+    s.smax = stack_max;
+    s.ovf = overflow;
+    s.glb = (glb_int_t *)spill + (int64_t)blockIdx.x * blockDim.x * max(stack_max - NVDR_STACK_LDS, 0) + threadIdx.x;
     return s;
 }
 #define NVDR_STACK_LDS_BYTES(threads) ((size_t)(threads) * NVDR_STACK_LDS * sizeof(int))

@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_visibility_kernel(BvhV
                                                                              unsigned long long *counters, int *spill)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const TravStack stack = make_stack(smem, spill);
+    const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
     unsigned nb = 0, nt = 0;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
         const bool occ = bvh_any_hit<COUNT>(bvh, ro[3 * r], ro[3 * r + 1], ro[3 * r + 2], rd[3 * r], rd[3 * r + 1],
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_closest_kernel(BvhView
                                                                           float *__restrict__ out_uv, int *spill)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const TravStack stack = make_stack(smem, spill);
+    const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
         const float ox = ro[3 * r], oy = ro[3 * r + 1], oz = ro[3 * r + 2];
         const float dx = rd[3 * r], dy = rd[3 * r + 1], dz = rd[3 * r + 2];
@@ -346,6 +346,26 @@ __global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal
 // ---------------------------------------------------------------------------------------------
 // host side
 
+// A traversal kernel of an EARLIER launch on this context pushed beyond the stack bound (bvh.h): its visibility results
+// were not trustworthy.  The flag lives in host-mapped memory, so this costs no synchronisation.
+int ctx_check_overflow(nvdr_ctx *c, const char *who)
+{
+    if (c->ovf_host && *(volatile int *)c->ovf_host != 0) {
+        nvdr_set_error("%s: a traversal launch on this context overflowed its %d-entry stack (degenerate BVH); "
+                       "the visibility it produced is invalid", who, c->stack_max);
+        return -2;
+    }
+    return 0;
+}
+
+extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
+{
+    NVDR_REQUIRE(c != nullptr, "nvdr_ctx_check: ctx is NULL");
+    NVDR_HIP_TRY(hipSetDevice(c->device));
+    NVDR_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    return ctx_check_overflow(c, "nvdr_ctx_check");
+}
+
 static int ctx_free_bvh(nvdr_ctx *c)
 {
     hipFree(c->nodes); hipFree(c->wide); hipFree(c->tris);
@@ -375,12 +395,30 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         return (int)e;
     }
     hipMemset(c->dinfo, 0, sizeof(BvhDeviceInfo));
-    e = hipMalloc((void **)&c->spill, sizeof(int) * (size_t)(NVDR_STACK_MAX - NVDR_STACK_LDS) * NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK);
+    // host-mapped flag a traversal kernel raises when a stack push would exceed the context's bound (bvh.h)
+    e = hipHostMalloc((void **)&c->ovf_host, sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->ovf_host = 0;
+        e = hipHostGetDevicePointer((void **)&c->ovf_dev, c->ovf_host, 0);
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&c->chunk_counts, sizeof(unsigned) * NVDR_MAX_CHUNKS);
     if (e != hipSuccess) {
         hipFree(c->dinfo);
+        if (c->ovf_host) hipHostFree(c->ovf_host);
         delete c;
-        nvdr_set_error("nvdr_ctx_create: hipMalloc(spill) failed: %s", hipGetErrorString(e));
+        nvdr_set_error("nvdr_ctx_create: allocation failed: %s", hipGetErrorString(e));
         return (int)e;
+    }
+    hipMemset(c->chunk_counts, 0, sizeof(unsigned) * NVDR_MAX_CHUNKS);
+    if (const char *e = getenv("NVDR_STREAM_BUDGET_MB")) {
+        const long long mb = atoll(e);
+        if (mb >= 1) c->stream_budget = (int64_t)mb << 20;
+    }
+    // NVDR_DEBUG (experiments only: 1 skip tracing, 2 skip the light gradient, 8 trace dead samples, 16 light-gradient
+    // atomics instead of the band gather) is read ONCE here, not per launch, and announced when set
+    if (const char *dbg = getenv("NVDR_DEBUG")) {
+        c->debug = (unsigned)atoi(dbg);
+        if (c->debug) fprintf(stderr, "[nvdr] NVDR_DEBUG=%u is active on this context (experiment switches; not for production)\n", c->debug);
     }
     (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (c->n_cus <= 0) c->n_cus = 256;
@@ -394,12 +432,14 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     hipSetDevice(c->device);
     ctx_free_bvh(c);
     if (c->prof_ev[0][0])
-        for (int i = 0; i < 128; ++i)
+        for (int i = 0; i < NVDR_PROF_RING; ++i)
             for (int k = 0; k < 4; ++k) hipEventDestroy(c->prof_ev[i][k]);
     hipFree(c->dinfo);
     hipFree(c->spill);
     hipFree(c->pix_list);
-    hipFree(c->rays); hipFree(c->texel); hipFree(c->vis); hipFree(c->live); hipFree(c->pix_origin); hipFree(c->lg_xcd);
+    hipFree(c->chunk_counts);
+    hipFree(c->rays); hipFree(c->texel); hipFree(c->vis); hipFree(c->live); hipFree(c->pix_origin); hipFree(c->lg_part);
+    if (c->ovf_host) hipHostFree(c->ovf_host);
     delete c;
     return 0;
 }
@@ -449,6 +489,21 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         int r = ctx_reserve(c, n_tris);
         if (r) return r;
     }
+    int r0 = ctx_check_overflow(c, "nvdr_bvh_build");
+    if (r0) return r0;
+    // spill columns for the proven stack bound of a tree over n_tris triangles (bvh.h); grow-only
+    const int smax = nvdr_stack_bound(n_tris);
+    if (smax > c->spill_cap) {
+        NVDR_HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(c->spill);
+        c->spill = nullptr;
+        c->spill_cap = 0;
+        const size_t depth = (size_t)(smax > NVDR_STACK_LDS ? smax - NVDR_STACK_LDS : 0);
+        NVDR_HIP_TRY(hipMalloc((void **)&c->spill, sizeof(int) * (depth > 0 ? depth : 1) * NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK));
+        c->spill_cap = smax;
+    }
+    // NVDR_DEBUG bit 32 (tests only): pretend the stack is one entry deeper than its LDS part, to exercise the overflow report
+    c->stack_max = (c->debug & 32u) ? NVDR_STACK_LDS + 1 : c->spill_cap;
     const int n = (int)n_tris;
     bvh_init_info_kernel<<<1, 64, 0, stream>>>(c->dinfo);
     bvh_bounds_kernel<<<min(div_up(n_verts, 256), 1024u), 256, 0, stream>>>(verts, n_verts, c->dinfo);
@@ -496,8 +551,11 @@ extern "C" int nvdr_bvh_info_get(nvdr_ctx *c, nvdr_bvh_info *out, void *stream_)
     for (int a = 0; a < 3; ++a) {
         out->aabb_min[a] = ordered_to_float(h.bounds[a]);
         out->aabb_max[a] = ordered_to_float(h.bounds[3 + a]);
+        out->grid_lo[a] = h.g_lo[a];
+        out->grid_scale[a] = h.g_scale[a];
     }
-    return 0;
+    out->stack_max = c->stack_max;
+    return ctx_check_overflow(c, "nvdr_bvh_info_get");
 }
 
 extern "C" int nvdr_bvh_export(nvdr_ctx *c, float *nodes_host, float *tri_host, void *stream_)
@@ -516,6 +574,7 @@ extern "C" int nvdr_trace_visibility(nvdr_ctx *c, const float *ro, const float *
                                      unsigned long long *counters, void *stream_)
 {
     NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_trace_visibility: no BVH built");
+    if (int r0 = ctx_check_overflow(c, "nvdr_trace_visibility")) return r0;
     if (n_rays <= 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
     const size_t lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
@@ -532,6 +591,7 @@ extern "C" int nvdr_trace_closest(nvdr_ctx *c, const float *ro, const float *rd,
                                   int32_t *out_tri, float *out_uv, void *stream_)
 {
     NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_trace_closest: no BVH built");
+    if (int r0 = ctx_check_overflow(c, "nvdr_trace_closest")) return r0;
     if (n_rays <= 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
     trace_closest_kernel<<<query_grid(c, n_rays), NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream>>>(

@@ -67,10 +67,21 @@ struct ShadeParams {
     uint8_t *vis;             // 1 = unoccluded
     uint32_t *live;           // compacted list of the stream slots stage 2 has to traverse
     unsigned *ray_count;      // its length (device counter)
-    float *g_light_xcd;       // [8][Hl*Wl*3] per-XCD private light-gradient accumulators (backward)
+    float *g_light_xcd;       // [8][Hl*Wl*3] per-XCD private light-gradient accumulators (backward, atomics mode only)
     int light_elems;          // Hl*Wl*3
-    unsigned debug;           // NVDR_DEBUG bits: 1 skip tracing, 2 skip light-gradient atomics
+    unsigned debug;           // NVDR_DEBUG bits (read once per context): 1 skip tracing, 2 skip the light gradient
+    // the chunk of the covered-pixel list this launch of the three stages works on: pixels [pix_begin, pix_begin + pix_cap)
+    unsigned pix_begin, pix_cap;
+    int reuse;                // backward: the forward's stream is still in the context IF the whole launch fitted one chunk
+    int lg_records;           // backward: 1 = write (texel, rgb) records for the band gather, 0 = global atomics
 };
+
+// pixels of this chunk (the covered-pixel count lives on the device; chunks behind it are empty launches)
+__device__ __forceinline__ unsigned chunk_pixels(const ShadeParams &p)
+{
+    const unsigned total = *p.pix_count;
+    return total > p.pix_begin ? min(total - p.pix_begin, p.pix_cap) : 0u;
+}
 
 // ---------------------------------------------------------------------------------------------
 // work-list compaction: covered pixels (mask > 0, kernel.cu:478) in raster order per wave
@@ -93,7 +104,17 @@ __global__ void compact_pixels_kernel(const float *__restrict__ mask, int64_t ms
     if (on) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)i;
 }
 
-__global__ void zero_count_kernel(unsigned *a, unsigned *b) { *a = 0; *b = 0; }
+// start of an env-shade launch: reset the covered-pixel counter (not when the forward's work list is reused) and the
+// live-ray counters of the chunks -- unless the stored ray stream is going to be reused, which is decided HERE, on the
+// device, because only the device knows whether the forward's covered pixels fitted one chunk
+__global__ void begin_launch_kernel(unsigned *pix_count, unsigned *chunk_counts, int n_chunks, int reuse, unsigned cap)
+{
+    const bool keep = reuse && *pix_count <= cap;
+    __syncthreads();
+    if (!reuse && threadIdx.x == 0) *pix_count = 0;
+    if (!keep)
+        for (int i = threadIdx.x; i < n_chunks; i += blockDim.x) chunk_counts[i] = 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // RNG (kernel.cu:30-45)
@@ -372,7 +393,8 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = p.L, G = 64 >> p.log2L;
     const int slot = lane >> p.log2L, sub = lane & (L - 1);
-    const unsigned P = *p.pix_count;
+    if (p.reuse && *p.pix_count <= p.pix_cap) return;     // backward pass: the forward's stream is still valid (one chunk)
+    const unsigned P = chunk_pixels(p);
     const unsigned n_groups = (P + G - 1) / G;
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
     const unsigned S = p.S, n = p.n;
@@ -388,9 +410,9 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     lcg_skip_coeff(5u * (unsigned)sub, jump_m, jump_a);
 
     for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
-        const unsigned pi = grp * G + slot;
+        const unsigned pi = grp * G + slot;                 // index inside the chunk
         const bool valid = pi < P;
-        const int lin = p.pix_list[valid ? pi : 0];
+        const int lin = p.pix_list[p.pix_begin + (valid ? pi : 0u)];
         const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
         const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
         const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
@@ -455,8 +477,9 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 deadB = (cull && !(dot3(nrm, dirB) > 0.0f)) ? 0x80000000u : 0u;
                 p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(__float_as_uint(pdfA_light + pdfA_bsdf) | deadA));
                 p.rays[rB] = make_float4(dirB.x, dirB.y, dirB.z, __uint_as_float(__float_as_uint(pdfB_light + pdfB_bsdf) | deadB));
-                p.texel[rA] = tyA * p.light.n1 + txA;
-                p.texel[rB] = tyB * p.light.n1 + txB;
+                // texel < 0 marks a slot without light-gradient record (dead here; occluded / zero after the backward pass)
+                p.texel[rA] = deadA ? -1 : tyA * p.light.n1 + txA;
+                p.texel[rB] = deadB ? -1 : tyB * p.light.n1 + txB;
             }
             // append the live slots to this wavefront's LDS staging buffer (ballot ranks; `staged` is wave-uniform)
             const unsigned long long mA = __ballot(deadA == 0u), mB = __ballot(deadB == 0u);
@@ -499,7 +522,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
                                                                           unsigned long long *counters)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const TravStack stack = make_stack(smem, spill);
+    const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
     const int lane = threadIdx.x & 63;
     const unsigned total = *ray_count;
     const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
@@ -583,13 +606,13 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
             float t0, t1, t2, t3;
             const bool h0 = slot_hit(q0, g, NVDR_RAY_TMAX, t0), h1 = slot_hit(q1, g, NVDR_RAY_TMAX, t1);
             const bool h2 = slot_hit(q2, g, NVDR_RAY_TMAX, t2), h3 = slot_hit(q3, g, NVDR_RAY_TMAX, t3);
-            if (COUNT) n_box += 4;
             const float BIG = 3.0e38f;
             const float u0 = h0 ? t0 : BIG, u1 = h1 ? t1 : BIG, u2 = h2 ? t2 : BIG, u3 = h3 ? t3 : BIG;
             const float um = fminf(fminf(u0, u1), fminf(u2, u3));
             const int best = (h0 & (u0 == um)) ? 0 : (h1 & (u1 == um)) ? 1 : (h2 & (u2 == um)) ? 2 : 3;
             const bool any = h0 | h1 | h2 | h3;
             const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
+            if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
             nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
             // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs 0.67 ms)
             if (h0 & (best != 0)) { stack.push(sp, c0); sp++; }
@@ -648,21 +671,21 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = p.L, G = 64 >> p.log2L;
     const int slot = lane >> p.log2L, sub = lane & (L - 1);
-    const unsigned P = *p.pix_count;
+    const unsigned P = chunk_pixels(p);
     const unsigned n_groups = (P + G - 1) / G;
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
     const unsigned S = p.S, n = p.n;
     const float sample_frac = 1.0f / (float)(n * n);
     // HW_REG_XCC_ID (hwreg 20), bits [3:0]: the XCD this wave runs on
     const unsigned xcc = BACKWARD ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0u;
-    float *xcd_light = BACKWARD ? p.g_light_xcd + (int64_t)xcc * p.light_elems : nullptr;
+    float *xcd_light = (BACKWARD && !p.lg_records) ? p.g_light_xcd + (int64_t)xcc * p.light_elems : nullptr;
     const bool use_bits = BACKWARD && p.vis_cache != nullptr;    // replay the caller's cached forward bits
     const bool save_bits = !BACKWARD && p.vis_cache != nullptr;
 
     for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
         const unsigned pi = grp * G + slot;
         const bool valid = pi < P;
-        const int lin = p.pix_list[valid ? pi : 0];
+        const int lin = p.pix_list[p.pix_begin + (valid ? pi : 0u)];
         const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
         const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
         const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
@@ -769,11 +792,20 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 for (int r = 0; r < 2; ++r) {
                     // adding +-0 never changes an accumulator that started at +0: occluded and dead samples are skipped
                     const F3 lg = lg_add[r];
-                    if (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f) {
+                    const bool nz = lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f;
+                    if (p.lg_records) {
+                        // Band gather (light_grad_band_kernel): the addend REPLACES the sample's ray in the stream -- this
+                        // lane read it above and nobody needs it again -- and a slot without addend gets texel -1.
+                        // No atomic leaves the workgroup: 21 M addends per 8-view launch were 63 M memory-side fp32 atomics.
+                        if ((dead >> r) & 1u) continue;         // stage 1 already wrote texel -1
+                        const int64_t ri = r == 0 ? rA : rB;
+                        if (nz) p.rays[ri] = make_float4(lg.x, lg.y, lg.z, 0.0f);
+                        else p.texel[ri] = -1;
+                    } else if (nz) {
                         float *g = xcd_light + (int64_t)lg_at[r] * 3;
-                        __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -807,16 +839,110 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     }
 }
 
-// light_grad = sum over the 8 per-XCD copies (runs after the gradient kernel: the kernel boundary makes every XCD's
-// L2 contents visible)
-__global__ void __launch_bounds__(256) light_grad_reduce_kernel(const float *__restrict__ xcd, int n, float *__restrict__ out)
+// ---------------------------------------------------------------------------------------------
+// light gradient (eval_light_bwd, kernel.cu:203-211) without global atomics: BAND GATHER.
+//
+// The reference adds every sample's addend to light_grad[texel] with three atomicAdds.  On MI355X fp32 atomics are
+// executed at the memory side (rocprofv3, round 1: one 64-byte fabric write per atomic, 63 M of them per 8-view launch,
+// WRITE_SIZE 3.75 GB against 0.5 GB of algorithmic addends) -- a third of the backward shading kernel's time.  Here the
+// backward kernel leaves a (texel, rgb) RECORD per non-zero addend in the ray stream (the rgb overwrites the ray the lane
+// has just consumed; texel = -1 marks slots without addend) and this kernel reduces the records by key:
+//   * the probe is cut into `n_bands` bands of consecutive texels whose fp32 accumulators (band_texels * 12 B) fit the LDS
+//     of one workgroup (96 KB -> 8 bands at 256x256);
+//   * workgroup (g, band) scans the g-th slice of the key array (coalesced int4 loads, 4 B per slot) and fetches the 16-byte
+//     record only of keys inside its band, adding it into LDS with ds_add_f32 (hot sun texels serialise inside the LDS
+//     atomic unit, not on the fabric);
+//   * it then writes its band as ONE plain partial row; light_grad_reduce_kernel sums the partial rows.
+// Cost model per 8-view launch (58 M slots, 21 M records): keys 8 bands x 233 MB = 1.9 GB (mostly Infinity-Cache hits, the
+// key array is 233 MB), records 21 M x 64-B sectors = 1.3 GB, partials 25 MB: ~0.5 ms instead of ~3 ms.
+
+#define NVDR_LG_THREADS 1024
+
+__global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const int *__restrict__ texel, const float4 *__restrict__ recs,
+                                                                          const unsigned *__restrict__ pix_count, unsigned pix_begin,
+                                                                          unsigned pix_cap, unsigned rays_per_pixel, int band_texels,
+                                                                          int n_texels, float *__restrict__ partials)
+{
+    extern __shared__ __attribute__((aligned(16))) float lg_acc[];
+    const unsigned Ptot = *pix_count;
+    const unsigned P = Ptot > pix_begin ? min(Ptot - pix_begin, pix_cap) : 0u;
+    if (P == 0) return;                                     // light_grad_reduce_kernel makes the same test
+    const int g = blockIdx.x, G = gridDim.x, band = blockIdx.y;
+    const int t_lo = band * band_texels, t_hi = min(t_lo + band_texels, n_texels);
+    const int n_acc = (t_hi - t_lo) * 3;
+    for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) lg_acc[i] = 0.0f;
+    __syncthreads();
+    const unsigned total = P * rays_per_pixel;              // < 2^31 by the chunk size
+    const unsigned n4 = (total + 3u) >> 2;
+    const unsigned per = (n4 + G - 1) / G;
+    const unsigned b4 = g * per, e4 = min(b4 + per, n4);
+    const int4 *__restrict__ keys = (const int4 *)texel;    // the allocation is padded to a multiple of 4 entries
+    for (unsigned q = b4 + threadIdx.x; q < e4; q += NVDR_LG_THREADS) {
+        const int4 k4 = keys[q];
+        const int kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned slot = 4u * q + j;
+            const int t = kk[j];
+            if (slot < total && t >= t_lo && t < t_hi) {
+                const float4 v = recs[slot];
+                float *a = lg_acc + (t - t_lo) * 3;
+                __hip_atomic_fetch_add(a + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    float *out = partials + (int64_t)g * n_texels * 3 + (int64_t)t_lo * 3;
+    for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) out[i] = lg_acc[i];
+}
+
+// light_grad (+)= sum over the `rows` partial rows (band gather: one row per slice of the key array; atomics mode: the 8
+// per-XCD copies).  With pix_count != NULL the chunk may be empty: then the gather wrote nothing and the sum is zero.
+__global__ void __launch_bounds__(256) light_grad_reduce_kernel(const float *__restrict__ parts, int n, int rows, float *__restrict__ out,
+                                                               int accumulate, const unsigned *__restrict__ pix_count, unsigned pix_begin)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc += xcd[(int64_t)k * n + i];
-    out[i] = acc;
+    if (pix_count == nullptr || *pix_count > pix_begin)
+        for (int k = 0; k < rows; ++k) acc += parts[(int64_t)k * n + i];
+    if (accumulate) out[i] += acc;
+    else out[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// canonical traversal work of the live rays (counting launches only): the BINARY any-hit walk of bvh.h over the same
+// rays, i.e. node visits and triangle tests of the reference accounting layout (32-B BVH2 node, 36-B triangle),
+// independent of how speculative the production kernel's wide walk is.  tests/test_gpu_bvh.py checks the same counter
+// against a CPU walk of the exported tree (oracle_bvh2_walk).
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK) bvh2_count_kernel(BvhView bvh, const float4 *__restrict__ rays,
+                                                                       const float4 *__restrict__ pix_origin,
+                                                                       const uint32_t *__restrict__ live,
+                                                                       const unsigned *__restrict__ ray_count, unsigned rays_per_pixel,
+                                                                       int *spill, unsigned long long *out)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
+    const unsigned total = *ray_count;
+    unsigned nb = 0, nt = 0, nr = 0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned slot = live[i];
+        const float4 rd = rays[slot], ro = pix_origin[slot / rays_per_pixel];
+        (void)bvh_any_hit<true>(bvh, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, stack, nb, nt);
+        nr++;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        nb += __shfl_xor(nb, o);
+        nt += __shfl_xor(nt, o);
+        nr += __shfl_xor(nr, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], (unsigned long long)(nb >> 1));   // the binary walk counts two box tests per node visit
+        atomicAdd(&out[1], (unsigned long long)nt);
+        atomicAdd(&out[2], (unsigned long long)nr);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -842,20 +968,42 @@ static int check_gb(const nvdr_tensor &t, int64_t N, int64_t H, int64_t W, const
     return 0;
 }
 
-// grow-only scratch for the ray stream (sized for the worst case: every pixel covered)
-static int reserve_stream(nvdr_ctx *c, int64_t npix, unsigned S, hipStream_t stream)
+// Scratch for the ray stream.  Round 1 sized it for the worst case -- every pixel of the launch covered -- which was
+// 6.7 GB for the 8-view benchmark (23 % coverage) and rejected launches beyond 2^31 rays.  Now the stream holds ONE CHUNK
+// of `cap` covered pixels (x 2S rays x 25 B), cap from the context's byte budget (nvdr_ctx_set_stream_budget; default
+// 2 GiB or NVDR_STREAM_BUDGET_MB, read once when the context is created), and a launch
+// walks the compacted pixel list chunk by chunk: gen -> trace -> shade per chunk.  The host never learns the covered
+// count (no synchronisation): it issues ceil(N*H*W / cap) chunks and the ones behind the device-side count are empty
+// launches (~4 us each).  Slot numbers are chunk-local, so the 31-bit limit applies to cap * 2S only.
+static int64_t stream_chunk_pixels(const nvdr_ctx *c, int64_t npix, unsigned S)
 {
-    const size_t rays = (size_t)npix * 2 * S;
-    if (c->stream_cap_rays >= rays && c->pix_cap >= npix) return 0;
+    const int64_t per_pixel = (int64_t)2 * S * (16 + 4 + 1 + 4) + 16;
+    int64_t cap = c->stream_budget / per_pixel;
+    const int64_t lim31 = ((1ll << 31) - 64) / (2ll * S);          // chunk-local slot numbers stay below 2^31
+    if (cap > lim31) cap = lim31;
+    const int64_t min_cap = (npix + NVDR_MAX_CHUNKS - 1) / NVDR_MAX_CHUNKS;
+    if (cap < min_cap) cap = min_cap;
+    if (cap < 64) cap = 64;
+    if (cap > npix) cap = npix;
+    return cap;
+}
+
+static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, unsigned S, hipStream_t stream)
+{
+    const size_t rays = ((size_t)cap * 2 * S + 3) & ~(size_t)3;   // the band gather reads the keys as int4
+    if (c->stream_cap_rays >= rays && c->pix_cap >= npix && c->stream_cap_pixels >= cap) return 0;
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
     if (c->pix_cap < npix) {
         (void)hipFree(c->pix_list);
-        (void)hipFree(c->pix_origin);
         c->pix_list = nullptr;
-        c->pix_origin = nullptr;
         NVDR_HIP_TRY(hipMalloc((void **)&c->pix_list, sizeof(int) * npix));
-        NVDR_HIP_TRY(hipMalloc((void **)&c->pix_origin, sizeof(float4) * npix));
         c->pix_cap = npix;
+    }
+    if (c->stream_cap_pixels < cap) {
+        (void)hipFree(c->pix_origin);
+        c->pix_origin = nullptr;
+        NVDR_HIP_TRY(hipMalloc((void **)&c->pix_origin, sizeof(float4) * cap));
+        c->stream_cap_pixels = cap;
     }
     if (c->stream_cap_rays < rays) {
         (void)hipFree(c->rays);
@@ -863,19 +1011,41 @@ static int reserve_stream(nvdr_ctx *c, int64_t npix, unsigned S, hipStream_t str
         (void)hipFree(c->vis);
         (void)hipFree(c->live);
         c->rays = nullptr; c->texel = nullptr; c->vis = nullptr; c->live = nullptr;
+        c->stream_cap_rays = 0;
         NVDR_HIP_TRY(hipMalloc((void **)&c->rays, sizeof(float4) * rays));
         NVDR_HIP_TRY(hipMalloc((void **)&c->texel, sizeof(int) * rays));
         NVDR_HIP_TRY(hipMalloc((void **)&c->vis, rays));
         NVDR_HIP_TRY(hipMalloc((void **)&c->live, sizeof(uint32_t) * rays));
         c->stream_cap_rays = rays;
     }
+    c->stream_id = 0;
     return 0;
+}
+
+// LDS the band gather may use per workgroup (bytes); > 64 KB needs the attribute below
+static size_t lg_lds_budget()
+{
+    static size_t budget = 0;
+    if (budget) return budget;
+    size_t kb = 96;
+    if (const char *e = getenv("NVDR_LG_LDS_KB")) kb = (size_t)atoll(e);
+    if (kb < 8) kb = 8;
+    if (kb > 160) kb = 160;
+    size_t want = kb * 1024;
+    if (want > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)light_grad_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+        (void)hipGetLastError();
+        want = 64 * 1024;
+    }
+    budget = want;
+    return budget;
 }
 
 static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool backward, hipStream_t stream)
 {
     NVDR_REQUIRE(c && a, "env_shade: NULL argument");
     NVDR_REQUIRE(c->n_tris > 0, "env_shade: no BVH built on this context (call optix_build_bvh first)");
+    if (int r0 = ctx_check_overflow(c, "env_shade")) return r0;
     NVDR_REQUIRE(a->bsdf <= 2, "env_shade: BSDF index %u out of range", a->bsdf);
     NVDR_REQUIRE(a->n_samples_x >= 1 && a->n_samples_x <= 256, "env_shade: n_samples_x %u out of range", a->n_samples_x);
     const int64_t N = a->ro.size[0], H = a->ro.size[1], W = a->ro.size[2];
@@ -896,9 +1066,9 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     NVDR_REQUIRE(a->pdf.size[0] == a->cols.size[0] && a->pdf.size[1] == a->cols.size[1] && a->rows.size[0] == a->pdf.size[0],
                  "env_shade: pdf/rows/cols shapes disagree");
     const int64_t npix = N * H * W;
-    NVDR_REQUIRE((double)npix * 2.0 * S < 2147483647.0, "env_shade: %lld pixels x %u rays exceed the 31-bit ray index; split the batch",
-                 (long long)npix, 2 * S);
     NVDR_HIP_TRY(hipSetDevice(c->device));
+    const int64_t cap = stream_chunk_pixels(c, npix, S);
+    const int n_chunks = (int)((npix + cap - 1) / cap);
 
     ShadeParams p;
     memset(&p, 0, sizeof(p));
@@ -921,6 +1091,25 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     p.L = L; p.log2L = lg;
     p.vis_cache = a->vis_cache;
     p.vis_words = (int)((S + 31) / 32);
+    p.debug = c->debug;
+    p.pix_cap = (unsigned)cap;
+
+    // light gradient: band gather when the probe's accumulators fit <= 16 LDS bands, memory-side atomics otherwise
+    const int n_texels = (int)(a->light.size[0] * a->light.size[1]);
+    int n_bands = 0, band_texels = 0, lg_rows = 8;
+    size_t lg_lds = 0;
+    if (backward) {
+        const size_t lds_budget = lg_lds_budget();
+        const int max_band = (int)(lds_budget / 12);
+        n_bands = (n_texels + max_band - 1) / max_band;
+        p.lg_records = (n_bands <= 16 && !(c->debug & 16u)) ? 1 : 0;
+        if (p.lg_records) {
+            band_texels = (n_texels + n_bands - 1) / n_bands;
+            lg_lds = (size_t)band_texels * 12;
+            lg_rows = c->n_cus / n_bands < 1 ? 1 : c->n_cus / n_bands;
+        }
+    }
+
     if (!backward) {
         NVDR_REQUIRE(a->diff && a->spec, "env_shade_fwd: NULL output");
         p.diff = a->diff; p.spec = a->spec;
@@ -946,30 +1135,34 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             NVDR_HIP_TRY(hipMemsetAsync(p.g_kd, 0, sizeof(float) * 3 * npix, stream));
             NVDR_HIP_TRY(hipMemsetAsync(p.g_ks, 0, sizeof(float) * 3 * npix, stream));
         }
-        p.light_elems = (int)(3 * a->light.size[0] * a->light.size[1]);
-        if (c->lg_cap < (size_t)p.light_elems * 8) {
+        p.light_elems = 3 * n_texels;
+        const size_t need = (size_t)p.light_elems * (size_t)(lg_rows > 8 ? lg_rows : 8);
+        if (c->lg_cap < need) {
             NVDR_HIP_TRY(hipStreamSynchronize(stream));
-            (void)hipFree(c->lg_xcd);
-            c->lg_xcd = nullptr;
-            NVDR_HIP_TRY(hipMalloc((void **)&c->lg_xcd, sizeof(float) * (size_t)p.light_elems * 8));
-            c->lg_cap = (size_t)p.light_elems * 8;
+            (void)hipFree(c->lg_part);
+            c->lg_part = nullptr;
+            c->lg_cap = 0;
+            NVDR_HIP_TRY(hipMalloc((void **)&c->lg_part, sizeof(float) * need));
+            c->lg_cap = need;
         }
-        p.g_light_xcd = c->lg_xcd;
-        NVDR_HIP_TRY(hipMemsetAsync(c->lg_xcd, 0, sizeof(float) * (size_t)p.light_elems * 8, stream));
+        p.g_light_xcd = c->lg_part;
+        if (!p.lg_records || (c->debug & 2u)) {
+            NVDR_HIP_TRY(hipMemsetAsync(c->lg_part, 0, sizeof(float) * (size_t)p.light_elems * 8, stream));
+            if (c->debug & 2u) NVDR_HIP_TRY(hipMemsetAsync(p.g_light, 0, sizeof(float) * p.light_elems, stream));
+        }
     }
-    if ((r = reserve_stream(c, npix, S, stream))) return r;
+    if ((r = reserve_stream(c, npix, cap, S, stream))) return r;
     p.pix_list = c->pix_list;
     p.pix_count = &c->dinfo->pix_count;
     p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.vis = c->vis;
-    p.live = c->live; p.ray_count = &c->dinfo->ray_count;
-    const char *dbg = getenv("NVDR_DEBUG");
-    p.debug = dbg ? (unsigned)atoi(dbg) : 0u;
+    p.live = c->live;
 
-    // backward pass of a forward launch whose ray stream is still in the context: no need to rebuild it
+    // backward pass of a forward launch whose work list (and, if it fitted one chunk, ray stream) is still in the context
     const bool reuse = backward && a->reuse_stream_id != 0 && a->reuse_stream_id == c->stream_id;
+    p.reuse = reuse ? 1 : 0;
     // persistent grids (the covered-pixel count lives on the device)
     const int waves_per_block = 4;
-    const int64_t max_groups = (npix + (64 / L) - 1) / (64 / L);
+    const int64_t max_groups = (cap + (64 / L) - 1) / (64 / L);
     // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading); NVDR_PBLOCKS="g,f,b"
     // overrides them for tuning
     int per_cu[3] = {8, 6, 6};   // measured (bob 512^2 x 64 spp, 1 and 8 views per launch): within 3 % of the best for each kernel
@@ -980,53 +1173,82 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (pb[k] * waves_per_block > max_groups) pb[k] = (max_groups + waves_per_block - 1) / waves_per_block;
         if (pb[k] < 1) pb[k] = 1;
     }
-    hipEvent_t *pe = nullptr;
-    if (c->profiling) {
-        const int slot = (int)(c->prof_n % 128);
-        pe = c->prof_ev[slot];
-        c->prof_kind[slot] = backward ? 1 : 0;
-        c->prof_n++;
-        NVDR_HIP_TRY(hipEventRecord(pe[0], stream));
-    }
-    if (!reuse) {
-        c->stream_id = 0; // invalid while being rewritten
-        zero_count_kernel<<<1, 1, 0, stream>>>(&c->dinfo->pix_count, &c->dinfo->ray_count);
-        compact_pixels_kernel<<<div_up(npix, 256), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
-                                                                      &c->dinfo->pix_count);
-        env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
-        c->stream_id = ++c->stream_seq;
-    }
-    if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
-    const bool replay = backward && p.vis_cache != nullptr;   // forward bits handed back by the caller: no traversal
-    if (!replay) {
-        if (p.debug & 1u) {
-            NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)npix * 2 * S, stream));
-        } else {
 #ifndef NVDR_TRACE_BLOCKS_PER_CU
 #define NVDR_TRACE_BLOCKS_PER_CU 8
 #endif
-            int64_t tblocks = (int64_t)c->n_cus * NVDR_TRACE_BLOCKS_PER_CU;
-            if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
-            const int64_t need = (npix * 2 * S + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
-            if (tblocks > need) tblocks = need < 1 ? 1 : need;
-            const size_t lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
-            if (a->counters)
-                env_trace_kernel<true><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
-                                                                                             p.ray_count, 2 * S, c->vis, c->spill, a->counters);
-            else
-                env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
-                                                                                              p.ray_count, 2 * S, c->vis, c->spill, nullptr);
+    int64_t tblocks = (int64_t)c->n_cus * NVDR_TRACE_BLOCKS_PER_CU;
+    if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
+    {
+        const int64_t need = (cap * 2 * S + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
+        if (tblocks > need) tblocks = need < 1 ? 1 : need;
+    }
+    const size_t trace_lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
+    const bool replay = backward && p.vis_cache != nullptr;   // forward bits handed back by the caller: no traversal
+
+    c->stream_id = 0; // invalid while being rewritten
+    begin_launch_kernel<<<1, 256, 0, stream>>>(&c->dinfo->pix_count, c->chunk_counts, n_chunks, p.reuse, p.pix_cap);
+    if (!reuse)
+        compact_pixels_kernel<<<div_up(npix, 256), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
+                                                                      &c->dinfo->pix_count);
+    for (int k = 0; k < n_chunks; ++k) {
+        p.pix_begin = (unsigned)((int64_t)k * cap);
+        p.ray_count = c->chunk_counts + k;
+        hipEvent_t *pe = nullptr;
+        if (c->profiling) {
+            const int slot = (int)(c->prof_n % NVDR_PROF_RING);
+            pe = c->prof_ev[slot];
+            c->prof_kind[slot] = (backward ? 1 : 0) | (k == 0 ? 2 : 0);
+            c->prof_n++;
+            NVDR_HIP_TRY(hipEventRecord(pe[0], stream));
         }
+        // stage 1 (skipped on the host when the forward's stream is known to be whole: one chunk covers the launch;
+        // otherwise the kernel itself decides from the device-side pixel count)
+        if (!(reuse && n_chunks == 1)) env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
+        if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
+        // stage 2
+        if (!replay) {
+            if (c->debug & 1u) {
+                NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)cap * 2 * S, stream));
+            } else if (a->counters) {
+                env_trace_kernel<true><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
+                                                                                                  p.ray_count, 2 * S, c->vis, c->spill, a->counters);
+                bvh2_count_kernel<<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, p.ray_count,
+                                                                                            2 * S, c->spill, a->counters + NVDR_COUNTERS_BVH2);
+            } else {
+                env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
+                                                                                                   p.ray_count, 2 * S, c->vis, c->spill, nullptr);
+            }
+        }
+        if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
+        // stage 3
+        if (backward) {
+            env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
+            if (p.lg_records && !(c->debug & 2u)) {
+                light_grad_band_kernel<<<dim3((unsigned)lg_rows, (unsigned)n_bands), NVDR_LG_THREADS, lg_lds, stream>>>(
+                    c->texel, c->rays, p.pix_count, p.pix_begin, p.pix_cap, 2 * S, band_texels, n_texels, c->lg_part);
+                light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, lg_rows, p.g_light,
+                                                                                         k > 0 ? 1 : 0, p.pix_count, p.pix_begin);
+            }
+        } else {
+            env_shade_kernel<false><<<(unsigned)pb[1], 256, 0, stream>>>(p);
+        }
+        if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));
     }
-    if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
-    if (backward) {
-        env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
-        light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_xcd, p.light_elems, p.g_light);
-    } else {
-        env_shade_kernel<false><<<(unsigned)pb[1], 256, 0, stream>>>(p);
-    }
-    if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));
+    if (backward && !p.lg_records && !(c->debug & 2u))
+        light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, 8, p.g_light, 0, nullptr, 0);
     NVDR_LAUNCH_CHECK();
+    // The stream a later backward pass may reuse is the one a FORWARD launch wrote; the record-writing backward pass
+    // consumes it (ray directions are overwritten by light-gradient records), so it is invalid afterwards.
+    c->stream_id = (backward && p.lg_records) ? 0 : (reuse ? a->reuse_stream_id : ++c->stream_seq);
+    return 0;
+}
+
+extern "C" int nvdr_ctx_set_stream_budget(nvdr_ctx *c, int64_t bytes)
+{
+    NVDR_REQUIRE(c, "nvdr_ctx_set_stream_budget: NULL ctx");
+    NVDR_REQUIRE(bytes >= (1 << 20), "nvdr_ctx_set_stream_budget: %lld bytes is below the 1 MiB minimum", (long long)bytes);
+    c->stream_budget = bytes;
+    c->stream_id = 0;     // a stream written with another chunk size must not be reused
     return 0;
 }
 
@@ -1035,7 +1257,7 @@ extern "C" int nvdr_ctx_set_profiling(nvdr_ctx *c, int enable)
     NVDR_REQUIRE(c, "nvdr_ctx_set_profiling: NULL ctx");
     NVDR_HIP_TRY(hipSetDevice(c->device));
     if (enable && !c->prof_ev[0][0]) {
-        for (int i = 0; i < 128; ++i)
+        for (int i = 0; i < NVDR_PROF_RING; ++i)
             for (int k = 0; k < 4; ++k) NVDR_HIP_TRY(hipEventCreate(&c->prof_ev[i][k]));
     }
     c->profiling = enable != 0;
@@ -1048,17 +1270,23 @@ extern "C" int nvdr_env_shade_stage_times(nvdr_ctx *c, int backward, double *ms,
     NVDR_REQUIRE(c && ms && count, "nvdr_env_shade_stage_times: NULL argument");
     ms[0] = ms[1] = ms[2] = 0.0;
     *count = 0;
-    const int64_t n = c->prof_n < 128 ? c->prof_n : 128;
+    const int64_t n = c->prof_n < NVDR_PROF_RING ? c->prof_n : NVDR_PROF_RING;
     if (n == 0) return 0;
-    NVDR_HIP_TRY(hipEventSynchronize(c->prof_ev[(c->prof_n - 1) % 128][3]));
-    for (int64_t i = 0; i < n; ++i) {
-        if (c->prof_kind[i] != (backward ? 1 : 0)) continue;
+    NVDR_HIP_TRY(hipEventSynchronize(c->prof_ev[(c->prof_n - 1) % NVDR_PROF_RING][3]));
+    // the ring holds one record per (launch, chunk); a launch whose first chunk has been overwritten is left out
+    const int64_t first = c->prof_n - n;
+    bool counting = false;
+    for (int64_t j = first; j < c->prof_n; ++j) {
+        const int i = (int)(j % NVDR_PROF_RING);
+        if (c->prof_kind[i] & 2) counting = (c->prof_kind[i] & 1) == (backward ? 1 : 0);
+        else if ((c->prof_kind[i] & 1) != (backward ? 1 : 0)) counting = false;
+        if (!counting) continue;
         for (int k = 0; k < 3; ++k) {
             float t = 0.0f;
             NVDR_HIP_TRY(hipEventElapsedTime(&t, c->prof_ev[i][k], c->prof_ev[i][k + 1]));
             ms[k] += t;
         }
-        (*count)++;
+        if (c->prof_kind[i] & 2) (*count)++;
     }
     return 0;
 }

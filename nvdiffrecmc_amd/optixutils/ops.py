@@ -51,6 +51,23 @@ class OptiXContext:
 
     def __init__(self, device=None):
         self.cpp_wrapper = _HipContext(device)
+        # Behavioural switches live on the CONTEXT (round 1 kept them in process-global class attributes):
+        #   cache_visibility   reuse the forward's visibility bits in backward when the seed is fixed (identical rays; the
+        #                      reference re-traces every ray, torch_bindings.cpp:238,266).  None = the module default.
+        #   pixel_index_offset added to the linear pixel index that seeds the RNG (data-parallel shards: first_view * H * W)
+        self.cache_visibility = None
+        self.pixel_index_offset = None
+
+    def set_stream_budget(self, megabytes):
+        """HBM the ray stream between the three env-shade stages may take (default 2048 MB); larger launches are processed
+        in chunks of covered pixels with identical results."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')
+
+    def check(self):
+        """Synchronise and raise if any traversal launch on this context ever overflowed its stack (never silent)."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_ctx_check(w.handle, _lib.stream_ptr()), 'nvdr_ctx_check')
 
     def set_profiling(self, enable=True):
         """Record HIP events around the three env-shade stages of every launch on this context (bench.py)."""
@@ -71,7 +88,19 @@ class OptiXContext:
         info = _lib.NvdrBvhInfo()
         _lib.check(w.lib.nvdr_bvh_info_get(w.handle, ctypes.byref(info), _lib.stream_ptr()), 'nvdr_bvh_info_get')
         return {'n_tris': info.n_tris, 'n_nodes': info.n_nodes, 'height': info.height,
-                'aabb_min': list(info.aabb_min), 'aabb_max': list(info.aabb_max)}
+                'aabb_min': list(info.aabb_min), 'aabb_max': list(info.aabb_max),
+                'grid_lo': list(info.grid_lo), 'grid_scale': list(info.grid_scale), 'stack_max': info.stack_max}
+
+    def bvh_export(self):
+        """Host copies of the binary tree: nodes uint32 [n_nodes, 8] (32-B records, csrc/bvh.h) and triangle records
+        float32 [n_tris, 12] in Morton order (v0, e1, e2, original index bits, 0, 0)."""
+        w = self.cpp_wrapper
+        info = self.bvh_info()
+        nodes = np.zeros((max(info['n_nodes'], 1), 8), dtype=np.uint32)
+        tris = np.zeros((info['n_tris'], 12), dtype=np.float32)
+        _lib.check(w.lib.nvdr_bvh_export(w.handle, nodes.ctypes.data_as(ctypes.c_void_p), tris.ctypes.data_as(ctypes.c_void_p),
+                                         _lib.stream_ptr()), 'nvdr_bvh_export')
+        return nodes[:info['n_nodes']], tris
 
 
 def optix_build_bvh(optix_ctx, verts, tris, rebuild):
@@ -109,33 +138,49 @@ def _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks
     return a
 
 
+def _perms_for(n_samples_x, device):
+    """(32k) table of random permutations that decorrelate the BSDF and light strata: one per (device, n_samples_x),
+    created lazily and cached for the process (ops.py:79,84-86; the reference keys by n_samples_x only -- it runs one
+    device per process).  Tests inject a seeded CPU-generated table through set_permutation_table()."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), n_samples_x)
+    t = _optix_env_shade_func._random_perm.get(key)
+    if t is None:
+        t = torch.argsort(torch.rand(32768, n_samples_x * n_samples_x, device=device), dim=-1).int()
+        _optix_env_shade_func._random_perm[key] = t
+    return t
+
+
 class _optix_env_shade_func(torch.autograd.Function):
-    # (32k) tables with random permutations that decorrelate the BSDF and light strata, one per
-    # n_samples_x, created lazily and cached for the process (ops.py:79,84-86).  Tests inject a
-    # seeded CPU-generated table through set_permutation_table() so the oracle sees the same one.
-    _random_perm = {}
-    # reuse the forward's visibility bits in backward when the seed is fixed (identical rays);
-    # the reference re-traces every ray (torch_bindings.cpp:238,266).  Results are identical.
+    _random_perm = {}          # (device type, device index, n_samples_x) -> int32 [32768, S]
+    # module defaults of the per-context switches (OptiXContext.cache_visibility / .pixel_index_offset)
     cache_visibility = True
     pixel_index_offset = 0
+
+    @staticmethod
+    def _switches(optix_ctx):
+        cv = getattr(optix_ctx, 'cache_visibility', None)
+        off = getattr(optix_ctx, 'pixel_index_offset', None)
+        return (_optix_env_shade_func.cache_visibility if cv is None else bool(cv),
+                _optix_env_shade_func.pixel_index_offset if off is None else int(off))
 
     @staticmethod
     def forward(ctx, optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF,
                 n_samples_x, rnd_seed, shadow_scale):
         _rnd_seed = np.random.randint(2**31) if rnd_seed is None else rnd_seed
-        if n_samples_x not in _optix_env_shade_func._random_perm:
-            _optix_env_shade_func._random_perm[n_samples_x] = torch.argsort(
-                torch.rand(32768, n_samples_x * n_samples_x, device=ro.device), dim=-1).int()
-        perms = _optix_env_shade_func._random_perm[n_samples_x]
+        perms = _perms_for(n_samples_x, ro.device)
         w = optix_ctx.cpp_wrapper
-        off = _optix_env_shade_func.pixel_index_offset
+        cache_vis, off = _optix_env_shade_func._switches(optix_ctx)
         a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
                        BSDF, n_samples_x, _rnd_seed, shadow_scale, off)
         N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
-        diff, spec = torch.empty(2, N, H, W, 3, dtype=torch.float32, device=ro.device).unbind(0)   # one zero-fill
+        # independent storages like the reference's two torch::zeros (torch_bindings.cpp:148-149): views of one packed
+        # buffer would make any in-place op on an output an autograd error; the library zero-fills them
+        diff = torch.empty(N, H, W, 3, dtype=torch.float32, device=ro.device)
+        spec = torch.empty(N, H, W, 3, dtype=torch.float32, device=ro.device)
         a.diff, a.spec = diff.data_ptr(), spec.data_ptr()
         vis = None
-        if rnd_seed is not None and _optix_env_shade_func.cache_visibility:
+        if rnd_seed is not None and cache_vis:
             words = (n_samples_x * n_samples_x + 31) // 32
             vis = torch.empty(N * H * W * 2 * words, dtype=torch.int32, device=ro.device)
             a.vis_cache = vis.data_ptr()
@@ -159,7 +204,7 @@ class _optix_env_shade_func(torch.autograd.Function):
         optix_ctx = ctx.optix_ctx
         _rnd_seed = np.random.randint(2**31) if ctx.rnd_seed is None else ctx.rnd_seed
         mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols = ctx.saved_tensors
-        perms = _optix_env_shade_func._random_perm[ctx.n_samples_x]
+        perms = _perms_for(ctx.n_samples_x, ro.device)
         w = optix_ctx.cpp_wrapper
         a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
                        ctx.BSDF, ctx.n_samples_x, _rnd_seed, ctx.shadow_scale, ctx.pixel_index_offset)
@@ -168,8 +213,8 @@ class _optix_env_shade_func(torch.autograd.Function):
         diff_grad, spec_grad = diff_grad.contiguous(), spec_grad.contiguous()
         a.diff_grad = _lib.tensor_view(diff_grad, lead=False)
         a.spec_grad = _lib.tensor_view(spec_grad, lead=False)
-        # one allocation for the four per-pixel gradients: the library zero-fills contiguous outputs with one memset
-        gb_pos_grad, gb_normal_grad, gb_kd_grad, gb_ks_grad = torch.empty(4, N, H, W, 3, dtype=torch.float32, device=dev).unbind(0)
+        # independent storages (a leaf's .grad may keep one of them alive; round 1 handed out views of one 4x buffer)
+        gb_pos_grad, gb_normal_grad, gb_kd_grad, gb_ks_grad = (torch.empty(N, H, W, 3, dtype=torch.float32, device=dev) for _ in range(4))
         light_grad = torch.empty(light.shape[0], light.shape[1], 3, dtype=torch.float32, device=dev)
         a.gb_pos_grad, a.gb_normal_grad = gb_pos_grad.data_ptr(), gb_normal_grad.data_ptr()
         a.gb_kd_grad, a.gb_ks_grad, a.light_grad = gb_kd_grad.data_ptr(), gb_ks_grad.data_ptr(), light_grad.data_ptr()
@@ -188,12 +233,17 @@ class _optix_env_shade_func(torch.autograd.Function):
 
 def set_permutation_table(n_samples_x, perms):
     """Install a specific permutation table (int32 [NP, n_samples_x^2], on the GPU) -- parity tests only."""
-    _optix_env_shade_func._random_perm[n_samples_x] = perms
+    d = perms.device
+    _optix_env_shade_func._random_perm[(d.type, d.index if d.index is not None else torch.cuda.current_device(), n_samples_x)] = perms
 
 
-def set_pixel_index_offset(offset):
-    """Data-parallel shards: offset added to the linear pixel index that seeds the RNG (rank * H * W)."""
-    _optix_env_shade_func.pixel_index_offset = int(offset)
+def set_pixel_index_offset(offset, optix_ctx=None):
+    """Data-parallel shards: offset added to the linear pixel index that seeds the RNG (first_view * H * W); per context
+    when one is given, otherwise the module default."""
+    if optix_ctx is not None:
+        optix_ctx.pixel_index_offset = int(offset)
+    else:
+        _optix_env_shade_func.pixel_index_offset = int(offset)
 
 
 def optix_env_shade(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols,
@@ -274,26 +324,25 @@ def trace_closest(optix_ctx, ro, rd):
 def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols,
                                BSDF='pbr', n_samples_x=8, rnd_seed=0, shadow_scale=1.0):
     """Run the COUNTING build of the forward kernel once: returns (covered pixels, box tests, triangle tests,
-    rays traversed).  Rays traversed is below 2*S*pixels: samples under the shading horizon are never traced."""
-    if n_samples_x not in _optix_env_shade_func._random_perm:
-        _optix_env_shade_func._random_perm[n_samples_x] = torch.argsort(
-            torch.rand(32768, n_samples_x * n_samples_x, device=ro.device), dim=-1).int()
-    perms = _optix_env_shade_func._random_perm[n_samples_x]
+    rays traversed).  Rays traversed is below 2*S*pixels: samples under the shading horizon are never traced.
+    env_shade_traversal_counts.bvh2 = (node visits, triangle tests, rays) of the canonical binary walk over the same rays."""
+    perms = _perms_for(n_samples_x, ro.device)
     w = optix_ctx.cpp_wrapper
     a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
                    ['pbr', 'diffuse', 'white'].index(BSDF), n_samples_x, rnd_seed, shadow_scale,
-                   _optix_env_shade_func.pixel_index_offset)
+                   _optix_env_shade_func._switches(optix_ctx)[1])
     N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
     diff = torch.empty(N, H, W, 3, dtype=torch.float32, device=ro.device)
     spec = torch.empty_like(diff)
-    cnt = torch.zeros(8 + 2 * 8192, dtype=torch.int64, device=ro.device)
+    cnt = torch.zeros(_lib.COUNTERS_LEN, dtype=torch.int64, device=ro.device)
     a.diff, a.spec, a.counters = diff.data_ptr(), spec.data_ptr(), cnt.data_ptr()
     _lib.check(w.lib.nvdr_env_shade_fwd(w.handle, ctypes.byref(a), _lib.stream_ptr()), 'env_shade_fwd(count)')
     npx = ctypes.c_int64()
     _lib.check(w.lib.nvdr_env_shade_last_pixel_count(w.handle, ctypes.byref(npx), _lib.stream_ptr()), 'pixel_count')
     c = cnt.cpu()
     env_shade_traversal_counts.balance = (int(c[3]), int(c[4]), int(c[5]))   # sum, max of per-wave ticks (100 MHz), waves
-    env_shade_traversal_counts.wave_ticks = c[8:8 + 2 * int(c[5])].view(-1, 2)   # (begin, end) per wavefront
+    env_shade_traversal_counts.wave_ticks = c[8:8 + 2 * min(int(c[5]), 8192)].view(-1, 2)   # (begin, end) per wavefront
     env_shade_traversal_counts.clock_mhz = 100.0 * int(c[6]) / max(int(c[3]), 1)     # shader clock the waves ran at
     env_shade_traversal_counts.xcd_mask = int(c[7])
+    env_shade_traversal_counts.bvh2 = tuple(int(v) for v in c[_lib.COUNTERS_BVH2:_lib.COUNTERS_BVH2 + 3])
     return int(npx.value), int(c[0]), int(c[1]), int(c[2])

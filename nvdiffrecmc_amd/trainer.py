@@ -66,12 +66,16 @@ class _broadcast_pixels(torch.autograd.Function):
 
 class DirectLightingStep:
     def __init__(self, mesh_name='bob', res=512, n_samples_x=8, view=0, n_views=8, device='cuda', env='E1',
-                 probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True):
+                 probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
+                 denoiser_demodulate=True, light_grad_scale=64.0):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
         self.retrace_backward = retrace_backward
         self.fused = fused
+        self.denoiser_demodulate = denoiser_demodulate    # FLAGS.denoiser_demodulate (train.py:525, default True)
+        self.light_grad_scale = light_grad_scale          # lgt.base.grad *= 64 (train.py:439-440)
+        self.total_views = n_views if isinstance(n_views, int) else len(n_views)
         mesh = sc.load_mesh(mesh_name, device='cpu')
         if subdiv:
             mesh['v_pos'], mesh['t_pos_idx'] = sc.subdivide(mesh['v_pos'], mesh['t_pos_idx'], subdiv)
@@ -168,12 +172,19 @@ class DirectLightingStep:
         nrm = ru.prepare_shading_normal(self.gb_pos, self.view_pos, None, self.gb_smooth_nrm, self.gb_tangent,
                                         self.gb_geom_nrm, two_sided_shading=True, opengl=True)
         ro = self.gb_pos + nrm * 0.001
-        ou.ops.set_pixel_index_offset(self.pixel_index_offset)
-        ou.ops._optix_env_shade_func.cache_visibility = not self.retrace_backward
+        self.ctx.pixel_index_offset = self.pixel_index_offset          # per-context switches (ops.OptiXContext)
+        self.ctx.cache_visibility = not self.retrace_backward
         diff, spec = ou.optix_env_shade(self.ctx, self.mask, ro, self.gb_pos, nrm, self.view_pos, kd, ks, light.base,
                                         light._pdf, light.rows[:, 0], light.cols, BSDF='pbr', n_samples_x=self.n,
                                         rnd_seed=self.seed, shadow_scale=1.0)
         self.seed += 1
+        if self.denoiser is not None and not self.denoiser_demodulate:
+            # the non-demodulated branch of shade() (render.py:124-131): ONE filter pass over the combined colour
+            shaded = ru.shade_composite(diff, spec, kd, ks) if self.fused else diff * (kd * (1.0 - ks[..., 2:3])) + spec
+            if self.fused:
+                cw = ou.ops._bilateral_denoiser_func.apply(shaded, _safe_normalize(nrm), self.gb_depth, self.denoiser.sigma)
+                return cw[..., 0:3] / cw[..., 3:4]
+            return self.denoiser.forward(torch.cat((shaded, nrm, self.gb_depth), dim=-1))
         if self.fused:
             # same arithmetic as the branch below; the normal is normalised once for both filter passes, the filter
             # kernel is called without the 8-channel cat, and its (colour sum, weight) output goes straight into the
@@ -200,7 +211,11 @@ class DirectLightingStep:
 
     def step(self, world_size=1):
         loss = self.forward_backward()
-        self.allreduce_bytes = allreduce_gradients(self.params, world_size)
+        # weighted by this rank's share of the batch: the loss is a mean over the views a rank renders, the batch mean
+        # over all ranks needs sum(local_views * grad) / total_views (equal to the plain average for even shards)
+        self.allreduce_bytes = allreduce_gradients(self.params, world_size, local_weight=self.nv)
+        if self.light.base.grad is not None and self.light_grad_scale != 1.0:
+            self.light.base.grad *= self.light_grad_scale       # train.py:439-440
         self.opt.step()
         with torch.no_grad():
             self.kd_tex.clamp_(0.0, 1.0)

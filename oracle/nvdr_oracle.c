@@ -15,7 +15,7 @@
  *
  * Parity status: PINNED against the reference itself -- oracle/_ref builds the reference's own
  * kernel.cu / bsdf.h / denoising.cu for the CPU through a small shim (oracle/ref_shim/, recipe
- * oracle/Makefile) and tests/test_oracle_vs_ref.py compares the two in this container; the
+ * oracle/Makefile) and tests/test_oracle_pins.py compares the two in this container; the
  * resulting vectors are committed under tests/golden/.  Two things are ours by necessity:
  *   - shadow-ray visibility: closed-source OptiX in the reference (optixTrace, kernel.cu:104-116);
  *     here a brute-force loop over all triangles with the predicate of include/nvdr_raytri.h;
@@ -860,6 +860,100 @@ void oracle_light_update_pdf(const float *base, long Hl, long Wl, float *pdf, fl
     float lastr = rows[Hl - 1];
     float denr = lastr > 0 ? lastr : 1.0f;
     for (long y = 0; y < Hl; ++y) rows[y] /= denr;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * CPU walk of the binary tree the GPU built (nvdr_bvh_export): the canonical any-hit traversal of
+ * nvdiffrecmc_amd/csrc/bvh.h (visit_node / box_hit / bvh_any_hit2), restated in plain C so that the node-visit and
+ * triangle-test counters of the GPU counting kernels can be checked against something that does not run on the GPU
+ * ("n measured by a counting build ... must equal the CPU traversal of the same BVH").  The reference has no
+ * counterpart (OptiX's traversal is closed: optixTrace, kernel.cu:104-116).
+ *   nodes: uint32 [n_nodes, 8]  six words of 16-bit quantised child boxes + two child references (< 0: ~leaf slot)
+ *   trirec: float [n_tris, 12]  (v0, e1, e2, ...) in Morton order
+ * out_vis[r] = 1 when ray r hits nothing; counts[0] += node visits, counts[1] += triangle tests. */
+typedef struct { float nx, ny, nz, ix, iy, iz; } grid_ray;
+
+static inline int w_box_hit(float minx, float miny, float minz, float maxx, float maxy, float maxz, const grid_ray *r,
+                            float tmax, float *tnear)
+{
+    const float x0 = fmaf(minx, r->ix, r->nx), x1 = fmaf(maxx, r->ix, r->nx);
+    const float y0 = fmaf(miny, r->iy, r->ny), y1 = fmaf(maxy, r->iy, r->ny);
+    const float z0 = fmaf(minz, r->iz, r->nz), z1 = fmaf(maxz, r->iz, r->nz);
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+    *tnear = tn;
+    return tn <= tf;
+}
+
+void oracle_bvh2_walk(const uint32_t *nodes, const float *trirec, long n_tris, const float *g_lo, const float *g_scale,
+                      const float *ro, const float *rd, long n_rays, uint8_t *out_vis, long long *counts, int n_threads)
+{
+    long long n_node = 0, n_tri = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : n_node, n_tri)
+#endif
+    for (long r = 0; r < n_rays; ++r) {
+        const float ox = ro[3 * r], oy = ro[3 * r + 1], oz = ro[3 * r + 2];
+        const float dx = rd[3 * r], dy = rd[3 * r + 1], dz = rd[3 * r + 2];
+        int occluded = 0;
+        float t, u, v, det;
+        if (n_tris == 1) {
+            const float *q = trirec;
+            n_tri++;
+            occluded = nvdr_ray_tri(ox, oy, oz, dx, dy, dz, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], &t, &u, &v, &det);
+            out_vis[r] = occluded ? 0 : 1;
+            continue;
+        }
+        grid_ray g;
+        g.ix = 1.0f / (dx * g_scale[0]);
+        g.iy = 1.0f / (dy * g_scale[1]);
+        g.iz = 1.0f / (dz * g_scale[2]);
+        g.nx = -((ox - g_lo[0]) * g_scale[0] + 2.0f) * g.ix;
+        g.ny = -((oy - g_lo[1]) * g_scale[1] + 2.0f) * g.iy;
+        g.nz = -((oz - g_lo[2]) * g_scale[2] + 2.0f) * g.iz;
+        int stack[128];
+        int sp = 0, cur = 0, done = 0;
+        while (!done) {
+            if (cur >= 0) {
+                const uint32_t *w = nodes + 8 * (long)cur;
+                float tl, tr;
+                n_node++;
+                const int hl = w_box_hit((float)(w[0] & 0xffffu), (float)(w[0] >> 16), (float)(w[1] & 0xffffu), (float)(w[1] >> 16),
+                                         (float)(w[2] & 0xffffu), (float)(w[2] >> 16), &g, NVDR_RAY_TMAX, &tl);
+                const int hr = w_box_hit((float)(w[3] & 0xffffu), (float)(w[3] >> 16), (float)(w[4] & 0xffffu), (float)(w[4] >> 16),
+                                         (float)(w[5] & 0xffffu), (float)(w[5] >> 16), &g, NVDR_RAY_TMAX, &tr);
+                const int cl = (int)w[6], cr = (int)w[7];
+                if (hl && hr) {
+                    const int left_first = tl <= tr;
+                    stack[sp++] = left_first ? cr : cl;
+                    cur = left_first ? cl : cr;
+                } else if (hl) {
+                    cur = cl;
+                } else if (hr) {
+                    cur = cr;
+                } else if (sp > 0) {
+                    cur = stack[--sp];
+                } else {
+                    done = 1;
+                }
+            } else {
+                const float *q = trirec + 12 * (long)(~cur);
+                n_tri++;
+                if (nvdr_ray_tri(ox, oy, oz, dx, dy, dz, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], &t, &u, &v, &det)) {
+                    occluded = 1;
+                    done = 1;
+                } else if (sp > 0) {
+                    cur = stack[--sp];
+                } else {
+                    done = 1;
+                }
+            }
+        }
+        out_vis[r] = occluded ? 0 : 1;
+    }
+    counts[0] += n_node;
+    counts[1] += n_tri;
 }
 
 int oracle_max_threads(void)

@@ -231,6 +231,23 @@ def closest(verts, tris, ro, rd, n_threads=1):
     return t, tri, uv
 
 
+def bvh2_walk(nodes, trirec, grid_lo, grid_scale, ro, rd, n_threads=1):
+    """CPU walk of the binary tree exported by the GPU (nvdr_bvh_export): -> (vis uint8 [R], node visits, triangle tests).
+    nodes: numpy uint32 [n_nodes, 8]; trirec: numpy float32 [n_tris, 12]; grid_lo / grid_scale: 3 floats each."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.uint32)
+    trirec = np.ascontiguousarray(trirec, dtype=np.float32)
+    ro, rd = _cpu(ro).contiguous(), _cpu(rd).contiguous()
+    R = ro.shape[0]
+    out = torch.empty(R, dtype=torch.uint8)
+    lo = (c_float * 3)(*grid_lo)
+    sc = (c_float * 3)(*grid_scale)
+    cnt = (ctypes.c_longlong * 2)(0, 0)
+    _load(LIB).oracle_bvh2_walk(nodes.ctypes.data_as(c_void_p), trirec.ctypes.data_as(c_void_p), c_long(trirec.shape[0]), lo, sc,
+                                c_void_p(ro.data_ptr()), c_void_p(rd.data_ptr()), c_long(R), c_void_p(out.data_ptr()), cnt,
+                                c_int(n_threads))
+    return out, int(cnt[0]), int(cnt[1])
+
+
 def light_update_pdf(base):
     base = _cpu(base).contiguous()
     H, W = base.shape[0], base.shape[1]

@@ -1,7 +1,7 @@
 // ref_driver.cpp -- runs the REFERENCE's own env-shade raygen program and bilateral-denoiser kernels
 // on the CPU.  The reference sources are #included from where they lie (NVDR_REF_ROOT, set by the
 // Makefile); nothing from them is copied into this repository.  Output: oracle/_ref/libnvdr_ref.so,
-// used by tests/test_oracle_vs_ref.py to pin oracle/nvdr_oracle.c, and optionally by bench.py as the
+// used by tests/test_oracle_pins.py to pin oracle/nvdr_oracle.c, and optionally by bench.py as the
 // "reference" CPU baseline.
 #include "cuda_shim.h"
 #include "optix.h"

@@ -79,3 +79,37 @@ def test_two_rank_gradient_allreduce_equals_batch_mean():
         assert torch.equal(ug, torch.zeros(5))
         assert nbytes == (16 * 16 * 3 + 3 + 5) * 4
     assert not torch.equal(got[0][1], torch.zeros_like(got[0][1]))
+
+
+def _worker_uneven(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    views = shard_views(3, rank, world)                  # rank 0: views 0, 1 -- rank 1: view 2
+    # each rank's gradient is the gradient of ITS mean over its views (what loss.backward() of a local batch yields)
+    g = torch.stack([torch.full((4,), float(10 ** v)) for v in views]).mean(0)
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = g.clone()
+    allreduce_gradients([p], world, local_weight=len(views))
+    q.put((rank, p.grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_shards_keep_the_batch_mean():
+    """3 views on 2 ranks: the plain average of the two local means would weight view 2 twice; the weighted bucket
+    reproduces the mean over the three views."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.full((4,), (1.0 + 10.0 + 100.0) / 3.0)
+    for rank, g in got:
+        assert torch.allclose(g, want, rtol=1e-6)

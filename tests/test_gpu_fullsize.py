@@ -94,6 +94,100 @@ def test_fullsize_sparse_subset_vs_oracle(dev):
     assert_close(leaves['light'].grad, b['light_grad'], 1e-4, floor=1e-3 * b['light_grad'].abs().max().item())
 
 
+@pytest.mark.parametrize('cache_vis', [False, True], ids=['retrace', 'cached_visibility'])
+def test_config3_spot_256spp_sparse_subset_vs_oracle(cache_vis, dev):
+    """BASELINE configs[2]: spot, 512x512, n_samples_x = 16 (S = 256: four full rounds of 64 lanes per pixel, eight words
+    of cached visibility bits per plane) on a sparse pixel subset against the oracle's brute force, forward and backward,
+    with the re-tracing backward and with the forward's visibility bits replayed (env_shade.hip stage 3)."""
+    from nvdiffrecmc_amd import optixutils as ou
+    res, n, seed = 512, 16, 5
+    mesh, ctx, kw, perms = _gpu_scene('spot', res, n, dev)
+    sub = torch.zeros_like(kw['mask'])
+    sub[:, 11::29, 3::31] = kw['mask'][:, 11::29, 3::31]
+    kws = dict(kw, mask=sub)
+    g = torch.Generator().manual_seed(2)
+    dg, sg = torch.rand(1, res, res, 3, generator=g), torch.rand(1, res, res, 3, generator=g)
+    leaves = {k: kws[k].clone().requires_grad_(True) for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')}
+    kq = dict(kws, **leaves)
+    ctx.cache_visibility = cache_vis
+    d, s = _shade(ctx, kq, n, seed)
+    ((d * dg.to(dev)).sum() + (s * sg.to(dev)).sum()).backward()
+    cpu = {k: v.detach().cpu().contiguous() for k, v in kws.items()}
+    f = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT)
+    b = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, diff_grad=dg, spec_grad=sg, n_threads=NT)
+    assert 30 < f['covered'] < 200
+    assert_close(d, f['diff'], 4e-6)            # 512 additions per pixel instead of 128: twice the summation-order slack
+    assert_close(s, f['spec'], 4e-6)
+    for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks'):
+        ref = b[k + '_grad']
+        assert_close(leaves[k].grad, ref, 2e-4, floor=1e-3 * max(ref.abs().max().item(), 1e-3), what=k)
+    assert_close(leaves['light'].grad, b['light_grad'], 1e-4, floor=1e-3 * b['light_grad'].abs().max().item())
+    ctx.check()
+
+
+def test_chunked_ray_stream_is_bit_identical(dev):
+    """The ray stream holds one chunk of covered pixels (OptiXContext.set_stream_budget): a launch cut into many chunks gives
+    the bits of the one-chunk launch, forward and backward (per-pixel gradients exactly, the light gradient up to add order)."""
+    from nvdiffrecmc_amd import optixutils as ou
+    res, n, seed = 256, 4, 9
+    mesh, ctx, kw, perms = _gpu_scene('bob', res, n, dev)
+    g = torch.Generator().manual_seed(3)
+    dg, sg = torch.rand(1, res, res, 3, generator=g).to(dev), torch.rand(1, res, res, 3, generator=g).to(dev)
+
+    def run(cache_vis):
+        leaves = {k: kw[k].clone().requires_grad_(True) for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')}
+        ctx.cache_visibility = cache_vis
+        d, s = _shade(ctx, dict(kw, **leaves), n, seed)
+        ((d * dg).sum() + (s * sg).sum()).backward()
+        return [d.detach(), s.detach()] + [leaves[k].grad for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')]
+
+    whole = run(False)
+    ctx.set_stream_budget(1)                               # 1 MB / (32 rays x 25 B + 16 B) -> 1285 pixels per chunk: ~12 non-empty chunks of 51
+    for cache_vis in (False, True):
+        parts = run(cache_vis)
+        for a, b in zip(whole[:6], parts[:6]):
+            assert torch.equal(a, b)
+        assert_close(parts[6], whole[6], 1e-4, floor=1e-3 * whole[6].abs().max().item())
+    ctx.set_stream_budget(2048)
+    again = run(False)
+    for a, b in zip(whole[:6], again[:6]):
+        assert torch.equal(a, b)
+
+
+def test_light_gradient_band_gather_equals_atomics(dev, monkeypatch):
+    """The LDS band gather of the light gradient (no global atomics) against the reference's formulation (three atomicAdds
+    per sample, kernel.cu:203-211; NVDR_DEBUG bit 16 selects it): same sums up to the order of the additions."""
+    from nvdiffrecmc_amd import optixutils as ou
+    res, n, seed = 192, 8, 4
+    mesh, ctx, kw, perms = _gpu_scene('bob', res, n, dev)
+    g = torch.Generator().manual_seed(5)
+    dg, sg = torch.rand(1, res, res, 3, generator=g).to(dev), torch.rand(1, res, res, 3, generator=g).to(dev)
+
+    def light_grad(c):
+        light = kw['light'].clone().requires_grad_(True)
+        d, s = _shade(c, dict(kw, light=light), n, seed)
+        ((d * dg).sum() + (s * sg).sum()).backward()
+        return light.grad
+
+    gathered = light_grad(ctx)
+    monkeypatch.setenv('NVDR_DEBUG', '16')
+    ctx2 = ou.OptiXContext()
+    monkeypatch.delenv('NVDR_DEBUG')
+    ou.optix_build_bvh(ctx2, mesh['v_pos'].to(dev), mesh['t_pos_idx'].to(dev), 1)
+    atomics = light_grad(ctx2)
+    assert atomics.abs().max().item() > 0
+    assert_close(gathered, atomics, 1e-4, floor=1e-3 * atomics.abs().max().item())
+    # a second backward through the same graph regenerates the stream the first one consumed
+    light = kw['light'].clone().requires_grad_(True)
+    d, s = _shade(ctx, dict(kw, light=light), n, seed)
+    loss = (d * dg).sum() + (s * sg).sum()
+    loss.backward(retain_graph=True)
+    g1 = light.grad.clone()
+    light.grad = None
+    loss.backward()
+    assert_close(light.grad, g1, 1e-4, floor=1e-3 * g1.abs().max().item())
+
+
 def test_dmtet_sized_mesh_800(dev):
     """configs[3] stand-in: 800x800, n_samples_x = 8 on a 171k-triangle mesh (bob subdivided twice): finite, deterministic,
     and identical visibility-driven result after a refit to the same vertices."""

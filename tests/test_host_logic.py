@@ -124,3 +124,74 @@ def test_broadcast_pixels_column_sum_and_composite_reference():
     ref = (d4[..., :3] / d4[..., 3:]) * kd * (1 - ks[..., 2:3]) + s4[..., :3] / s4[..., 3:]
     assert torch.allclose(torch_ref.shade_composite(d4, s4, kd, ks, 'pbr'), ref, rtol=1e-6)
     assert torch.allclose(torch_ref.shade_composite(d4[..., :3], s4[..., :3], kd, ks, 'diffuse'), d4[..., :3] * kd, rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2
+
+def _cpu_lbvh(v, t):
+    """A tiny median-split binary tree in the record layout of nvdiffrecmc_amd/csrc/bvh.h (32-B nodes, 16-bit quantised
+    child boxes, conservative rounding) -- only to exercise oracle_bvh2_walk without a GPU."""
+    import numpy as np
+    v, t = v.numpy().astype(np.float32), t.numpy()
+    tri = v[t]                                                    # [T,3,3]
+    lo, hi = v.min(0), v.max(0)
+    scale = max(float((hi - lo).max()), float(np.abs(lo).max()), float(np.abs(hi).max()))
+    pad = np.float32(1e-5 * scale)
+    g_lo = (lo - 2 * pad).astype(np.float32)
+    g_scale = (np.float32(65531.0) / np.maximum((hi + 2 * pad) - g_lo, 1e-6 * scale + 1e-30)).astype(np.float32)
+    order = np.argsort(tri.mean(1)[:, 0], kind='stable')
+    T = len(order)
+    trirec = np.zeros((T, 12), np.float32)
+    for k, o in enumerate(order):
+        a, b, c = tri[o]
+        trirec[k, 0:3], trirec[k, 3:6], trirec[k, 6:9] = a, b - a, c - a
+    qbox = np.zeros((T, 6), np.int64)
+    for k, o in enumerate(order):
+        mn, mx = tri[o].min(0) - pad, tri[o].max(0) + pad
+        qbox[k, :3] = np.clip(np.floor((mn - g_lo) * g_scale + 2.0) - 1, 0, 65535)
+        qbox[k, 3:] = np.clip(np.ceil((mx - g_lo) * g_scale + 2.0) + 1, 0, 65535)
+    nodes = []
+
+    def build(a, b):                                              # leaves [a, b) -> (reference, box)
+        if b - a == 1:
+            return ~a, qbox[a]
+        idx = len(nodes)
+        nodes.append(None)
+        m = (a + b) // 2
+        cl, bl = build(a, m)
+        cr, br = build(m, b)
+        w = [int(bl[0]) | int(bl[1]) << 16, int(bl[2]) | int(bl[3]) << 16, int(bl[4]) | int(bl[5]) << 16,
+             int(br[0]) | int(br[1]) << 16, int(br[2]) | int(br[3]) << 16, int(br[4]) | int(br[5]) << 16,
+             cl & 0xffffffff, cr & 0xffffffff]
+        nodes[idx] = w
+        return idx, np.concatenate([np.minimum(bl[:3], br[:3]), np.maximum(bl[3:], br[3:])])
+
+    build(0, T)
+    return np.array(nodes, dtype=np.uint32), trirec, g_lo, g_scale
+
+
+def test_cpu_walk_of_a_bvh2_equals_bruteforce():
+    """oracle_bvh2_walk (the CPU checker of the GPU's traversal counters) answers like the brute-force loop."""
+    from oracle import oracle as orc
+    from nvdiffrecmc_amd import scene as sc
+    mesh = sc.load_mesh('spot')
+    v, t = mesh['v_pos'], mesh['t_pos_idx'][:600].contiguous()
+    nodes, trirec, g_lo, g_scale = _cpu_lbvh(v, t)
+    g = torch.Generator().manual_seed(4)
+    ro = (torch.randn(20000, 3, generator=g) * 0.4).contiguous()
+    rd = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1).contiguous()
+    rd[:300] = torch.eye(3).repeat(100, 1)
+    ref = orc.visibility(v, t, ro, rd, n_threads=2)
+    vis, n_node, n_tri = orc.bvh2_walk(nodes, trirec, list(g_lo), list(g_scale), ro, rd, n_threads=2)
+    assert torch.equal(vis, ref)
+    assert 0.02 < ref.float().mean().item() < 0.999
+    assert n_node > ro.shape[0] and n_tri > 0 and n_node < ro.shape[0] * 600
+
+
+def test_stack_bound_formula():
+    """nvdr_stack_bound (csrc/bvh.h) restated: h_max = 30 + ceil(log2 n); wide walk <= 3 * (ceil(h_max / 2) + 1) <= 104."""
+    import math
+    for n, expect in ((1, 48), (2, 51), (10688, 69), (171008, 75), (1 << 24, 84), ((1 << 30) - 1, 93)):
+        h = 30 + (0 if n <= 1 else math.ceil(math.log2(n)))
+        assert min(max(3 * ((h + 1) // 2 + 1), h), 104) == expect

@@ -1,60 +1,100 @@
 #!/usr/bin/env python3
 """bench.py -- MC shadow rays/s and fwd+bwd iterations/s of the direct-lighting hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config bob512|spot512x256|dmtet800] [--scaling strong|weak]
+
+`--gpus N` with N > 1 spawns N ranks itself (one process per GPU, RCCL = torch.distributed backend "nccl") unless the
+process was already started by a launcher (WORLD_SIZE set), e.g.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): bob mesh (10 688 triangles), 512x512, n_samples_x = 8 (64 spp,
-128 shadow rays per covered pixel per pass), 256x256 synthetic "sky + suns" probe, one camera view
-per GPU (weak scaling).  One step = one optimisation iteration of nvdiffrecmc_amd/trainer.py:
-update_pdf + BVH rebuild + shading normal + env-shade fwd + 2x bilateral denoiser + combine +
-log-sRGB L1 image loss + full backward (the env-shade backward RE-TRACES every ray, as the
-reference does) + gradient all-reduce (N > 1) + Adam.  Inputs are resident in HBM before the timed
-region.  `value` = shadow rays actually traced per second, whole job.
+Workloads (BASELINE.json `configs`):
+  bob512      (default; configs[1], the configuration `metric` is quoted on)  bob, 10 688 triangles, 512x512,
+              n_samples_x = 8 (64 spp, 128 shadow rays per covered pixel and pass), batch of 8 views per iteration
+              (configs/bob.json:8), 256x256 synthetic "sky + suns" probe.
+  spot512x256 (configs[2])  spot, 5 856 triangles, metal, 512x512, n_samples_x = 16 (256 spp), batch of 4 views.
+  dmtet800    (configs[3] stand-in)  bob subdivided three times = 684 032 triangles (the size of a 128^3 DMTet
+              extraction; 43 MB of nodes + triangles: does NOT fit the 4 MB L2s), 800x800, n_samples_x = 8, batch 8.
+One step = one optimisation iteration of nvdiffrecmc_amd/trainer.py: update_pdf + BVH rebuild + shading normal +
+env-shade fwd + 2x bilateral denoiser + composite + log-sRGB L1 image loss + full backward (the env-shade backward
+RE-TRACES every ray, as the reference does) + gradient all-reduce (N > 1) + Adam.  Inputs are resident in HBM before
+the timed region.  `value` = shadow rays actually traversed per second, whole job.
+
+Scaling: `strong` (default, north_star's split): ONE batch of views is dealt over the GPUs (8 views on one GPU ... one
+view per GPU on eight), one flat RCCL all-reduce of the shared-parameter gradients per iteration.  `weak`: every GPU
+renders a whole batch (global batch = batch x N).
+
+Timing protocol: max(20 - W, 0) untimed settle iterations (SURVEY 8d asks for >= 20 warm iterations), then W warm-up
+steps, then EXACTLY K steps between barriers (`value`, `ms_per_step`), then an extended phase (>= 50 further steps
+and >= 3 s) whose per-step HIP-event times give `median_ms_per_step`.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel, env_trace_kernel (persistent-wavefront shadow-ray traversal): algorithmic
-                  bytes per launch (32 B per box test + 36 B per triangle test, counts measured by the
-                  counting build of the same kernel, + its 17 B/ray stream) over its average duration from HIP
-                  events the library records on the launch stream inside the timed steps, vs 8 TB/s.
-  cpu_baseline -- the CPU oracle (plain C, OpenMP over pixels, brute-force visibility) on a 1/4 pixel
-                  subset of the same view, fwd + bwd, on this box's host cores (rank 0, N = 1 only).
+  roofline     -- the dominant kernel, env_trace_kernel<false> (persistent-wavefront shadow-ray traversal).  It is
+                  VALU-issue bound on cache-resident data (counters below), so `bound` is "valu": `achieved` =
+                  active-lane VALU operations per second (SQ_INSTS_VALU x active-lane fraction, rocprofv3 PMC pass of
+                  THIS run, / the kernel's average duration from HIP events recorded on the launch stream inside the
+                  timed steps), `peak` = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz.  The HBM and L2 fractions of the same
+                  kernel are reported beside it (`hbm`: PMC traffic 2*FETCH_SIZE + WRITE_SIZE; `l2`: TCC_REQ x 64 B),
+                  and `algorithmic` holds SURVEY 8d's byte model (32-B BVH2 node visits + 36-B triangle tests of the
+                  CANONICAL binary walk over the same rays, measured by a counting kernel) over the same duration.
+  cpu_baseline -- the reference's own raygen program compiled for the CPU (oracle/_ref; our plain-C restatement when it
+                  did not travel), OpenMP over pixels, brute-force visibility, on a pixel subset of the same view.
 """
 import argparse
 import json
+import math
 import os
+import shutil
+import socket
+import sqlite3
+import statistics
+import subprocess
 import sys
+import tempfile
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
+HBM_PEAK_GBS = 8000.0      # MI355X spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured streaming ceiling
+L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth, same guide
+N_CUS, SIMDS_PER_CU, LANES_PER_SIMD, CLOCK_GHZ = 256, 4, 32, 2.4
+VALU_PEAK_TLANEOPS = N_CUS * SIMDS_PER_CU * LANES_PER_SIMD * CLOCK_GHZ * 1e9 / 1e12   # 78.6 T lane-ops/s (x2 flop = 157.3 TFLOP/s)
+
+PRESETS = {
+    'bob512': dict(mesh='bob', res=512, n=8, batch=8, subdiv=0,
+                   metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 64spp bob mesh)',
+                   what='bob.json 512x512, 64 spp (n_samples_x=8)'),
+    'spot512x256': dict(mesh='spot', res=512, n=16, batch=4, subdiv=0,
+                        metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 256spp spot_metal)',
+                        what='spot_metal.json 512x512, 256 spp (n_samples_x=16)'),
+    'dmtet800': dict(mesh='bob', res=800, n=8, batch=8, subdiv=3,
+                     metric='MC shadow rays/sec (fwd+bwd train iteration, 800x800 64spp, 684k-triangle DMTet-sized mesh)',
+                     what='nerf_lego.json stand-in: bob subdivided 3x (684 032 triangles), 800x800, 64 spp (n_samples_x=8)'),
+}
+DOMINANT = 'env_trace_kernel<false>'
 
 
-def algorithmic_bytes(N, H, W, P, S, probe, n_box, n_tri, n_traced=None):
-    """B = B_stream + B_tables + B_trav for one forward pass, and the share the traversal kernel
-    (env_trace_kernel) moves: B_trav + its ray stream (16 B direction+pdf in, 1 B visibility out per ray, 16 B origin per pixel)."""
+def algorithmic_bytes(N, H, W, P, S, probe, bvh2_nodes, bvh2_tris, n_traced):
+    """B = B_stream + B_tables + B_trav for one forward pass, and the share the traversal kernel moves:
+    B_trav (32 B per BVH2 node visit + 36 B per triangle test of the canonical binary walk) + its ray stream (16 B
+    direction + pdf per slot in, 4 B list entry + 1 B visibility per traversed ray, 16 B origin per pixel)."""
     NHW = N * H * W
     R = 2 * S * P
     b_stream = 4 * NHW + 60 * P + 24 * NHW
     m = (probe - 1).bit_length() + 1  # ceil(log2(size-1)) + 1 bisection steps
     b_tables = P * S * (8 + 4 * (m + 2) + 4 * (m + 2) + 2 * (4 + 12))
-    b_trav = 32 * n_box + 36 * n_tri
-    # every slot of the stream is read (16 B: direction + pdf sum, the sign bit flags a dead sample); only traversed
-    # rays fetch their pixel's origin and write a visibility byte
-    b_trace_kernel = b_trav + 16 * R + 1 * (R if n_traced is None else n_traced) + 16 * P
+    b_trav = 32 * bvh2_nodes + 36 * bvh2_tris
+    b_trace_kernel = b_trav + (16 + 4 + 1) * n_traced + 16 * P
     return b_stream + b_tables + b_trav, b_trace_kernel, b_trav
 
 
-def cpu_baseline(res, n, view, n_views, stride=2):
+def cpu_baseline(mesh_name, res, n, view, n_views, stride=2):
     """Oracle fwd+bwd on every stride-th pixel in x and y of the same view; returns the JSON object."""
+    import torch
     from oracle import oracle as orc, scene_cpu
     nt = orc.max_threads()
-    inp = scene_cpu.make_inputs('bob', res, res, n, view=view, n_views=n_views, n_threads=nt)
+    inp = scene_cpu.make_inputs(mesh_name, res, res, n, view=view, n_views=n_views, n_threads=nt)
     m = inp['mesh']
     sub = torch.zeros_like(inp['mask'])
     sub[:, ::stride, ::stride] = inp['mask'][:, ::stride, ::stride]
@@ -72,29 +112,196 @@ def cpu_baseline(res, n, view, n_views, stride=2):
     dt = time.perf_counter() - t0
     rays = 2 * (2 * n * n * f['covered'])
     return {'value': rays / dt, 'unit': 'rays/s', 'cores': nt, 'kind': kind,
-            'sample': '%s, env-shade fwd+bwd (OpenMP over pixels, brute-force visibility over 10688 triangles), every %dth pixel '
-                      'in x and y of the %dx%d view (%d covered pixels, %d rays), %.1f s' % (what, stride, res, res, f['covered'], rays, dt)}
+            'sample': '%s, env-shade fwd+bwd (OpenMP over pixels, brute-force visibility over %d triangles), every %dth pixel '
+                      'in x and y of the %dx%d view (%d covered pixels, %d rays), %.1f s' % (what, m['t_pos_idx'].shape[0], stride, res, res,
+                                                                                           f['covered'], rays, dt)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rocprofv3 PMC passes of this very workload (rank 0, N = 1): counters cannot be read in-process, so the bench re-runs
+# itself for a few steps under the profiler, one pass per counter group (separate --pmc passes, kernel trace only: no
+# sys/hip/hsa trace domains), and reads the per-dispatch sums out of the rocpd database.
+
+PMC_PASSES = [
+    ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_INST_ANY',
+     'SQ_WAVES', 'GRBM_GUI_ACTIVE'],
+    ['FETCH_SIZE'],
+    ['WRITE_SIZE', 'TCC_REQ_sum', 'TCC_MISS_sum'],
+]
+
+
+def _pmc_read(db_path):
+    """{kernel name: {counter: per-dispatch total}, ...} and {kernel name: dispatches}."""
+    db = sqlite3.connect(db_path)
+    cols = [r[1] for r in db.execute('pragma table_info(pmc_events)')]
+    name_col = 'counter_name' if 'counter_name' in cols else ('name' if 'name' in cols else cols[0])
+    val_col = 'value' if 'value' in cols else ('counter_value' if 'counter_value' in cols else cols[-1])
+    q = ('select k.name, p.%s, count(distinct p.dispatch_id), sum(p.%s) from pmc_events p join kernels k '
+         'on k.dispatch_id = p.dispatch_id group by k.name, p.%s' % (name_col, val_col, name_col))
+    out, disp = {}, {}
+    for name, ctr, n, total in db.execute(q).fetchall():
+        out.setdefault(name, {})[ctr] = total / max(n, 1)
+        disp[name] = n
+    return out, disp
+
+
+def collect_pmc(args, keep_dir=None):
+    """Run the PMC passes; returns (counters per kernel, note) -- counters is None when rocprofv3 is unavailable or failed."""
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    merged, notes = {}, []
+    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child', '--config', args.config, '--steps', '2', '--warmup', '1',
+             '--scaling', args.scaling]
+    for flag, v in (('--res', args.res), ('--n-samples-x', args.n_samples_x), ('--mesh', args.mesh), ('--subdiv', args.subdiv), ('--batch', args.batch)):
+        if v is not None:
+            child += [flag, str(v)]
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    for i, group in enumerate(PMC_PASSES):
+        d = tempfile.mkdtemp(prefix='nvdr_pmc%d_' % i, dir='/tmp')
+        cmd = [exe, '--kernel-trace', '--pmc'] + group + ['-d', d, '-o', 'r', '--'] + child
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=args.pmc_timeout)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith('_results.db')]
+            if r.returncode != 0 or not dbs:
+                notes.append('pass %d (%s) failed rc=%d: %s' % (i, ' '.join(group), r.returncode, (r.stderr or r.stdout)[-300:]))
+                continue
+            ctrs, disp = _pmc_read(dbs[0])
+            for kname, c in ctrs.items():
+                merged.setdefault(kname, {}).update(c)
+                merged[kname]['dispatches_pass%d' % i] = disp.get(kname, 0)
+            if keep_dir:
+                os.makedirs(keep_dir, exist_ok=True)
+                shutil.copy(dbs[0], os.path.join(keep_dir, 'pmc_pass%d.db' % i))
+        except subprocess.TimeoutExpired:
+            notes.append('pass %d (%s) timed out after %d s' % (i, ' '.join(group), args.pmc_timeout))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (merged or None), '; '.join(notes)
+
+
+def find_kernel(counters, needle):
+    for name, c in counters.items():
+        if needle in name:
+            return c
+    return None
+
+
+def valu_figures(c, kernel_ms):
+    """VALU-side figures of one kernel from its per-launch counter sums and its (un-profiled) duration."""
+    insts, thread_cyc, active = c.get('SQ_INSTS_VALU'), c.get('SQ_THREAD_CYCLES_VALU'), c.get('SQ_ACTIVE_INST_VALU')
+    if not (insts and thread_cyc and active and kernel_ms):
+        return None
+    lane_frac = thread_cyc / (64.0 * active)            # average share of the 64 lanes a VALU instruction executes for
+    lane_ops = insts * 64.0 * lane_frac                 # active-lane VALU operations per launch
+    achieved = lane_ops / (kernel_ms * 1e-3) / 1e12
+    cycles = c.get('GRBM_GUI_ACTIVE')
+    out = {'valu_wave_instructions': insts, 'active_lane_fraction': lane_frac, 'active_lane_ops': lane_ops,
+           'achieved_Tlaneops': achieved, 'frac_of_lane_peak': achieved / VALU_PEAK_TLANEOPS,
+           # issue slots: one wave64 VALU instruction per SIMD every 2 cycles (SIMD-32, MI355X_MICROARCH.md), lanes ignored
+           'issue_frac_of_peak': insts * 2.0 / (N_CUS * SIMDS_PER_CU * CLOCK_GHZ * 1e9 * kernel_ms * 1e-3)}
+    if cycles:
+        out['profiled_kernel_cycles'] = cycles
+        # SQ_ACTIVE_INST_VALU counts quad-cycles: share of the kernel's cycles a SIMD spends issuing VALU work, as the
+        # counter block itself accounts it (4 cycles per instruction) -- the "VALUBusy" of the profiler
+        out['valu_busy_counter'] = active * 4.0 / (N_CUS * SIMDS_PER_CU * cycles)
+    if c.get('SQ_WAVE_CYCLES') and c.get('SQ_WAIT_INST_ANY'):
+        out['wave_time_waiting_on_issue_or_memory'] = c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']
+    return out
+
+
+def mem_figures(c, kernel_ms):
+    out = {}
+    if c.get('FETCH_SIZE') is not None and c.get('WRITE_SIZE') is not None:
+        # gfx950: FETCH_SIZE tallies the 128-B requests of wide reads at 64 B (MI355X_MICROARCH.md, HBM): doubled. KB units.
+        out['hbm_bytes'] = (2.0 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024.0
+        out['fetch_bytes_corrected'] = 2.0 * c['FETCH_SIZE'] * 1024.0
+        out['write_bytes'] = c['WRITE_SIZE'] * 1024.0
+        if kernel_ms:
+            out['hbm_GBs'] = out['hbm_bytes'] / (kernel_ms * 1e-3) / 1e9
+            out['hbm_frac'] = out['hbm_GBs'] / HBM_PEAK_GBS
+    if c.get('TCC_REQ_sum'):
+        out['l2_requests'] = c['TCC_REQ_sum']
+        if c.get('TCC_MISS_sum') is not None:
+            out['l2_hit'] = 1.0 - c['TCC_MISS_sum'] / c['TCC_REQ_sum']
+        if kernel_ms:
+            out['l2_GBs_at_64B_per_request'] = c['TCC_REQ_sum'] * 64.0 / (kernel_ms * 1e-3) / 1e9
+            out['l2_frac'] = out['l2_GBs_at_64B_per_request'] / L2_PEAK_GBS
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', choices=sorted(PRESETS), default='bob512')
+    ap.add_argument('--res', type=int, default=None, help='override the preset')
+    ap.add_argument('--n-samples-x', type=int, default=None)
+    ap.add_argument('--mesh', default=None)
+    ap.add_argument('--subdiv', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=None, help='views per iteration: in total for strong, per GPU for weak scaling')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.frac becomes null)')
+    ap.add_argument('--pmc-timeout', type=int, default=240)
+    ap.add_argument('--pmc-keep', default=None, help='directory to keep the rocpd databases of the counter passes in')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-extended', action='store_true', help='skip the extended median phase and the cached-visibility loop')
+    return ap.parse_args()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawned(local_rank, world, port, args):
+    os.environ.update({'RANK': str(local_rank), 'LOCAL_RANK': str(local_rank), 'WORLD_SIZE': str(world),
+                       'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port)})
+    run(args)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--res', type=int, default=512)
-    ap.add_argument('--n-samples-x', type=int, default=8)
-    ap.add_argument('--mesh', default='bob')
-    ap.add_argument('--batch', type=int, default=8, help='views per iteration (configs/bob.json:8): per GPU for weak, in total for strong scaling')
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+    args = parse_args()
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU fallback')
+    if 'WORLD_SIZE' in os.environ:
+        if int(os.environ['WORLD_SIZE']) != args.gpus:
+            raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks' % (args.gpus, os.environ['WORLD_SIZE']))
+        run(args)
+    elif args.gpus > 1:
+        # no launcher: start one process per GPU ourselves
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and not os.environ.get('NVDR_BENCH_OVERSUBSCRIBE'):
+            raise SystemExit('bench.py: --gpus %d requested but only %d GPU(s) are visible' % (args.gpus, n_dev))
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned, args=(args.gpus, _free_port(), args), nprocs=args.gpus, join=True)
+    else:
+        run(args)
 
+
+def run(args):
+    import torch
+    preset = dict(PRESETS[args.config])
+    for k, a in (('mesh', args.mesh), ('res', args.res), ('n', args.n_samples_x), ('batch', args.batch), ('subdiv', args.subdiv)):
+        if a is not None:
+            preset[k] = a
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU fallback')
-    dev_index = local_rank % torch.cuda.device_count()   # one process per GPU; the modulo only matters for 1-GPU dry runs
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not os.environ.get('NVDR_BENCH_OVERSUBSCRIBE'):
+        raise SystemExit('bench.py: %d ranks but only %d GPU(s) visible (one process per GPU)' % (world, n_dev))
+    dev_index = local_rank % n_dev                    # the modulo only matters for oversubscribed 1-GPU dry runs
     torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
@@ -105,25 +312,30 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()                 # what the collective library actually initialised
     dev = torch.device('cuda', dev_index)
 
     from nvdiffrecmc_amd.trainer import DirectLightingStep
     from nvdiffrecmc_amd import optixutils as ou
-    # Every GPU renders the batch of the reference config (configs/bob.json:8: 8 views per iteration, stacked along N like
-    # the reference's render()): per-GPU work is fixed, the global batch is 8 * world views ("weak").  --scaling strong
-    # instead shards ONE batch of 8 views over the GPUs (8 on one GPU ... 1 view per GPU on eight: north_star's
-    # "batch=8 views sharded across 8xMI355X").  Every rank seeds its pixels as its slice of the global batch launch.
     from nvdiffrecmc_amd.parallel import shard_views
-    n_views = args.batch * world if args.scaling == 'weak' else max(world, args.batch)
-    H = W = args.res
+    batch, H, n = preset['batch'], preset['res'], preset['n']
+    W = H
+    # strong: ONE batch of `batch` views dealt over the GPUs (north_star: "batch=8 views sharded across 8xMI355X");
+    # weak: every GPU renders a whole batch.  Every rank seeds its pixels as its slice of the global batch launch.
+    n_views = batch * world if args.scaling == 'weak' else batch
+    if n_views < world:
+        raise SystemExit('bench.py: a batch of %d views cannot be dealt over %d GPUs (--batch / --scaling weak)' % (n_views, world))
     my_views = shard_views(n_views, rank, world)
     if not my_views:
         raise SystemExit('bench.py: rank %d of %d has no view of the batch of %d' % (rank, world, n_views))
-    step = DirectLightingStep(args.mesh, args.res, args.n_samples_x, view=my_views, n_views=n_views, device=dev,
-                              pixel_index_offset=my_views[0] * H * W, retrace_backward=True)
+    step = DirectLightingStep(preset['mesh'], H, n, view=my_views, n_views=n_views, device=dev,
+                              pixel_index_offset=my_views[0] * H * W, retrace_backward=True, subdiv=preset['subdiv'])
 
-    # per-stage HIP-event timing recorded by the library on the launch stream itself (ring of the last 128 launches)
-    step.ctx.set_profiling(True)
+    if args.pmc_child:          # under rocprofv3: a few plain iterations, nothing else
+        for _ in range(args.warmup + args.steps):
+            step.step(world)
+        torch.cuda.synchronize()
+        return
 
     def barrier():
         torch.cuda.synchronize()
@@ -131,44 +343,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    settle = max(0, 20 - args.warmup)                 # >= 20 warm iterations before anything is timed
+    for _ in range(settle + args.warmup):
         step.step(world)
-    step.ctx.set_profiling(True)   # clears the ring
+    # per-stage HIP-event timing recorded by the library on the launch stream itself (ring of the last launches)
+    step.ctx.set_profiling(True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for a, b in ev:
+        a.record()
         step.step(world)
+        b.record()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
+    step_ms = [a.elapsed_time(b) for a, b in ev]
     n_f, (gen_ms, trace_ms, shade_ms) = step.ctx.stage_times(backward=False)
     n_b, (bgen_ms, btrace_ms, bshade_ms) = step.ctx.stage_times(backward=True)
     step.ctx.set_profiling(False)
 
-    # second, shorter timed loop: the same iteration with the forward pass's visibility bits replayed in backward
-    # (identical gradients, no second traversal) -- reported as an extra, never as `value`
-    step.retrace_backward = False
-    k2 = max(5, args.steps // 2)
-    for _ in range(2):
-        step.step(world)
-    barrier()
-    t1 = time.perf_counter()
-    for _ in range(k2):
-        step.step(world)
-    barrier()
-    dt2 = time.perf_counter() - t1
-    if dist is not None:
-        tt = torch.tensor([dt2], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt2 = float(tt.item())
-    step.retrace_backward = True
+    # extended phase: more samples of the same iteration for the median (>= 50 steps and >= 3 s), then the same iteration
+    # with the forward's visibility bits replayed in backward (identical gradients, no second traversal; an extra, never `value`)
+    ext_ms, dt2, k2 = [], None, 0
+    if not args.no_extended:
+        t_ext = time.perf_counter()
+        while True:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            step.step(world)
+            b.record()
+            b.synchronize()
+            ext_ms.append(a.elapsed_time(b))
+            more = len(ext_ms) < 50 or (time.perf_counter() - t_ext < 3.0 and len(ext_ms) < 2000)
+            if dist is not None:     # all ranks must run the same number of collectives: agree on when to stop
+                flag = torch.tensor([1.0 if more else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                more = flag.item() != 0.0
+            if not more:
+                break
+        step.retrace_backward = False
+        k2 = max(5, args.steps // 2)
+        for _ in range(2):
+            step.step(world)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step.step(world)
+        barrier()
+        dt2 = max_over_ranks(time.perf_counter() - t1)
+        step.retrace_backward = True
 
-    S = args.n_samples_x ** 2
-    # counting build of the same forward kernel on this rank's view -> measured traversal work and the number of rays
-    # actually traversed (dead samples -- dot(n, wi) <= 0, zero through the BSDF's own gates -- are never traced)
+    S = n * n
+    # counting build of the same forward kernel on this rank's views -> rays actually traversed (dead samples --
+    # dot(n, wi) <= 0, zero through the BSDF's own gates -- are never traced), wide-walk box tests, and the canonical
+    # binary walk's node visits / triangle tests over the same rays (the algorithmic-byte model)
     light = step.light
     with torch.no_grad():
         from nvdiffrecmc_amd import renderutils as ru
@@ -179,60 +414,102 @@ def main():
         ro = step.gb_pos + nrm * 0.001
         P, n_box, n_tri, n_traced = ou.ops.env_shade_traversal_counts(step.ctx, step.mask, ro, step.gb_pos, nrm, step.view_pos, kd, ks,
                                                                      light.base, light._pdf, light.rows[:, 0], light.cols,
-                                                                     n_samples_x=args.n_samples_x, rnd_seed=0)
+                                                                     n_samples_x=n, rnd_seed=0)
+        bvh2_nodes, bvh2_tris, bvh2_rays = ou.ops.env_shade_traversal_counts.bvh2
+        clock_mhz = ou.ops.env_shade_traversal_counts.clock_mhz
     rays_pass = torch.tensor([step.rays_per_pass(), n_traced], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(rays_pass, op=dist.ReduceOp.SUM)
     queries_step_total = 2.0 * float(rays_pass[0].item())  # forward + backward shadow-ray queries (2*S per covered pixel), all ranks
     rays_step_total = 2.0 * float(rays_pass[1].item())     # of which traversed: forward + re-traced backward, all ranks
     fwd_ms = gen_ms + trace_ms + shade_ms
+    n_tris = int(step.mesh['t_pos_idx'].shape[0])
 
     if rank == 0:
         probe = light.base.shape[0]
-        bytes_fwd, bytes_trace, b_trav = algorithmic_bytes(step.nv, H, W, P, S, probe, n_box, n_tri, n_traced)
-        achieved = bytes_trace / (trace_ms * 1e-3) / 1e9
-        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (counters cannot be read in-process)
-        traffic, traffic_src = None, None
-        try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')))
-            traffic = (2.0 * pm['FETCH_SIZE_KB_per_launch'] + pm['WRITE_SIZE_KB_per_launch']) * 1024.0
-            traffic_src = pm['source']
-        except Exception:
-            pass
+        bytes_fwd, bytes_trace, b_trav = algorithmic_bytes(step.nv, H, W, P, S, probe, bvh2_nodes, bvh2_tris, n_traced)
         R = 2 * S * P
+        roof = {'bound': 'valu', 'achieved': None, 'peak': VALU_PEAK_TLANEOPS, 'unit': 'T lane-ops/s', 'frac': None, 'traffic': None,
+                'kernel': DOMINANT, 'kernel_ms_hip_events': trace_ms, 'launches_timed': n_f,
+                'rays_per_launch': n_traced, 'kernel_rays_per_sec': n_traced / (trace_ms * 1e-3),
+                'why_valu': 'rocprofv3 counters of this run: VALU issue dominates the kernel while its HBM and L2 fractions (hbm, l2 below) '
+                            'are small -- divergent traversal of a tree that is cache resident; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz',
+                'shader_clock_mhz_counting_launch': clock_mhz,
+                'algorithmic': {'model': 'SURVEY 8d: 32 B per BVH2 node visit + 36 B per triangle test of the canonical binary any-hit walk '
+                                         '(counting kernel over the same live rays; equals a CPU walk of the exported tree, tests/test_gpu_bvh.py) '
+                                         '+ 21 B per traversed ray + 16 B per pixel of ray stream',
+                                'bytes_per_launch': bytes_trace, 'traversal_bytes_per_launch': b_trav,
+                                'bvh2_node_visits_per_ray': bvh2_nodes / max(bvh2_rays, 1), 'bvh2_tri_tests_per_ray': bvh2_tris / max(bvh2_rays, 1),
+                                'wide_walk_box_tests_per_ray': n_box / max(n_traced, 1), 'wide_walk_tri_tests_per_ray': n_tri / max(n_traced, 1),
+                                'GBs': bytes_trace / (trace_ms * 1e-3) / 1e9,
+                                'frac_of_hbm_peak_if_it_were_hbm_traffic': bytes_trace / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                'forward_pass': {'gen_ms': gen_ms, 'trace_ms': trace_ms, 'shade_ms': shade_ms, 'algorithmic_bytes': bytes_fwd,
+                                 'rays_per_sec': n_traced / (fwd_ms * 1e-3)},
+                'backward_pass': {'gen_ms': bgen_ms, 'trace_ms': btrace_ms, 'shade_and_light_gradient_ms': bshade_ms, 'launches_timed': n_b}}
+        if world == 1 and not args.no_pmc:
+            t_p = time.perf_counter()
+            counters, note = collect_pmc(args, keep_dir=args.pmc_keep)
+            roof['pmc_seconds'] = time.perf_counter() - t_p
+            if note:
+                roof['pmc_note'] = note
+            c = find_kernel(counters, DOMINANT) if counters else None
+            if c:
+                v = valu_figures(c, trace_ms)
+                mem = mem_figures(c, trace_ms)
+                if v:
+                    roof['achieved'] = v['achieved_Tlaneops']
+                    roof['frac'] = v['frac_of_lane_peak']
+                    roof['valu'] = v
+                roof['traffic'] = mem.get('hbm_bytes')
+                roof['hbm'] = {k: mem[k] for k in ('hbm_bytes', 'fetch_bytes_corrected', 'write_bytes', 'hbm_GBs', 'hbm_frac') if k in mem}
+                roof['l2'] = {k: mem[k] for k in ('l2_requests', 'l2_hit', 'l2_GBs_at_64B_per_request', 'l2_frac') if k in mem}
+                roof['traffic_source'] = 'rocprofv3 --kernel-trace --pmc passes of this run (bench.py --pmc-child, %d dispatches)' % int(c.get('dispatches_pass1', 0))
+                # the other env-shade kernels from the same passes (durations: HIP-event stage times, backward stage 3 includes the gather)
+                others = {}
+                for needle, ms in (('env_shade_kernel<true>', None), ('env_gen_kernel', gen_ms), ('env_shade_kernel<false>', shade_ms),
+                                   ('light_grad_band_kernel', None)):
+                    oc = find_kernel(counters, needle)
+                    if oc:
+                        mm = mem_figures(oc, ms)
+                        vv = valu_figures(oc, ms) if ms else None
+                        others[needle] = {'hbm_bytes': mm.get('hbm_bytes'), 'hbm_GBs': mm.get('hbm_GBs'), 'l2_hit': mm.get('l2_hit'),
+                                          'valu_wave_instructions': oc.get('SQ_INSTS_VALU'),
+                                          'active_lane_fraction': (oc['SQ_THREAD_CYCLES_VALU'] / (64.0 * oc['SQ_ACTIVE_INST_VALU'])
+                                                                   if oc.get('SQ_ACTIVE_INST_VALU') else None),
+                                          'frac_of_lane_peak': vv['frac_of_lane_peak'] if vv else None}
+                roof['other_kernels'] = others
+        else:
+            roof['pmc_note'] = 'counter passes skipped (%s)' % ('--no-pmc' if args.no_pmc else 'N > 1: counters are collected at N = 1 only')
+        med = statistics.median(ext_ms) if ext_ms else statistics.median(step_ms)
         out = {
-            'metric': 'MC shadow rays/sec (fwd+bwd train iteration, 512x512 64spp bob mesh)',
+            'metric': preset['metric'],
             'value': rays_step_total * args.steps / dt,       # TRAVERSED rays only
             'unit': 'rays/s',
             'shadow_ray_queries_per_sec': queries_step_total * args.steps / dt,   # 2*S per covered pixel per pass, traversed or not
             'iters_per_sec': args.steps / dt,
-            'iters_per_sec_cached_visibility': k2 / dt2,
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'iters_per_sec_cached_visibility': (k2 / dt2) if dt2 else None,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'settle_steps_before_warmup': settle,
             'ms_per_step': dt / args.steps * 1e3,
+            'median_ms_per_step': med, 'median_over_steps': len(ext_ms) if ext_ms else len(step_ms),
+            'min_ms_per_step': min(ext_ms or step_ms), 'max_ms_per_step': max(ext_ms or step_ms),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'bob.json %dx%d, %d spp (n_samples_x=%d), batch of %d views per iteration (configs/bob.json:8; %s), LBVH + HIP traversal + GGX shading + bilateral denoiser + log-sRGB L1 loss, fwd+bwd+Adam'
-                                   % (H, W, S, args.n_samples_x, n_views, '%d per GPU' % args.batch if args.scaling == 'weak' else 'one batch sharded over the GPUs'),
-                       'mesh_triangles': int(step.mesh['t_pos_idx'].shape[0]), 'covered_pixels_rank0': P,
+            'config': {'workload': '%s, batch of %d views per iteration (%s), LBVH + HIP traversal + GGX shading + bilateral denoiser + log-sRGB L1 loss, fwd+bwd+Adam'
+                                   % (preset['what'], n_views, 'one batch dealt over the GPUs' if args.scaling == 'strong' else '%d per GPU' % batch),
+                       'preset': args.config, 'mesh_triangles': n_tris, 'covered_pixels_rank0': P,
                        'shadow_ray_queries_per_pass_rank0': R, 'rays_traversed_per_pass_rank0': n_traced,
-                       'dead_samples': '%.1f%% of the queries have dot(n,wi)<=0, are zero through the BSDF gates whatever their visibility and are answered without traversal (outputs bit-identical; NVDR_DEBUG=8 traces them); value counts traversed rays only' % (100.0 * (1.0 - n_traced / R)),
+                       'dead_samples': '%.1f%% of the queries have dot(n,wi)<=0, are zero through the BSDF gates whatever their visibility and are answered without traversal (outputs bit-identical; NVDR_DEBUG=8 traces them); value counts traversed rays only' % (100.0 * (1.0 - n_traced / max(R, 1))),
                        'views_per_iteration': n_views, 'views_rank0': step.nv, 'probe': '%dx%d E1' % (probe, probe),
-                       'backward': 're-traces all shadow rays', 'parallelism': 'dp%d (%d views per GPU)' % (world, step.nv)},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'env_trace_kernel<false>',
-                         'kernel_ms_hip_events': trace_ms, 'launches_timed': n_f,
-                         'algorithmic_bytes_per_launch': bytes_trace, 'traversal_bytes_per_launch': b_trav,
-                         'box_tests_per_ray': n_box / n_traced, 'tri_tests_per_ray': n_tri / n_traced,
-                         'rays_per_launch': n_traced, 'kernel_rays_per_sec': n_traced / (trace_ms * 1e-3),
-                         'forward_pass': {'gen_ms': gen_ms, 'trace_ms': trace_ms, 'shade_ms': shade_ms,
-                                          'algorithmic_bytes': bytes_fwd, 'achieved_GBs': bytes_fwd / (fwd_ms * 1e-3) / 1e9,
-                                          'rays_per_sec': n_traced / (fwd_ms * 1e-3)},
-                         'backward_pass': {'gen_ms': bgen_ms, 'trace_ms': btrace_ms, 'shade_ms': bshade_ms, 'launches_timed': n_b}},
+                       'backward': 're-traces all shadow rays', 'parallelism': 'dp%d (%d views per GPU)' % (world, step.nv),
+                       'allreduce_bytes_per_step': getattr(step, 'allreduce_bytes', 0)},
+            'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.res, args.n_samples_x, 0, n_views)
+        if world == 1 and not args.no_cpu_baseline and not preset['subdiv']:
+            # bounded sample: ~4e10 ray-triangle tests (10-30 s on the box's host cores) = covered pixels x 4S rays x triangles
+            stride = max(2, int(math.ceil(math.sqrt(0.23 * H * W * 4 * S * n_tris / 4e10))))
+            out['cpu_baseline'] = cpu_baseline(preset['mesh'], H, n, 0, n_views, stride=stride)
         else:
-            out['cpu_baseline'] = None
+            out['cpu_baseline'] = None   # N > 1, --no-cpu-baseline, or a subdivided mesh (brute force over 684 k triangles is not a bounded sample)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

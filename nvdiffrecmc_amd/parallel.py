@@ -14,7 +14,7 @@ def shard_views(n_views, rank, world_size):
     return list(range(rank * per, min(n_views, (rank + 1) * per)))
 
 
-def allreduce_gradients(params, world_size=None, group=None, average=True, local_weight=None):
+def allreduce_gradients(params, world_size=None, group=None, average=True, local_weight=None, skip_single=True):
     """Sum (or average: the loss is a mean over the batch of views, renderutils/ops.py:494) the .grad of
     `params` across ranks through ONE flat bucket.  Parameters without a gradient contribute zeros, so
     every rank sends the same layout.
@@ -26,7 +26,7 @@ def allreduce_gradients(params, world_size=None, group=None, average=True, local
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     ws = world_size or dist.get_world_size(group)
-    if ws == 1:
+    if ws == 1 and skip_single:      # skip_single=False: run the collective anyway (single-rank RCCL smoke test)
         return 0
     grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params]
     weighted = average and local_weight is not None

@@ -1,0 +1,91 @@
+"""The data-parallel leg on real hardware: RCCL (torch.distributed backend "nccl") initialised on the GPU, the flat gradient
+bucket reduced on device tensors, and bench.py starting its own ranks.  A one-GPU box can only run world_size 1 through
+RCCL (it refuses two ranks on one device); the two-rank run below therefore uses gloo for the collective -- the sharding,
+seeding and bucket code is the same."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_RCCL_SNIPPET = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from nvdiffrecmc_amd.parallel import allreduce_gradients
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+a = torch.nn.Parameter(torch.zeros(256, 256, 3, device='cuda'))
+b = torch.nn.Parameter(torch.zeros(3, device='cuda'))
+c = torch.nn.Parameter(torch.zeros(5, device='cuda'))          # no gradient: contributes zeros
+a.grad = torch.arange(256 * 256 * 3, dtype=torch.float32, device='cuda').view(256, 256, 3) * 1e-3
+b.grad = torch.tensor([1.0, 2.0, 3.0], device='cuda')
+want_a, want_b = a.grad.clone(), b.grad.clone()
+n = allreduce_gradients([a, b, c], skip_single=False, local_weight=3)   # ONE RCCL all-reduce over the flat bucket
+torch.cuda.synchronize()
+assert n == (256 * 256 * 3 + 3 + 5) * 4, n
+assert torch.allclose(a.grad, want_a) and torch.allclose(b.grad, want_b) and torch.equal(c.grad, torch.zeros(5, device='cuda'))
+t = torch.ones(1 << 20, device='cuda')
+dist.all_reduce(t)
+dist.barrier()
+assert float(t.sum()) == float(1 << 20)
+dist.destroy_process_group()
+print('RCCL_OK')
+'''
+
+
+def test_rccl_world1_allreduce_of_the_gradient_bucket(dev):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', _RCCL_SNIPPET % ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _bench(extra, env_extra=None, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--res', '128', '--n-samples-x', '4',
+           '--no-pmc', '--no-cpu-baseline', '--no-extended'] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    return r
+
+
+def test_bench_spawns_its_own_ranks_and_shards_one_batch(dev):
+    """bench.py --gpus 2 without a launcher starts two ranks itself, deals ONE batch of views over them (strong scaling,
+    north_star's split) and reports the initialised world size.  (Both ranks share the one GPU of this box.)"""
+    one = _bench(['--gpus', '1', '--batch', '4'])
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = _bench(['--gpus', '2', '--batch', '4'], {'NVDR_BENCH_OVERSUBSCRIBE': '1', 'NVDR_BENCH_BACKEND': 'gloo'})
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    j2 = json.loads(two.stdout.strip().splitlines()[-1])
+    assert j1['n_gpus'] == 1 and j2['n_gpus'] == 2 and j2['scaling'] == 'strong'
+    assert j1['config']['views_per_iteration'] == j2['config']['views_per_iteration'] == 4
+    assert j1['config']['views_rank0'] == 4 and j2['config']['views_rank0'] == 2
+    assert j2['config']['allreduce_bytes_per_step'] > 0
+    # the same batch either way: the traversed rays of a step are the same set (the rank offset keeps the RNG streams)
+    r1 = j1['value'] * j1['ms_per_step']
+    r2 = j2['value'] * j2['ms_per_step']
+    assert abs(r1 - r2) < 1e-6 * r1
+
+
+def test_bench_refuses_more_ranks_than_gpus(dev):
+    if torch.cuda.device_count() >= 64:
+        pytest.skip('needs fewer than 64 GPUs')
+    r = _bench(['--gpus', '64', '--batch', '64'])
+    assert r.returncode != 0 and 'visible' in (r.stdout + r.stderr)

@@ -86,6 +86,10 @@ int nvdr_bvh_export(nvdr_ctx *ctx, float *nodes_host, float *tri_records_host, v
 int nvdr_trace_visibility(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis,
                           unsigned long long *counters, void *stream);
 
+/* Same answer through the PRODUCTION shadow-ray kernel of env-shade (persistent wavefronts over the four-slot wide nodes):
+ * a test hook that lets arbitrary rays -- grazing, degenerate meshes -- reach the kernel the renderer actually runs. */
+int nvdr_trace_visibility_wide(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis, void *stream);
+
 /* Closest hit of R rays: out_t f32[R] (<0 = miss), out_tri i32[R] (original triangle index, -1 = miss),
  * out_uv f32[R,2] barycentrics of v1, v2.  G-buffer producer building block. */
 int nvdr_trace_closest(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, float *out_t,

@@ -53,6 +53,7 @@ _SIGNATURES = {
     'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
     'nvdr_bvh_export': [c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_trace_visibility': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    'nvdr_trace_visibility_wide': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     'nvdr_trace_closest': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_env_shade_fwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_bwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],

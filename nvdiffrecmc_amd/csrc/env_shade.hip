@@ -1243,6 +1243,43 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     return 0;
 }
 
+// Test hook: any-hit visibility of ARBITRARY rays through the PRODUCTION shadow-ray kernel (env_trace_kernel: persistent
+// wavefronts, wide nodes, lane refill) -- the rays are packed into a one-ray-per-pixel stream.  nvdr_trace_visibility
+// (bvh.hip) answers the same question with the binary walk; tests require the two to agree bit for bit.
+__global__ void pack_rays_kernel(const float *__restrict__ ro, const float *__restrict__ rd, unsigned n, float4 *__restrict__ rays,
+                                 float4 *__restrict__ origin, uint32_t *__restrict__ live, unsigned *count)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *count = n;
+    if (i >= n) return;
+    rays[i] = make_float4(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2], 1.0f);
+    origin[i] = make_float4(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2], 0.0f);
+    live[i] = i;
+}
+
+extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis, void *stream_)
+{
+    NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_trace_visibility_wide: no BVH built");
+    NVDR_REQUIRE(n_rays < (1ll << 30), "nvdr_trace_visibility_wide: too many rays");
+    if (int r0 = ctx_check_overflow(c, "nvdr_trace_visibility_wide")) return r0;
+    if (n_rays <= 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    NVDR_HIP_TRY(hipSetDevice(c->device));
+    int r = reserve_stream(c, n_rays, n_rays, 1, stream);
+    if (r) return r;
+    c->stream_id = 0;
+    pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts);
+    int64_t tblocks = (int64_t)c->n_cus * 8;
+    if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
+    const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
+    if (tblocks > need) tblocks = need;
+    env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream>>>(
+        bvh_view(c), c->rays, c->pix_origin, c->live, c->chunk_counts, 1u, c->vis, c->spill, nullptr);
+    NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
+    NVDR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int nvdr_ctx_set_stream_budget(nvdr_ctx *c, int64_t bytes)
 {
     NVDR_REQUIRE(c, "nvdr_ctx_set_stream_budget: NULL ctx");

@@ -306,6 +306,18 @@ def trace_visibility(optix_ctx, ro, rd, count=False):
     return (vis, cnt) if count else vis
 
 
+def trace_visibility_wide(optix_ctx, ro, rd):
+    """trace_visibility through the PRODUCTION shadow-ray kernel (wide nodes, persistent wavefronts); test hook."""
+    w = optix_ctx.cpp_wrapper
+    _lib.require_cuda_f32(ro, 'ro')
+    _lib.require_cuda_f32(rd, 'rd')
+    ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
+    vis = torch.empty(ro.shape[0], dtype=torch.uint8, device=ro.device)
+    _lib.check(w.lib.nvdr_trace_visibility_wide(w.handle, _lib.ptr(ro), _lib.ptr(rd), ro.shape[0], _lib.ptr(vis), _lib.stream_ptr()),
+               'trace_visibility_wide')
+    return vis
+
+
 def trace_closest(optix_ctx, ro, rd):
     """Closest hit: (t [R] (<0 miss), triangle index [R] int32 (-1 miss), barycentrics [R,2])."""
     w = optix_ctx.cpp_wrapper

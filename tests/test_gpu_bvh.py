@@ -167,6 +167,7 @@ def test_predicate_vs_independent_fp64(mesh_name, dev):
     gd = torch.nn.functional.normalize(target - go, dim=-1)
     ro, rd = torch.cat([ro, go]).contiguous().to(dev), torch.cat([rd, gd]).contiguous().to(dev)
     got = ou.trace_visibility(ctx, ro, rd)
+    assert torch.equal(ou.trace_visibility_wide(ctx, ro, rd), got)     # the production (wide-node) kernel answers identically
     ref, clear = _fp64_visibility(v, t, ro, rd)
     diff = got != ref
     n_clear = int(clear.sum())
@@ -213,12 +214,24 @@ def test_degenerate_meshes_match_bruteforce(kind, dev):
     info = ctx.bvh_info()
     assert info['height'] <= 30 + 17 and info['stack_max'] >= info['height']     # h <= 30 + ceil(log2 n)
     assert info['stack_max'] >= 3 * ((info['height'] + 1) // 2 + 1) or info['stack_max'] == 104
-    ro, rd = _rays(6000, 21, 0.5)
+    # half random rays (near and far origins), half aimed at interior points of random triangles (certain hits, deep descents)
+    ro, rd = _rays(3000, 21, 0.3)
+    ro2, rd2 = _rays(3000, 22, 1.5)
+    g = torch.Generator().manual_seed(23)
+    ti = torch.randint(0, t.shape[0], (3000,), generator=g)
+    tri = v[t[ti].long()]                                            # [R,3,3]
+    w = torch.rand(3000, 3, generator=g) + 0.05
+    w = w / w.sum(-1, keepdim=True)
+    target = (tri * w[..., None]).sum(1)
+    ro3 = target + torch.nn.functional.normalize(torch.randn(3000, 3, generator=g), dim=-1) * 2.0
+    rd3 = torch.nn.functional.normalize(target - ro3, dim=-1)
+    ro, rd = torch.cat([ro, ro2, ro3]).contiguous(), torch.cat([rd, rd2, rd3]).contiguous()
     ref = orc.visibility(v, t, ro, rd, n_threads=NT)
     assert torch.equal(ou.trace_visibility(ctx, ro.to(dev), rd.to(dev)).cpu(), ref)
-    # the production shadow-ray kernel (wide walk) on the same tree, through env-shade with a synthetic one-row G-buffer
+    assert torch.equal(ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev)).cpu(), ref)    # the production wide walk
     ctx.check()
     assert 0.0 < ref.float().mean().item() < 1.0
+    assert ref[6000:].float().mean().item() < 0.5                    # the aimed rays do hit
 
 
 def test_stack_overflow_is_reported_not_silent(dev, monkeypatch):
@@ -232,7 +245,7 @@ def test_stack_overflow_is_reported_not_silent(dev, monkeypatch):
     ou.optix_build_bvh(ctx, v.to(dev), t.to(dev), rebuild=1)
     assert ctx.bvh_info()['stack_max'] == 13
     ro, rd = _rays(20000, 22, 0.05)
-    ou.trace_visibility(ctx, ro.to(dev), rd.to(dev))
+    ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev))
     with pytest.raises(RuntimeError, match='overflow'):
         ctx.check()
     with pytest.raises(RuntimeError, match='overflow'):

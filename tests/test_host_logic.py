@@ -99,10 +99,18 @@ def test_use_python_formulations_agree_with_oracle():
 
 def test_bench_algorithmic_byte_formula():
     import bench
-    total, trace, trav = bench.algorithmic_bytes(1, 512, 512, 1000, 64, 256, n_box=10, n_tri=2)
+    # 10 BVH2 node visits (32 B each, the reference accounting layout) + 2 triangle tests (36 B) by 90 000 traversed rays
+    total, trace, trav = bench.algorithmic_bytes(1, 512, 512, 1000, 64, 256, bvh2_nodes=10, bvh2_tris=2, n_traced=90000)
     assert trav == 32 * 10 + 36 * 2
     assert total == trav + (4 * 512 * 512 + 60 * 1000 + 24 * 512 * 512) + 1000 * 64 * 128   # 128 B per stratum at 256^2
-    assert trace == trav + 17 * (2 * 64 * 1000) + 16 * 1000
+    assert trace == trav + 21 * 90000 + 16 * 1000       # per traversed ray: 16 B direction + 4 B list entry + 1 B visibility
+    # the roofline object never reports a fraction above 1 of a real ceiling: VALU lane peak = 256 x 4 x 32 x 2.4 GHz
+    assert abs(bench.VALU_PEAK_TLANEOPS - 78.6432) < 1e-3
+    v = bench.valu_figures({'SQ_INSTS_VALU': 2.29e9, 'SQ_THREAD_CYCLES_VALU': 64 * 0.58 * 2.297e9, 'SQ_ACTIVE_INST_VALU': 2.297e9,
+                            'GRBM_GUI_ACTIVE': 10.5e6}, 4.5)
+    assert 0.0 < v['frac_of_lane_peak'] < 1.0 and abs(v['active_lane_fraction'] - 0.58) < 1e-6
+    m = bench.mem_figures({'FETCH_SIZE': 737442.3, 'WRITE_SIZE': 224857.5, 'TCC_REQ_sum': 1.88e8, 'TCC_MISS_sum': 1.2e7}, 4.5)
+    assert abs(m['hbm_bytes'] - (2 * 737442.3 + 224857.5) * 1024) < 1 and 0 < m['hbm_frac'] < 1 and 0 < m['l2_frac'] < 1
 
 
 def test_broadcast_pixels_column_sum_and_composite_reference():

@@ -252,6 +252,8 @@ def parse_args():
     ap.add_argument('--pmc-keep', default=None, help='directory to keep the rocpd databases of the counter passes in')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-extended', action='store_true', help='skip the extended median phase and the cached-visibility loop')
+    ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
+                    help='capture the iteration in HIP graphs (auto: when a rank renders <= 2 views, the launch-bound regime)')
     return ap.parse_args()
 
 
@@ -328,8 +330,11 @@ def run(args):
     my_views = shard_views(n_views, rank, world)
     if not my_views:
         raise SystemExit('bench.py: rank %d of %d has no view of the batch of %d' % (rank, world, n_views))
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and len(my_views) <= 2)
+    if args.pmc_child:
+        use_graph = False
     step = DirectLightingStep(preset['mesh'], H, n, view=my_views, n_views=n_views, device=dev,
-                              pixel_index_offset=my_views[0] * H * W, retrace_backward=True, subdiv=preset['subdiv'])
+                              pixel_index_offset=my_views[0] * H * W, retrace_backward=True, subdiv=preset['subdiv'], use_graph=use_graph)
 
     if args.pmc_child:          # under rocprofv3: a few plain iterations, nothing else
         for _ in range(args.warmup + args.steps):
@@ -351,10 +356,14 @@ def run(args):
         return float(tt.item())
 
     settle = max(0, 20 - args.warmup)                 # >= 20 warm iterations before anything is timed
+    if use_graph and settle + args.warmup < 4:
+        settle = 4 - args.warmup                      # the graphs are captured after three eager iterations
     for _ in range(settle + args.warmup):
         step.step(world)
-    # per-stage HIP-event timing recorded by the library on the launch stream itself (ring of the last launches)
-    step.ctx.set_profiling(True)
+    # per-stage HIP-event timing recorded by the library on the launch stream itself (ring of the last launches); a
+    # replayed graph cannot carry them, so in graph mode the stage times come from an eager phase after the timed ones
+    if not use_graph:
+        step.ctx.set_profiling(True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -365,9 +374,10 @@ def run(args):
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     step_ms = [a.elapsed_time(b) for a, b in ev]
-    n_f, (gen_ms, trace_ms, shade_ms) = step.ctx.stage_times(backward=False)
-    n_b, (bgen_ms, btrace_ms, bshade_ms) = step.ctx.stage_times(backward=True)
-    step.ctx.set_profiling(False)
+    if not use_graph:
+        n_f, (gen_ms, trace_ms, shade_ms) = step.ctx.stage_times(backward=False)
+        n_b, (bgen_ms, btrace_ms, bshade_ms) = step.ctx.stage_times(backward=True)
+        step.ctx.set_profiling(False)
 
     # extended phase: more samples of the same iteration for the median (>= 50 steps and >= 3 s), then the same iteration
     # with the forward's visibility bits replayed in backward (identical gradients, no second traversal; an extra, never `value`)
@@ -388,6 +398,18 @@ def run(args):
                 more = flag.item() != 0.0
             if not more:
                 break
+    if use_graph:                                     # leave graph mode for good: stage times of the same kernels, eagerly
+        step.force_eager = True
+        for _ in range(2):
+            step.step(world)
+        step.ctx.set_profiling(True)
+        for _ in range(10):
+            step.step(world)
+        barrier()
+        n_f, (gen_ms, trace_ms, shade_ms) = step.ctx.stage_times(backward=False)
+        n_b, (bgen_ms, btrace_ms, bshade_ms) = step.ctx.stage_times(backward=True)
+        step.ctx.set_profiling(False)
+    if not args.no_extended:
         step.retrace_backward = False
         k2 = max(5, args.steps // 2)
         for _ in range(2):
@@ -489,6 +511,7 @@ def run(args):
             'iters_per_sec': args.steps / dt,
             'iters_per_sec_cached_visibility': (k2 / dt2) if dt2 else None,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'settle_steps_before_warmup': settle,
+            'hip_graph': bool(use_graph),
             'ms_per_step': dt / args.steps * 1e3,
             'median_ms_per_step': med, 'median_over_steps': len(ext_ms) if ext_ms else len(step_ms),
             'min_ms_per_step': min(ext_ms or step_ms), 'max_ms_per_step': max(ext_ms or step_ms),

@@ -95,6 +95,30 @@ int nvdr_trace_visibility_wide(nvdr_ctx *ctx, const float *ro, const float *rd, 
 int nvdr_trace_closest(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, float *out_t,
                        int32_t *out_tri, float *out_uv, void *stream);
 
+/* ---- G-buffer producer (additive): what render_layer obtains from nvdiffrast's rasterize + interpolate
+ * (render/render.py:208-234, :279) for N camera views, from primary rays traced through the context's BVH.
+ * All pointers are device pointers; index arrays are int32 [T,3]; outputs are contiguous NHWC float32. */
+typedef struct nvdr_gbuffer_args {
+    const float   *v_pos;     const int32_t *t_pos_idx;   /* [V,3], the mesh the context's BVH was built from */
+    const float   *v_nrm;     const int32_t *t_nrm_idx;   /* [Vn,3] */
+    const float   *v_tng;     const int32_t *t_tng_idx;   /* [Vn,3] tangents (render/mesh.py:181-219) */
+    const float   *v_tex;     const int32_t *t_tex_idx;   /* [Vt,2] */
+    int64_t        n_tris;
+    const float   *mvp;       /* [N,4,4] row-major model-view-projection (render.py:271 v_pos_clip = mtx_in @ v_pos) */
+    const float   *cam;       /* [N,4,3]: eye, U, V, W -- the primary ray through NDC (X, Y) is normalize(X U + Y V + W) */
+    int32_t        n, h, w;
+    float *rast;                /* [N,H,W,4] (u, v, z/w, triangle_id + 1): nvdiffrast's rasterize output; 0 = background */
+    float *rast_db;             /* [N,H,W,4] (du/dX, du/dY, dv/dX, dv/dY) per pixel */
+    float *gb_pos;              /* [N,H,W,3] render.py:208 */
+    float *gb_geometric_normal; /* [N,H,W,3] render.py:211-216 */
+    float *gb_normal;           /* [N,H,W,3] render.py:220 */
+    float *gb_tangent;          /* [N,H,W,3] render.py:221 */
+    float *gb_texc;             /* [N,H,W,2] render.py:225 */
+    float *gb_texc_deriv;       /* [N,H,W,4] render.py:225 */
+    float *gb_depth;            /* [N,H,W,2] (z/w, |dz|) render.py:228-234 */
+} nvdr_gbuffer_args;
+int nvdr_render_gbuffer(nvdr_ctx *ctx, const nvdr_gbuffer_args *args, void *stream);
+
 /* ---- env_shade_fwd / env_shade_bwd (torch_bindings.cpp:123-272; raygen program kernel.cu:463-542) */
 #define NVDR_COUNTERS_BVH2 (8 + 2 * 8192)
 #define NVDR_COUNTERS_LEN (NVDR_COUNTERS_BVH2 + 8)
@@ -152,6 +176,10 @@ typedef struct nvdr_env_shade_args {
        traced again (or, with vis_cache, only re-shaded).  0 = always regenerate.  A backward pass consumes the stream
        (it leaves light-gradient records in it): a second backward pass with the same id regenerates it. */
     uint64_t reuse_stream_id;
+    /* optional (may be NULL): device pointer to ONE uint32 added to rnd_seed by the kernels themselves.  A host-side seed
+       is a launch parameter and would be frozen into a captured HIP graph; with the counter in device memory a replayed
+       iteration draws fresh samples (render.py:112-116 increments its seed once per shade() call). */
+    const uint32_t *rnd_seed_offset;
 } nvdr_env_shade_args;
 int nvdr_env_shade_fwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
 int nvdr_env_shade_bwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);

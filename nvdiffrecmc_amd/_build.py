@@ -24,6 +24,7 @@ SOURCES = [
     'denoise.hip',
     'renderutils.hip',
     'light.hip',
+    'gbuffer.hip',
 ]
 
 # -ffp-contract=off: the sampling math must round exactly like the CPU oracle

@@ -36,7 +36,16 @@ class NvdrEnvShadeArgs(ctypes.Structure):
         ('diff', c_void_p), ('spec', c_void_p),
         ('diff_grad', NvdrTensor), ('spec_grad', NvdrTensor),
         ('gb_pos_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_kd_grad', c_void_p), ('gb_ks_grad', c_void_p),
-        ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p), ('reuse_stream_id', ctypes.c_uint64)]
+        ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p), ('reuse_stream_id', ctypes.c_uint64), ('rnd_seed_offset', c_void_p)]
+
+
+class NvdrGbufferArgs(ctypes.Structure):
+    _fields_ = [('v_pos', c_void_p), ('t_pos_idx', c_void_p), ('v_nrm', c_void_p), ('t_nrm_idx', c_void_p),
+                ('v_tng', c_void_p), ('t_tng_idx', c_void_p), ('v_tex', c_void_p), ('t_tex_idx', c_void_p),
+                ('n_tris', c_int64), ('mvp', c_void_p), ('cam', c_void_p),
+                ('n', ctypes.c_int32), ('h', ctypes.c_int32), ('w', ctypes.c_int32)] + [
+        (k, c_void_p) for k in ('rast', 'rast_db', 'gb_pos', 'gb_geometric_normal', 'gb_normal', 'gb_tangent', 'gb_texc',
+                                'gb_texc_deriv', 'gb_depth')]
 
 
 _T = ctypes.POINTER(NvdrTensor)
@@ -55,6 +64,7 @@ _SIGNATURES = {
     'nvdr_trace_visibility': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     'nvdr_trace_visibility_wide': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     'nvdr_trace_closest': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    'nvdr_render_gbuffer': [c_void_p, ctypes.POINTER(NvdrGbufferArgs), c_void_p],
     'nvdr_env_shade_fwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_bwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_last_pixel_count': [c_void_p, ctypes.POINTER(c_int64), c_void_p],

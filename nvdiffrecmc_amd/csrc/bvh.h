@@ -117,6 +117,7 @@ struct nvdr_ctx {
     int *texel = nullptr;
     uint8_t *vis = nullptr;
     uint32_t *live = nullptr;      // stream slots of the rays that need traversal (dead samples left out)
+    unsigned *queues = nullptr;    // [256][32] chunk counters of the traversal kernel, one 128-B line each (NVDR_TRACE_QUEUES)
     float4 *pix_origin = nullptr;
     size_t stream_cap_rays = 0;
     uint64_t stream_id = 0;        // id of the ray stream currently held in rays/texel/pix_origin/pix_list
@@ -356,6 +357,56 @@ __device__ __forceinline__ unsigned bvh_any_hit2(const BvhView &bvh, float ox, f
         }
     }
     return occluded;
+}
+
+// Closest hit (ordered binary walk, shrinking tmax): returns the ORIGINAL index of the nearest triangle (-1 = miss) and its
+// distance / barycentrics of v1, v2.  Used by nvdr_trace_closest and the G-buffer producer (gbuffer.hip).
+__device__ __forceinline__ int bvh_closest_hit(const BvhView &bvh, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               const TravStack &stack, float &best_t, float &best_u, float &best_v)
+{
+    best_t = NVDR_RAY_TMAX;
+    best_u = 0.0f;
+    best_v = 0.0f;
+    int best = -1;
+    auto test_leaf = [&](int slot) {
+        const float4 a = bvh.tris[3 * slot + 0], b = bvh.tris[3 * slot + 1], c = bvh.tris[3 * slot + 2];
+        float t, u, v, det;
+        if (nvdr_ray_tri(ox, oy, oz, dx, dy, dz, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, &t, &u, &v, &det)) {
+            const float tt = t / det;
+            if (tt < best_t) {
+                best_t = tt;
+                best_u = u / det;
+                best_v = v / det;
+                best = __float_as_int(c.y);
+            }
+        }
+    };
+    if (bvh.n_tris == 1) {
+        test_leaf(0);
+        return best;
+    }
+    const GridRay g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
+    int sp = 0, cur = 0;
+    while (true) {
+        NodeHit h = visit_node(bvh.nodes, cur, g, best_t);
+        if (h.hl && h.cl < 0) { test_leaf(~h.cl); h.hl = false; }
+        if (h.hr && h.cr < 0) { test_leaf(~h.cr); h.hr = false; }
+        if (h.hl && h.hr) {
+            const bool left_first = h.tl <= h.tr;
+            stack.push(sp, left_first ? h.cr : h.cl);
+            sp++;
+            cur = left_first ? h.cl : h.cr;
+        } else if (h.hl) {
+            cur = h.cl;
+        } else if (h.hr) {
+            cur = h.cr;
+        } else {
+            if (sp == 0) break;
+            sp--;
+            cur = stack.pop(sp);
+        }
+    }
+    return best;
 }
 
 // one ray per lane

@@ -269,48 +269,9 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_closest_kernel(BvhView
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * blockDim.x) {
-        const float ox = ro[3 * r], oy = ro[3 * r + 1], oz = ro[3 * r + 2];
-        const float dx = rd[3 * r], dy = rd[3 * r + 1], dz = rd[3 * r + 2];
-        float best_t = NVDR_RAY_TMAX, best_u = 0.0f, best_v = 0.0f;
-        int best = -1;
-        auto test_leaf = [&](int slot) {
-            const float4 a = bvh.tris[3 * slot + 0], b = bvh.tris[3 * slot + 1], c = bvh.tris[3 * slot + 2];
-            float t, u, v, det;
-            if (nvdr_ray_tri(ox, oy, oz, dx, dy, dz, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, &t, &u, &v, &det)) {
-                const float tt = t / det;
-                if (tt < best_t) {
-                    best_t = tt;
-                    best_u = u / det;
-                    best_v = v / det;
-                    best = __float_as_int(c.y);
-                }
-            }
-        };
-        if (bvh.n_tris == 1) {
-            test_leaf(0);
-        } else {
-            const GridRay g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
-            int sp = 0, cur = 0;
-            while (true) {
-                NodeHit h = visit_node(bvh.nodes, cur, g, best_t);
-                if (h.hl && h.cl < 0) { test_leaf(~h.cl); h.hl = false; }
-                if (h.hr && h.cr < 0) { test_leaf(~h.cr); h.hr = false; }
-                if (h.hl && h.hr) {
-                    const bool left_first = h.tl <= h.tr;
-                    stack.push(sp, left_first ? h.cr : h.cl);
-                    sp++;
-                    cur = left_first ? h.cl : h.cr;
-                } else if (h.hl) {
-                    cur = h.cl;
-                } else if (h.hr) {
-                    cur = h.cr;
-                } else {
-                    if (sp == 0) break;
-                    sp--;
-                    cur = stack.pop(sp);
-                }
-            }
-        }
+        float best_t, best_u, best_v;
+        const int best = bvh_closest_hit(bvh, ro[3 * r], ro[3 * r + 1], ro[3 * r + 2], rd[3 * r], rd[3 * r + 1], rd[3 * r + 2], stack,
+                                         best_t, best_u, best_v);
         out_t[r] = best >= 0 ? best_t : -1.0f;
         out_tri[r] = best;
         out_uv[2 * r] = best_u;
@@ -402,6 +363,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         e = hipHostGetDevicePointer((void **)&c->ovf_dev, c->ovf_host, 0);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&c->chunk_counts, sizeof(unsigned) * NVDR_MAX_CHUNKS);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->queues, sizeof(unsigned) * 32 * 256);
     if (e != hipSuccess) {
         hipFree(c->dinfo);
         if (c->ovf_host) hipHostFree(c->ovf_host);
@@ -438,6 +400,7 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     hipFree(c->spill);
     hipFree(c->pix_list);
     hipFree(c->chunk_counts);
+    hipFree(c->queues);
     hipFree(c->rays); hipFree(c->texel); hipFree(c->vis); hipFree(c->live); hipFree(c->pix_origin); hipFree(c->lg_part);
     if (c->ovf_host) hipHostFree(c->ovf_host);
     delete c;

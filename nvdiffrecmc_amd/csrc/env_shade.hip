@@ -72,9 +72,12 @@ struct ShadeParams {
     unsigned debug;           // NVDR_DEBUG bits (read once per context): 1 skip tracing, 2 skip the light gradient
     // the chunk of the covered-pixel list this launch of the three stages works on: pixels [pix_begin, pix_begin + pix_cap)
     unsigned pix_begin, pix_cap;
+    const unsigned *seed_dev; // optional: a seed offset read from device memory (captured HIP graphs replay with fresh seeds)
     int reuse;                // backward: the forward's stream is still in the context IF the whole launch fitted one chunk
     int lg_records;           // backward: 1 = write (texel, rgb) records for the band gather, 0 = global atomics
 };
+
+__device__ __forceinline__ unsigned launch_seed(const ShadeParams &p) { return p.seed_dev ? p.seed + *p.seed_dev : p.seed; }
 
 // pixels of this chunk (the covered-pixel count lives on the device; chunks behind it are empty launches)
 __device__ __forceinline__ unsigned chunk_pixels(const ShadeParams &p)
@@ -429,7 +432,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         const float specularWeight = albedo(specColor, wo, nrm);
         const float pDiffuse = (diffuseWeight + specularWeight) > 0.f ? diffuseWeight / (diffuseWeight + specularWeight) : 1.f;
         const float pSpecular = 1.0f - pDiffuse;
-        unsigned a_seed = p.seed, b_seed = (unsigned)lin + p.pix_offset;
+        unsigned a_seed = launch_seed(p), b_seed = (unsigned)lin + p.pix_offset;
         unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
         const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
         const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
@@ -506,6 +509,17 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
 #ifndef NVDR_TRACE_CHUNK_LOG2
 #define NVDR_TRACE_CHUNK_LOG2 6
 #endif
+// NVDR_TRACE_QUEUES > 0: chunks of NVDR_TRACE_QCHUNK rays are CLAIMED from that many device counters (one cache line each,
+// wave w uses counter w % Q and gets the chunks q, q + Q, q + 2Q ...) instead of being dealt round-robin: all waves of the
+// chip then work inside one moving window of the list (neighbouring pixels -> the same subtrees stay in L2) and a wave that
+// drew cheap rays simply claims more.  One counter serialises at ~70 ns per claim (round 1: 1.4-2.5 ms); 64 of them see
+// < 1 M claims/s each.  0 = static round-robin chunks.
+#ifndef NVDR_TRACE_QUEUES
+#define NVDR_TRACE_QUEUES 0
+#endif
+#ifndef NVDR_TRACE_QCHUNK
+#define NVDR_TRACE_QCHUNK 256
+#endif
 #ifndef NVDR_TRACE_ALIGN
 #define NVDR_TRACE_ALIGN 8
 #endif
@@ -519,7 +533,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
                                                                           const unsigned *__restrict__ ray_count,
                                                                           unsigned rays_per_pixel,
                                                                           uint8_t *__restrict__ vis, int *spill,
-                                                                          unsigned long long *counters)
+                                                                          unsigned long long *counters, unsigned *queues)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
@@ -534,9 +548,19 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     // atomics: 1.4 ms with 1024-ray chunks, 2.5 ms with 256) and is not needed: per-wave clocks of the counting build
     // show all waves starting together and finishing evenly spread over [T/8, T] for ANY chunk size down to 2 rays --
     // the signature of oldest-first issue among the 8 waves of a SIMD that is busy to the end, not of imbalance.
+#if NVDR_TRACE_QUEUES
+    const unsigned Q = NVDR_TRACE_QUEUES, QC = NVDR_TRACE_QCHUNK;
+    const unsigned n_qchunks = (total + QC - 1u) / QC;
+    unsigned *my_queue = queues + (wid % Q) * 32u;
+    unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
+    bool more = total > 0;
+    (void)n_waves;
+#else
     unsigned next = 0;                                      // wave-uniform virtual cursor
     const unsigned CL = NVDR_TRACE_CHUNK_LOG2, CS = 1u << CL;
     const unsigned end = ((total + CS - 1u) / CS + n_waves - 1) / n_waves * CS;
+    (void)queues;
+#endif
     unsigned n_box = 0, n_tri = 0, n_ray = 0;
     const bool single = bvh.n_tris == 1;
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
@@ -566,10 +590,25 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     while (true) {
         const unsigned long long idle = __ballot(ray < 0);
         const int n_idle = __popcll(idle);
+#if NVDR_TRACE_QUEUES
+        if (n_idle >= NVDR_REFILL_MIN && next >= end && more) {
+            unsigned j = 0;
+            if (lane == 0) j = atomicAdd(my_queue, 1u);
+            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+            const unsigned c = j * Q + (wid % Q);
+            more = c < n_qchunks;
+            next = more ? c * QC : 0u;
+            end = more ? min(next + QC, total) : 0u;
+        }
+#endif
         if (next < end && n_idle >= NVDR_REFILL_MIN) {
             // refill every idle lane from the wave's range (no atomics: the cursor is wave-uniform)
             const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+#if NVDR_TRACE_QUEUES
+            const unsigned at = take;
+#else
             const unsigned at = (((take >> CL) * n_waves + wid) << CL) | (take & (CS - 1u));
+#endif
             if (ray < 0 && take < end && at < total) {
                 const unsigned slot = live[at];
                 ray = (int)slot;
@@ -584,6 +623,9 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
             }
             next += (unsigned)n_idle;
         } else if (n_idle == 64) {
+#if NVDR_TRACE_QUEUES
+            if (!more)
+#endif
             break;
         }
         const unsigned long long on_leaf = __ballot(ray >= 0 && cur < 0);
@@ -697,7 +739,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
         F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
         // the two permutation rows of this pixel (kernel.cu:504-505) give the stream slot of every sample
-        unsigned a_seed = p.seed, b_seed = (unsigned)lin + p.pix_offset;
+        unsigned a_seed = launch_seed(p), b_seed = (unsigned)lin + p.pix_offset;
         unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
         const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
         const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
@@ -1086,6 +1128,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     p.N = (int)N; p.H = (int)H; p.W = (int)W;
     p.bsdf = a->bsdf; p.n = a->n_samples_x; p.S = S; p.seed = a->rnd_seed; p.pix_offset = a->pixel_index_offset;
     p.shadow_scale = a->shadow_scale;
+    p.seed_dev = a->rnd_seed_offset;
     int L = 1, lg = 0;
     while (L < (int)S && L < 64) { L <<= 1; lg++; }
     p.L = L; p.log2L = lg;
@@ -1206,17 +1249,18 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (!(reuse && n_chunks == 1)) env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
         // stage 2
+        if (!replay && NVDR_TRACE_QUEUES) NVDR_HIP_TRY(hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream));
         if (!replay) {
             if (c->debug & 1u) {
                 NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)cap * 2 * S, stream));
             } else if (a->counters) {
                 env_trace_kernel<true><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
-                                                                                                  p.ray_count, 2 * S, c->vis, c->spill, a->counters);
+                                                                                                  p.ray_count, 2 * S, c->vis, c->spill, a->counters, c->queues);
                 bvh2_count_kernel<<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, p.ray_count,
                                                                                             2 * S, c->spill, a->counters + NVDR_COUNTERS_BVH2);
             } else {
                 env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
-                                                                                                   p.ray_count, 2 * S, c->vis, c->spill, nullptr);
+                                                                                                   p.ray_count, 2 * S, c->vis, c->spill, nullptr, c->queues);
             }
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
@@ -1268,13 +1312,14 @@ extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const fl
     int r = reserve_stream(c, n_rays, n_rays, 1, stream);
     if (r) return r;
     c->stream_id = 0;
+    if (NVDR_TRACE_QUEUES) NVDR_HIP_TRY(hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream));
     pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts);
     int64_t tblocks = (int64_t)c->n_cus * 8;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
     if (tblocks > need) tblocks = need;
     env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream>>>(
-        bvh_view(c), c->rays, c->pix_origin, c->live, c->chunk_counts, 1u, c->vis, c->spill, nullptr);
+        bvh_view(c), c->rays, c->pix_origin, c->live, c->chunk_counts, 1u, c->vis, c->spill, nullptr, c->queues);
     NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
     NVDR_LAUNCH_CHECK();
     return 0;

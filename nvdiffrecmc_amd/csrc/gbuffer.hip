@@ -1,0 +1,144 @@
+// gbuffer.hip -- G-buffer producer: primary visibility + attribute interpolation in ONE kernel.
+//
+// Replaces, for the benchmark path, what render_layer gets from nvdiffrast (render/render.py:170-234):
+//   rast, rast_db = dr.rasterize(...)                          render.py:279 (CUDA/OpenGL rasteriser: does not exist on ROCm)
+//   gb_pos, gb_geometric_normal, gb_normal, gb_tangent          render.py:208-222  (interpolate of v_pos / face normals / v_nrm / v_tng)
+//   gb_texc, gb_texc_deriv                                      render.py:225-226
+//   gb_depth = (z/w, |dz|)                                      render.py:228-234
+// Here a pixel's primary ray is traced through the LBVH the shadow rays use (closest hit, bvh.h), and the hit is turned into
+// the same per-pixel records nvdiffrast produces:
+//   rast    = (u, v, z/w, triangle_id + 1)     u, v = perspective-correct barycentrics of vertex 0 and 1 (nvdiffrast's
+//             convention: attr = u a0 + v a1 + (1-u-v) a2); 0 for background pixels
+//   rast_db = (du/dX, du/dY, dv/dX, dv/dY)     per PIXEL, from the triangle's clip-space plane equations (analytic, like
+//             the rasteriser), not finite differences
+// Attribute interpolation, the face normal, and the depth pair follow render.py line by line -- including the reference's
+// quirk that `clip_pos_deriv[..., 2:3]` / `[..., 3:4]` (render.py:232) pick d(clip.y)/dX and d(clip.y)/dY out of nvdiffrast's
+// interleaved (dA/dX, dA/dY) layout rather than the z and w derivatives: the denoiser's depth weight sees the reference's numbers.
+// Not differentiable (the reference gets geometry gradients from dr.antialias + interpolate; out of scope).
+#include "bvh.h"
+#include "bsdf_device.h"
+
+struct GbufferParams {
+    const float *v_pos; const int *t_pos;
+    const float *v_nrm; const int *t_nrm;
+    const float *v_tng; const int *t_tng;
+    const float *v_tex; const int *t_tex;
+    const float *mvp;      // [N,4,4] row-major
+    const float *cam;      // [N,4,3]: eye, U, V, W  (ray through NDC (X, Y): normalize(X U + Y V + W))
+    int N, H, W;
+    float *rast, *rast_db, *gb_pos, *gb_gnrm, *gb_nrm, *gb_tng, *gb_texc, *gb_texc_db, *gb_depth;
+};
+
+__device__ __forceinline__ F3 load3(const float *p, int i) { return f3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+__device__ __forceinline__ void store3(float *p, int64_t i, F3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+// nvdiffrast's interpolation: u a0 + v a1 + (1 - u - v) a2
+__device__ __forceinline__ F3 interp3(F3 a0, F3 a1, F3 a2, float u, float v) { return (a0 * u + a1 * v) + a2 * (1.0f - u - v); }
+
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, GbufferParams p, int *spill)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
+    const int64_t total = (int64_t)p.N * p.H * p.W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % p.W), y = (int)((i / p.W) % p.H), z = (int)(i / ((int64_t)p.W * p.H));
+        const float X = ((float)x + 0.5f) / (float)p.W * 2.0f - 1.0f;      // NDC of the pixel centre; row 0 = Y -1 (rasteriser layout)
+        const float Y = ((float)y + 0.5f) / (float)p.H * 2.0f - 1.0f;
+        const float *cam = p.cam + 12 * z;
+        const F3 eye = f3(cam[0], cam[1], cam[2]);
+        F3 d = (f3(cam[3], cam[4], cam[5]) * X + f3(cam[6], cam[7], cam[8]) * Y) + f3(cam[9], cam[10], cam[11]);
+        d = d * (1.0f / sqrtf(dot3(d, d)));
+        float t, bu, bv;
+        const int tri = bvh_closest_hit(bvh, eye.x, eye.y, eye.z, d.x, d.y, d.z, stack, t, bu, bv);
+
+        float4 rast = make_float4(0.f, 0.f, 0.f, 0.f), rdb = make_float4(0.f, 0.f, 0.f, 0.f);
+        F3 pos = f3(0.f), gn = f3(0.f), nrm = f3(0.f), tng = f3(0.f);
+        float tc0 = 0.f, tc1 = 0.f, tdb[4] = {0.f, 0.f, 0.f, 0.f}, z0 = 0.f, zg = 0.f;
+        if (tri >= 0) {
+            const int i0 = p.t_pos[3 * tri], i1 = p.t_pos[3 * tri + 1], i2 = p.t_pos[3 * tri + 2];
+            const F3 p0 = load3(p.v_pos, i0), p1 = load3(p.v_pos, i1), p2 = load3(p.v_pos, i2);
+            const float u = 1.0f - bu - bv, v = bu;        // Moeller-Trumbore weights of (v1, v2) -> nvdiffrast's (v0, v1)
+            // clip-space vertices (x, y, z, w) = mvp * (p, 1)
+            const float *M = p.mvp + 16 * z;
+            float cx[3], cy[3], cz[3], cw[3];
+            const F3 pv[3] = {p0, p1, p2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                cx[k] = M[0] * pv[k].x + M[1] * pv[k].y + M[2] * pv[k].z + M[3];
+                cy[k] = M[4] * pv[k].x + M[5] * pv[k].y + M[6] * pv[k].z + M[7];
+                cz[k] = M[8] * pv[k].x + M[9] * pv[k].y + M[10] * pv[k].z + M[11];
+                cw[k] = M[12] * pv[k].x + M[13] * pv[k].y + M[14] * pv[k].z + M[15];
+            }
+            // Plane equations of the perspective-correct barycentrics: beta_k(X, Y) = n_k / (n_0 + n_1 + n_2) with
+            // n_k = A_k X + B_k Y + C_k, (A_k, B_k, C_k) = row k of adj([cx; cy; cw]).  d(beta_k)/dX = (A_k - beta_k sum(A)) / s.
+            const float A0 = cy[1] * cw[2] - cy[2] * cw[1], B0 = cx[2] * cw[1] - cx[1] * cw[2], C0 = cx[1] * cy[2] - cx[2] * cy[1];
+            const float A1 = cy[2] * cw[0] - cy[0] * cw[2], B1 = cx[0] * cw[2] - cx[2] * cw[0], C1 = cx[2] * cy[0] - cx[0] * cy[2];
+            const float A2 = cy[0] * cw[1] - cy[1] * cw[0], B2 = cx[1] * cw[0] - cx[0] * cw[1], C2 = cx[0] * cy[1] - cx[1] * cy[0];
+            const float s = (A0 + A1 + A2) * X + (B0 + B1 + B2) * Y + (C0 + C1 + C2);
+            const float is = fabsf(s) > 1e-30f ? 1.0f / s : 0.0f;
+            const float px = 2.0f / (float)p.W, py = 2.0f / (float)p.H;             // NDC per pixel
+            const float dudx = (A0 - u * (A0 + A1 + A2)) * is * px, dudy = (B0 - u * (B0 + B1 + B2)) * is * py;
+            const float dvdx = (A1 - v * (A0 + A1 + A2)) * is * px, dvdy = (B1 - v * (B0 + B1 + B2)) * is * py;
+            const float w2 = 1.0f - u - v;
+            const float zc = u * cz[0] + v * cz[1] + w2 * cz[2], wc = u * cw[0] + v * cw[1] + w2 * cw[2];
+            rast = make_float4(u, v, zc / wc, (float)(tri + 1));
+            rdb = make_float4(dudx, dudy, dvdx, dvdy);
+            // render.py:208-222
+            pos = interp3(p0, p1, p2, u, v);
+            const F3 fn = safe_normalize(cross3(p1 - p0, p2 - p0));
+            gn = interp3(fn, fn, fn, u, v);
+            nrm = interp3(load3(p.v_nrm, p.t_nrm[3 * tri]), load3(p.v_nrm, p.t_nrm[3 * tri + 1]), load3(p.v_nrm, p.t_nrm[3 * tri + 2]), u, v);
+            tng = interp3(load3(p.v_tng, p.t_tng[3 * tri]), load3(p.v_tng, p.t_tng[3 * tri + 1]), load3(p.v_tng, p.t_tng[3 * tri + 2]), u, v);
+            // render.py:225-226: texture coordinate + its image-space derivatives (ds/dX, ds/dY, dt/dX, dt/dY)
+            const int j0 = p.t_tex[3 * tri], j1 = p.t_tex[3 * tri + 1], j2 = p.t_tex[3 * tri + 2];
+            const float s0 = p.v_tex[2 * j0], t0 = p.v_tex[2 * j0 + 1], s1 = p.v_tex[2 * j1], t1 = p.v_tex[2 * j1 + 1];
+            const float s2 = p.v_tex[2 * j2], t2 = p.v_tex[2 * j2 + 1];
+            tc0 = (s0 * u + s1 * v) + s2 * w2;
+            tc1 = (t0 * u + t1 * v) + t2 * w2;
+            tdb[0] = dudx * (s0 - s2) + dvdx * (s1 - s2); tdb[1] = dudy * (s0 - s2) + dvdy * (s1 - s2);
+            tdb[2] = dudx * (t0 - t2) + dvdx * (t1 - t2); tdb[3] = dudy * (t0 - t2) + dvdy * (t1 - t2);
+            // render.py:228-234.  clip_pos_deriv is [x/dX, x/dY, y/dX, y/dY, z/dX, ...]: channels 2 and 3 are the Y-clip derivatives
+            const float eps = 0.00001f;
+            const float dyx = dudx * (cy[0] - cy[2]) + dvdx * (cy[1] - cy[2]);
+            const float dyy = dudy * (cy[0] - cy[2]) + dvdy * (cy[1] - cy[2]);
+            z0 = fmaxf(zc, eps) / fmaxf(wc, eps);
+            const float z1 = fmaxf(zc + fabsf(dyx), eps) / fmaxf(wc + fabsf(dyy), eps);
+            zg = fabsf(z1 - z0);
+        }
+        ((float4 *)p.rast)[i] = rast;
+        ((float4 *)p.rast_db)[i] = rdb;
+        store3(p.gb_pos, i, pos);
+        store3(p.gb_gnrm, i, gn);
+        store3(p.gb_nrm, i, nrm);
+        store3(p.gb_tng, i, tng);
+        p.gb_texc[2 * i] = tc0; p.gb_texc[2 * i + 1] = tc1;
+        ((float4 *)p.gb_texc_db)[i] = make_float4(tdb[0], tdb[1], tdb[2], tdb[3]);
+        p.gb_depth[2 * i] = z0; p.gb_depth[2 * i + 1] = zg;
+    }
+}
+
+unsigned query_grid(const nvdr_ctx *c, int64_t items);   // bvh.hip
+
+extern "C" int nvdr_render_gbuffer(nvdr_ctx *c, const nvdr_gbuffer_args *a, void *stream_)
+{
+    NVDR_REQUIRE(c && a, "nvdr_render_gbuffer: NULL argument");
+    NVDR_REQUIRE(c->n_tris > 0, "nvdr_render_gbuffer: no BVH built on this context (call optix_build_bvh first)");
+    NVDR_REQUIRE(a->n_tris == c->n_tris, "nvdr_render_gbuffer: the mesh has %lld triangles, the BVH of this context %lld",
+                 (long long)a->n_tris, (long long)c->n_tris);
+    NVDR_REQUIRE(a->v_pos && a->t_pos_idx && a->v_nrm && a->t_nrm_idx && a->v_tng && a->t_tng_idx && a->v_tex && a->t_tex_idx,
+                 "nvdr_render_gbuffer: NULL mesh attribute");
+    NVDR_REQUIRE(a->mvp && a->cam && a->n > 0 && a->h > 0 && a->w > 0, "nvdr_render_gbuffer: bad view block");
+    NVDR_REQUIRE(a->rast && a->rast_db && a->gb_pos && a->gb_geometric_normal && a->gb_normal && a->gb_tangent && a->gb_texc &&
+                     a->gb_texc_deriv && a->gb_depth, "nvdr_render_gbuffer: NULL output");
+    if (int r0 = ctx_check_overflow(c, "nvdr_render_gbuffer")) return r0;
+    NVDR_HIP_TRY(hipSetDevice(c->device));
+    GbufferParams p;
+    p.v_pos = a->v_pos; p.t_pos = a->t_pos_idx; p.v_nrm = a->v_nrm; p.t_nrm = a->t_nrm_idx;
+    p.v_tng = a->v_tng; p.t_tng = a->t_tng_idx; p.v_tex = a->v_tex; p.t_tex = a->t_tex_idx;
+    p.mvp = a->mvp; p.cam = a->cam; p.N = a->n; p.H = a->h; p.W = a->w;
+    p.rast = a->rast; p.rast_db = a->rast_db; p.gb_pos = a->gb_pos; p.gb_gnrm = a->gb_geometric_normal; p.gb_nrm = a->gb_normal;
+    p.gb_tng = a->gb_tangent; p.gb_texc = a->gb_texc; p.gb_texc_db = a->gb_texc_deriv; p.gb_depth = a->gb_depth;
+    const int64_t total = (int64_t)p.N * p.H * p.W;
+    gbuffer_kernel<<<query_grid(c, total), NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), (hipStream_t)stream_>>>(bvh_view(c), p, c->spill);
+    NVDR_LAUNCH_CHECK();
+    return 0;
+}

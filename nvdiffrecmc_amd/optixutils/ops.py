@@ -55,8 +55,11 @@ class OptiXContext:
         #   cache_visibility   reuse the forward's visibility bits in backward when the seed is fixed (identical rays; the
         #                      reference re-traces every ray, torch_bindings.cpp:238,266).  None = the module default.
         #   pixel_index_offset added to the linear pixel index that seeds the RNG (data-parallel shards: first_view * H * W)
+        #   seed_offset        int32 device tensor [1] the kernels add to rnd_seed (None: no offset).  A captured HIP graph
+        #                      freezes host-side launch parameters; a seed counter in device memory lets replays draw new samples
         self.cache_visibility = None
         self.pixel_index_offset = None
+        self.seed_offset = None
 
     def set_stream_budget(self, megabytes):
         """HBM the ray stream between the three env-shade stages may take (default 2048 MB); larger launches are processed
@@ -135,6 +138,10 @@ def _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks
     a.bsdf, a.n_samples_x, a.rnd_seed = int(BSDF), int(n_samples_x), int(rnd_seed) & 0xFFFFFFFF
     a.shadow_scale = float(shadow_scale)
     a.pixel_index_offset = int(pixel_index_offset)
+    so = getattr(optix_ctx, 'seed_offset', None)
+    if so is not None:
+        _lib.require_cuda_f32(so, 'seed_offset', torch.int32)
+        a.rnd_seed_offset = so.data_ptr()
     return a
 
 
@@ -331,6 +338,46 @@ def trace_closest(optix_ctx, ro, rd):
     _lib.check(w.lib.nvdr_trace_closest(w.handle, _lib.ptr(ro), _lib.ptr(rd), R, _lib.ptr(t), _lib.ptr(tri), _lib.ptr(uv),
                                         _lib.stream_ptr()), 'trace_closest')
     return t, tri, uv
+
+
+_GB_CHANNELS = (('rast', 4), ('rast_db', 4), ('gb_pos', 3), ('gb_geometric_normal', 3), ('gb_normal', 3), ('gb_tangent', 3),
+                ('gb_texc', 2), ('gb_texc_deriv', 4), ('gb_depth', 2))
+
+
+def render_gbuffer(optix_ctx, mesh, mvp, cam, resolution):
+    """G-buffers of N views from primary rays through the context's BVH: what render_layer takes from nvdiffrast's
+    rasterize + interpolate (render/render.py:208-234).  mesh: dict with v_pos, t_pos_idx, v_nrm, t_nrm_idx, v_tng, t_tng_idx,
+    v_tex, t_tex_idx (GPU tensors; the BVH must have been built from v_pos / t_pos_idx); mvp [N,4,4]; cam [N,4,3] =
+    (eye, U, V, W) per view (scene.camera_rays); resolution (H, W).  Returns a dict of contiguous NHWC tensors:
+    rast (u, v, z/w, id + 1), rast_db, gb_pos, gb_geometric_normal, gb_normal, gb_tangent, gb_texc, gb_texc_deriv, gb_depth."""
+    w = optix_ctx.cpp_wrapper
+    H, W = int(resolution[0]), int(resolution[1])
+    a = _lib.NvdrGbufferArgs()
+    keep = []
+    for k, dt in (('v_pos', torch.float32), ('t_pos_idx', torch.int32), ('v_nrm', torch.float32), ('t_nrm_idx', torch.int32),
+                  ('v_tng', torch.float32), ('t_tng_idx', torch.int32), ('v_tex', torch.float32), ('t_tex_idx', torch.int32)):
+        t = mesh[k]
+        _lib.require_cuda_f32(t, k, dt)
+        t = t.contiguous()
+        keep.append(t)
+        setattr(a, k, t.data_ptr())
+    a.n_tris = mesh['t_pos_idx'].shape[0]
+    for k in ('t_nrm_idx', 't_tng_idx', 't_tex_idx'):
+        if mesh[k].shape[0] != a.n_tris:
+            raise RuntimeError('%s must have one row per triangle' % k)
+    _lib.require_cuda_f32(mvp, 'mvp')
+    _lib.require_cuda_f32(cam, 'cam')
+    mvp, cam = mvp.contiguous(), cam.contiguous()
+    N = mvp.shape[0]
+    if tuple(mvp.shape) != (N, 4, 4) or tuple(cam.shape) != (N, 4, 3):
+        raise RuntimeError('mvp must be [N,4,4] and cam [N,4,3] (got %s, %s)' % (tuple(mvp.shape), tuple(cam.shape)))
+    a.mvp, a.cam, a.n, a.h, a.w = mvp.data_ptr(), cam.data_ptr(), N, H, W
+    out = {}
+    for k, ch in _GB_CHANNELS:
+        out[k] = torch.empty(N, H, W, ch, dtype=torch.float32, device=mvp.device)
+        setattr(a, k, out[k].data_ptr())
+    _lib.check(w.lib.nvdr_render_gbuffer(w.handle, ctypes.byref(a), _lib.stream_ptr()), 'render_gbuffer')
+    return out
 
 
 def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols,

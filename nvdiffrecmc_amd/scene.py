@@ -28,9 +28,54 @@ def load_mesh(name='bob', device='cpu'):
     m = {k: torch.from_numpy(d[k]) for k in ('v_pos', 'v_tex', 't_pos_idx', 't_tex_idx', 'ks')}
     m['kd_tex'] = torch.from_numpy(d['kd_tex'].astype(np.float32))
     m = {k: v.to(device) for k, v in m.items()}
-    m['v_nrm'] = auto_normals(m['v_pos'], m['t_pos_idx'])
     m['name'] = name
+    return finish_mesh(m)
+
+
+def finish_mesh(m):
+    """Vertex normals (render/mesh.py:150-178: one per position vertex, so t_nrm_idx = t_pos_idx) and tangents
+    (render/mesh.py:181-219, t_tng_idx = t_nrm_idx) of a mesh dict with v_pos, t_pos_idx, v_tex, t_tex_idx."""
+    m['v_nrm'] = auto_normals(m['v_pos'], m['t_pos_idx'])
+    m['t_nrm_idx'] = m['t_pos_idx']
+    m['v_tng'] = compute_tangents(m)
+    m['t_tng_idx'] = m['t_nrm_idx']
     return m
+
+
+def _safe_normalize(x, eps=1e-20):
+    return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=eps))       # render/util.py:27-31
+
+
+def compute_tangents(m):
+    """Per-vertex tangents, behaviour of render/mesh.py:181-219: per-triangle tangent from the uv parametrisation, averaged
+    over the triangles of a (normal-indexed) vertex, Gram-Schmidt against the vertex normal."""
+    tp, tt, tn = m['t_pos_idx'].long(), m['t_tex_idx'].long(), m['t_nrm_idx'].long()
+    pos = [m['v_pos'][tp[:, i]] for i in range(3)]
+    tex = [m['v_tex'][tt[:, i]] for i in range(3)]
+    uve1, uve2 = tex[1] - tex[0], tex[2] - tex[0]
+    pe1, pe2 = pos[1] - pos[0], pos[2] - pos[0]
+    nom = pe1 * uve2[..., 1:2] - pe2 * uve1[..., 1:2]
+    denom = uve1[..., 0:1] * uve2[..., 1:2] - uve1[..., 1:2] * uve2[..., 0:1]
+    tang = nom / torch.where(denom > 0.0, torch.clamp(denom, min=1e-6), torch.clamp(denom, max=-1e-6))
+    tangents, tansum = torch.zeros_like(m['v_nrm']), torch.zeros_like(m['v_nrm'])
+    for i in range(3):
+        idx = tn[:, i:i + 1].repeat(1, 3)
+        tangents.scatter_add_(0, idx, tang)
+        tansum.scatter_add_(0, idx, torch.ones_like(tang))
+    tangents = tangents / tansum.clamp(min=1.0)          # (a vertex no triangle references keeps a zero tangent instead of 0/0)
+    tangents = _safe_normalize(tangents)
+    return _safe_normalize(tangents - (tangents * m['v_nrm']).sum(-1, keepdim=True) * m['v_nrm']).contiguous()
+
+
+def subdivide_mesh(m, levels):
+    """Midpoint subdivision of positions AND texture coordinates (each in its own index space: every triangle splits into the
+    same four children in both, so the rows of t_pos_idx and t_tex_idx stay aligned), then fresh normals / tangents."""
+    m = dict(m)
+    m['v_pos'], m['t_pos_idx'] = subdivide(m['v_pos'], m['t_pos_idx'], levels)
+    vt3 = torch.cat([m['v_tex'], torch.zeros_like(m['v_tex'][:, :1])], dim=-1)
+    vt3, m['t_tex_idx'] = subdivide(vt3, m['t_tex_idx'], levels)
+    m['v_tex'] = vt3[:, :2].contiguous()
+    return finish_mesh(m)
 
 
 def auto_normals(v_pos, t_pos_idx):
@@ -93,6 +138,15 @@ def camera(k, n_views, radius=3.0, aspect=1.0):
     mvp = perspective(aspect=aspect) @ mv
     campos = torch.linalg.inv(mv)[:3, 3]
     return mv, mvp, campos
+
+
+def camera_rays(mv, aspect=1.0, fovy=math.radians(45.0)):
+    """[4,3] = (eye, U, V, W): the primary ray through NDC (X, Y) of the view `mv` is normalize(X U + Y V + W) from eye --
+    the pinhole camera perspective() projects with (Y flipped as in render/util.py:185-194)."""
+    yt = math.tan(fovy / 2)
+    rot = mv[:3, :3]
+    eye = torch.linalg.inv(mv)[:3, 3]
+    return torch.stack([eye, yt * aspect * rot[0], -yt * rot[1], -rot[2]]).contiguous()
 
 
 def primary_rays(mv, H, W, fovy=math.radians(45.0)):

@@ -14,9 +14,10 @@ the parts that touch the hot path:
     gradient all-reduce (new: one view per GPU)          --                -> parallel.py
     Adam on kd texture, ks, light                        train.py:452-461
 
-What replaces the parts that do not exist on ROCm: the G-buffer comes from primary rays traced
-through the same BVH (closest-hit kernel) instead of nvdiffrast, so it is NOT differentiable
-w.r.t. geometry; kd is a nearest-texel lookup into a trainable texture instead of dr.texture.
+What replaces the parts that do not exist on ROCm: the G-buffer comes from ONE HIP kernel (csrc/gbuffer.hip:
+primary rays through the same BVH + the attribute interpolation / tangents / (z/w, |dz|) of render_layer,
+render.py:208-234) instead of nvdiffrast, so it is NOT differentiable w.r.t. geometry; kd is a nearest-texel
+lookup into a trainable texture instead of dr.texture.
 """
 import math
 
@@ -67,7 +68,7 @@ class _broadcast_pixels(torch.autograd.Function):
 class DirectLightingStep:
     def __init__(self, mesh_name='bob', res=512, n_samples_x=8, view=0, n_views=8, device='cuda', env='E1',
                  probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
-                 denoiser_demodulate=True, light_grad_scale=64.0):
+                 denoiser_demodulate=True, light_grad_scale=64.0, use_graph=False):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
@@ -76,64 +77,46 @@ class DirectLightingStep:
         self.denoiser_demodulate = denoiser_demodulate    # FLAGS.denoiser_demodulate (train.py:525, default True)
         self.light_grad_scale = light_grad_scale          # lgt.base.grad *= 64 (train.py:439-440)
         self.total_views = n_views if isinstance(n_views, int) else len(n_views)
+        # use_graph: capture the iteration in HIP graphs (one submit instead of ~110 launches) once it has run a few times
+        # eagerly.  What makes that legal: nothing on the path synchronises the host or allocates after warm-up, and the
+        # random seed of shade() lives in device memory (OptiXContext.seed_offset), so a replay draws fresh samples.
+        self.use_graph = use_graph
+        self._graphs = None
+        self._eager_steps = 0
+        self.force_eager = False          # set once at the END of a run to leave graph mode for good (p.grad then belongs to eager)
         mesh = sc.load_mesh(mesh_name, device='cpu')
         if subdiv:
-            mesh['v_pos'], mesh['t_pos_idx'] = sc.subdivide(mesh['v_pos'], mesh['t_pos_idx'], subdiv)
-            mesh['v_nrm'] = sc.auto_normals(mesh['v_pos'], mesh['t_pos_idx'])
-            mesh['t_tex_idx'] = torch.zeros_like(mesh['t_pos_idx'])
+            mesh = sc.subdivide_mesh(mesh, subdiv)       # a DMTet-sized stand-in (positions and uvs subdivided, new normals / tangents)
         self.mesh = {k: (v.to(self.dev) if isinstance(v, torch.Tensor) else v) for k, v in mesh.items()}
         self.ctx = ou.OptiXContext()
         ou.optix_build_bvh(self.ctx, self.mesh['v_pos'], self.mesh['t_pos_idx'], rebuild=1)
 
-        # ---- G-buffers from primary rays, one per view of this rank's batch (stands in for rasterize + interpolate,
-        # render.py:208-234); the views are stacked along N exactly like the reference's batch (configs/bob.json:8)
+        # ---- G-buffers of this rank's views in ONE kernel launch (csrc/gbuffer.hip): primary rays through the same BVH +
+        # the attribute interpolation, face normal, tangents and (z/w, |dz|) pair of render_layer (render.py:208-234); stands
+        # in for nvdiffrast's rasterize + interpolate.  The views are stacked along N like the reference's batch (configs/bob.json:8).
         H = W = res
         views = list(view) if isinstance(view, (list, tuple)) else [view]
         self.views = views
-        gbs, texels, campos_all = [], [], []
-        for vw in views:
-            mv, mvp, campos = sc.camera(vw, n_views)
-            ro, rd = sc.primary_rays(mv, res, res)
-            ro, rd = ro.to(self.dev), rd.to(self.dev)
-            t, tri, uv = ou.trace_closest(self.ctx, ro, rd)
-            t, tri, uv = t.view(H, W), tri.view(H, W), uv.view(H, W, 2)
-            gb = sc.gbuffer_from_hits(self.mesh, t, tri, uv, ro, rd, kd_mode='texture' if not subdiv else 'flat')
-            z = gb['depth']
-            dz = torch.zeros_like(z)
-            dz[:, 1:-1, 1:-1] = 0.5 * ((z[:, 1:-1, 2:] - z[:, 1:-1, :-2]).abs() + (z[:, 2:, 1:-1] - z[:, :-2, 1:-1]).abs())
-            gb['gb_depth'] = torch.cat((z, dz.clamp(max=0.1)), dim=-1)           # (z, |dz|), render.py:228-234
-            gbs.append(gb)
-            campos_all.append(campos.to(self.dev)[None, None, None, :])
-            # texel addresses of the kd lookup (fixed: geometry is locked, configs/bob.json:14)
-            if not subdiv:
-                tidx = self.mesh['t_tex_idx'].long()[tri.clamp(min=0).long()]
-                vt = self.mesh['v_tex']
-                w0 = 1.0 - uv[..., 0:1] - uv[..., 1:2]
-                tc = w0 * vt[tidx[..., 0]] + uv[..., 0:1] * vt[tidx[..., 1]] + uv[..., 1:2] * vt[tidx[..., 2]]
-                R = self.mesh['kd_tex'].shape[0]
-                ix = (tc[..., 0] * R).long().clamp(0, R - 1)
-                iy = ((1.0 - tc[..., 1]) * R).long().clamp(0, R - 1)
-                texels.append((iy * R + ix).view(-1))
-            else:
-                texels.append(torch.zeros(H * W, dtype=torch.long, device=self.dev))
-        cat = lambda k: torch.cat([g[k] for g in gbs], dim=0).contiguous()
+        cams = [sc.camera(vw, n_views) for vw in views]
+        mvp = torch.stack([c[1] for c in cams]).to(self.dev)
+        cam = torch.stack([sc.camera_rays(c[0]) for c in cams]).to(self.dev)
+        gb = ou.render_gbuffer(self.ctx, self.mesh, mvp, cam, (H, W))
         self.nv = len(views)
-        self.mask = cat('mask')                                 # [V,H,W]
-        self.gb_pos = cat('gb_pos')
-        self.gb_geom_nrm = cat('gb_geometric_normal')
-        self.gb_smooth_nrm = cat('gb_normal')
-        up = torch.tensor([0.0, 1.0, 0.0], device=self.dev)
-        tng = torch.cross(up.expand_as(self.gb_smooth_nrm), self.gb_smooth_nrm, dim=-1)
-        self.gb_tangent = (torch.nn.functional.normalize(tng, dim=-1) * self.mask[..., None]).contiguous()
-        self.view_pos = torch.cat(campos_all, dim=0).contiguous()            # [V,1,1,3]
-        self.gb_depth = cat('gb_depth')
-        self.texel = torch.cat(texels)
-        if not subdiv:
-            R = self.mesh['kd_tex'].shape[0]
-            kd_true = self.mesh['kd_tex'].reshape(-1, 3)
-        else:
-            R = 64
-            kd_true = torch.full((R * R, 3), 0.5, device=self.dev)
+        self.mask = (gb['rast'][..., 3] > 0).float().contiguous()     # the reference passes rast[..., -1] (triangle id + 1 > 0)
+        self.gb_pos = gb['gb_pos']
+        self.gb_geom_nrm = gb['gb_geometric_normal']
+        self.gb_smooth_nrm = gb['gb_normal']
+        self.gb_tangent = gb['gb_tangent']
+        self.gb_depth = gb['gb_depth']
+        self.view_pos = torch.stack([c[2] for c in cams]).to(self.dev)[:, None, None, :].contiguous()    # [V,1,1,3]
+        # texel addresses of the kd lookup (fixed: geometry is locked, configs/bob.json:14); nearest texel of a trainable
+        # texture instead of dr.texture's trilinear mip lookup (outside the path)
+        R = self.mesh['kd_tex'].shape[0]
+        tc = gb['gb_texc']
+        ix = (tc[..., 0] * R).long().clamp(0, R - 1)
+        iy = ((1.0 - tc[..., 1]) * R).long().clamp(0, R - 1)
+        self.texel = (iy * R + ix).view(-1)
+        kd_true = self.mesh['kd_tex'].reshape(-1, 3)
         self.tex_res = R
         # only covered pixels look the texture up (the background would pile ~200k duplicates on one texel)
         self.cov = self.mask.view(-1).nonzero().view(-1)
@@ -143,7 +126,9 @@ class DirectLightingStep:
         self.denoiser = BilateralDenoiser(influence=1.0) if denoise else None
         light_true = EnvironmentLight(sc.env_map(env, probe_res).to(self.dev))
         ks_true = self.mesh['ks'].clone()
-        self.seed = 0
+        # the global seed counter of render.py:19,112-116 -- kept in DEVICE memory and added to rnd_seed by the kernels
+        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.ctx.seed_offset = self.seed_dev
         with torch.no_grad():
             self.target = self._render(kd_true, ks_true, light_true).detach()
         self.kd_tex = torch.nn.Parameter(torch.full_like(kd_true, 0.5))
@@ -154,10 +139,18 @@ class DirectLightingStep:
         # the same Adam as the reference (train.py:452-461); `fused` only selects torch's single-kernel implementation
         # (8 multi_tensor_apply launches -> 1) where this build of torch has it for the device
         try:
-            self.opt = torch.optim.Adam(self.params, lr=lr, fused=self.dev.type == 'cuda')
+            self.opt = torch.optim.Adam(self.params, lr=lr, fused=self.dev.type == 'cuda', capturable=use_graph)
         except (RuntimeError, TypeError):
-            self.opt = torch.optim.Adam(self.params, lr=lr)
+            self.opt = torch.optim.Adam(self.params, lr=lr, capturable=use_graph)
         self.covered = int(self.mask.sum().item())
+
+    @property
+    def seed(self):
+        return int(self.seed_dev.item())
+
+    @seed.setter
+    def seed(self, v):
+        self.seed_dev.fill_(int(v))
 
     # rays per pass counted from the actual mask: 2 per stratum per covered pixel
     def rays_per_pass(self):
@@ -176,8 +169,8 @@ class DirectLightingStep:
         self.ctx.cache_visibility = not self.retrace_backward
         diff, spec = ou.optix_env_shade(self.ctx, self.mask, ro, self.gb_pos, nrm, self.view_pos, kd, ks, light.base,
                                         light._pdf, light.rows[:, 0], light.cols, BSDF='pbr', n_samples_x=self.n,
-                                        rnd_seed=self.seed, shadow_scale=1.0)
-        self.seed += 1
+                                        rnd_seed=0, shadow_scale=1.0)      # effective seed = 0 + the device counter
+        self.seed_dev += 1                                                  # render.py:116, on the device (graph-capturable)
         if self.denoiser is not None and not self.denoiser_demodulate:
             # the non-demodulated branch of shade() (render.py:124-131): ONE filter pass over the combined colour
             shaded = ru.shade_composite(diff, spec, kd, ks) if self.fused else diff * (kd * (1.0 - ks[..., 2:3])) + spec
@@ -209,11 +202,8 @@ class DirectLightingStep:
         loss.backward()
         return loss
 
-    def step(self, world_size=1):
-        loss = self.forward_backward()
-        # weighted by this rank's share of the batch: the loss is a mean over the views a rank renders, the batch mean
-        # over all ranks needs sum(local_views * grad) / total_views (equal to the plain average for even shards)
-        self.allreduce_bytes = allreduce_gradients(self.params, world_size, local_weight=self.nv)
+    def _update(self):
+        """Everything after the gradient exchange: light-gradient scale, Adam, clamps (train.py:439-476)."""
         if self.light.base.grad is not None and self.light_grad_scale != 1.0:
             self.light.base.grad *= self.light_grad_scale       # train.py:439-440
         self.opt.step()
@@ -221,4 +211,38 @@ class DirectLightingStep:
             self.kd_tex.clamp_(0.0, 1.0)
             self.ks.copy_(torch.maximum(self.ks.clamp(max=1.0), self._ks_min))  # ks_min of configs/bob.json: roughness >= 0.08
             self.light.base.clamp_(min=0.0)
+
+    def _capture(self, world_size):
+        """Two HIP graphs: (A) update_pdf + BVH rebuild + render + loss + backward, (B) light-gradient scale + Adam + clamps.
+        The gradient all-reduce (world > 1) runs between them on the same stream; with one rank A and B are one graph."""
+        torch.cuda.synchronize()
+        self.opt.zero_grad(set_to_none=True)
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._loss_static = self.forward_backward()
+            if world_size == 1:
+                self._update()
+        gb = None
+        if world_size > 1:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self._update()
+        self._graphs = (ga, gb)
+
+    def step(self, world_size=1):
+        if self.use_graph and not self.force_eager and self._graphs is None and self._eager_steps >= 3:
+            self._capture(world_size)
+        if self._graphs is not None and not self.force_eager:
+            ga, gb = self._graphs
+            ga.replay()
+            if gb is not None:
+                self.allreduce_bytes = allreduce_gradients(self.params, world_size, local_weight=self.nv)
+                gb.replay()
+            return self._loss_static
+        self._eager_steps += 1
+        loss = self.forward_backward()
+        # weighted by this rank's share of the batch: the loss is a mean over the views a rank renders, the batch mean
+        # over all ranks needs sum(local_views * grad) / total_views (equal to the plain average for even shards)
+        self.allreduce_bytes = allreduce_gradients(self.params, world_size, local_weight=self.nv)
+        self._update()
         return loss

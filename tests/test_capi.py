@@ -38,7 +38,7 @@ def test_python_binding_covers_the_header():
 def test_struct_layouts_match_the_header():
     # nvdr_tensor: pointer + 4 sizes + 4 strides; the env-shade block: 12 tensors, 5 scalars (+pad), 2 ptrs, 2 tensors, 6 ptrs
     assert ctypes.sizeof(_lib.NvdrTensor) == 8 + 4 * 8 + 4 * 8
-    assert ctypes.sizeof(_lib.NvdrEnvShadeArgs) == 12 * 72 + 24 + 2 * 8 + 2 * 72 + 8 * 8
+    assert ctypes.sizeof(_lib.NvdrEnvShadeArgs) == 12 * 72 + 24 + 2 * 8 + 2 * 72 + 9 * 8
     from oracle import oracle as orc
     assert ctypes.sizeof(orc.EnvShadeArgs) == ctypes.sizeof(_lib.NvdrEnvShadeArgs)
 

@@ -203,3 +203,21 @@ def test_stack_bound_formula():
     for n, expect in ((1, 48), (2, 51), (10688, 69), (171008, 75), (1 << 24, 84), ((1 << 30) - 1, 93)):
         h = 30 + (0 if n <= 1 else math.ceil(math.log2(n)))
         assert min(max(3 * ((h + 1) // 2 + 1), h), 104) == expect
+
+
+def test_render_layer_restatement_interpolates_like_nvdiffrast():
+    """oracle/render_layer_ref.py: barycentric convention (u, v weigh vertex 0 and 1), zero background, interleaved derivative
+    layout, and the (z/w, |dz|) pair of render.py:228-234 on a hand-made one-triangle rast."""
+    from oracle import render_layer_ref as rl
+    attr = torch.tensor([[1.0, 10.0], [2.0, 20.0], [4.0, 40.0]])
+    tri = torch.tensor([[0, 1, 2]], dtype=torch.int32)
+    rast = torch.zeros(1, 1, 3, 4)
+    rast[0, 0, 0] = torch.tensor([1.0, 0.0, 0.5, 1.0])        # all weight on vertex 0
+    rast[0, 0, 1] = torch.tensor([0.25, 0.5, 0.5, 1.0])       # 0.25 a0 + 0.5 a1 + 0.25 a2
+    db = torch.zeros(1, 1, 3, 4)
+    db[0, 0, 1] = torch.tensor([0.1, 0.0, 0.0, 0.2])          # du/dX = 0.1, dv/dY = 0.2
+    out, d = rl.interpolate(attr, rast, tri, db)
+    assert torch.allclose(out[0, 0, 0], attr[0]) and torch.allclose(out[0, 0, 1], torch.tensor([2.25, 22.5]))
+    assert torch.equal(out[0, 0, 2], torch.zeros(2)) and torch.equal(d[0, 0, 2], torch.zeros(4))
+    # (dA0/dX, dA0/dY, dA1/dX, dA1/dY) = (0.1 (a0 - a2), 0.2 (a1 - a2)) per channel
+    assert torch.allclose(d[0, 0, 1], torch.tensor([0.1 * (1 - 4), 0.2 * (2 - 4), 0.1 * (10 - 40), 0.2 * (20 - 40)]))

@@ -126,22 +126,34 @@ PMC_PASSES = [
     ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_INST_ANY',
      'SQ_WAVES', 'GRBM_GUI_ACTIVE'],
     ['FETCH_SIZE'],
-    ['WRITE_SIZE', 'TCC_REQ_sum', 'TCC_MISS_sum'],
+    ['TCC_REQ_sum', 'WRITE_SIZE', 'TCC_MISS_sum'],
 ]
 
 
-def _pmc_read(db_path):
-    """{kernel name: {counter: per-dispatch total}, ...} and {kernel name: dispatches}."""
+PER_XCD_CYCLE_COUNTERS = ('GRBM_GUI_ACTIVE',)    # one row per XCD, each the cycle count of the whole dispatch: averaged, not summed
+
+
+def _pmc_read(db_path, lead):
+    """{kernel name: {counter: per-launch total}} and {kernel name: launches counted}.  A rocpd database holds several rows
+    per (dispatch, counter) -- one per XCD / shader engine -- which are summed.  An env-shade launch issues its kernels once
+    per chunk of the ray stream and the chunks behind the covered-pixel count are empty dispatches (~4 us): only dispatches
+    whose `lead` counter reaches 10 % of the kernel's largest are averaged."""
     db = sqlite3.connect(db_path)
     cols = [r[1] for r in db.execute('pragma table_info(pmc_events)')]
     name_col = 'counter_name' if 'counter_name' in cols else ('name' if 'name' in cols else cols[0])
     val_col = 'value' if 'value' in cols else ('counter_value' if 'counter_value' in cols else cols[-1])
-    q = ('select k.name, p.%s, count(distinct p.dispatch_id), sum(p.%s) from pmc_events p join kernels k '
-         'on k.dispatch_id = p.dispatch_id group by k.name, p.%s' % (name_col, val_col, name_col))
+    q = ('select k.name, p.dispatch_id, p.%s, sum(p.%s), count(*) from pmc_events p join kernels k '
+         'on k.dispatch_id = p.dispatch_id group by k.name, p.dispatch_id, p.%s' % (name_col, val_col, name_col))
+    per = {}
+    for name, did, ctr, total, rows in db.execute(q).fetchall():
+        per.setdefault(name, {}).setdefault(did, {})[ctr] = total / rows if ctr in PER_XCD_CYCLE_COUNTERS else total
     out, disp = {}, {}
-    for name, ctr, n, total in db.execute(q).fetchall():
-        out.setdefault(name, {})[ctr] = total / max(n, 1)
-        disp[name] = n
+    for name, dd in per.items():
+        top = max((c.get(lead, 0.0) for c in dd.values()), default=0.0)
+        real = [c for c in dd.values() if c.get(lead, 0.0) >= 0.1 * top] if top > 0 else list(dd.values())
+        disp[name] = len(real)
+        keys = set().union(*[set(c) for c in real]) if real else set()
+        out[name] = {k: sum(c.get(k, 0.0) for c in real) / len(real) for k in keys}
     return out, disp
 
 
@@ -168,7 +180,7 @@ def collect_pmc(args, keep_dir=None):
             if r.returncode != 0 or not dbs:
                 notes.append('pass %d (%s) failed rc=%d: %s' % (i, ' '.join(group), r.returncode, (r.stderr or r.stdout)[-300:]))
                 continue
-            ctrs, disp = _pmc_read(dbs[0])
+            ctrs, disp = _pmc_read(dbs[0], group[0])
             for kname, c in ctrs.items():
                 merged.setdefault(kname, {}).update(c)
                 merged[kname]['dispatches_pass%d' % i] = disp.get(kname, 0)

@@ -92,6 +92,19 @@ def test_fullsize_sparse_subset_vs_oracle(dev):
     assert_close(leaves['gb_normal'].grad, b['gb_normal_grad'], 2e-4, floor=1e-3 * b['gb_normal_grad'].abs().max().item())
     assert_close(leaves['gb_ks'].grad, b['gb_ks_grad'], 2e-4, floor=1e-3 * b['gb_ks_grad'].abs().max().item())
     assert_close(leaves['light'].grad, b['light_grad'], 1e-4, floor=1e-3 * b['light_grad'].abs().max().item())
+    # the same benchmark-sized launch against the REFERENCE's own raygen program (oracle/_ref: kernel.cu compiled for the CPU,
+    # travels to the GPU box prebuilt): with this library's transcendentals tightly, with libm on >= 99.8 % of the values
+    if orc.have_ref():
+        for impl, rtol, outl in (('ref_detmath', 5e-6, 0.0), ('ref', 1e-4, 0.002)):
+            rf = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT, impl=impl)
+            rb = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, diff_grad=dg, spec_grad=sg,
+                               n_threads=NT, impl=impl)
+            assert_close(d, rf['diff'], rtol, frac_outliers=outl, what=impl + ' diff')
+            assert_close(s, rf['spec'], rtol, frac_outliers=outl, what=impl + ' spec')
+            assert_close(leaves['gb_normal'].grad, rb['gb_normal_grad'], 1e-3, floor=1e-3 * rb['gb_normal_grad'].abs().max().item(),
+                         frac_outliers=outl, what=impl + ' gb_normal_grad')
+            assert_close(leaves['light'].grad, rb['light_grad'], 1e-3, floor=1e-3 * rb['light_grad'].abs().max().item(),
+                         frac_outliers=outl, what=impl + ' light_grad')
 
 
 @pytest.mark.parametrize('cache_vis', [False, True], ids=['retrace', 'cached_visibility'])

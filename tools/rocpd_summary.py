@@ -12,14 +12,18 @@ rows = db.execute("""select name, count(*), sum(duration), avg(duration), min(du
 tot = sum(r[2] for r in rows) or 1
 # the median is the steady-state figure: the average of a kernel includes its first launches, which pay the first touch
 # of freshly allocated scratch (a handful of 5-ms outliers for the traversal kernel)
-lines = ['| kernel | calls | total us | avg us | median us | min us | max us | % | vgpr | agpr | sgpr | lds B | scratch B | grid_x | wg_x |',
-         '|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|']
+# 'real': dispatches lasting >= 10 % of the kernel's longest -- an env-shade launch issues its kernels once per chunk of the ray
+# stream and the chunks behind the covered-pixel count are empty ~4-us dispatches that would drown the average
+lines = ['| kernel | calls | total us | avg us | real calls | real avg us | real median us | min us | max us | % | vgpr | agpr | sgpr | lds B | scratch B | grid_x | wg_x |',
+         '|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|']
 for r in rows:
     d = [x[0] for x in db.execute('select duration from kernels where name = ? order by duration', (r[0],)).fetchall()]
-    med = d[len(d) // 2] if d else 0
+    real = [x for x in d if x >= 0.1 * d[-1]] if d else []
+    med = real[len(real) // 2] if real else 0
+    ravg = sum(real) / len(real) if real else 0
     name = r[0] if len(r[0]) < 110 else r[0][:107] + '...'
-    lines.append('| %s | %d | %.1f | %.2f | %.2f | %.2f | %.2f | %.2f | %s | %s | %s | %s | %s | %s | %s |' % (
-        name, r[1], r[2] / 1e3, r[3] / 1e3, med / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10], r[11], r[12]))
+    lines.append('| %s | %d | %.1f | %.2f | %d | %.2f | %.2f | %.2f | %.2f | %.2f | %s | %s | %s | %s | %s | %s | %s |' % (
+        name, r[1], r[2] / 1e3, r[3] / 1e3, len(real), ravg / 1e3, med / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10], r[11], r[12]))
 out = '\n'.join(lines)
 if len(sys.argv) > 2:
     open(sys.argv[2], 'w').write(out + '\n')

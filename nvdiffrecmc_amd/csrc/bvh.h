@@ -169,11 +169,15 @@ struct TravStack {
     int gstride;    // spill stride between two levels of a lane = threads of the workgroup
     int smax;       // entries this lane may hold (LDS + spill); see the note at NVDR_STACK_MAX
     int *ovf;       // host-mapped overflow flag of the context
-    __device__ __forceinline__ void push(int sp, int v) const
+    // returns the new depth.  Beyond the bound the entry is NOT stored and the depth does not grow (that subtree is skipped:
+    // the walk stays finite -- an earlier version kept counting and re-popped one entry over and over, which hung the GPU in
+    // the overflow test) and the context's flag is raised: never silently, the NEXT call on the context and nvdr_ctx_check report it
+    __device__ __forceinline__ int push(int sp, int v) const
     {
-        if (sp < NVDR_STACK_LDS) lds[sp * 64] = v;
-        else if (sp < smax) glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v;
-        else *ovf = 1;   // never silently: the launcher of the NEXT call on this context (and nvdr_ctx_check) reports it
+        if (sp < NVDR_STACK_LDS) { lds[sp * 64] = v; return sp + 1; }
+        if (sp < smax) { glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v; return sp + 1; }
+        *ovf = 1;
+        return sp;
     }
     // peek returns what a pop at depth sp would yield without changing anything (branch-free loops read it every step)
     __device__ __forceinline__ int peek(int sp) const
@@ -323,8 +327,7 @@ __device__ __forceinline__ unsigned bvh_any_hit2(const BvhView &bvh, float ox, f
             if (COUNT) n_box += 2;
             if (h.hl && h.hr) {
                 const bool left_first = h.tl <= h.tr;
-                stack.push(sp, left_first ? h.cr : h.cl);
-                sp++;
+                sp = stack.push(sp, left_first ? h.cr : h.cl);
                 cur = left_first ? h.cl : h.cr;
             } else if (h.hl) {
                 cur = h.cl;
@@ -393,8 +396,7 @@ __device__ __forceinline__ int bvh_closest_hit(const BvhView &bvh, float ox, flo
         if (h.hr && h.cr < 0) { test_leaf(~h.cr); h.hr = false; }
         if (h.hl && h.hr) {
             const bool left_first = h.tl <= h.tr;
-            stack.push(sp, left_first ? h.cr : h.cl);
-            sp++;
+            sp = stack.push(sp, left_first ? h.cr : h.cl);
             cur = left_first ? h.cl : h.cr;
         } else if (h.hl) {
             cur = h.cl;

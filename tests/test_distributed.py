@@ -53,7 +53,8 @@ def _worker(rank, world, port, q):
     unused = torch.nn.Parameter(torch.zeros(5))             # a parameter without gradient must not break the bucket layout
     light.grad, ks.grad = lg.clone(), ksg.clone()
     nbytes = allreduce_gradients([light, ks, unused], world)
-    q.put((rank, light.grad.clone(), ks.grad.clone(), unused.grad.clone(), nbytes))
+    # numpy copies travel by value (a torch tensor is passed as a file descriptor that dies with this process)
+    q.put((rank, light.grad.numpy().copy(), ks.grad.numpy().copy(), unused.grad.numpy().copy(), nbytes))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,6 +68,7 @@ def test_two_rank_gradient_allreduce_equals_batch_mean():
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
+    got = [(r, torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(c), n) for r, a, b, c, n in got]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -91,7 +93,7 @@ def _worker_uneven(rank, world, port, q):
     p = torch.nn.Parameter(torch.zeros(4))
     p.grad = g.clone()
     allreduce_gradients([p], world, local_weight=len(views))
-    q.put((rank, p.grad.clone()))
+    q.put((rank, p.grad.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -112,4 +114,4 @@ def test_uneven_shards_keep_the_batch_mean():
         assert p.exitcode == 0
     want = torch.full((4,), (1.0 + 10.0 + 100.0) / 3.0)
     for rank, g in got:
-        assert torch.allclose(g, want, rtol=1e-6)
+        assert torch.allclose(torch.from_numpy(g), want, rtol=1e-6)

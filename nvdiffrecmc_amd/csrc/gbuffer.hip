@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, 
 
         float4 rast = make_float4(0.f, 0.f, 0.f, 0.f), rdb = make_float4(0.f, 0.f, 0.f, 0.f);
         F3 pos = f3(0.f), gn = f3(0.f), nrm = f3(0.f), tng = f3(0.f);
-        float tc0 = 0.f, tc1 = 0.f, tdb[4] = {0.f, 0.f, 0.f, 0.f}, z0 = 0.f, zg = 0.f;
+        // background: every interpolated attribute is 0, so render.py:230 gives z0 = clamp(0, eps) / clamp(0, eps) = 1 and |dz| = 0
+        float tc0 = 0.f, tc1 = 0.f, tdb[4] = {0.f, 0.f, 0.f, 0.f}, z0 = 1.f, zg = 0.f;
         if (tri >= 0) {
             const int i0 = p.t_pos[3 * tri], i1 = p.t_pos[3 * tri + 1], i2 = p.t_pos[3 * tri + 2];
             const F3 p0 = load3(p.v_pos, i0), p1 = load3(p.v_pos, i1), p2 = load3(p.v_pos, i2);

@@ -124,7 +124,7 @@ def optix_build_bvh(optix_ctx, verts, tris, rebuild):
 # ----------------------------------------------------------------------------------------------
 
 def _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
-               BSDF, n_samples_x, rnd_seed, shadow_scale, pixel_index_offset):
+               BSDF, n_samples_x, rnd_seed, shadow_scale, pixel_index_offset, seed_offset=None):
     a = _lib.NvdrEnvShadeArgs()
     for name, t, nd in (('mask', mask, 3), ('ro', ro, 4), ('gb_pos', gb_pos, 4), ('gb_normal', gb_normal, 4),
                         ('gb_view_pos', gb_view_pos, 4), ('gb_kd', gb_kd, 4), ('gb_ks', gb_ks, 4), ('light', light, 3),
@@ -138,10 +138,9 @@ def _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks
     a.bsdf, a.n_samples_x, a.rnd_seed = int(BSDF), int(n_samples_x), int(rnd_seed) & 0xFFFFFFFF
     a.shadow_scale = float(shadow_scale)
     a.pixel_index_offset = int(pixel_index_offset)
-    so = getattr(optix_ctx, 'seed_offset', None)
-    if so is not None:
-        _lib.require_cuda_f32(so, 'seed_offset', torch.int32)
-        a.rnd_seed_offset = so.data_ptr()
+    if seed_offset is not None:
+        _lib.require_cuda_f32(seed_offset, 'seed_offset', torch.int32)
+        a.rnd_seed_offset = seed_offset.data_ptr()
     return a
 
 
@@ -178,8 +177,12 @@ class _optix_env_shade_func(torch.autograd.Function):
         perms = _perms_for(n_samples_x, ro.device)
         w = optix_ctx.cpp_wrapper
         cache_vis, off = _optix_env_shade_func._switches(optix_ctx)
+        # the device-resident seed counter is SNAPSHOT here: the caller advances it right after this call (render.py:116),
+        # long before backward runs, and backward must repeat the forward's samples (same slots, same cached visibility bits)
+        so = getattr(optix_ctx, 'seed_offset', None)
+        seed_snap = so.clone() if (so is not None and rnd_seed is not None) else so
         a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
-                       BSDF, n_samples_x, _rnd_seed, shadow_scale, off)
+                       BSDF, n_samples_x, _rnd_seed, shadow_scale, off, seed_snap)
         N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
         # independent storages like the reference's two torch::zeros (torch_bindings.cpp:148-149): views of one packed
         # buffer would make any in-place op on an output an autograd error; the library zero-fills them
@@ -203,6 +206,7 @@ class _optix_env_shade_func(torch.autograd.Function):
         ctx.shadow_scale = shadow_scale
         ctx.vis = vis
         ctx.pixel_index_offset = off
+        ctx.seed_snap = seed_snap
         ctx.bvh_geom = w._geom
         return diff, spec
 
@@ -214,7 +218,7 @@ class _optix_env_shade_func(torch.autograd.Function):
         perms = _perms_for(ctx.n_samples_x, ro.device)
         w = optix_ctx.cpp_wrapper
         a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
-                       ctx.BSDF, ctx.n_samples_x, _rnd_seed, ctx.shadow_scale, ctx.pixel_index_offset)
+                       ctx.BSDF, ctx.n_samples_x, _rnd_seed, ctx.shadow_scale, ctx.pixel_index_offset, ctx.seed_snap)
         N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
         dev = ro.device
         diff_grad, spec_grad = diff_grad.contiguous(), spec_grad.contiguous()
@@ -389,7 +393,7 @@ def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_p
     w = optix_ctx.cpp_wrapper
     a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
                    ['pbr', 'diffuse', 'white'].index(BSDF), n_samples_x, rnd_seed, shadow_scale,
-                   _optix_env_shade_func._switches(optix_ctx)[1])
+                   _optix_env_shade_func._switches(optix_ctx)[1], getattr(optix_ctx, 'seed_offset', None))
     N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
     diff = torch.empty(N, H, W, 3, dtype=torch.float32, device=ro.device)
     spec = torch.empty_like(diff)

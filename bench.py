@@ -184,13 +184,25 @@ def collect_pmc(args, keep_dir=None):
             for kname, c in ctrs.items():
                 merged.setdefault(kname, {}).update(c)
                 merged[kname]['dispatches_pass%d' % i] = disp.get(kname, 0)
-            if keep_dir:
-                os.makedirs(keep_dir, exist_ok=True)
-                shutil.copy(dbs[0], os.path.join(keep_dir, 'pmc_pass%d.db' % i))
         except subprocess.TimeoutExpired:
             notes.append('pass %d (%s) timed out after %d s' % (i, ' '.join(group), args.pmc_timeout))
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    if keep_dir and merged:
+        # the raw per-launch counter sums behind the roofline object, as a small table (the rocpd databases are ~30 MB each)
+        os.makedirs(keep_dir, exist_ok=True)
+        with open(os.path.join(keep_dir, 'pmc_counters_%s.md' % args.config), 'w') as f:
+            f.write('rocprofv3 --kernel-trace --pmc <group> -- python bench.py --pmc-child --config %s --steps 2 --warmup 1 (one pass per group: %s); '
+                    'per-launch sums over the non-empty dispatches\n\n| kernel | counter | per launch | launches |\n|---|---|---|---|\n'
+                    % (args.config, ' / '.join(' '.join(g) for g in PMC_PASSES)))
+            for kname in sorted(merged):
+                if not any(t in kname for t in ('env_', 'light_grad', 'bilateral', 'bvh_', 'gbuffer', 'image_loss', 'compact')):
+                    continue
+                for ctr in sorted(merged[kname]):
+                    if ctr.startswith('dispatches_pass'):
+                        continue
+                    n = max(merged[kname].get('dispatches_pass%d' % i, 0) for i in range(len(PMC_PASSES)))
+                    f.write('| %s | %s | %.6g | %d |\n' % (kname[:90], ctr, merged[kname][ctr], n))
     return (merged or None), '; '.join(notes)
 
 
@@ -261,7 +273,7 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.frac becomes null)')
     ap.add_argument('--pmc-timeout', type=int, default=240)
-    ap.add_argument('--pmc-keep', default=None, help='directory to keep the rocpd databases of the counter passes in')
+    ap.add_argument('--pmc-keep', default=None, help='directory to write the per-kernel counter table of the PMC passes to')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-extended', action='store_true', help='skip the extended median phase and the cached-visibility loop')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',

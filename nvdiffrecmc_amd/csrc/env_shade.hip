@@ -35,6 +35,10 @@
 #ifndef NVDR_SHADE_OCC
 #define NVDR_SHADE_OCC 1
 #endif
+// 1: the two samples of a stratum are shaded by a rolled loop in the backward kernel (half the code, fewer live registers)
+#ifndef NVDR_BWD_ROLL
+#define NVDR_BWD_ROLL 0
+#endif
 #ifndef NVDR_GEN_OCC
 #define NVDR_GEN_OCC 4   // 128 VGPRs (14 dwords spilled) instead of 150: 4 waves per SIMD, -3 % time
 #endif
@@ -745,20 +749,16 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         }
         F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
         F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
-        // the two permutation rows of this pixel (kernel.cu:504-505) give the stream slot of every sample
-        unsigned a_seed = launch_seed(p), b_seed = (unsigned)lin + p.pix_offset;
-        unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
-        const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
-        const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
-
+        // Stage 1 stored the pixel's samples BY STRATUM (slot s = the light-sampled ray of stratum s, slot S + s the
+        // BSDF-sampled one): shading only sums over them, so this stage walks the slots in order -- no permutation rows, no
+        // RNG, two dependent loads less per sample than walking them by sample index as round 1 did.  Bit s of a cached
+        // visibility plane is therefore the ray of stratum s, for the forward pass that writes it and the backward that replays it.
         for (unsigned base = 0; base < S; base += L) {
-            const unsigned i = base + sub;
+            const unsigned i = base + sub;                  // stratum
             const bool active = valid && i < S;
             const unsigned ii = active ? i : 0;
-            const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
-            const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)ii * p.perm_s1];
             const int64_t rbase = (int64_t)(valid ? pi : 0) * 2 * S;
-            const int64_t rA = rbase + pl, rB = rbase + S + pb;
+            const int64_t rA = rbase + ii, rB = rbase + S + ii;
             // the two rays of this stratum; a set sign bit on the pdf sum marks a dead sample (stage 1)
             const float4 rdA = p.rays[rA], rdB = p.rays[rB];
             const unsigned dead = active ? ((__float_as_uint(rdA.w) >> 31) | ((__float_as_uint(rdB.w) >> 31) << 1)) : 3u;
@@ -795,7 +795,29 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             if (!active) continue;
             F3 lg_add[2] = {f3(0.0f), f3(0.0f)};
             int lg_at[2] = {0, 0};
+            // light-gradient addend of one sample: a record for the band gather, or (fallback) three global atomics
+            auto emit_light_grad = [&](int r, F3 lg, int at) {
+                // adding +-0 never changes an accumulator that started at +0: occluded and dead samples are skipped
+                const bool nz = lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f;
+                if (p.lg_records) {
+                    // Band gather (light_grad_band_kernel): the addend REPLACES the sample's ray in the stream -- this
+                    // lane read it above and nobody needs it again -- and a slot without addend gets texel -1.
+                    // No atomic leaves the workgroup: 21 M addends per 8-view launch were 63 M memory-side fp32 atomics.
+                    const int64_t ri = r == 0 ? rA : rB;
+                    if (nz) p.rays[ri] = make_float4(lg.x, lg.y, lg.z, 0.0f);
+                    else p.texel[ri] = -1;
+                } else if (nz) {
+                    float *g = xcd_light + (int64_t)at * 3;
+                    __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            };
+#if NVDR_BWD_ROLL
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
             for (int r = 0; r < 2; ++r) {
                 if ((dead >> r) & 1u) continue;         // contributes exactly zero to every output
                 const int64_t ri = r == 0 ? rA : rB;
@@ -821,8 +843,13 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     // that spreads hot texels over 8 addresses (measured: a few per cent); what really helped was not
                     // issuing the zero addends.  The atomics of both samples are issued together after the loop over r
                     // (no effect on time, but it keeps them out of the way of the second sample's loads).
+                    const int at = (p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel;   // bit 4: contention experiment
+#if NVDR_BWD_ROLL
+                    if (!(p.debug & 2u)) emit_light_grad(r, lg, at);
+#else
                     lg_add[r] = lg;
-                    lg_at[r] = (p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel;   // bit 4: contention experiment
+                    lg_at[r] = at;
+#endif
                     const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
                     const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
                     if (p.bsdf == 1 || p.bsdf == 2) {
@@ -836,28 +863,15 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
                 }
             }
+#if !NVDR_BWD_ROLL
             if (BACKWARD && !(p.debug & 2u)) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    // adding +-0 never changes an accumulator that started at +0: occluded and dead samples are skipped
-                    const F3 lg = lg_add[r];
-                    const bool nz = lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f;
-                    if (p.lg_records) {
-                        // Band gather (light_grad_band_kernel): the addend REPLACES the sample's ray in the stream -- this
-                        // lane read it above and nobody needs it again -- and a slot without addend gets texel -1.
-                        // No atomic leaves the workgroup: 21 M addends per 8-view launch were 63 M memory-side fp32 atomics.
-                        if ((dead >> r) & 1u) continue;         // stage 1 already wrote texel -1
-                        const int64_t ri = r == 0 ? rA : rB;
-                        if (nz) p.rays[ri] = make_float4(lg.x, lg.y, lg.z, 0.0f);
-                        else p.texel[ri] = -1;
-                    } else if (nz) {
-                        float *g = xcd_light + (int64_t)lg_at[r] * 3;
-                        __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+                for (int r = 0; r < 2; ++r)
+                    if (!((dead >> r) & 1u)) emit_light_grad(r, lg_add[r], lg_at[r]);      // dead: stage 1 already wrote texel -1
             }
+#else
+            (void)lg_add; (void)lg_at;
+#endif
         }
 
         if (!BACKWARD) {

@@ -31,13 +31,16 @@
 
 #define NVDR_PI_DBL 3.14159265358979323846
 
-// minimum workgroups per CU the per-pixel kernels are compiled for (register budget = 512 / (4 waves * this / 4 SIMDs))
+// minimum waves per SIMD the backward shading kernel is compiled for (register budget = 512 / this).  Measured in one GPU
+// session (8-view launch, backward shading + light-gradient gather): unrolled sample loop, 192 VGPRs, 2 waves/SIMD 4.85 ms;
+// rolled loop 170 VGPRs 4.75 ms; rolled + 3 waves/SIMD (168 VGPRs, 3 dwords spilled) 4.07 ms; rolled + 4 waves/SIMD (128
+// VGPRs, 43 spilled) 5.30 ms.
 #ifndef NVDR_SHADE_OCC
-#define NVDR_SHADE_OCC 1
+#define NVDR_SHADE_OCC 3
 #endif
 // 1: the two samples of a stratum are shaded by a rolled loop in the backward kernel (half the code, fewer live registers)
 #ifndef NVDR_BWD_ROLL
-#define NVDR_BWD_ROLL 0
+#define NVDR_BWD_ROLL 1
 #endif
 #ifndef NVDR_GEN_OCC
 #define NVDR_GEN_OCC 4   // 128 VGPRs (14 dwords spilled) instead of 150: 4 waves per SIMD, -3 % time

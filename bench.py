@@ -398,6 +398,7 @@ def run(args):
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     step_ms = [a.elapsed_time(b) for a, b in ev]
+    graph_active = step._graphs is not None            # False also when the capture failed and the harness fell back to eager
     if not use_graph:
         n_f, (gen_ms, trace_ms, shade_ms) = step.ctx.stage_times(backward=False)
         n_b, (bgen_ms, btrace_ms, bshade_ms) = step.ctx.stage_times(backward=True)
@@ -535,7 +536,7 @@ def run(args):
             'iters_per_sec': args.steps / dt,
             'iters_per_sec_cached_visibility': (k2 / dt2) if dt2 else None,
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'settle_steps_before_warmup': settle,
-            'hip_graph': bool(use_graph),
+            'hip_graph': bool(graph_active),
             'ms_per_step': dt / args.steps * 1e3,
             'median_ms_per_step': med, 'median_over_steps': len(ext_ms) if ext_ms else len(step_ms),
             'min_ms_per_step': min(ext_ms or step_ms), 'max_ms_per_step': max(ext_ms or step_ms),

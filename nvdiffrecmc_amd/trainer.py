@@ -231,7 +231,14 @@ class DirectLightingStep:
 
     def step(self, world_size=1):
         if self.use_graph and not self.force_eager and self._graphs is None and self._eager_steps >= 3:
-            self._capture(world_size)
+            try:
+                self._capture(world_size)
+            except Exception as e:      # a runtime that cannot capture this iteration keeps running it eagerly (same results)
+                import warnings
+                warnings.warn('HIP-graph capture of the iteration failed (%s: %s); continuing eagerly' % (type(e).__name__, e))
+                self.use_graph, self._graphs = False, None
+                torch.cuda.synchronize()
+                self.opt.zero_grad(set_to_none=True)
         if self._graphs is not None and not self.force_eager:
             ga, gb = self._graphs
             ga.replay()

@@ -26,6 +26,7 @@ def run(iters=12):
     st.ctx.set_profiling(True)
     for it in range(iters):
         if it == 2: st.ctx.set_profiling(True)
+        if os.environ.get('PROBE_REBUILD'): ou.optix_build_bvh(st.ctx, st.mesh['v_pos'], st.mesh['t_pos_idx'], rebuild=1)   # as the training iteration does
         g = [t.clone().requires_grad_(True) for t in (st.gb_pos, nrm, kd, ks, L.base.detach())]
         d, s = ou.optix_env_shade(st.ctx, st.mask, ro, g[0], g[1], st.view_pos, g[2], g[3], g[4], L._pdf, L.rows[:, 0], L.cols,
                                   n_samples_x=n, rnd_seed=it, shadow_scale=1.0)

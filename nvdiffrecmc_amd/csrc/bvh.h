@@ -92,6 +92,8 @@ struct nvdr_ctx {
     uint4 *nodes = nullptr;        // [2 * cap]
     uint4 *wide = nullptr;         // [4 * cap] four-slot nodes derived from nodes[]
     float4 *tris = nullptr;        // [3 * cap]
+    void *bvh_array_base[3] = {nullptr, nullptr, nullptr};   // what to hipFree for nodes / wide / tris (bvh_array_alloc)
+    int bvh_alloc_mode = 0;        // NVDR_BVH_ALLOC: 0 hipMalloc, 1 physically contiguous, 2 pointer aligned to 2 MB
     uint32_t *keys[2] = {nullptr, nullptr};
     uint32_t *vals[2] = {nullptr, nullptr};
     int *parent = nullptr;         // [2T]: parents of internal nodes [0,T-1) then of leaves [T, 2T)

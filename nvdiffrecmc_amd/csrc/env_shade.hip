@@ -707,8 +707,8 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
             // per 100 MHz tick, i.e. the clock the waves actually ran at) and the set of XCDs that ran waves
             atomicAdd(&counters[6], (unsigned long long)__builtin_readcyclecounter() - c_begin);
             atomicOr(&counters[7], 1ull << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
-            counters[8 + 2 * wid] = t_begin;                 // per-wave begin / end ticks (wid < 8192)
-            counters[9 + 2 * wid] = t_begin + dt;
+            counters[8 + 2 * wid] = t_begin;                 // per-wave begin / end ticks (wid < 8192); the XCD it ran on in the top byte
+            counters[9 + 2 * wid] = (t_begin + dt) | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 56);
         }
     }
 }

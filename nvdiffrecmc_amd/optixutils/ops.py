@@ -404,7 +404,10 @@ def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_p
     _lib.check(w.lib.nvdr_env_shade_last_pixel_count(w.handle, ctypes.byref(npx), _lib.stream_ptr()), 'pixel_count')
     c = cnt.cpu()
     env_shade_traversal_counts.balance = (int(c[3]), int(c[4]), int(c[5]))   # sum, max of per-wave ticks (100 MHz), waves
-    env_shade_traversal_counts.wave_ticks = c[8:8 + 2 * min(int(c[5]), 8192)].view(-1, 2)   # (begin, end) per wavefront
+    wt = c[8:8 + 2 * min(int(c[5]), 8192)].view(-1, 2).clone()
+    env_shade_traversal_counts.wave_xcd = (wt[:, 1] >> 56) & 7                                  # XCD every wavefront ran on
+    wt[:, 1] &= (1 << 56) - 1
+    env_shade_traversal_counts.wave_ticks = wt                                                   # (begin, end) per wavefront, 100 MHz ticks
     env_shade_traversal_counts.clock_mhz = 100.0 * int(c[6]) / max(int(c[3]), 1)     # shader clock the waves ran at
     env_shade_traversal_counts.xcd_mask = int(c[7])
     env_shade_traversal_counts.bvh2 = tuple(int(v) for v in c[_lib.COUNTERS_BVH2:_lib.COUNTERS_BVH2 + 3])

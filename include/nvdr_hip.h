@@ -54,6 +54,11 @@ int nvdr_ctx_check(nvdr_ctx *ctx, void *stream);
  * exceed the chunk is processed chunk by chunk with identical results.  The reference needs no scratch (one thread per
  * pixel keeps its rays in registers); a worst-case allocation would be N*H*W*2S*25 B (16 GB for 8 x 800^2 x 64 spp). */
 int nvdr_ctx_set_stream_budget(nvdr_ctx *ctx, int64_t bytes);
+/* The shadow-ray traversal kernel is compiled as three identical copies; in a fraction of processes ONE copy runs 2-20x
+ * slower for the life of the process (profiles/r02_slow_mode.md).  copy = 0, 1, 2 selects which one this context launches;
+ * nvdr_ctx_trace_pcs reports the program counters the copies (and the counting build, out[3]) ran at (diagnostics). */
+int nvdr_ctx_set_trace_variant(nvdr_ctx *ctx, int copy);
+int nvdr_ctx_trace_pcs(nvdr_ctx *ctx, unsigned long long *out_host4, void *stream);
 
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
  * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);

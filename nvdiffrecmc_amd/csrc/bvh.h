@@ -119,6 +119,7 @@ struct nvdr_ctx {
     int *texel = nullptr;
     uint8_t *vis = nullptr;
     uint32_t *live = nullptr;      // stream slots of the rays that need traversal (dead samples left out)
+    int trace_copy = 0;            // which of the three identical copies of env_trace_kernel this context launches
     unsigned *queues = nullptr;    // [256][32] chunk counters of the traversal kernel, one 128-B line each (NVDR_TRACE_QUEUES)
     float4 *pix_origin = nullptr;
     size_t stream_cap_rays = 0;

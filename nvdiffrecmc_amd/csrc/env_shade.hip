@@ -540,7 +540,11 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
 #ifndef NVDR_TRACE_PAD
 #define NVDR_TRACE_PAD 10
 #endif
-template <bool COUNT>
+// COPY: identical code emitted three times at different addresses / loop offsets.  Round 2 found that the per-process slow
+// mode belongs to ONE INSTANTIATION of this kernel in that process (profiles/r02_slow_mode.md: the production kernel takes
+// 40 ms where the counting build of the same source, in the same process on the same rays, takes 2 ms): the launcher can
+// therefore time the copies on its first launches and keep the fastest (nvdr_ctx::trace_copy).
+template <bool COUNT, int COPY>
 __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView bvh, const float4 *__restrict__ rays,
                                                                           const float4 *__restrict__ pix_origin,
                                                                           const uint32_t *__restrict__ live,
@@ -599,8 +603,13 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView 
     // other kernels are unaffected).  It first looked like a code-placement effect because it came and went with
     // unrelated edits; ruled out since: code placement, LDS footprint (17 vs 12 KB per workgroup), spill-buffer layout,
     // grid size (8 resident vs 16 workgroups per CU).
+    if (wid == 0 && lane == 0) {       // diagnostics: where this instantiation's code lives in this process (last counter line)
+        unsigned long long pc;
+        asm volatile("s_getpc_b64 %0" : "=s"(pc));
+        *(unsigned long long *)(queues + 32 * 255 + 2 * (COPY + (COUNT ? 3 : 0))) = pc;
+    }
     asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
-    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
+    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD + 24 * COPY));
     while (true) {
         const unsigned long long idle = __ballot(ray < 0);
         const int n_idle = __popcll(idle);
@@ -1034,6 +1043,42 @@ static int check_gb(const nvdr_tensor &t, int64_t N, int64_t H, int64_t W, const
     return 0;
 }
 
+// the production traversal launch: one of three identical copies of the kernel (nvdr_ctx::trace_copy)
+static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t stream, const unsigned *ray_count, unsigned rays_per_pixel)
+{
+    switch (c->trace_copy) {
+    case 1:
+        env_trace_kernel<false, 1><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, ray_count, rays_per_pixel,
+                                                                            c->vis, c->spill, nullptr, c->queues);
+        break;
+    case 2:
+        env_trace_kernel<false, 2><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, ray_count, rays_per_pixel,
+                                                                            c->vis, c->spill, nullptr, c->queues);
+        break;
+    default:
+        env_trace_kernel<false, 0><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, ray_count, rays_per_pixel,
+                                                                            c->vis, c->spill, nullptr, c->queues);
+    }
+}
+
+extern "C" int nvdr_ctx_set_trace_variant(nvdr_ctx *c, int copy)
+{
+    NVDR_REQUIRE(c && copy >= 0 && copy <= 2, "nvdr_ctx_set_trace_variant: copy must be 0, 1 or 2");
+    c->trace_copy = copy;
+    return 0;
+}
+
+// diagnostics: the program counter each instantiation of the traversal kernel reported on its last launch
+// (out[0..2] = production copies, out[3] = counting build); synchronises `stream`
+extern "C" int nvdr_ctx_trace_pcs(nvdr_ctx *c, unsigned long long *out_host, void *stream_)
+{
+    NVDR_REQUIRE(c && out_host, "nvdr_ctx_trace_pcs: NULL argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    NVDR_HIP_TRY(hipMemcpyAsync(out_host, c->queues + 32 * 255, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, stream));
+    NVDR_HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
 // Scratch for the ray stream.  Round 1 sized it for the worst case -- every pixel of the launch covered -- which was
 // 6.7 GB for the 8-view benchmark (23 % coverage) and rejected launches beyond 2^31 rays.  Now the stream holds ONE CHUNK
 // of `cap` covered pixels (x 2S rays x 25 B), cap from the context's byte budget (nvdr_ctx_set_stream_budget; default
@@ -1278,13 +1323,12 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             if (c->debug & 1u) {
                 NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)cap * 2 * S, stream));
             } else if (a->counters) {
-                env_trace_kernel<true><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
-                                                                                                  p.ray_count, 2 * S, c->vis, c->spill, a->counters, c->queues);
+                env_trace_kernel<true, 0><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
+                                                                                                     p.ray_count, 2 * S, c->vis, c->spill, a->counters, c->queues);
                 bvh2_count_kernel<<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, p.ray_count,
                                                                                             2 * S, c->spill, a->counters + NVDR_COUNTERS_BVH2);
             } else {
-                env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
-                                                                                                   p.ray_count, 2 * S, c->vis, c->spill, nullptr, c->queues);
+                launch_trace(c, (unsigned)tblocks, trace_lds, stream, p.ray_count, 2 * S);
             }
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
@@ -1342,8 +1386,7 @@ extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const fl
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
     if (tblocks > need) tblocks = need;
-    env_trace_kernel<false><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream>>>(
-        bvh_view(c), c->rays, c->pix_origin, c->live, c->chunk_counts, 1u, c->vis, c->spill, nullptr, c->queues);
+    launch_trace(c, (unsigned)tblocks, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u);
     NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
     NVDR_LAUNCH_CHECK();
     return 0;

@@ -67,6 +67,18 @@ class OptiXContext:
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')
 
+    def set_trace_variant(self, copy):
+        """Select which of the three identical copies of the traversal kernel this context launches (0, 1, 2)."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_ctx_set_trace_variant(w.handle, int(copy)), 'nvdr_ctx_set_trace_variant')
+
+    def trace_pcs(self):
+        """Program counters of the traversal-kernel copies 0..2 and of the counting build on their last launch (diagnostics)."""
+        w = self.cpp_wrapper
+        out = (ctypes.c_uint64 * 4)()
+        _lib.check(w.lib.nvdr_ctx_trace_pcs(w.handle, out, _lib.stream_ptr()), 'nvdr_ctx_trace_pcs')
+        return [int(v) for v in out]
+
     def check(self):
         """Synchronise and raise if any traversal launch on this context ever overflowed its stack (never silent)."""
         w = self.cpp_wrapper

@@ -92,8 +92,6 @@ struct nvdr_ctx {
     uint4 *nodes = nullptr;        // [2 * cap]
     uint4 *wide = nullptr;         // [4 * cap] four-slot nodes derived from nodes[]
     float4 *tris = nullptr;        // [3 * cap]
-    void *bvh_array_base[3] = {nullptr, nullptr, nullptr};   // what to hipFree for nodes / wide / tris (bvh_array_alloc)
-    int bvh_alloc_mode = 0;        // NVDR_BVH_ALLOC: 0 hipMalloc, 1 physically contiguous, 2 pointer aligned to 2 MB
     uint32_t *keys[2] = {nullptr, nullptr};
     uint32_t *vals[2] = {nullptr, nullptr};
     int *parent = nullptr;         // [2T]: parents of internal nodes [0,T-1) then of leaves [T, 2T)
@@ -119,7 +117,8 @@ struct nvdr_ctx {
     int *texel = nullptr;
     uint8_t *vis = nullptr;
     uint32_t *live = nullptr;      // stream slots of the rays that need traversal (dead samples left out)
-    int trace_copy = 0;            // which of the three identical copies of env_trace_kernel this context launches
+    int trace_copy = -1;           // instance of the traversal kernel this context launches; -1 = the process's selection (env_shade.hip)
+    unsigned trace_flags = 0;      // NVDR_TRACE_* bits of trace_kernel.h (chunk dealing)
     unsigned *queues = nullptr;    // [256][32] chunk counters of the traversal kernel, one 128-B line each (NVDR_TRACE_QUEUES)
     float4 *pix_origin = nullptr;
     size_t stream_cap_rays = 0;

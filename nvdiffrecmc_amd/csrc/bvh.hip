@@ -327,34 +327,9 @@ extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
     return ctx_check_overflow(c, "nvdr_ctx_check");
 }
 
-// The three arrays every traversal step reads at random (nodes, wide nodes, triangles).  How they are mapped decides the
-// TLB reach of the walk (profiles/r02_slow_mode.md: the same launch takes 2.5 ms or 48 ms in different processes on a
-// 684 k-triangle mesh).  NVDR_BVH_ALLOC (read once per context): "default" = hipMalloc, "contig" = physically contiguous
-// VRAM (hipDeviceMallocContiguous), "align2m" = hipMalloc with the pointer rounded up to a 2 MB boundary.
-static hipError_t bvh_array_alloc(nvdr_ctx *c, void **out, size_t bytes, int slot)
-{
-    void *base = nullptr;
-    hipError_t e;
-    if (c->bvh_alloc_mode == 1) {
-        e = hipExtMallocWithFlags(&base, bytes, hipDeviceMallocContiguous);
-        if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&base, bytes); }
-        *out = base;
-    } else if (c->bvh_alloc_mode == 2) {
-        const size_t A = (size_t)2 << 20;
-        e = hipMalloc(&base, bytes + A);
-        *out = (void *)(((uintptr_t)base + A - 1) & ~(uintptr_t)(A - 1));
-    } else {
-        e = hipMalloc(&base, bytes);
-        *out = base;
-    }
-    c->bvh_array_base[slot] = e == hipSuccess ? base : nullptr;
-    if (e != hipSuccess) *out = nullptr;
-    return e;
-}
-
 static int ctx_free_bvh(nvdr_ctx *c)
 {
-    for (int k = 0; k < 3; ++k) { hipFree(c->bvh_array_base[k]); c->bvh_array_base[k] = nullptr; }
+    hipFree(c->nodes); hipFree(c->wide); hipFree(c->tris);
     hipFree(c->keys[0]); hipFree(c->keys[1]); hipFree(c->vals[0]); hipFree(c->vals[1]);
     hipFree(c->parent); hipFree(c->flags); hipFree(c->heights); hipFree(c->sort_tmp);
     c->nodes = nullptr;
@@ -397,10 +372,8 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         return (int)e;
     }
     hipMemset(c->chunk_counts, 0, sizeof(unsigned) * NVDR_MAX_CHUNKS);
-    if (const char *e = getenv("NVDR_BVH_ALLOC")) {
-        c->bvh_alloc_mode = !strcmp(e, "contig") ? 1 : !strcmp(e, "align2m") ? 2 : 0;
-        if (c->bvh_alloc_mode) fprintf(stderr, "[nvdr] NVDR_BVH_ALLOC=%s\n", e);
-    }
+    // NVDR_TRACE_XCD (read once here): 1 = the traversal kernel deals its ray chunks per XCD (trace_kernel.h), 0 = interleaved
+    if (const char *e = getenv("NVDR_TRACE_XCD")) c->trace_flags = atoi(e) ? NVDR_TRACE_XCD_PARTITION : 0u;
     if (const char *e = getenv("NVDR_STREAM_BUDGET_MB")) {
         const long long mb = atoll(e);
         if (mb >= 1) c->stream_budget = (int64_t)mb << 20;
@@ -444,9 +417,9 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     NVDR_HIP_TRY(hipDeviceSynchronize());
     ctx_free_bvh(c);
     const int64_t cap = n_tris + n_tris / 2 + 64;
-    NVDR_HIP_TRY(bvh_array_alloc(c, (void **)&c->nodes, sizeof(uint4) * 2 * cap, 0));
-    NVDR_HIP_TRY(bvh_array_alloc(c, (void **)&c->wide, sizeof(uint4) * 4 * cap, 1));
-    NVDR_HIP_TRY(bvh_array_alloc(c, (void **)&c->tris, sizeof(float4) * 3 * cap, 2));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->nodes, sizeof(uint4) * 2 * cap));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->wide, sizeof(uint4) * 4 * cap));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->tris, sizeof(float4) * 3 * cap));
     for (int i = 0; i < 2; ++i) {
         NVDR_HIP_TRY(hipMalloc((void **)&c->keys[i], sizeof(uint32_t) * cap));
         NVDR_HIP_TRY(hipMalloc((void **)&c->vals[i], sizeof(uint32_t) * cap));

@@ -26,7 +26,10 @@
 // The sampling math mirrors the evaluation order and the fp32/fp64 promotions of the reference
 // source and uses include/nvdr_detmath.h for sin/cos/acos/atan2, which makes every
 // discrete decision (texel, lobe, visibility) bit-identical to the CPU oracle.
-#include "bvh.h"
+#include <dlfcn.h>
+#include <mutex>
+
+#include "trace_kernel.h"
 #include "bsdf_device.h"
 
 #define NVDR_PI_DBL 3.14159265358979323846
@@ -510,216 +513,14 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
 }
 
 // ---------------------------------------------------------------------------------------------
-// stage 2: persistent-wavefront any-hit traversal of the ray stream
+// stage 2: persistent-wavefront any-hit traversal of the ray stream -- the body is in trace_kernel.h (it is also compiled
+// into a stand-alone code object, trace_module.hip).  Three placement copies + the counting build live in this library.
 
-#ifndef NVDR_REFILL_MIN
-#define NVDR_REFILL_MIN 16
-#endif
-#ifndef NVDR_LEAF_MIN
-#define NVDR_LEAF_MIN 8
-#endif
-#ifndef NVDR_TRACE_CHUNK_LOG2
-#define NVDR_TRACE_CHUNK_LOG2 6
-#endif
-// NVDR_TRACE_QUEUES > 0: chunks of NVDR_TRACE_QCHUNK rays are CLAIMED from that many device counters (one cache line each,
-// wave w uses counter w % Q and gets the chunks q, q + Q, q + 2Q ...) instead of being dealt round-robin: all waves of the
-// chip then work inside one moving window of the list (neighbouring pixels -> the same subtrees stay in L2) and a wave that
-// drew cheap rays simply claims more.  One counter serialises at ~70 ns per claim (round 1: 1.4-2.5 ms); 64 of them see
-// < 1 M claims/s each.  0 = static round-robin chunks.
-// Measured (round 2, same GPU session, 8-view launch, 43 M live rays): round-robin 4.30 ms, 64 queues x 256 rays 3.75 ms
-// (-13 %), 128 x 256 4.06 ms, 64 x 128 4.07 ms.
-#ifndef NVDR_TRACE_QUEUES
-#define NVDR_TRACE_QUEUES 64
-#endif
-#ifndef NVDR_TRACE_QCHUNK
-#define NVDR_TRACE_QCHUNK 256
-#endif
-#ifndef NVDR_TRACE_ALIGN
-#define NVDR_TRACE_ALIGN 8
-#endif
-#ifndef NVDR_TRACE_PAD
-#define NVDR_TRACE_PAD 10
-#endif
-// COPY: identical code emitted three times at different addresses / loop offsets.  Round 2 found that the per-process slow
-// mode belongs to ONE INSTANTIATION of this kernel in that process (profiles/r02_slow_mode.md: the production kernel takes
-// 40 ms where the counting build of the same source, in the same process on the same rays, takes 2 ms): the launcher can
-// therefore time the copies on its first launches and keep the fastest (nvdr_ctx::trace_copy).
 template <bool COUNT, int COPY>
-__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(BvhView bvh, const float4 *__restrict__ rays,
-                                                                          const float4 *__restrict__ pix_origin,
-                                                                          const uint32_t *__restrict__ live,
-                                                                          const unsigned *__restrict__ ray_count,
-                                                                          unsigned rays_per_pixel,
-                                                                          uint8_t *__restrict__ vis, int *spill,
-                                                                          unsigned long long *counters, unsigned *queues)
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(TraceLaunch a)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
-    const int lane = threadIdx.x & 63;
-    const unsigned total = *ray_count;
-    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
-    const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    // Round-robin chunks: the list is cut into chunks of 64 rays and wave w walks chunks w, w + n_waves, w + 2 n_waves ...
-    // (virtual cursor v -> list position ((v >> 6) * n_waves + w) * 64 + (v & 63)): every wave gets the same mix of cheap
-    // and expensive pixels with no communication (0.82 -> 0.77 ms against one contiguous range per wave; chunks of
-    // 16 rays the same, 256 slower).  Claiming chunks from a device counter was far worse (same-address device-scope
-    // atomics: 1.4 ms with 1024-ray chunks, 2.5 ms with 256) and is not needed: per-wave clocks of the counting build
-    // show all waves starting together and finishing evenly spread over [T/8, T] for ANY chunk size down to 2 rays --
-    // the signature of oldest-first issue among the 8 waves of a SIMD that is busy to the end, not of imbalance.
-#if NVDR_TRACE_QUEUES
-    const unsigned Q = NVDR_TRACE_QUEUES, QC = NVDR_TRACE_QCHUNK;
-    const unsigned n_qchunks = (total + QC - 1u) / QC;
-    unsigned *my_queue = queues + (wid % Q) * 32u;
-    unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
-    bool more = total > 0;
-    (void)n_waves;
-#else
-    unsigned next = 0;                                      // wave-uniform virtual cursor
-    const unsigned CL = NVDR_TRACE_CHUNK_LOG2, CS = 1u << CL;
-    const unsigned end = ((total + CS - 1u) / CS + n_waves - 1) / n_waves * CS;
-    (void)queues;
-#endif
-    unsigned n_box = 0, n_tri = 0, n_ray = 0;
-    const bool single = bvh.n_tris == 1;
-    const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
-    const unsigned long long c_begin = COUNT ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
-
-    int ray = -1, cur = 0, sp = 0;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
-    GridRay g;
-    g.nx = g.ny = g.nz = g.ix = g.iy = g.iz = 0.0f;
-    g.px = g.py = g.pz = 0u;
-    // The three arms of an iteration -- refill, leaf step, node step -- are gated by WAVE-UNIFORM lane counts so that
-    // the two expensive rare ones are never issued for a handful of lanes:
-    //   refill : when >= NVDR_REFILL_MIN lanes are idle (or nobody can step) and the range still has rays;
-    //   leaf   : when >= NVDR_LEAF_MIN lanes are parked on a leaf, or no lane has a node to visit;
-    //   node   : whenever some lane has one.
-    // Measured (same GPU session, bob 512^2 x 64 spp): ungated 1.36 ms, (16, 8) 1.23-1.31 ms, one-arm-per-iteration
-    // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
-    // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
-    // The loop is placed at a fixed offset from a 256-byte boundary so that edits elsewhere in this file cannot move it
-    // relative to the instruction-cache lines.  OPEN ISSUE: in ~20 % of fresh processes the one-view launch of this kernel
-    // takes 1.16 ms instead of 0.68 ms for the whole life of the process (tools/mode_run.sh; same binary, same inputs; the
-    // other kernels are unaffected).  It first looked like a code-placement effect because it came and went with
-    // unrelated edits; ruled out since: code placement, LDS footprint (17 vs 12 KB per workgroup), spill-buffer layout,
-    // grid size (8 resident vs 16 workgroups per CU).
-    if (wid == 0 && lane == 0) {       // diagnostics: where this instantiation's code lives in this process (last counter line)
-        unsigned long long pc;
-        asm volatile("s_getpc_b64 %0" : "=s"(pc));
-        *(unsigned long long *)(queues + 32 * 255 + 2 * (COPY + (COUNT ? 3 : 0))) = pc;
-    }
-    asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
-    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD + 24 * COPY));
-    while (true) {
-        const unsigned long long idle = __ballot(ray < 0);
-        const int n_idle = __popcll(idle);
-#if NVDR_TRACE_QUEUES
-        if (n_idle >= NVDR_REFILL_MIN && next >= end && more) {
-            unsigned j = 0;
-            if (lane == 0) j = atomicAdd(my_queue, 1u);
-            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-            const unsigned c = j * Q + (wid % Q);
-            more = c < n_qchunks;
-            next = more ? c * QC : 0u;
-            end = more ? min(next + QC, total) : 0u;
-        }
-#endif
-        if (next < end && n_idle >= NVDR_REFILL_MIN) {
-            // refill every idle lane from the wave's range (no atomics: the cursor is wave-uniform)
-            const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-#if NVDR_TRACE_QUEUES
-            const unsigned at = take;
-#else
-            const unsigned at = (((take >> CL) * n_waves + wid) << CL) | (take & (CS - 1u));
-#endif
-            if (ray < 0 && take < end && at < total) {
-                const unsigned slot = live[at];
-                ray = (int)slot;
-                if (COUNT) n_ray++;
-                const float4 rd = rays[slot];
-                const float4 ro = pix_origin[slot / rays_per_pixel];
-                ox = ro.x; oy = ro.y; oz = ro.z;
-                dx = rd.x; dy = rd.y; dz = rd.z;
-                g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
-                cur = single ? ~0 : 0;
-                sp = 0;
-            }
-            next += (unsigned)n_idle;
-        } else if (n_idle == 64) {
-#if NVDR_TRACE_QUEUES
-            if (!more)
-#endif
-            break;
-        }
-        const unsigned long long on_leaf = __ballot(ray >= 0 && cur < 0);
-        const int n_leaf = __popcll(on_leaf);
-        const int n_node = __popcll(__ballot(ray >= 0 && cur >= 0));
-        const int POP = NVDR_TRAV_DONE, HIT = NVDR_TRAV_DONE - 1, WAIT = NVDR_TRAV_DONE - 2;
-        const bool leaf_turn = n_leaf >= NVDR_LEAF_MIN || n_node == 0;   // parked leaves are tested in batches
-        const bool node_turn = n_node > 0;
-        int nxt = WAIT;                                 // next node / leaf, or one of the markers
-        if (leaf_turn && ray >= 0 && cur < 0) {
-            if (COUNT) n_tri++;
-            nxt = tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz) ? HIT : POP;
-        }
-        const int popv = stack.peek(sp);                // value a pop would return (unused when sp == 0)
-        if (node_turn && ray >= 0 && cur >= 0) {
-            // one step = the four grandchildren of `cur` (bvh.h "wide"): test all, continue with the nearest hit, push
-            // the other hits.  Any-hit needs no exact order; nearest-first just finds occluders sooner.
-            const uint4 *w4 = bvh.wide + 4 * (int64_t)cur;
-            const uint4 q0 = w4[0], q1 = w4[1], q2 = w4[2], q3 = w4[3];
-            float t0, t1, t2, t3;
-            const bool h0 = slot_hit(q0, g, NVDR_RAY_TMAX, t0), h1 = slot_hit(q1, g, NVDR_RAY_TMAX, t1);
-            const bool h2 = slot_hit(q2, g, NVDR_RAY_TMAX, t2), h3 = slot_hit(q3, g, NVDR_RAY_TMAX, t3);
-            const float BIG = 3.0e38f;
-            const float u0 = h0 ? t0 : BIG, u1 = h1 ? t1 : BIG, u2 = h2 ? t2 : BIG, u3 = h3 ? t3 : BIG;
-            const float um = fminf(fminf(u0, u1), fminf(u2, u3));
-            const int best = (h0 & (u0 == um)) ? 0 : (h1 & (u1 == um)) ? 1 : (h2 & (u2 == um)) ? 2 : 3;
-            const bool any = h0 | h1 | h2 | h3;
-            const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
-            if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
-            nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
-            // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs 0.67 ms)
-            if (h0 & (best != 0)) sp = stack.push(sp, c0);
-            if (h1 & (best != 1)) sp = stack.push(sp, c1);
-            if (h2 & (best != 2)) sp = stack.push(sp, c2);
-            if (h3 & (best != 3)) sp = stack.push(sp, c3);
-        }
-        bool finished = false;
-        if (nxt != WAIT) {
-            const bool pop = nxt == POP;
-            finished = (nxt == HIT) | (pop & (sp == 0));
-            sp -= (pop & (sp > 0)) ? 1 : 0;
-            cur = pop ? popv : nxt;
-        }
-        if (finished) {
-            vis[ray] = nxt == HIT ? 0 : 1;
-            ray = -1;
-        }
-    }
-    if (COUNT) {
-        for (int o = 32; o >= 1; o >>= 1) {
-            n_box += __shfl_xor(n_box, o);
-            n_tri += __shfl_xor(n_tri, o);
-            n_ray += __shfl_xor(n_ray, o);
-        }
-        if (lane == 0) {
-            atomicAdd(&counters[0], (unsigned long long)n_box);
-            atomicAdd(&counters[1], (unsigned long long)n_tri);
-            atomicAdd(&counters[2], (unsigned long long)n_ray);
-            // load balance of the static ranges: sum and maximum of the per-wave busy time (100 MHz ticks), wave count
-            const unsigned long long dt = wall_clock64() - t_begin;
-            atomicAdd(&counters[3], dt);
-            atomicMax(&counters[4], dt);
-            atomicAdd(&counters[5], 1ull);
-            // diagnostics for the per-process slow mode: shader-clock cycles spent (sum over waves; / counters[3] = cycles
-            // per 100 MHz tick, i.e. the clock the waves actually ran at) and the set of XCDs that ran waves
-            atomicAdd(&counters[6], (unsigned long long)__builtin_readcyclecounter() - c_begin);
-            atomicOr(&counters[7], 1ull << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
-            counters[8 + 2 * wid] = t_begin;                 // per-wave begin / end ticks (wid < 8192); the XCD it ran on in the top byte
-            counters[9 + 2 * wid] = (t_begin + dt) | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 56);
-        }
-    }
+    env_trace_body<COUNT, COPY>(a, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1043,38 +844,205 @@ static int check_gb(const nvdr_tensor &t, int64_t N, int64_t H, int64_t W, const
     return 0;
 }
 
-// the production traversal launch: one of three identical copies of the kernel (nvdr_ctx::trace_copy)
-static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t stream, const unsigned *ray_count, unsigned rays_per_pixel)
+// ---------------------------------------------------------------------------------------------
+// Which INSTANCE of the traversal kernel this process launches.
+//
+// In roughly one fresh process out of seven the shadow-ray kernel runs 1.75x (bob, everything in L2) to 12-20x (684 k
+// triangles) slower for the whole life of the process, and the condition belongs to ONE instance of the kernel's code in
+// that process: the counting build of the same source, in the same process on the same rays, is not affected
+// (profiles/r02_slow_mode.md).  The library therefore holds several instances of the same code -- three copies at different
+// offsets of this code object (candidates 0-2) and a stand-alone code object, nvdr_trace_gfx950.hsaco, that is loaded up
+// to NVDR_TRACE_MODULES times into memory of its own (candidates 3, 4) -- and the first forward launch that is long
+// enough to tell (>= 0.15 ms) times all of them once on its own rays (the kernel is idempotent) and keeps the fastest
+// for the process: one extra host synchronisation in the life of a process, never inside a stream capture.
+// NVDR_TRACE_SELECT = off | auto (default) | 0..4 (force a candidate); nvdr_ctx_set_trace_variant overrides per context.
+#define NVDR_TRACE_LIB_COPIES 3
+#define NVDR_TRACE_MODULES 2
+#define NVDR_TRACE_CANDIDATES (NVDR_TRACE_LIB_COPIES + NVDR_TRACE_MODULES)
+#define NVDR_TRACE_MAX_DEVICES 16
+
+struct TraceSelect {
+    std::mutex mu;
+    bool env_read = false;
+    bool enabled = true;
+    int forced = -1;
+    int decided = 0;                 // 1: `choice` is final for this process
+    int choice = 0;
+    int attempts = 0;                // calibrations that were too short to decide
+    float ms[NVDR_TRACE_CANDIDATES] = {0, 0, 0, 0, 0};   // the deciding (or last) calibration; < 0 = candidate unavailable
+    hipModule_t mod[NVDR_TRACE_MODULES] = {};
+    hipFunction_t fn[NVDR_TRACE_MODULES] = {};
+    int mod_state[NVDR_TRACE_MODULES] = {0, 0};          // 0 not tried, 1 loaded, -1 failed
+};
+static TraceSelect g_trace_select[NVDR_TRACE_MAX_DEVICES];
+
+static TraceSelect &trace_select(const nvdr_ctx *c)
 {
-    switch (c->trace_copy) {
-    case 1:
-        env_trace_kernel<false, 1><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, ray_count, rays_per_pixel,
-                                                                            c->vis, c->spill, nullptr, c->queues);
-        break;
-    case 2:
-        env_trace_kernel<false, 2><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, ray_count, rays_per_pixel,
-                                                                            c->vis, c->spill, nullptr, c->queues);
-        break;
-    default:
-        env_trace_kernel<false, 0><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, ray_count, rays_per_pixel,
-                                                                            c->vis, c->spill, nullptr, c->queues);
+    TraceSelect &s = g_trace_select[(c->device >= 0 && c->device < NVDR_TRACE_MAX_DEVICES) ? c->device : 0];
+    if (!s.env_read) {
+        s.env_read = true;
+        if (const char *e = getenv("NVDR_TRACE_SELECT")) {
+            if (!strcmp(e, "off")) s.enabled = false;
+            else if (e[0] >= '0' && e[0] < '0' + NVDR_TRACE_CANDIDATES && !e[1]) { s.forced = e[0] - '0'; s.choice = s.forced; s.decided = 1; }
+            if (!s.enabled || s.forced >= 0) fprintf(stderr, "[nvdr] NVDR_TRACE_SELECT=%s\n", e);
+        }
+    }
+    return s;
+}
+
+// the stand-alone code object lies next to this library
+static std::string trace_module_path()
+{
+    Dl_info info;
+    if (!dladdr((const void *)&nvdr_last_error, &info) || !info.dli_fname) return std::string();
+    std::string p = info.dli_fname;
+    const size_t k = p.rfind('/');
+    return (k == std::string::npos ? std::string() : p.substr(0, k + 1)) + "nvdr_trace_gfx950.hsaco";
+}
+
+static bool trace_module_ready(TraceSelect &s, int m)
+{
+    if (s.mod_state[m] == 0) {
+        const std::string path = trace_module_path();
+        hipError_t e = path.empty() ? hipErrorFileNotFound : hipModuleLoad(&s.mod[m], path.c_str());
+        if (e == hipSuccess) e = hipModuleGetFunction(&s.fn[m], s.mod[m], "nvdr_trace_module_kernel");
+        s.mod_state[m] = e == hipSuccess ? 1 : -1;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            fprintf(stderr, "[nvdr] traversal code object %s not loaded (%s): that instance is left out of the selection\n", path.c_str(),
+                    hipGetErrorString(e));
+        }
+    }
+    return s.mod_state[m] == 1;
+}
+
+static hipError_t launch_trace_candidate(TraceSelect &s, int k, const TraceLaunch &L, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    switch (k) {
+    case 0: env_trace_kernel<false, 0><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(L); return hipGetLastError();
+    case 1: env_trace_kernel<false, 1><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(L); return hipGetLastError();
+    case 2: env_trace_kernel<false, 2><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(L); return hipGetLastError();
+    default: {
+        const int m = k - NVDR_TRACE_LIB_COPIES;
+        if (m < 0 || m >= NVDR_TRACE_MODULES || !trace_module_ready(s, m)) return hipErrorInvalidValue;
+        TraceLaunch tmp = L;
+        void *args[] = {&tmp};
+        return hipModuleLaunchKernel(s.fn[m], blocks, 1, 1, NVDR_QUERY_BLOCK, 1, 1, (unsigned)lds, stream, args, nullptr);
+    }
     }
 }
 
-extern "C" int nvdr_ctx_set_trace_variant(nvdr_ctx *c, int copy)
+static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_count, unsigned rays_per_pixel, unsigned long long *counters)
 {
-    NVDR_REQUIRE(c && copy >= 0 && copy <= 2, "nvdr_ctx_set_trace_variant: copy must be 0, 1 or 2");
-    c->trace_copy = copy;
+    TraceLaunch L;
+    L.bvh = bvh_view(c);
+    L.rays = c->rays; L.pix_origin = c->pix_origin; L.live = c->live;
+    L.ray_count = ray_count; L.rays_per_pixel = rays_per_pixel; L.flags = c->trace_flags;
+    L.vis = c->vis; L.spill = c->spill; L.counters = counters; L.queues = c->queues;
+    return L;
+}
+
+// Times every available instance once on the rays of this launch and fixes the process's choice when the launch was long
+// enough to tell.  The regular launch has already run (warm caches, valid results); every instance rewrites the same bits.
+static int trace_calibrate(nvdr_ctx *c, TraceSelect &s, const TraceLaunch &L, unsigned blocks, size_t lds, hipStream_t stream)
+{
+    hipEvent_t ev[2 * NVDR_TRACE_CANDIDATES] = {};
+    bool have[NVDR_TRACE_CANDIDATES];
+    int rc = 0;
+    for (int k = 0; k < NVDR_TRACE_CANDIDATES; ++k)
+        have[k] = k < NVDR_TRACE_LIB_COPIES || trace_module_ready(s, k - NVDR_TRACE_LIB_COPIES);
+    for (int k = 0; k < 2 * NVDR_TRACE_CANDIDATES && !rc; ++k)
+        if (hipEventCreate(&ev[k]) != hipSuccess) rc = -1;
+    for (int k = 0; k < NVDR_TRACE_CANDIDATES && !rc; ++k) {
+        if (!have[k]) continue;
+        if (hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream) != hipSuccess || hipEventRecord(ev[2 * k], stream) != hipSuccess ||
+            launch_trace_candidate(s, k, L, blocks, lds, stream) != hipSuccess || hipEventRecord(ev[2 * k + 1], stream) != hipSuccess)
+            rc = -1;
+    }
+    if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = -1;
+    int best = -1;
+    for (int k = 0; k < NVDR_TRACE_CANDIDATES && !rc; ++k) {
+        s.ms[k] = -1.0f;
+        if (have[k] && hipEventElapsedTime(&s.ms[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) s.ms[k] = -1.0f;
+        if (s.ms[k] >= 0.0f && (best < 0 || s.ms[k] < s.ms[best])) best = k;
+    }
+    for (int k = 0; k < 2 * NVDR_TRACE_CANDIDATES; ++k)
+        if (ev[k]) (void)hipEventDestroy(ev[k]);
+    if (rc || best < 0) {
+        (void)hipGetLastError();
+        s.decided = 1;                       // never retried: the default instance stays
+        fprintf(stderr, "[nvdr] timing the traversal-kernel instances failed; the default instance stays\n");
+        return 0;
+    }
+    if (s.ms[best] >= 0.15f) {
+        // a healthy process shows the instances within a few per cent of each other; the slow mode is >= 1.7x
+        s.choice = (s.ms[0] >= 0.0f && s.ms[0] <= 1.25f * s.ms[best]) ? 0 : best;
+        s.decided = 1;
+        if (s.choice != 0)
+            fprintf(stderr, "[nvdr] traversal kernel: instance %d selected for this process (ms per instance: %.3f %.3f %.3f %.3f %.3f)\n", s.choice,
+                    s.ms[0], s.ms[1], s.ms[2], s.ms[3], s.ms[4]);
+    } else if (++s.attempts >= 16) {
+        s.decided = 1;                       // only tiny launches in this process: nothing to gain
+    }
     return 0;
 }
 
-// diagnostics: the program counter each instantiation of the traversal kernel reported on its last launch
-// (out[0..2] = production copies, out[3] = counting build); synchronises `stream`
+// the production traversal launch
+static int launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t stream, const unsigned *ray_count, unsigned rays_per_pixel,
+                        bool may_calibrate)
+{
+    TraceSelect &s = trace_select(c);
+    const TraceLaunch L = make_trace_launch(c, ray_count, rays_per_pixel, nullptr);
+    const int k = c->trace_copy >= 0 ? c->trace_copy : s.choice;
+    hipError_t e = launch_trace_candidate(s, k, L, blocks, lds, stream);
+    NVDR_REQUIRE(e == hipSuccess, "env_shade: launching instance %d of the traversal kernel failed: %s", k, hipGetErrorString(e));
+    if (may_calibrate && c->trace_copy < 0 && s.enabled && !s.decided) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+        if (cap == hipStreamCaptureStatusNone) {
+            std::lock_guard<std::mutex> lock(s.mu);
+            if (!s.decided) return trace_calibrate(c, s, L, blocks, lds, stream);
+        }
+    }
+    return 0;
+}
+
+extern "C" int nvdr_ctx_set_trace_variant(nvdr_ctx *c, int instance)
+{
+    NVDR_REQUIRE(c && instance >= -1 && instance < NVDR_TRACE_CANDIDATES, "nvdr_ctx_set_trace_variant: instance must be -1 (the process's selection) or 0..%d",
+                 NVDR_TRACE_CANDIDATES - 1);
+    if (instance >= NVDR_TRACE_LIB_COPIES) {
+        NVDR_HIP_TRY(hipSetDevice(c->device));
+        NVDR_REQUIRE(trace_module_ready(trace_select(c), instance - NVDR_TRACE_LIB_COPIES),
+                     "nvdr_ctx_set_trace_variant: the stand-alone traversal code object (nvdr_trace_gfx950.hsaco) could not be loaded");
+    }
+    c->trace_copy = instance;
+    return 0;
+}
+
+extern "C" int nvdr_ctx_set_trace_flags(nvdr_ctx *c, unsigned flags)
+{
+    NVDR_REQUIRE(c && (flags & ~NVDR_TRACE_XCD_PARTITION) == 0u, "nvdr_ctx_set_trace_flags: unknown flag bits 0x%x", flags);
+    c->trace_flags = flags;
+    return 0;
+}
+
+extern "C" int nvdr_trace_select_get(int device, nvdr_trace_select_info *out)
+{
+    NVDR_REQUIRE(out && device >= 0 && device < NVDR_TRACE_MAX_DEVICES, "nvdr_trace_select_get: bad argument");
+    const TraceSelect &s = g_trace_select[device];
+    out->decided = s.decided; out->choice = s.choice; out->attempts = s.attempts; out->n_candidates = NVDR_TRACE_CANDIDATES;
+    for (int k = 0; k < 8; ++k) out->ms[k] = k < NVDR_TRACE_CANDIDATES ? s.ms[k] : -1.0f;
+    return 0;
+}
+
+// diagnostics: the program counter each instance of the traversal kernel reported on its last launch (out[0..2] = copies
+// in this library, out[3] = the stand-alone code object, whichever load ran last, out[4] = counting build); synchronises `stream`
 extern "C" int nvdr_ctx_trace_pcs(nvdr_ctx *c, unsigned long long *out_host, void *stream_)
 {
     NVDR_REQUIRE(c && out_host, "nvdr_ctx_trace_pcs: NULL argument");
     hipStream_t stream = (hipStream_t)stream_;
-    NVDR_HIP_TRY(hipMemcpyAsync(out_host, c->queues + 32 * 255, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, stream));
+    NVDR_HIP_TRY(hipMemcpyAsync(out_host, c->queues + 32 * 255, sizeof(unsigned long long) * 5, hipMemcpyDeviceToHost, stream));
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }
@@ -1318,17 +1286,17 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (!(reuse && n_chunks == 1)) env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
         // stage 2
-        if (!replay && NVDR_TRACE_QUEUES) NVDR_HIP_TRY(hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream));
+        if (!replay) NVDR_HIP_TRY(hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream));
         if (!replay) {
             if (c->debug & 1u) {
                 NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)cap * 2 * S, stream));
             } else if (a->counters) {
-                env_trace_kernel<true, 0><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live,
-                                                                                                     p.ray_count, 2 * S, c->vis, c->spill, a->counters, c->queues);
+                env_trace_kernel<true, 0><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(make_trace_launch(c, p.ray_count, 2 * S, a->counters));
                 bvh2_count_kernel<<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, p.ray_count,
                                                                                             2 * S, c->spill, a->counters + NVDR_COUNTERS_BVH2);
             } else {
-                launch_trace(c, (unsigned)tblocks, trace_lds, stream, p.ray_count, 2 * S);
+                // (the first forward launches of a process also time the kernel's instances: see launch_trace)
+                if ((r = launch_trace(c, (unsigned)tblocks, trace_lds, stream, p.ray_count, 2 * S, !backward && n_chunks == 1))) return r;
             }
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
@@ -1380,13 +1348,13 @@ extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const fl
     int r = reserve_stream(c, n_rays, n_rays, 1, stream);
     if (r) return r;
     c->stream_id = 0;
-    if (NVDR_TRACE_QUEUES) NVDR_HIP_TRY(hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream));
+    NVDR_HIP_TRY(hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream));
     pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts);
     int64_t tblocks = (int64_t)c->n_cus * 8;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
     if (tblocks > need) tblocks = need;
-    launch_trace(c, (unsigned)tblocks, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u);
+    if ((r = launch_trace(c, (unsigned)tblocks, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u, false))) return r;
     NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
     NVDR_LAUNCH_CHECK();
     return 0;

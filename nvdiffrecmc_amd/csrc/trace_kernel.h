@@ -1,0 +1,262 @@
+// trace_kernel.h -- stage 2 of env-shade: persistent-wavefront any-hit traversal of the ray stream.
+//
+// Replaces optixTrace inside __raygen__rg (render/optixutils/c_src/envsampling/kernel.cu:101-118).  The body lives in a
+// header because it is compiled TWICE: into libnvdr_hip.so (env_shade.hip: three placement copies + the counting build)
+// and into a stand-alone code object (trace_module.hip -> nvdr_trace_gfx950.hsaco) that the library can load any number
+// of times at run time.  Why: the per-process slow mode of this kernel (profiles/r02_slow_mode.md) belongs to ONE
+// INSTANCE of its code in that process -- the same source at another address runs at full speed -- so the launcher times
+// the instances it has on a real launch and keeps the fastest (env_shade.hip, "Which INSTANCE").
+#pragma once
+
+#include "bvh.h"
+
+#ifndef NVDR_REFILL_MIN
+#define NVDR_REFILL_MIN 16
+#endif
+#ifndef NVDR_LEAF_MIN
+#define NVDR_LEAF_MIN 8
+#endif
+// Chunks of NVDR_TRACE_QCHUNK rays are CLAIMED from device counters, one 128-B line each, instead of being dealt
+// round-robin: all waves then work inside a moving window of the list (neighbouring pixels -> the same subtrees stay in
+// L2) and a wave that drew cheap rays simply claims more.  One counter serialises at ~70 ns per claim (round 1: 1.4-2.5 ms
+// with a single counter); 64 of them see < 1 M claims/s each.
+// Measured (round 2, same GPU session, 8-view launch, 43 M live rays): static round-robin chunks 4.30 ms, 64 queues x 256
+// rays 3.75 ms (-13 %), 128 x 256 4.06 ms, 64 x 128 4.07 ms.
+#define NVDR_TRACE_QUEUES 64
+#ifndef NVDR_TRACE_QCHUNK
+#define NVDR_TRACE_QCHUNK 256
+#endif
+#ifndef NVDR_TRACE_ALIGN
+#define NVDR_TRACE_ALIGN 8
+#endif
+#ifndef NVDR_TRACE_PAD
+#define NVDR_TRACE_PAD 10
+#endif
+
+// flags of TraceLaunch: NVDR_TRACE_XCD_PARTITION (nvdr_hip.h)
+
+struct TraceLaunch {
+    BvhView bvh;
+    const float4 *rays;            // stream slot -> (dir.xyz, pdf sum)
+    const float4 *pix_origin;      // compacted pixel -> shadow-ray origin
+    const uint32_t *live;          // the stream slots to traverse
+    const unsigned *ray_count;     // their number (device counter)
+    unsigned rays_per_pixel;
+    unsigned flags;
+    uint8_t *vis;                  // stream slot -> 1 = unoccluded
+    int *spill;                    // HBM part of the traversal stacks (bvh.h)
+    unsigned long long *counters;  // counting build only (nvdr_hip.h NVDR_COUNTERS_*)
+    unsigned *queues;              // [256][32] chunk counters, zeroed before every launch; the last line holds diagnostics
+};
+
+// Two ways of dealing the chunks to the wavefronts, both through the same 64 counters:
+//   interleaved (flags = 0): wave w uses counter w % 64 and receives the chunks q, q + 64, q + 128 ...: the whole chip
+//       works inside ONE window of the list, every XCD's L2 ends up holding the same subtrees;
+//   XCD partitions (NVDR_TRACE_XCD_PARTITION): the list is cut into 8 contiguous parts, part p is served by the 8
+//       counters 8p .. 8p+7, and a wave starts on the part of the XCD it runs on (HW_REG_XCC_ID).  Neighbouring pixels
+//       visit neighbouring subtrees, so the 8 L2s (4 MB each, not coherent, not shared) now cache 8 DIFFERENT regions of
+//       a tree that does not fit one of them.  A wave whose part is used up steals from the next part (a plain load of
+//       the counter first: used-up parts cost no atomic), so the load balance of the claiming scheme is kept.
+// Visibility does not depend on the dealing (each ray is traversed exactly once by somebody).
+struct ChunkDealer {
+    unsigned *queues;
+    unsigned n_chunks, total;      // chunks of NVDR_TRACE_QCHUNK rays, rays
+    unsigned sub;                  // interleaved: this wave's counter; partitions: its counter inside a part
+    unsigned part, tried;          // partitions: current part, parts already found used up
+    bool partitioned;
+
+    // Every counter must be served by somebody.  Interleaved: chunk c sits on counter c % 64 and the launcher starts at least
+    // min(chunks, 2048) workgroups of 4 waves, so counter c % 64 < waves.  Partitions: a wave only ever claims from the
+    // counters `sub` of the parts, so all 8 values of sub must exist: >= 64 waves, otherwise the launch is dealt interleaved.
+    __device__ __forceinline__ void init(unsigned *q, unsigned total_, unsigned wid, unsigned n_waves, unsigned flags)
+    {
+        queues = q;
+        total = total_;
+        n_chunks = (total_ + NVDR_TRACE_QCHUNK - 1u) / NVDR_TRACE_QCHUNK;
+        partitioned = (flags & NVDR_TRACE_XCD_PARTITION) != 0u && n_waves >= 64u;
+        part = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;     // HW_REG_XCC_ID
+        tried = 0;
+        sub = partitioned ? ((wid >> 3) & 7u) : (wid % NVDR_TRACE_QUEUES);
+    }
+    // wave-uniform: claims the next chunk for the whole wave; false = the list is used up
+    __device__ __forceinline__ bool claim(int lane, unsigned &next, unsigned &end)
+    {
+        if (!partitioned) {
+            unsigned j = 0;
+            if (lane == 0) j = atomicAdd(queues + sub * 32u, 1u);
+            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+            const unsigned c = j * NVDR_TRACE_QUEUES + sub;
+            if (c >= n_chunks) return false;
+            next = c * NVDR_TRACE_QCHUNK;
+            end = min(next + NVDR_TRACE_QCHUNK, total);
+            return true;
+        }
+        while (tried < 8u) {
+            // part p covers the chunks [lo, hi); its counter `sub` hands out lo + sub, lo + sub + 8, ...
+            const unsigned lo = (unsigned)(((unsigned long long)part * n_chunks) >> 3);
+            const unsigned hi = (unsigned)(((unsigned long long)(part + 1u) * n_chunks) >> 3);
+            unsigned *q = queues + (part * 8u + sub) * 32u;
+            unsigned j = 0xffffffffu;
+            if (lane == 0) {
+                // a foreign part is looked at before it is claimed from: at the end of a launch every wave walks all parts
+                const bool look = tried > 0u;
+                const unsigned seen = look ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                if (!look || ((unsigned long long)seen * 8u + sub + lo < hi)) j = atomicAdd(q, 1u);
+            }
+            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+            const unsigned long long c = (unsigned long long)j * 8u + sub + lo;
+            if (j != 0xffffffffu && c < hi) {
+                next = (unsigned)c * NVDR_TRACE_QCHUNK;
+                end = min(next + NVDR_TRACE_QCHUNK, total);
+                return true;
+            }
+            part = (part + 1u) & 7u;
+            tried++;
+        }
+        return false;
+    }
+};
+
+// COUNT: the counting build (box / triangle tests, per-wave clocks).  COPY: identical code emitted at different addresses
+// and loop offsets (see the file header).
+template <bool COUNT, int COPY>
+__device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
+{
+    const BvhView &bvh = a.bvh;
+    const float4 *__restrict__ rays = a.rays;
+    const float4 *__restrict__ pix_origin = a.pix_origin;
+    const uint32_t *__restrict__ live = a.live;
+    uint8_t *__restrict__ vis = a.vis;
+    unsigned long long *counters = a.counters;
+    const unsigned rays_per_pixel = a.rays_per_pixel;
+    const TravStack stack = make_stack(smem, a.spill, bvh.stack_max, bvh.overflow);
+    const int lane = threadIdx.x & 63;
+    const unsigned total = *a.ray_count;
+    const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    ChunkDealer dealer;
+    dealer.init(a.queues, total, wid, gridDim.x * (blockDim.x >> 6), a.flags);
+    unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
+    bool more = total > 0;
+    unsigned n_box = 0, n_tri = 0, n_ray = 0;
+    const bool single = bvh.n_tris == 1;
+    const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
+    const unsigned long long c_begin = COUNT ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+
+    int ray = -1, cur = 0, sp = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+    GridRay g;
+    g.nx = g.ny = g.nz = g.ix = g.iy = g.iz = 0.0f;
+    g.px = g.py = g.pz = 0u;
+    // The three arms of an iteration -- refill, leaf step, node step -- are gated by WAVE-UNIFORM lane counts so that
+    // the two expensive rare ones are never issued for a handful of lanes:
+    //   refill : when >= NVDR_REFILL_MIN lanes are idle (or nobody can step) and the range still has rays;
+    //   leaf   : when >= NVDR_LEAF_MIN lanes are parked on a leaf, or no lane has a node to visit;
+    //   node   : whenever some lane has one.
+    // Measured (same GPU session, bob 512^2 x 64 spp): ungated 1.36 ms, (16, 8) 1.23-1.31 ms, one-arm-per-iteration
+    // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
+    // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
+    // The loop is placed at a fixed offset from a 256-byte boundary so that edits elsewhere cannot move it relative to the
+    // instruction-cache lines.
+    if (wid == 0 && lane == 0) {       // diagnostics: where this instance's code lives in this process (last counter line)
+        unsigned long long pc;
+        asm volatile("s_getpc_b64 %0" : "=s"(pc));
+        *(unsigned long long *)(a.queues + 32 * 255 + 2 * ((COPY & 3) + (COUNT ? 4 : 0))) = pc;
+    }
+    asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
+    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD + 24 * COPY));
+    while (true) {
+        const unsigned long long idle = __ballot(ray < 0);
+        const int n_idle = __popcll(idle);
+        if (n_idle >= NVDR_REFILL_MIN && next >= end && more) {
+            more = dealer.claim(lane, next, end);
+            if (!more) next = end = 0u;
+        }
+        if (next < end && n_idle >= NVDR_REFILL_MIN) {
+            // refill every idle lane from the wave's chunk (no atomics: the cursor is wave-uniform)
+            const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+            if (ray < 0 && take < end) {
+                const unsigned slot = live[take];
+                ray = (int)slot;
+                if (COUNT) n_ray++;
+                const float4 rd = rays[slot];
+                const float4 ro = pix_origin[slot / rays_per_pixel];
+                ox = ro.x; oy = ro.y; oz = ro.z;
+                dx = rd.x; dy = rd.y; dz = rd.z;
+                g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
+                cur = single ? ~0 : 0;
+                sp = 0;
+            }
+            next += (unsigned)n_idle;
+        } else if (n_idle == 64) {
+            if (!more) break;
+        }
+        const unsigned long long on_leaf = __ballot(ray >= 0 && cur < 0);
+        const int n_leaf = __popcll(on_leaf);
+        const int n_node = __popcll(__ballot(ray >= 0 && cur >= 0));
+        const int POP = NVDR_TRAV_DONE, HIT = NVDR_TRAV_DONE - 1, WAIT = NVDR_TRAV_DONE - 2;
+        const bool leaf_turn = n_leaf >= NVDR_LEAF_MIN || n_node == 0;   // parked leaves are tested in batches
+        const bool node_turn = n_node > 0;
+        int nxt = WAIT;                                 // next node / leaf, or one of the markers
+        if (leaf_turn && ray >= 0 && cur < 0) {
+            if (COUNT) n_tri++;
+            nxt = tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz) ? HIT : POP;
+        }
+        const int popv = stack.peek(sp);                // value a pop would return (unused when sp == 0)
+        if (node_turn && ray >= 0 && cur >= 0) {
+            // one step = the four grandchildren of `cur` (bvh.h "wide"): test all, continue with the nearest hit, push
+            // the other hits.  Any-hit needs no exact order; nearest-first just finds occluders sooner.
+            const uint4 *w4 = bvh.wide + 4 * (int64_t)cur;
+            const uint4 q0 = w4[0], q1 = w4[1], q2 = w4[2], q3 = w4[3];
+            float t0, t1, t2, t3;
+            const bool h0 = slot_hit(q0, g, NVDR_RAY_TMAX, t0), h1 = slot_hit(q1, g, NVDR_RAY_TMAX, t1);
+            const bool h2 = slot_hit(q2, g, NVDR_RAY_TMAX, t2), h3 = slot_hit(q3, g, NVDR_RAY_TMAX, t3);
+            const float BIG = 3.0e38f;
+            const float u0 = h0 ? t0 : BIG, u1 = h1 ? t1 : BIG, u2 = h2 ? t2 : BIG, u3 = h3 ? t3 : BIG;
+            const float um = fminf(fminf(u0, u1), fminf(u2, u3));
+            const int best = (h0 & (u0 == um)) ? 0 : (h1 & (u1 == um)) ? 1 : (h2 & (u2 == um)) ? 2 : 3;
+            const bool any = h0 | h1 | h2 | h3;
+            const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
+            if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
+            nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
+            // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs 0.67 ms)
+            if (h0 & (best != 0)) sp = stack.push(sp, c0);
+            if (h1 & (best != 1)) sp = stack.push(sp, c1);
+            if (h2 & (best != 2)) sp = stack.push(sp, c2);
+            if (h3 & (best != 3)) sp = stack.push(sp, c3);
+        }
+        bool finished = false;
+        if (nxt != WAIT) {
+            const bool pop = nxt == POP;
+            finished = (nxt == HIT) | (pop & (sp == 0));
+            sp -= (pop & (sp > 0)) ? 1 : 0;
+            cur = pop ? popv : nxt;
+        }
+        if (finished) {
+            vis[ray] = nxt == HIT ? 0 : 1;
+            ray = -1;
+        }
+    }
+    if (COUNT) {
+        for (int o = 32; o >= 1; o >>= 1) {
+            n_box += __shfl_xor(n_box, o);
+            n_tri += __shfl_xor(n_tri, o);
+            n_ray += __shfl_xor(n_ray, o);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], (unsigned long long)n_box);
+            atomicAdd(&counters[1], (unsigned long long)n_tri);
+            atomicAdd(&counters[2], (unsigned long long)n_ray);
+            // load balance: sum and maximum of the per-wave busy time (100 MHz ticks), wave count
+            const unsigned long long dt = wall_clock64() - t_begin;
+            atomicAdd(&counters[3], dt);
+            atomicMax(&counters[4], dt);
+            atomicAdd(&counters[5], 1ull);
+            // shader-clock cycles spent (sum over waves; / counters[3] = cycles per 100 MHz tick, i.e. the clock the waves
+            // actually ran at) and the set of XCDs that ran waves
+            atomicAdd(&counters[6], (unsigned long long)__builtin_readcyclecounter() - c_begin);
+            atomicOr(&counters[7], 1ull << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
+            counters[8 + 2 * wid] = t_begin;                 // per-wave begin / end ticks (wid < 8192); the XCD it ran on in the top byte
+            counters[9 + 2 * wid] = (t_begin + dt) | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 56);
+        }
+    }
+}

@@ -67,9 +67,24 @@ def compute_tangents(m):
     return _safe_normalize(tangents - (tangents * m['v_nrm']).sum(-1, keepdim=True) * m['v_nrm']).contiguous()
 
 
-def subdivide_mesh(m, levels):
+def subdivide_mesh(m, levels, cache_key=None):
     """Midpoint subdivision of positions AND texture coordinates (each in its own index space: every triangle splits into the
-    same four children in both, so the rows of t_pos_idx and t_tex_idx stay aligned), then fresh normals / tangents."""
+    same four children in both, so the rows of t_pos_idx and t_tex_idx stay aligned), then fresh normals / tangents.
+    With NVDR_MESH_CACHE=<dir> and a cache_key the result is kept on disk (fresh-process surveys: 4 s per process saved)."""
+    import os
+    cache = os.environ.get('NVDR_MESH_CACHE')
+    path = os.path.join(cache, 'nvdr_mesh_%s_s%d.pt' % (cache_key, levels)) if (cache and cache_key) else None
+    if path and os.path.exists(path):
+        return torch.load(path)
+    out = _subdivide_mesh(m, levels)
+    if path:
+        tmp = '%s.%d.tmp' % (path, os.getpid())
+        torch.save(out, tmp)
+        os.replace(tmp, path)
+    return out
+
+
+def _subdivide_mesh(m, levels):
     m = dict(m)
     m['v_pos'], m['t_pos_idx'] = subdivide(m['v_pos'], m['t_pos_idx'], levels)
     vt3 = torch.cat([m['v_tex'], torch.zeros_like(m['v_tex'][:, :1])], dim=-1)

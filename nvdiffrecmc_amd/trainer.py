@@ -86,7 +86,7 @@ class DirectLightingStep:
         self.force_eager = False          # set once at the END of a run to leave graph mode for good (p.grad then belongs to eager)
         mesh = sc.load_mesh(mesh_name, device='cpu')
         if subdiv:
-            mesh = sc.subdivide_mesh(mesh, subdiv)       # a DMTet-sized stand-in (positions and uvs subdivided, new normals / tangents)
+            mesh = sc.subdivide_mesh(mesh, subdiv, cache_key=mesh_name)       # a DMTet-sized stand-in (positions and uvs subdivided, new normals / tangents)
         self.mesh = {k: (v.to(self.dev) if isinstance(v, torch.Tensor) else v) for k, v in mesh.items()}
         self.ctx = ou.OptiXContext()
         ou.optix_build_bvh(self.ctx, self.mesh['v_pos'], self.mesh['t_pos_idx'], rebuild=1)

@@ -32,6 +32,13 @@
 #ifndef NVDR_TRACE_PAD
 #define NVDR_TRACE_PAD 10
 #endif
+// experiments (tools/build_variants.sh), see the node step below
+#ifndef NVDR_TRACE_UNORDERED
+#define NVDR_TRACE_UNORDERED 0
+#endif
+#ifndef NVDR_TRACE_PUSH_FAST
+#define NVDR_TRACE_PUSH_FAST 0
+#endif
 
 // flags of TraceLaunch: NVDR_TRACE_XCD_PARTITION (nvdr_hip.h)
 
@@ -210,19 +217,39 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             float t0, t1, t2, t3;
             const bool h0 = slot_hit(q0, g, NVDR_RAY_TMAX, t0), h1 = slot_hit(q1, g, NVDR_RAY_TMAX, t1);
             const bool h2 = slot_hit(q2, g, NVDR_RAY_TMAX, t2), h3 = slot_hit(q3, g, NVDR_RAY_TMAX, t3);
+            const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
+            if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
+            const bool any = h0 | h1 | h2 | h3;
+#if NVDR_TRACE_UNORDERED
+            // experiment: continue with the FIRST hit slot instead of the nearest (any-hit: the answer cannot change)
+            const int best = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+            (void)t0; (void)t1; (void)t2; (void)t3;
+#else
             const float BIG = 3.0e38f;
             const float u0 = h0 ? t0 : BIG, u1 = h1 ? t1 : BIG, u2 = h2 ? t2 : BIG, u3 = h3 ? t3 : BIG;
             const float um = fminf(fminf(u0, u1), fminf(u2, u3));
             const int best = (h0 & (u0 == um)) ? 0 : (h1 & (u1 == um)) ? 1 : (h2 & (u2 == um)) ? 2 : 3;
-            const bool any = h0 | h1 | h2 | h3;
-            const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
-            if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
+#endif
             nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
-            // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs 0.67 ms)
-            if (h0 & (best != 0)) sp = stack.push(sp, c0);
-            if (h1 & (best != 1)) sp = stack.push(sp, c1);
-            if (h2 & (best != 2)) sp = stack.push(sp, c2);
-            if (h3 & (best != 3)) sp = stack.push(sp, c3);
+            const bool p0 = h0 & (best != 0), p1 = h1 & (best != 1), p2 = h2 & (best != 2), p3 = h3 & (best != 3);
+#if NVDR_TRACE_PUSH_FAST
+            // experiment: a step pushes at most 3 entries; when NO lane of the wave can leave the LDS part of its stack in this
+            // step (wave-uniform test, one ballot) the pushes are plain conditional LDS writes without the nested spill /
+            // overflow branches of TravStack::push
+            if (__ballot(sp + 3 > NVDR_STACK_LDS) == 0ull) {
+                if (p0) { stack.lds[sp * 64] = c0; sp++; }
+                if (p1) { stack.lds[sp * 64] = c1; sp++; }
+                if (p2) { stack.lds[sp * 64] = c2; sp++; }
+                if (p3) { stack.lds[sp * 64] = c3; sp++; }
+            } else
+#endif
+            {
+                // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs 0.67 ms)
+                if (p0) sp = stack.push(sp, c0);
+                if (p1) sp = stack.push(sp, c1);
+                if (p2) sp = stack.push(sp, c2);
+                if (p3) sp = stack.push(sp, c3);
+            }
         }
         bool finished = false;
         if (nxt != WAIT) {

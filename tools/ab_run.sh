@@ -9,7 +9,7 @@ for f in ${AB_WITH_CURRENT:+/tmp/libnvdr_hip.so.orig} $B/variants/libnvdr_hip.so
   tag=${f##*.so.}
   cp $f $B/libnvdr_hip.so
   echo "== $tag"
-  timeout 180 python tools/stage_probe.py ${PROBE_CFGS:-8,6,6} 2>&1 | grep "fwd gen\|counting\|Error\|error"
+  timeout 180 python tools/stage_probe.py ${PROBE_CFGS:-8,6,6} 2>&1 | grep "workload\|fwd gen\|counting\|Error\|error"
   if [ "$AB_TEST" = "all" ] || { [ -n "$AB_TEST" ] && [ $first = 1 ]; }; then timeout 600 python -m pytest tests/test_gpu_env_shade.py tests/test_gpu_fullsize.py tests/test_gpu_bvh.py -q -m gpu -x 2>&1 | tail -2; fi
   first=0
 done

@@ -1,0 +1,69 @@
+"""A/B of library variants INSIDE ONE PROCESS: every variant of libnvdr_hip.so under csrc/build/variants/ (and the current build)
+is loaded side by side (separate dlopen handles, separate globals), gets its own DirectLightingStep, and the variants are timed
+in interleaved rounds -- fresh processes differ by +-8 % on identical code, which buries most kernel experiments.
+    PROBE_VIEWS=8 python tools/ab_inproc.py [rounds]"""
+import ctypes, glob, os, statistics, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nvdiffrecmc_amd import _lib, _build
+from nvdiffrecmc_amd.trainer import DirectLightingStep
+from nvdiffrecmc_amd import optixutils as ou, renderutils as ru
+
+res = int(os.environ.get('PROBE_RES', '512'))
+subdiv = int(os.environ.get('PROBE_SUBDIV', '0'))
+nviews = int(os.environ.get('PROBE_VIEWS', '8'))
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+base = _build.LIB
+paths = [('current', base)] + [(p.split('.so.')[-1], p) for p in sorted(glob.glob(os.path.join(_build.BUILD, 'variants', 'libnvdr_hip.so.*')))]
+only = os.environ.get('AB_ONLY')
+if only:
+    paths = [pp for pp in paths if pp[0] in only.split(',') or pp[0] == 'current']
+want_xcd = not only or 'xcdpart' in only.split(',')
+
+if want_xcd:
+    paths.append(('xcdpart', base))            # the current build with the per-XCD chunk dealing switched on
+steps = {}
+for tag, path in paths:
+    _lib._lib = None
+    _build.LIB = path                      # _lib.load() binds the signatures of whatever this points to
+    lib = _lib.load()
+    st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
+    assert st.ctx.cpp_wrapper.lib is lib
+    if tag == 'xcdpart':
+        st.ctx.set_trace_xcd_partition(True)
+    with torch.no_grad():
+        m = st.mask[..., None]
+        kd = (st.kd_tex[st.texel].view(st.nv, res, res, 3) * m).contiguous()
+        ks = (st.ks.view(1, 1, 1, 3) * m).contiguous()
+        nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)
+        ro = st.gb_pos + nrm * 0.001
+    steps[tag] = (st, kd, ks, nrm, ro)
+_build.LIB = base
+
+
+def run(tag, iters=5):
+    st, kd, ks, nrm, ro = steps[tag]
+    L = st.light
+    st.ctx.set_profiling(True)
+    for it in range(iters):
+        if it == 1:
+            st.ctx.set_profiling(True)
+        ou.optix_env_shade(st.ctx, st.mask, ro, st.gb_pos, nrm, st.view_pos, kd, ks, L.base.detach(), L._pdf, L.rows[:, 0], L.cols,
+                           n_samples_x=8, rnd_seed=it, shadow_scale=1.0)
+    torch.cuda.synchronize()
+    n, (g, t, sh) = st.ctx.stage_times(backward=False)
+    st.ctx.set_profiling(False)
+    return t
+
+
+for tag in steps:
+    run(tag, 3)                            # warm every variant
+times = {tag: [] for tag in steps}
+for r in range(rounds):
+    for tag in steps:
+        times[tag].append(run(tag))
+ref = statistics.median(times['current'])
+print('traversal kernel, %d views, %d rounds interleaved in one process (ms): median [min .. max], vs current' % (nviews, rounds))
+for tag in steps:
+    v = times[tag]
+    print('  %-10s %.3f [%.3f .. %.3f]  %+.1f %%' % (tag, statistics.median(v), min(v), max(v), 100.0 * (statistics.median(v) / ref - 1.0)))

@@ -77,6 +77,10 @@ int nvdr_ctx_trace_pcs(nvdr_ctx *ctx, unsigned long long *out_host5, void *strea
  * of a tree that does not fit one of them) with stealing.  Results are identical.  Default: NVDR_TRACE_XCD read when the
  * context is created. */
 #define NVDR_TRACE_XCD_PARTITION 1u
+/* experiments (profiles/r02_slow_mode.md): reset the kernel's chunk counters with hipMemsetAsync instead of the 64-thread
+ * kernel -- inside the stage-2 timing bracket as rounds 1-2 did, or before it */
+#define NVDR_TRACE_MEMSET_INSIDE 2u
+#define NVDR_TRACE_MEMSET_BEFORE 4u
 int nvdr_ctx_set_trace_flags(nvdr_ctx *ctx, unsigned flags);
 
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]

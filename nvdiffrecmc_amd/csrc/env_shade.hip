@@ -932,6 +932,17 @@ static hipError_t launch_trace_candidate(TraceSelect &s, int k, const TraceLaunc
     }
 }
 
+// The 64 chunk counters of the traversal kernel must read zero when it starts.  A 64-thread kernel on the launch stream does
+// that; NVDR_TRACE_MEMSET_* (nvdr_ctx_set_trace_flags, experiments) use hipMemsetAsync of the whole 32 KB instead.
+__global__ void zero_queues_kernel(unsigned *queues) { queues[threadIdx.x * 32u] = 0u; }
+
+static hipError_t reset_queues(const nvdr_ctx *c, hipStream_t stream, bool use_memset)
+{
+    if (use_memset) return hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream);
+    zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
+    return hipGetLastError();
+}
+
 static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_count, unsigned rays_per_pixel, unsigned long long *counters)
 {
     TraceLaunch L;
@@ -955,7 +966,7 @@ static int trace_calibrate(nvdr_ctx *c, TraceSelect &s, const TraceLaunch &L, un
         if (hipEventCreate(&ev[k]) != hipSuccess) rc = -1;
     for (int k = 0; k < NVDR_TRACE_CANDIDATES && !rc; ++k) {
         if (!have[k]) continue;
-        if (hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream) != hipSuccess || hipEventRecord(ev[2 * k], stream) != hipSuccess ||
+        if (reset_queues(c, stream, (c->trace_flags & NVDR_TRACE_MEMSET_INSIDE) != 0u) != hipSuccess || hipEventRecord(ev[2 * k], stream) != hipSuccess ||
             launch_trace_candidate(s, k, L, blocks, lds, stream) != hipSuccess || hipEventRecord(ev[2 * k + 1], stream) != hipSuccess)
             rc = -1;
     }
@@ -1022,7 +1033,8 @@ extern "C" int nvdr_ctx_set_trace_variant(nvdr_ctx *c, int instance)
 
 extern "C" int nvdr_ctx_set_trace_flags(nvdr_ctx *c, unsigned flags)
 {
-    NVDR_REQUIRE(c && (flags & ~NVDR_TRACE_XCD_PARTITION) == 0u, "nvdr_ctx_set_trace_flags: unknown flag bits 0x%x", flags);
+    NVDR_REQUIRE(c && (flags & ~(NVDR_TRACE_XCD_PARTITION | NVDR_TRACE_MEMSET_INSIDE | NVDR_TRACE_MEMSET_BEFORE)) == 0u,
+                 "nvdr_ctx_set_trace_flags: unknown flag bits 0x%x", flags);
     c->trace_flags = flags;
     return 0;
 }
@@ -1284,9 +1296,11 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         // stage 1 (skipped on the host when the forward's stream is known to be whole: one chunk covers the launch;
         // otherwise the kernel itself decides from the device-side pixel count)
         if (!(reuse && n_chunks == 1)) env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
+        // (experiment switch: the counters reset by hipMemsetAsync BEFORE the stage-2 bracket, i.e. timed with stage 1)
+        if (!replay && (c->trace_flags & NVDR_TRACE_MEMSET_BEFORE)) NVDR_HIP_TRY(reset_queues(c, stream, true));
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
         // stage 2
-        if (!replay) NVDR_HIP_TRY(hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream));
+        if (!replay && !(c->trace_flags & NVDR_TRACE_MEMSET_BEFORE)) NVDR_HIP_TRY(reset_queues(c, stream, (c->trace_flags & NVDR_TRACE_MEMSET_INSIDE) != 0u));
         if (!replay) {
             if (c->debug & 1u) {
                 NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)cap * 2 * S, stream));
@@ -1348,7 +1362,7 @@ extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const fl
     int r = reserve_stream(c, n_rays, n_rays, 1, stream);
     if (r) return r;
     c->stream_id = 0;
-    NVDR_HIP_TRY(hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream));
+    NVDR_HIP_TRY(reset_queues(c, stream, false));
     pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts);
     int64_t tblocks = (int64_t)c->n_cus * 8;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;

@@ -34,7 +34,7 @@
 #endif
 // experiments (tools/build_variants.sh), see the node step below
 #ifndef NVDR_TRACE_UNORDERED
-#define NVDR_TRACE_UNORDERED 0
+#define NVDR_TRACE_UNORDERED 1
 #endif
 #ifndef NVDR_TRACE_PUSH_FAST
 #define NVDR_TRACE_PUSH_FAST 0

@@ -78,6 +78,11 @@ class OptiXContext:
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_trace_flags(w.handle, _lib.TRACE_XCD_PARTITION if on else 0), 'nvdr_ctx_set_trace_flags')
 
+    def set_trace_flags(self, flags):
+        """Raw NVDR_TRACE_* flag word (include/nvdr_hip.h); experiments."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_ctx_set_trace_flags(w.handle, int(flags)), 'nvdr_ctx_set_trace_flags')
+
     def trace_selection(self):
         """Which instance of the traversal kernel this process launches on this context's device and the timings that decided
         it: dict(decided, choice, attempts, ms=[per instance; None = unavailable])."""

@@ -54,33 +54,11 @@ int nvdr_ctx_check(nvdr_ctx *ctx, void *stream);
  * exceed the chunk is processed chunk by chunk with identical results.  The reference needs no scratch (one thread per
  * pixel keeps its rays in registers); a worst-case allocation would be N*H*W*2S*25 B (16 GB for 8 x 800^2 x 64 spp). */
 int nvdr_ctx_set_stream_budget(nvdr_ctx *ctx, int64_t bytes);
-/* Instances of the shadow-ray traversal kernel.  In a fraction of fresh processes ONE instance of the kernel's code runs
- * 2-20x slower for the life of the process while the same code at another address is unaffected
- * (profiles/r02_slow_mode.md).  The library holds five instances -- 0, 1, 2: copies inside libnvdr_hip.so; 3, 4: loads of
- * the stand-alone code object nvdr_trace_gfx950.hsaco -- and the first sufficiently long forward launch of a process times
- * them once on its own rays and keeps the fastest (NVDR_TRACE_SELECT=off|auto|0..4).  nvdr_ctx_set_trace_variant pins one
- * context to an instance (-1: back to the process's selection); nvdr_trace_select_get reports the selection of a device;
- * nvdr_ctx_trace_pcs the program counters the instances ran at (out[0..2] copies, out[3] code object, out[4] counting build).
- * The reference has no counterpart (optixLaunch of one PTX module, optix_wrapper.cpp:236-262). */
-typedef struct nvdr_trace_select_info {
-    int decided;        /* 1: `choice` is final for this process */
-    int choice;         /* instance the process launches */
-    int attempts;       /* calibrations that were too short (< 0.15 ms) to decide */
-    int n_candidates;
-    float ms[8];        /* time of every instance in the deciding (or last) calibration; < 0: instance unavailable */
-} nvdr_trace_select_info;
-int nvdr_ctx_set_trace_variant(nvdr_ctx *ctx, int instance);
-int nvdr_trace_select_get(int device, nvdr_trace_select_info *out);
-int nvdr_ctx_trace_pcs(nvdr_ctx *ctx, unsigned long long *out_host5, void *stream);
-/* How the traversal kernel deals the chunks of the ray list to its wavefronts: 0 = interleaved over the whole chip,
- * NVDR_TRACE_XCD_PARTITION = one contiguous eighth of the list per XCD (each of the 8 L2s then caches a different region
- * of a tree that does not fit one of them) with stealing.  Results are identical.  Default: NVDR_TRACE_XCD read when the
- * context is created. */
+/* How the shadow-ray traversal kernel deals the chunks of the ray list to its wavefronts: 0 = interleaved over the whole
+ * chip (default), NVDR_TRACE_XCD_PARTITION = one contiguous eighth of the list per XCD with stealing (each of the 8 L2s
+ * then caches a different region of a tree that does not fit one of them).  Results are identical.  NVDR_TRACE_XCD=1 in
+ * the environment sets it when a context is created.  No reference counterpart (optixLaunch, optix_wrapper.cpp:236-262). */
 #define NVDR_TRACE_XCD_PARTITION 1u
-/* experiments (profiles/r02_slow_mode.md): reset the kernel's chunk counters with hipMemsetAsync instead of the 64-thread
- * kernel -- inside the stage-2 timing bracket as rounds 1-2 did, or before it */
-#define NVDR_TRACE_MEMSET_INSIDE 2u
-#define NVDR_TRACE_MEMSET_BEFORE 4u
 int nvdr_ctx_set_trace_flags(nvdr_ctx *ctx, unsigned flags);
 
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]

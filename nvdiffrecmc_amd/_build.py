@@ -15,9 +15,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'nvdiffrecmc_amd', 'csrc')
 BUILD = os.path.join(CSRC, 'build')
 LIB = os.path.join(BUILD, 'libnvdr_hip.so')
-# the shadow-ray traversal kernel once more, as a stand-alone code object the library loads at run time (csrc/trace_module.hip)
-TRACE_MODULE_SRC = 'trace_module.hip'
-TRACE_MODULE = os.path.join(BUILD, 'nvdr_trace_gfx950.hsaco')
 ARCH = 'gfx950'
 
 SOURCES = [
@@ -69,19 +66,6 @@ def _compile(src, force, hdr_mtime, verbose):
     return obj, True
 
 
-def _compile_trace_module(force, hdr_mtime, verbose):
-    sp = os.path.join(CSRC, TRACE_MODULE_SRC)
-    if (not force and os.path.exists(TRACE_MODULE) and os.path.getmtime(TRACE_MODULE) > os.path.getmtime(sp)
-            and os.path.getmtime(TRACE_MODULE) > hdr_mtime):
-        return
-    cmd = [_hipcc()] + [f for f in FLAGS if f != '-fPIC'] + ['--genco', sp, '-o', TRACE_MODULE]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError('hipcc --genco failed for %s:\n%s\n%s' % (TRACE_MODULE_SRC, r.stdout, r.stderr))
-
-
 def build(force=False, verbose=False):
     """Compile every HIP translation unit for gfx950 and link libnvdr_hip.so.  Returns its path."""
     os.makedirs(BUILD, exist_ok=True)
@@ -90,10 +74,8 @@ def build(force=False, verbose=False):
     missing = [s for s in SOURCES if s not in srcs]
     if missing:
         raise RuntimeError('missing HIP sources: %s' % missing)
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs) + 1)) as ex:
-        mod = ex.submit(_compile_trace_module, force, hdr_mtime, verbose)
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force, hdr_mtime, verbose), srcs))
-        mod.result()
     objs = [o for o, _ in res]
     if force or any(c for _, c in res) or not os.path.exists(LIB):
         cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', LIB]

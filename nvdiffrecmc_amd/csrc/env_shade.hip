@@ -26,9 +26,6 @@
 // The sampling math mirrors the evaluation order and the fp32/fp64 promotions of the reference
 // source and uses include/nvdr_detmath.h for sin/cos/acos/atan2, which makes every
 // discrete decision (texel, lobe, visibility) bit-identical to the CPU oracle.
-#include <dlfcn.h>
-#include <mutex>
-
 #include "trace_kernel.h"
 #include "bsdf_device.h"
 
@@ -513,14 +510,13 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
 }
 
 // ---------------------------------------------------------------------------------------------
-// stage 2: persistent-wavefront any-hit traversal of the ray stream -- the body is in trace_kernel.h (it is also compiled
-// into a stand-alone code object, trace_module.hip).  Three placement copies + the counting build live in this library.
+// stage 2: persistent-wavefront any-hit traversal of the ray stream -- trace_kernel.h
 
-template <bool COUNT, int COPY>
-__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, 8) env_trace_kernel(TraceLaunch a)
+template <bool COUNT>
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_kernel(TraceLaunch a)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    env_trace_body<COUNT, COPY>(a, smem);
+    env_trace_body<COUNT>(a, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -845,103 +841,10 @@ static int check_gb(const nvdr_tensor &t, int64_t N, int64_t H, int64_t W, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// Which INSTANCE of the traversal kernel this process launches.
-//
-// In roughly one fresh process out of seven the shadow-ray kernel runs 1.75x (bob, everything in L2) to 12-20x (684 k
-// triangles) slower for the whole life of the process, and the condition belongs to ONE instance of the kernel's code in
-// that process: the counting build of the same source, in the same process on the same rays, is not affected
-// (profiles/r02_slow_mode.md).  The library therefore holds several instances of the same code -- three copies at different
-// offsets of this code object (candidates 0-2) and a stand-alone code object, nvdr_trace_gfx950.hsaco, that is loaded up
-// to NVDR_TRACE_MODULES times into memory of its own (candidates 3, 4) -- and the first forward launch that is long
-// enough to tell (>= 0.15 ms) times all of them once on its own rays (the kernel is idempotent) and keeps the fastest
-// for the process: one extra host synchronisation in the life of a process, never inside a stream capture.
-// NVDR_TRACE_SELECT = off | auto (default) | 0..4 (force a candidate); nvdr_ctx_set_trace_variant overrides per context.
-#define NVDR_TRACE_LIB_COPIES 3
-#define NVDR_TRACE_MODULES 2
-#define NVDR_TRACE_CANDIDATES (NVDR_TRACE_LIB_COPIES + NVDR_TRACE_MODULES)
-#define NVDR_TRACE_MAX_DEVICES 16
+// the production traversal launch
 
-struct TraceSelect {
-    std::mutex mu;
-    bool env_read = false;
-    bool enabled = true;
-    int forced = -1;
-    int decided = 0;                 // 1: `choice` is final for this process
-    int choice = 0;
-    int attempts = 0;                // calibrations that were too short to decide
-    float ms[NVDR_TRACE_CANDIDATES] = {0, 0, 0, 0, 0};   // the deciding (or last) calibration; < 0 = candidate unavailable
-    hipModule_t mod[NVDR_TRACE_MODULES] = {};
-    hipFunction_t fn[NVDR_TRACE_MODULES] = {};
-    int mod_state[NVDR_TRACE_MODULES] = {0, 0};          // 0 not tried, 1 loaded, -1 failed
-};
-static TraceSelect g_trace_select[NVDR_TRACE_MAX_DEVICES];
-
-static TraceSelect &trace_select(const nvdr_ctx *c)
-{
-    TraceSelect &s = g_trace_select[(c->device >= 0 && c->device < NVDR_TRACE_MAX_DEVICES) ? c->device : 0];
-    if (!s.env_read) {
-        s.env_read = true;
-        if (const char *e = getenv("NVDR_TRACE_SELECT")) {
-            if (!strcmp(e, "off")) s.enabled = false;
-            else if (e[0] >= '0' && e[0] < '0' + NVDR_TRACE_CANDIDATES && !e[1]) { s.forced = e[0] - '0'; s.choice = s.forced; s.decided = 1; }
-            if (!s.enabled || s.forced >= 0) fprintf(stderr, "[nvdr] NVDR_TRACE_SELECT=%s\n", e);
-        }
-    }
-    return s;
-}
-
-// the stand-alone code object lies next to this library
-static std::string trace_module_path()
-{
-    Dl_info info;
-    if (!dladdr((const void *)&nvdr_last_error, &info) || !info.dli_fname) return std::string();
-    std::string p = info.dli_fname;
-    const size_t k = p.rfind('/');
-    return (k == std::string::npos ? std::string() : p.substr(0, k + 1)) + "nvdr_trace_gfx950.hsaco";
-}
-
-static bool trace_module_ready(TraceSelect &s, int m)
-{
-    if (s.mod_state[m] == 0) {
-        const std::string path = trace_module_path();
-        hipError_t e = path.empty() ? hipErrorFileNotFound : hipModuleLoad(&s.mod[m], path.c_str());
-        if (e == hipSuccess) e = hipModuleGetFunction(&s.fn[m], s.mod[m], "nvdr_trace_module_kernel");
-        s.mod_state[m] = e == hipSuccess ? 1 : -1;
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            fprintf(stderr, "[nvdr] traversal code object %s not loaded (%s): that instance is left out of the selection\n", path.c_str(),
-                    hipGetErrorString(e));
-        }
-    }
-    return s.mod_state[m] == 1;
-}
-
-static hipError_t launch_trace_candidate(TraceSelect &s, int k, const TraceLaunch &L, unsigned blocks, size_t lds, hipStream_t stream)
-{
-    switch (k) {
-    case 0: env_trace_kernel<false, 0><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(L); return hipGetLastError();
-    case 1: env_trace_kernel<false, 1><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(L); return hipGetLastError();
-    case 2: env_trace_kernel<false, 2><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(L); return hipGetLastError();
-    default: {
-        const int m = k - NVDR_TRACE_LIB_COPIES;
-        if (m < 0 || m >= NVDR_TRACE_MODULES || !trace_module_ready(s, m)) return hipErrorInvalidValue;
-        TraceLaunch tmp = L;
-        void *args[] = {&tmp};
-        return hipModuleLaunchKernel(s.fn[m], blocks, 1, 1, NVDR_QUERY_BLOCK, 1, 1, (unsigned)lds, stream, args, nullptr);
-    }
-    }
-}
-
-// The 64 chunk counters of the traversal kernel must read zero when it starts.  A 64-thread kernel on the launch stream does
-// that; NVDR_TRACE_MEMSET_* (nvdr_ctx_set_trace_flags, experiments) use hipMemsetAsync of the whole 32 KB instead.
+// The 64 chunk counters of the traversal kernel must read zero when it starts: a 64-thread kernel on the launch stream.
 __global__ void zero_queues_kernel(unsigned *queues) { queues[threadIdx.x * 32u] = 0u; }
-
-static hipError_t reset_queues(const nvdr_ctx *c, hipStream_t stream, bool use_memset)
-{
-    if (use_memset) return hipMemsetAsync(c->queues, 0, sizeof(unsigned) * 32 * 256, stream);
-    zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
-    return hipGetLastError();
-}
 
 static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_count, unsigned rays_per_pixel, unsigned long long *counters)
 {
@@ -953,109 +856,20 @@ static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_coun
     return L;
 }
 
-// Times every available instance once on the rays of this launch and fixes the process's choice when the launch was long
-// enough to tell.  The regular launch has already run (warm caches, valid results); every instance rewrites the same bits.
-static int trace_calibrate(nvdr_ctx *c, TraceSelect &s, const TraceLaunch &L, unsigned blocks, size_t lds, hipStream_t stream)
+static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t stream, const unsigned *ray_count, unsigned rays_per_pixel,
+                         unsigned long long *counters)
 {
-    hipEvent_t ev[2 * NVDR_TRACE_CANDIDATES] = {};
-    bool have[NVDR_TRACE_CANDIDATES];
-    int rc = 0;
-    for (int k = 0; k < NVDR_TRACE_CANDIDATES; ++k)
-        have[k] = k < NVDR_TRACE_LIB_COPIES || trace_module_ready(s, k - NVDR_TRACE_LIB_COPIES);
-    for (int k = 0; k < 2 * NVDR_TRACE_CANDIDATES && !rc; ++k)
-        if (hipEventCreate(&ev[k]) != hipSuccess) rc = -1;
-    for (int k = 0; k < NVDR_TRACE_CANDIDATES && !rc; ++k) {
-        if (!have[k]) continue;
-        if (reset_queues(c, stream, (c->trace_flags & NVDR_TRACE_MEMSET_INSIDE) != 0u) != hipSuccess || hipEventRecord(ev[2 * k], stream) != hipSuccess ||
-            launch_trace_candidate(s, k, L, blocks, lds, stream) != hipSuccess || hipEventRecord(ev[2 * k + 1], stream) != hipSuccess)
-            rc = -1;
-    }
-    if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = -1;
-    int best = -1;
-    for (int k = 0; k < NVDR_TRACE_CANDIDATES && !rc; ++k) {
-        s.ms[k] = -1.0f;
-        if (have[k] && hipEventElapsedTime(&s.ms[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) s.ms[k] = -1.0f;
-        if (s.ms[k] >= 0.0f && (best < 0 || s.ms[k] < s.ms[best])) best = k;
-    }
-    for (int k = 0; k < 2 * NVDR_TRACE_CANDIDATES; ++k)
-        if (ev[k]) (void)hipEventDestroy(ev[k]);
-    if (rc || best < 0) {
-        (void)hipGetLastError();
-        s.decided = 1;                       // never retried: the default instance stays
-        fprintf(stderr, "[nvdr] timing the traversal-kernel instances failed; the default instance stays\n");
-        return 0;
-    }
-    if (s.ms[best] >= 0.15f) {
-        // a healthy process shows the instances within a few per cent of each other; the slow mode is >= 1.7x
-        s.choice = (s.ms[0] >= 0.0f && s.ms[0] <= 1.25f * s.ms[best]) ? 0 : best;
-        s.decided = 1;
-        if (s.choice != 0)
-            fprintf(stderr, "[nvdr] traversal kernel: instance %d selected for this process (ms per instance: %.3f %.3f %.3f %.3f %.3f)\n", s.choice,
-                    s.ms[0], s.ms[1], s.ms[2], s.ms[3], s.ms[4]);
-    } else if (++s.attempts >= 16) {
-        s.decided = 1;                       // only tiny launches in this process: nothing to gain
-    }
-    return 0;
-}
-
-// the production traversal launch
-static int launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t stream, const unsigned *ray_count, unsigned rays_per_pixel,
-                        bool may_calibrate)
-{
-    TraceSelect &s = trace_select(c);
-    const TraceLaunch L = make_trace_launch(c, ray_count, rays_per_pixel, nullptr);
-    const int k = c->trace_copy >= 0 ? c->trace_copy : s.choice;
-    hipError_t e = launch_trace_candidate(s, k, L, blocks, lds, stream);
-    NVDR_REQUIRE(e == hipSuccess, "env_shade: launching instance %d of the traversal kernel failed: %s", k, hipGetErrorString(e));
-    if (may_calibrate && c->trace_copy < 0 && s.enabled && !s.decided) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
-        if (cap == hipStreamCaptureStatusNone) {
-            std::lock_guard<std::mutex> lock(s.mu);
-            if (!s.decided) return trace_calibrate(c, s, L, blocks, lds, stream);
-        }
-    }
-    return 0;
-}
-
-extern "C" int nvdr_ctx_set_trace_variant(nvdr_ctx *c, int instance)
-{
-    NVDR_REQUIRE(c && instance >= -1 && instance < NVDR_TRACE_CANDIDATES, "nvdr_ctx_set_trace_variant: instance must be -1 (the process's selection) or 0..%d",
-                 NVDR_TRACE_CANDIDATES - 1);
-    if (instance >= NVDR_TRACE_LIB_COPIES) {
-        NVDR_HIP_TRY(hipSetDevice(c->device));
-        NVDR_REQUIRE(trace_module_ready(trace_select(c), instance - NVDR_TRACE_LIB_COPIES),
-                     "nvdr_ctx_set_trace_variant: the stand-alone traversal code object (nvdr_trace_gfx950.hsaco) could not be loaded");
-    }
-    c->trace_copy = instance;
-    return 0;
+    zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
+    if (counters)
+        env_trace_kernel<true><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
+    else
+        env_trace_kernel<false><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
 }
 
 extern "C" int nvdr_ctx_set_trace_flags(nvdr_ctx *c, unsigned flags)
 {
-    NVDR_REQUIRE(c && (flags & ~(NVDR_TRACE_XCD_PARTITION | NVDR_TRACE_MEMSET_INSIDE | NVDR_TRACE_MEMSET_BEFORE)) == 0u,
-                 "nvdr_ctx_set_trace_flags: unknown flag bits 0x%x", flags);
+    NVDR_REQUIRE(c && (flags & ~NVDR_TRACE_XCD_PARTITION) == 0u, "nvdr_ctx_set_trace_flags: unknown flag bits 0x%x", flags);
     c->trace_flags = flags;
-    return 0;
-}
-
-extern "C" int nvdr_trace_select_get(int device, nvdr_trace_select_info *out)
-{
-    NVDR_REQUIRE(out && device >= 0 && device < NVDR_TRACE_MAX_DEVICES, "nvdr_trace_select_get: bad argument");
-    const TraceSelect &s = g_trace_select[device];
-    out->decided = s.decided; out->choice = s.choice; out->attempts = s.attempts; out->n_candidates = NVDR_TRACE_CANDIDATES;
-    for (int k = 0; k < 8; ++k) out->ms[k] = k < NVDR_TRACE_CANDIDATES ? s.ms[k] : -1.0f;
-    return 0;
-}
-
-// diagnostics: the program counter each instance of the traversal kernel reported on its last launch (out[0..2] = copies
-// in this library, out[3] = the stand-alone code object, whichever load ran last, out[4] = counting build); synchronises `stream`
-extern "C" int nvdr_ctx_trace_pcs(nvdr_ctx *c, unsigned long long *out_host, void *stream_)
-{
-    NVDR_REQUIRE(c && out_host, "nvdr_ctx_trace_pcs: NULL argument");
-    hipStream_t stream = (hipStream_t)stream_;
-    NVDR_HIP_TRY(hipMemcpyAsync(out_host, c->queues + 32 * 255, sizeof(unsigned long long) * 5, hipMemcpyDeviceToHost, stream));
-    NVDR_HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -1296,21 +1110,16 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         // stage 1 (skipped on the host when the forward's stream is known to be whole: one chunk covers the launch;
         // otherwise the kernel itself decides from the device-side pixel count)
         if (!(reuse && n_chunks == 1)) env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
-        // (experiment switch: the counters reset by hipMemsetAsync BEFORE the stage-2 bracket, i.e. timed with stage 1)
-        if (!replay && (c->trace_flags & NVDR_TRACE_MEMSET_BEFORE)) NVDR_HIP_TRY(reset_queues(c, stream, true));
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
         // stage 2
-        if (!replay && !(c->trace_flags & NVDR_TRACE_MEMSET_BEFORE)) NVDR_HIP_TRY(reset_queues(c, stream, (c->trace_flags & NVDR_TRACE_MEMSET_INSIDE) != 0u));
         if (!replay) {
             if (c->debug & 1u) {
                 NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)cap * 2 * S, stream));
-            } else if (a->counters) {
-                env_trace_kernel<true, 0><<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(make_trace_launch(c, p.ray_count, 2 * S, a->counters));
-                bvh2_count_kernel<<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, p.ray_count,
-                                                                                            2 * S, c->spill, a->counters + NVDR_COUNTERS_BVH2);
             } else {
-                // (the first forward launches of a process also time the kernel's instances: see launch_trace)
-                if ((r = launch_trace(c, (unsigned)tblocks, trace_lds, stream, p.ray_count, 2 * S, !backward && n_chunks == 1))) return r;
+                launch_trace(c, (unsigned)tblocks, trace_lds, stream, p.ray_count, 2 * S, a->counters);
+                if (a->counters)
+                    bvh2_count_kernel<<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, p.ray_count,
+                                                                                                2 * S, c->spill, a->counters + NVDR_COUNTERS_BVH2);
             }
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
@@ -1362,13 +1171,12 @@ extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const fl
     int r = reserve_stream(c, n_rays, n_rays, 1, stream);
     if (r) return r;
     c->stream_id = 0;
-    NVDR_HIP_TRY(reset_queues(c, stream, false));
     pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts);
     int64_t tblocks = (int64_t)c->n_cus * 8;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
     if (tblocks > need) tblocks = need;
-    if ((r = launch_trace(c, (unsigned)tblocks, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u, false))) return r;
+    launch_trace(c, (unsigned)tblocks, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u, nullptr);
     NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
     NVDR_LAUNCH_CHECK();
     return 0;

@@ -1,11 +1,6 @@
 // trace_kernel.h -- stage 2 of env-shade: persistent-wavefront any-hit traversal of the ray stream.
 //
-// Replaces optixTrace inside __raygen__rg (render/optixutils/c_src/envsampling/kernel.cu:101-118).  The body lives in a
-// header because it is compiled TWICE: into libnvdr_hip.so (env_shade.hip: three placement copies + the counting build)
-// and into a stand-alone code object (trace_module.hip -> nvdr_trace_gfx950.hsaco) that the library can load any number
-// of times at run time.  Why: the per-process slow mode of this kernel (profiles/r02_slow_mode.md) belongs to ONE
-// INSTANCE of its code in that process -- the same source at another address runs at full speed -- so the launcher times
-// the instances it has on a real launch and keeps the fastest (env_shade.hip, "Which INSTANCE").
+// Replaces optixTrace inside __raygen__rg (render/optixutils/c_src/envsampling/kernel.cu:101-118).
 #pragma once
 
 #include "bvh.h"
@@ -32,12 +27,15 @@
 #ifndef NVDR_TRACE_PAD
 #define NVDR_TRACE_PAD 10
 #endif
-// experiments (tools/build_variants.sh), see the node step below
-#ifndef NVDR_TRACE_UNORDERED
-#define NVDR_TRACE_UNORDERED 1
+#ifndef NVDR_TRACE_OCC
+#define NVDR_TRACE_OCC 8       // waves per SIMD the kernel is compiled for (= resident workgroups per CU of the persistent grid)
 #endif
-#ifndef NVDR_TRACE_PUSH_FAST
-#define NVDR_TRACE_PUSH_FAST 0
+// experiment switches of the node step (tools/build_variants.sh + tools/ab_inproc.py), see below
+#ifndef NVDR_TRACE_PICK
+#define NVDR_TRACE_PICK 0      // which hit slot the walk continues with: 0 first, 1 first internal node, 2 first leaf
+#endif
+#ifndef NVDR_TRACE_LAZY_PEEK
+#define NVDR_TRACE_LAZY_PEEK 0 // 1: the stack top is read only by lanes that pop
 #endif
 
 // flags of TraceLaunch: NVDR_TRACE_XCD_PARTITION (nvdr_hip.h)
@@ -124,9 +122,8 @@ struct ChunkDealer {
     }
 };
 
-// COUNT: the counting build (box / triangle tests, per-wave clocks).  COPY: identical code emitted at different addresses
-// and loop offsets (see the file header).
-template <bool COUNT, int COPY>
+// COUNT: the counting build (box / triangle tests, per-wave clocks)
+template <bool COUNT>
 __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
 {
     const BvhView &bvh = a.bvh;
@@ -164,13 +161,8 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
     // The loop is placed at a fixed offset from a 256-byte boundary so that edits elsewhere cannot move it relative to the
     // instruction-cache lines.
-    if (wid == 0 && lane == 0) {       // diagnostics: where this instance's code lives in this process (last counter line)
-        unsigned long long pc;
-        asm volatile("s_getpc_b64 %0" : "=s"(pc));
-        *(unsigned long long *)(a.queues + 32 * 255 + 2 * ((COPY & 3) + (COUNT ? 4 : 0))) = pc;
-    }
     asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
-    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD + 24 * COPY));
+    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
     while (true) {
         const unsigned long long idle = __ballot(ray < 0);
         const int n_idle = __popcll(idle);
@@ -208,53 +200,50 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             if (COUNT) n_tri++;
             nxt = tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz) ? HIT : POP;
         }
+#if !NVDR_TRACE_LAZY_PEEK
         const int popv = stack.peek(sp);                // value a pop would return (unused when sp == 0)
+#endif
         if (node_turn && ray >= 0 && cur >= 0) {
-            // one step = the four grandchildren of `cur` (bvh.h "wide"): test all, continue with the nearest hit, push
-            // the other hits.  Any-hit needs no exact order; nearest-first just finds occluders sooner.
+            // one step = the four grandchildren of `cur` (bvh.h "wide"): test all, continue with ONE hit slot, push the other
+            // hits.  Any-hit needs no order at all, and ordering does not pay here: continuing with the FIRST hit slot instead
+            // of the nearest one (4 selects + min3 + 3 compares + 3 selects less per step) also visits 3 % FEWER boxes on the
+            // benchmark's shadow rays (44.5 vs 46.0 per ray) -- measured -5 % (8 views), -8 % (one view), -9 % (684 k
+            // triangles) in interleaved in-process A/B runs (profiles/r02_ab_traversal_variants.md).
             const uint4 *w4 = bvh.wide + 4 * (int64_t)cur;
             const uint4 q0 = w4[0], q1 = w4[1], q2 = w4[2], q3 = w4[3];
             float t0, t1, t2, t3;
             const bool h0 = slot_hit(q0, g, NVDR_RAY_TMAX, t0), h1 = slot_hit(q1, g, NVDR_RAY_TMAX, t1);
             const bool h2 = slot_hit(q2, g, NVDR_RAY_TMAX, t2), h3 = slot_hit(q3, g, NVDR_RAY_TMAX, t3);
+            (void)t0; (void)t1; (void)t2; (void)t3;
             const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
             if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
             const bool any = h0 | h1 | h2 | h3;
-#if NVDR_TRACE_UNORDERED
-            // experiment: continue with the FIRST hit slot instead of the nearest (any-hit: the answer cannot change)
+#if NVDR_TRACE_PICK == 0
             const int best = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
-            (void)t0; (void)t1; (void)t2; (void)t3;
 #else
-            const float BIG = 3.0e38f;
-            const float u0 = h0 ? t0 : BIG, u1 = h1 ? t1 : BIG, u2 = h2 ? t2 : BIG, u3 = h3 ? t3 : BIG;
-            const float um = fminf(fminf(u0, u1), fminf(u2, u3));
-            const int best = (h0 & (u0 == um)) ? 0 : (h1 & (u1 == um)) ? 1 : (h2 & (u2 == um)) ? 2 : 3;
+            // experiment: prefer an internal node (leaves wait on the stack and are tested in larger batches) or a leaf (a hit
+            // triangle ends the ray at once)
+            const bool want_leaf = NVDR_TRACE_PICK == 2;
+            const bool a0 = h0 & ((c0 < 0) == want_leaf), a1 = h1 & ((c1 < 0) == want_leaf), a2 = h2 & ((c2 < 0) == want_leaf),
+                       a3 = h3 & ((c3 < 0) == want_leaf);
+            const int best = (a0 | a1 | a2 | a3) ? (a0 ? 0 : a1 ? 1 : a2 ? 2 : 3) : (h0 ? 0 : h1 ? 1 : h2 ? 2 : 3);
 #endif
             nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
-            const bool p0 = h0 & (best != 0), p1 = h1 & (best != 1), p2 = h2 & (best != 2), p3 = h3 & (best != 3);
-#if NVDR_TRACE_PUSH_FAST
-            // experiment: a step pushes at most 3 entries; when NO lane of the wave can leave the LDS part of its stack in this
-            // step (wave-uniform test, one ballot) the pushes are plain conditional LDS writes without the nested spill /
-            // overflow branches of TravStack::push
-            if (__ballot(sp + 3 > NVDR_STACK_LDS) == 0ull) {
-                if (p0) { stack.lds[sp * 64] = c0; sp++; }
-                if (p1) { stack.lds[sp * 64] = c1; sp++; }
-                if (p2) { stack.lds[sp * 64] = c2; sp++; }
-                if (p3) { stack.lds[sp * 64] = c3; sp++; }
-            } else
-#endif
-            {
-                // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs 0.67 ms)
-                if (p0) sp = stack.push(sp, c0);
-                if (p1) sp = stack.push(sp, c1);
-                if (p2) sp = stack.push(sp, c2);
-                if (p3) sp = stack.push(sp, c3);
-            }
+            // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs
+            // 0.67 ms; a wave-uniform "nobody can leave the LDS part of the stack" fast path: no gain either)
+            if (h0 & (best != 0)) sp = stack.push(sp, c0);
+            if (h1 & (best != 1)) sp = stack.push(sp, c1);
+            if (h2 & (best != 2)) sp = stack.push(sp, c2);
+            if (h3 & (best != 3)) sp = stack.push(sp, c3);
         }
         bool finished = false;
         if (nxt != WAIT) {
             const bool pop = nxt == POP;
             finished = (nxt == HIT) | (pop & (sp == 0));
+#if NVDR_TRACE_LAZY_PEEK
+            int popv = nxt;
+            if (pop & (sp > 0)) popv = stack.pop(sp - 1);
+#endif
             sp -= (pop & (sp > 0)) ? 1 : 0;
             cur = pop ? popv : nxt;
         }

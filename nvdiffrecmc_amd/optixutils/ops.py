@@ -67,38 +67,11 @@ class OptiXContext:
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')
 
-    def set_trace_variant(self, instance):
-        """Pin this context to one instance of the traversal kernel: 0, 1, 2 = the copies inside libnvdr_hip.so, 3, 4 = loads of
-        the stand-alone code object; -1 = back to the instance the process selected (see trace_selection)."""
-        w = self.cpp_wrapper
-        _lib.check(w.lib.nvdr_ctx_set_trace_variant(w.handle, int(instance)), 'nvdr_ctx_set_trace_variant')
-
     def set_trace_xcd_partition(self, on=True):
-        """Chunk dealing of the traversal kernel: one contiguous eighth of the ray list per XCD (True) or interleaved (False)."""
+        """Chunk dealing of the traversal kernel: one contiguous eighth of the ray list per XCD (True) or interleaved (False,
+        the default; csrc/trace_kernel.h).  Results are identical."""
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_trace_flags(w.handle, _lib.TRACE_XCD_PARTITION if on else 0), 'nvdr_ctx_set_trace_flags')
-
-    def set_trace_flags(self, flags):
-        """Raw NVDR_TRACE_* flag word (include/nvdr_hip.h); experiments."""
-        w = self.cpp_wrapper
-        _lib.check(w.lib.nvdr_ctx_set_trace_flags(w.handle, int(flags)), 'nvdr_ctx_set_trace_flags')
-
-    def trace_selection(self):
-        """Which instance of the traversal kernel this process launches on this context's device and the timings that decided
-        it: dict(decided, choice, attempts, ms=[per instance; None = unavailable])."""
-        w = self.cpp_wrapper
-        info = _lib.NvdrTraceSelectInfo()
-        _lib.check(w.lib.nvdr_trace_select_get(w.device, ctypes.byref(info)), 'nvdr_trace_select_get')
-        return {'decided': bool(info.decided), 'choice': int(info.choice), 'attempts': int(info.attempts),
-                'ms': [float(info.ms[k]) if info.ms[k] >= 0 else None for k in range(info.n_candidates)]}
-
-    def trace_pcs(self):
-        """Program counters the instances of the traversal kernel ran at on their last launch: [copy 0, 1, 2, code object,
-        counting build] (diagnostics)."""
-        w = self.cpp_wrapper
-        out = (ctypes.c_uint64 * 5)()
-        _lib.check(w.lib.nvdr_ctx_trace_pcs(w.handle, out, _lib.stream_ptr()), 'nvdr_ctx_trace_pcs')
-        return [int(v) for v in out]
 
     def check(self):
         """Synchronise and raise if any traversal launch on this context ever overflowed its stack (never silent)."""

@@ -268,11 +268,10 @@ def test_canonical_counters_equal_cpu_walk_of_exported_tree(dev):
     assert 5 < n_node / ro.shape[0] < 60
 
 
-def test_every_traversal_instance_and_dealing_gives_the_same_bits(dev):
-    """The production shadow-ray kernel exists five times (three copies inside the library + two loads of the stand-alone
-    code object, csrc/trace_module.hip) and deals its ray chunks either interleaved or per XCD (trace_kernel.h): every
-    combination must answer like the binary walk, bit for bit -- also when the list is shorter than the 64 counters serve
-    and when it does not divide by the chunk size."""
+def test_both_chunk_dealings_give_the_same_bits(dev):
+    """The production shadow-ray kernel deals its ray chunks either interleaved over the chip or one contiguous eighth of the
+    list per XCD with stealing (csrc/trace_kernel.h): both must answer like the binary walk, bit for bit -- also when the list
+    is shorter than the 64 counters serve and when it does not divide by the chunk size."""
     from nvdiffrecmc_amd import optixutils as ou
     mesh = sc.load_mesh('bob')
     ctx = make_ctx(mesh, dev)
@@ -280,34 +279,9 @@ def test_every_traversal_instance_and_dealing_gives_the_same_bits(dev):
         ro, rd = _rays(n, 31 + n)
         ro, rd = ro.to(dev), rd.to(dev)
         ref = ou.trace_visibility(ctx, ro, rd)
-        for inst in range(5):
-            ctx.set_trace_variant(inst)             # raises if the code object did not travel with the library
-            for part in (False, True):
-                ctx.set_trace_xcd_partition(part)
-                got = ou.trace_visibility_wide(ctx, ro, rd)
-                assert torch.equal(got, ref), 'instance %d, xcd partition %s, %d rays: %d differ' % (inst, part, n, int((got != ref).sum()))
-    ctx.set_trace_variant(-1)
+        for part in (False, True):
+            ctx.set_trace_xcd_partition(part)
+            got = ou.trace_visibility_wide(ctx, ro, rd)
+            assert torch.equal(got, ref), 'xcd partition %s, %d rays: %d differ' % (part, n, int((got != ref).sum()))
     ctx.set_trace_xcd_partition(False)
     ctx.check()
-    sel = ctx.trace_selection()
-    assert len(sel['ms']) == 5 and 0 <= sel['choice'] < 5
-
-
-def test_instance_selection_runs_on_a_long_forward_launch(dev):
-    """The first forward env-shade launch of a process that lasts >= 0.15 ms times all instances and fixes the choice;
-    whatever it picks, the image equals the one rendered by instance 0."""
-    from nvdiffrecmc_amd.trainer import DirectLightingStep
-    st = DirectLightingStep('bob', 256, 8, view=[0, 1], n_views=8, device=dev)
-    sel = st.ctx.trace_selection()
-    assert sel['decided'], sel
-    timed = [v for v in sel['ms'] if v is not None]
-    assert len(timed) == 5 and min(timed) > 0.0
-    if min(timed) >= 0.15:                          # a deciding calibration (earlier tests of this process may have used up the
-        assert sel['ms'][sel['choice']] <= 1.25 * min(timed) + 1e-6     # attempts on launches too short to tell: instance 0 stays)
-    st.seed = 5
-    with torch.no_grad():
-        a = st._render(st.kd_tex, st.ks, st.light).clone()
-        st.ctx.set_trace_variant(0)
-        st.seed = 5
-        b = st._render(st.kd_tex, st.ks, st.light)
-    assert torch.equal(a, b)

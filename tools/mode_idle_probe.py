@@ -22,8 +22,6 @@ with torch.no_grad():
     ro = st.gb_pos + nrm * 0.001
 L = st.light
 ctx = st.ctx
-ctx.set_trace_variant(0)
-print('first-launch calibration ms: %s' % ctx.trace_selection()['ms'])
 f = ou.ops.env_shade_traversal_counts
 for b in range(n_bursts):
     gap = gaps[b % len(gaps)]

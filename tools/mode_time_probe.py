@@ -21,8 +21,7 @@ with torch.no_grad():
     ro = st.gb_pos + nrm * 0.001
 L = st.light
 ctx = st.ctx
-ctx.set_trace_variant(0)
-print('set-up %.1f s after process start; first-launch calibration: %s' % (time.perf_counter() - t_start, ctx.trace_selection()['ms']))
+print('set-up %.1f s after process start' % (time.perf_counter() - t_start))
 log = []           # (seconds since t0, trace ms)
 events = []
 t0 = time.perf_counter()

@@ -37,7 +37,7 @@ def run(iters=12):
     st.ctx.set_profiling(False)
     return f, b
 
-print('workload: %s %dx%d n=%d covered=%d triangles=%d | traversal instance %s, NVDR_TRACE_XCD=%s' % (mesh, res, res, n, st.covered, st.mesh['t_pos_idx'].shape[0], st.ctx.trace_selection(), os.environ.get('NVDR_TRACE_XCD', '-')))
+print('workload: %s %dx%d n=%d covered=%d triangles=%d | NVDR_TRACE_XCD=%s' % (mesh, res, res, n, st.covered, st.mesh['t_pos_idx'].shape[0], os.environ.get('NVDR_TRACE_XCD', '-')))
 # BVH rebuild time (stream-ordered, no host sync inside)
 for _ in range(3): ou.optix_build_bvh(st.ctx, st.mesh['v_pos'], st.mesh['t_pos_idx'], rebuild=1)
 torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

@@ -217,24 +217,29 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             (void)t0; (void)t1; (void)t2; (void)t3;
             const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
             if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
-            const bool any = h0 | h1 | h2 | h3;
 #if NVDR_TRACE_PICK == 0
-            const int best = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;
+            // continue with the first hit slot; a later hit slot is pushed iff an earlier one was hit (slot 0 is never pushed)
+            nxt = h0 ? c0 : h1 ? c1 : h2 ? c2 : h3 ? c3 : POP;
+            const bool b01 = h0 | h1, b012 = b01 | h2;
+            if (h1 & h0) sp = stack.push(sp, c1);
+            if (h2 & b01) sp = stack.push(sp, c2);
+            if (h3 & b012) sp = stack.push(sp, c3);
 #else
             // experiment: prefer an internal node (leaves wait on the stack and are tested in larger batches) or a leaf (a hit
             // triangle ends the ray at once)
+            const bool any = h0 | h1 | h2 | h3;
             const bool want_leaf = NVDR_TRACE_PICK == 2;
             const bool a0 = h0 & ((c0 < 0) == want_leaf), a1 = h1 & ((c1 < 0) == want_leaf), a2 = h2 & ((c2 < 0) == want_leaf),
                        a3 = h3 & ((c3 < 0) == want_leaf);
             const int best = (a0 | a1 | a2 | a3) ? (a0 ? 0 : a1 ? 1 : a2 ? 2 : 3) : (h0 ? 0 : h1 ? 1 : h2 ? 2 : 3);
-#endif
             nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
-            // (unconditional LDS writes at the running depth + one rare spill branch instead of these four branches: 0.70 vs
-            // 0.67 ms; a wave-uniform "nobody can leave the LDS part of the stack" fast path: no gain either)
             if (h0 & (best != 0)) sp = stack.push(sp, c0);
             if (h1 & (best != 1)) sp = stack.push(sp, c1);
             if (h2 & (best != 2)) sp = stack.push(sp, c2);
             if (h3 & (best != 3)) sp = stack.push(sp, c3);
+#endif
+            // (unconditional LDS writes at the running depth + one rare spill branch instead of these branches: 0.70 vs 0.67 ms;
+            // a wave-uniform "nobody can leave the LDS part of the stack" fast path: no gain either)
         }
         bool finished = false;
         if (nxt != WAIT) {

@@ -41,29 +41,35 @@ for tag, path in paths:
 _build.LIB = base
 
 
-def run(tag, iters=5):
+def run(tag, iters=4):
+    """Average stage times (gen, trace, shade forward; trace, shade backward) over iters - 1 forward + backward passes."""
     st, kd, ks, nrm, ro = steps[tag]
     L = st.light
     st.ctx.set_profiling(True)
     for it in range(iters):
         if it == 1:
             st.ctx.set_profiling(True)
-        ou.optix_env_shade(st.ctx, st.mask, ro, st.gb_pos, nrm, st.view_pos, kd, ks, L.base.detach(), L._pdf, L.rows[:, 0], L.cols,
-                           n_samples_x=8, rnd_seed=it, shadow_scale=1.0)
+        g = [t.clone().requires_grad_(True) for t in (st.gb_pos, nrm, kd, ks, L.base.detach())]
+        d, s = ou.optix_env_shade(st.ctx, st.mask, ro, g[0], g[1], st.view_pos, g[2], g[3], g[4], L._pdf, L.rows[:, 0], L.cols,
+                                  n_samples_x=8, rnd_seed=it, shadow_scale=1.0)
+        torch.autograd.backward([d, s], [torch.ones_like(d), torch.ones_like(s)])
     torch.cuda.synchronize()
-    n, (g, t, sh) = st.ctx.stage_times(backward=False)
+    nf, f = st.ctx.stage_times(backward=False)
+    nb, b = st.ctx.stage_times(backward=True)
     st.ctx.set_profiling(False)
-    return t
+    return [f[0], f[1], f[2], b[1], b[2]]
 
 
+ou.ops._optix_env_shade_func.cache_visibility = False          # backward re-traces, as the benchmark does
 for tag in steps:
-    run(tag, 3)                            # warm every variant
+    run(tag, 2)                            # warm every variant
 times = {tag: [] for tag in steps}
 for r in range(rounds):
     for tag in steps:
         times[tag].append(run(tag))
-ref = statistics.median(times['current'])
-print('traversal kernel, %d views, %d rounds interleaved in one process (ms): median [min .. max], vs current' % (nviews, rounds))
+names = ['gen', 'trace', 'shade', 'bwd trace', 'bwd shade+gather']
+med = {tag: [statistics.median(v[k] for v in times[tag]) for k in range(5)] for tag in steps}
+print('env-shade stage times, %d views, %d rounds interleaved in one process: median ms (vs current)' % (nviews, rounds))
+print('  %-10s %s' % ('', '  '.join('%-18s' % n for n in names)))
 for tag in steps:
-    v = times[tag]
-    print('  %-10s %.3f [%.3f .. %.3f]  %+.1f %%' % (tag, statistics.median(v), min(v), max(v), 100.0 * (statistics.median(v) / ref - 1.0)))
+    print('  %-10s %s' % (tag, '  '.join('%7.3f (%+5.1f %%)  ' % (med[tag][k], 100.0 * (med[tag][k] / med['current'][k] - 1.0)) for k in range(5))))

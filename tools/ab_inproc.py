@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nvdiffrecmc_amd import _lib, _build
 from nvdiffrecmc_amd.trainer import DirectLightingStep
 from nvdiffrecmc_amd import optixutils as ou, renderutils as ru
+from tools.gpu_tenancy import snapshot
 
 res = int(os.environ.get('PROBE_RES', '512'))
 subdiv = int(os.environ.get('PROBE_SUBDIV', '0'))
@@ -73,3 +74,4 @@ print('env-shade stage times, %d views, %d rounds interleaved in one process: me
 print('  %-10s %s' % ('', '  '.join('%-18s' % n for n in names)))
 for tag in steps:
     print('  %-10s %s' % (tag, '  '.join('%7.3f (%+5.1f %%)  ' % (med[tag][k], 100.0 * (med[tag][k] / med['current'][k] - 1.0)) for k in range(5))))
+print('tenancy at the end: ' + snapshot())

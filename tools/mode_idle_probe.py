@@ -6,6 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nvdiffrecmc_amd.trainer import DirectLightingStep
 from nvdiffrecmc_amd import optixutils as ou, renderutils as ru
+from tools.gpu_tenancy import snapshot
 
 res = int(os.environ.get('PROBE_RES', '512'))
 subdiv = int(os.environ.get('PROBE_SUBDIV', '0'))
@@ -23,6 +24,7 @@ with torch.no_grad():
 L = st.light
 ctx = st.ctx
 f = ou.ops.env_shade_traversal_counts
+print('tenancy before: ' + snapshot())
 for b in range(n_bursts):
     gap = gaps[b % len(gaps)]
     torch.cuda.synchronize()
@@ -45,3 +47,6 @@ for b in range(n_bursts):
     per = ' '.join('%.0f' % busy[xcd == x].mean().item() for x in range(8) if (xcd == x).any())
     print('burst %2d after %.2f s idle: stage1 %.3f stage2 %.3f ms | counting launch %.0f us at %.0f MHz, wave busy us per XCD: %s'
           % (b, gap, statistics.median(a for a, _ in ts), statistics.median(t for _, t in ts), span, f.clock_mhz, per))
+    if statistics.median(t for _, t in ts) > float(os.environ.get('PROBE_SLOW_MS', '1e9')):
+        print('   slow burst, tenancy: ' + snapshot())
+print('tenancy after: ' + snapshot())

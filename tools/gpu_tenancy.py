@@ -34,5 +34,29 @@ def snapshot():
     return ' | '.join(out) + ' | kfd processes: %d (%s)%s' % (len(procs), ' '.join(procs[:12]), ' | own ' + ' '.join(own) if own else '')
 
 
+def cpu_state():
+    """CPU side of the box: cgroup quota / throttling counters (v1 and v2 layouts), cpus this process may run on, load average."""
+    out = {}
+    for path, key in (('/sys/fs/cgroup/cpu.max', 'cpu.max'), ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', 'cfs_quota_us'),
+                      ('/sys/fs/cgroup/cpu/cpu.cfs_period_us', 'cfs_period_us')):
+        v = _read(path)
+        if v is not None:
+            out[key] = v
+    for path in ('/sys/fs/cgroup/cpu.stat', '/sys/fs/cgroup/cpu/cpu.stat'):
+        v = _read(path)
+        if v:
+            for line in v.splitlines():
+                k, _, x = line.partition(' ')
+                if k in ('nr_throttled', 'throttled_usec', 'throttled_time', 'nr_periods'):
+                    out[k] = int(x)
+    try:
+        out['cpus_allowed'] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    out['loadavg'] = _read('/proc/loadavg')
+    return out
+
+
 if __name__ == '__main__':
     print(snapshot())
+    print(cpu_state())

@@ -5,6 +5,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nvdiffrecmc_amd.trainer import DirectLightingStep
 from nvdiffrecmc_amd import optixutils as ou, renderutils as ru
+from tools.gpu_tenancy import cpu_state
+import time as _time
 
 n = int(os.environ.get('PROBE_N', '8'))
 res = int(os.environ.get('PROBE_RES', '512'))
@@ -50,8 +52,11 @@ for cfg in sys.argv[1:] or ['4,4,4']:
     for tok in cfg.split(';'):
         if tok.startswith('dbg='): os.environ['NVDR_DEBUG'] = tok[4:]
         elif tok: os.environ['NVDR_PBLOCKS'] = tok
+    c0, w0 = cpu_state(), _time.perf_counter()
     f, b = run()
+    c1, w1 = cpu_state(), _time.perf_counter()
     print('%-16s fwd gen %.3f trace %.3f shade %.3f | bwd gen %.3f trace %.3f shade %.3f  (ms)' % ((cfg,) + tuple(f) + tuple(b)))
+    print('host side: %.1f ms wall per fwd+bwd pass (12 passes), torch threads %d, cpu state before %s after %s' % ((w1 - w0) / 12 * 1e3, torch.get_num_threads(), c0, c1))
 os.environ.pop('NVDR_PBLOCKS', None); os.environ['NVDR_DEBUG'] = '0'
 P, nb, nt, nr = ou.ops.env_shade_traversal_counts(st.ctx, st.mask, ro, st.gb_pos, nrm, st.view_pos, kd, ks, L.base.detach(), L._pdf, L.rows[:, 0], L.cols,
                                                   n_samples_x=n, rnd_seed=0)

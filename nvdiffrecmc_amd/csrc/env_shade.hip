@@ -82,7 +82,14 @@ struct ShadeParams {
     const unsigned *seed_dev; // optional: a seed offset read from device memory (captured HIP graphs replay with fresh seeds)
     int reuse;                // backward: the forward's stream is still in the context IF the whole launch fitted one chunk
     int lg_records;           // backward: 1 = write (texel, rgb) records for the band gather, 0 = global atomics
+    unsigned *queues;         // chunk counters of the traversal kernel: stages 1 and 3 leave them zeroed for the next stage-2 launch
 };
+
+// stages 1 and 3 (large grids) reset the 64 chunk counters the NEXT traversal launch on this stream starts from
+__device__ __forceinline__ void reset_trace_queues(const ShadeParams &p)
+{
+    if (blockIdx.x == 0 && threadIdx.x < NVDR_TRACE_QUEUES) p.queues[threadIdx.x * 32u] = 0u;
+}
 
 __device__ __forceinline__ unsigned launch_seed(const ShadeParams &p) { return p.seed_dev ? p.seed + *p.seed_dev : p.seed; }
 
@@ -408,6 +415,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = p.L, G = 64 >> p.log2L;
     const int slot = lane >> p.log2L, sub = lane & (L - 1);
+    reset_trace_queues(p);
     if (p.reuse && *p.pix_count <= p.pix_cap) return;     // backward pass: the forward's stream is still valid (one chunk)
     const unsigned P = chunk_pixels(p);
     const unsigned n_groups = (P + G - 1) / G;
@@ -533,6 +541,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = p.L, G = 64 >> p.log2L;
     const int slot = lane >> p.log2L, sub = lane & (L - 1);
+    reset_trace_queues(p);
     const unsigned P = chunk_pixels(p);
     const unsigned n_groups = (P + G - 1) / G;
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
@@ -859,7 +868,9 @@ static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_coun
 static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t stream, const unsigned *ray_count, unsigned rays_per_pixel,
                          unsigned long long *counters)
 {
-    zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
+    // experiment (NVDR_DEBUG bit 64): no tiny kernel in front of the persistent one; the counters were left zeroed by the stage-1 /
+    // stage-3 kernel that ran before on this stream
+    if (!(c->debug & 64u)) zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
     if (counters)
         env_trace_kernel<true><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
     else
@@ -1062,6 +1073,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     p.pix_count = &c->dinfo->pix_count;
     p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.vis = c->vis;
     p.live = c->live;
+    p.queues = c->queues;
 
     // backward pass of a forward launch whose work list (and, if it fitted one chunk, ray stream) is still in the context
     const bool reuse = backward && a->reuse_stream_id != 0 && a->reuse_stream_id == c->stream_id;
@@ -1150,10 +1162,11 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
 // wavefronts, wide nodes, lane refill) -- the rays are packed into a one-ray-per-pixel stream.  nvdr_trace_visibility
 // (bvh.hip) answers the same question with the binary walk; tests require the two to agree bit for bit.
 __global__ void pack_rays_kernel(const float *__restrict__ ro, const float *__restrict__ rd, unsigned n, float4 *__restrict__ rays,
-                                 float4 *__restrict__ origin, uint32_t *__restrict__ live, unsigned *count)
+                                 float4 *__restrict__ origin, uint32_t *__restrict__ live, unsigned *count, unsigned *queues)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *count = n;
+    if (i < NVDR_TRACE_QUEUES) queues[i * 32u] = 0u;
     if (i >= n) return;
     rays[i] = make_float4(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2], 1.0f);
     origin[i] = make_float4(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2], 0.0f);
@@ -1171,7 +1184,7 @@ extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const fl
     int r = reserve_stream(c, n_rays, n_rays, 1, stream);
     if (r) return r;
     c->stream_id = 0;
-    pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts);
+    pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts, c->queues);
     int64_t tblocks = (int64_t)c->n_cus * 8;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;

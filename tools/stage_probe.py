@@ -58,8 +58,12 @@ for cfg in sys.argv[1:] or ['4,4,4']:
     print('%-16s fwd gen %.3f trace %.3f shade %.3f | bwd gen %.3f trace %.3f shade %.3f  (ms)' % ((cfg,) + tuple(f) + tuple(b)))
     print('host side: %.1f ms wall per fwd+bwd pass (12 passes), torch threads %d, cpu state before %s after %s' % ((w1 - w0) / 12 * 1e3, torch.get_num_threads(), c0, c1))
 os.environ.pop('NVDR_PBLOCKS', None); os.environ['NVDR_DEBUG'] = '0'
+st.ctx.set_profiling(True)               # the bracket of the COUNTING launch too (stage 2 = counting kernel + canonical binary walk)
 P, nb, nt, nr = ou.ops.env_shade_traversal_counts(st.ctx, st.mask, ro, st.gb_pos, nrm, st.view_pos, kd, ks, L.base.detach(), L._pdf, L.rows[:, 0], L.cols,
                                                   n_samples_x=n, rnd_seed=0)
+_n, _cf = st.ctx.stage_times(backward=False)
+st.ctx.set_profiling(False)
+print('counting launch, event brackets: gen %.3f trace+binary-walk %.3f shade %.3f ms' % tuple(_cf))
 tot, mx, nw = ou.ops.env_shade_traversal_counts.balance
 print('counting build: %d rays traversed of %d, %.1f box %.2f tri tests/ray; per-wave busy time mean %.1f us max %.1f us over %d waves'
       % (nr, 2 * n * n * P, nb / nr, nt / nr, tot / max(nw, 1) / 100.0, mx / 100.0, nw))

@@ -54,13 +54,6 @@ int nvdr_ctx_check(nvdr_ctx *ctx, void *stream);
  * exceed the chunk is processed chunk by chunk with identical results.  The reference needs no scratch (one thread per
  * pixel keeps its rays in registers); a worst-case allocation would be N*H*W*2S*25 B (16 GB for 8 x 800^2 x 64 spp). */
 int nvdr_ctx_set_stream_budget(nvdr_ctx *ctx, int64_t bytes);
-/* How the shadow-ray traversal kernel deals the chunks of the ray list to its wavefronts: 0 = interleaved over the whole
- * chip (default), NVDR_TRACE_XCD_PARTITION = one contiguous eighth of the list per XCD with stealing (each of the 8 L2s
- * then caches a different region of a tree that does not fit one of them).  Results are identical.  NVDR_TRACE_XCD=1 in
- * the environment sets it when a context is created.  No reference counterpart (optixLaunch, optix_wrapper.cpp:236-262). */
-#define NVDR_TRACE_XCD_PARTITION 1u
-int nvdr_ctx_set_trace_flags(nvdr_ctx *ctx, unsigned flags);
-
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
  * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);
  * rebuild == 0: refit the bounds of the existing hierarchy to moved vertices (OPTIX_BUILD_OPERATION_UPDATE). */

@@ -24,7 +24,6 @@ class NvdrBvhInfo(ctypes.Structure):
                 ('aabb_min', c_float * 3), ('aabb_max', c_float * 3), ('grid_lo', c_float * 3), ('grid_scale', c_float * 3),
                 ('stack_max', ctypes.c_int32)]
 
-TRACE_XCD_PARTITION = 1        # NVDR_TRACE_XCD_PARTITION
 COUNTERS_BVH2 = 8 + 2 * 8192   # NVDR_COUNTERS_BVH2
 COUNTERS_LEN = COUNTERS_BVH2 + 8
 
@@ -59,7 +58,6 @@ _SIGNATURES = {
     'nvdr_ctx_destroy': [c_void_p],
     'nvdr_ctx_check': [c_void_p, c_void_p],
     'nvdr_ctx_set_stream_budget': [c_void_p, c_int64],
-    'nvdr_ctx_set_trace_flags': [c_void_p, c_uint32],
     'nvdr_bvh_build': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
     'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
     'nvdr_bvh_export': [c_void_p, c_void_p, c_void_p, c_void_p],

@@ -117,7 +117,6 @@ struct nvdr_ctx {
     int *texel = nullptr;
     uint8_t *vis = nullptr;
     uint32_t *live = nullptr;      // stream slots of the rays that need traversal (dead samples left out)
-    unsigned trace_flags = 0;      // NVDR_TRACE_* bits of trace_kernel.h (chunk dealing)
     unsigned *queues = nullptr;    // [256][32] chunk counters of the traversal kernel, one 128-B line each (NVDR_TRACE_QUEUES)
     float4 *pix_origin = nullptr;
     size_t stream_cap_rays = 0;

@@ -373,8 +373,6 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     }
     hipMemset(c->chunk_counts, 0, sizeof(unsigned) * NVDR_MAX_CHUNKS);
     hipMemset(c->queues, 0, sizeof(unsigned) * 32 * 256);
-    // NVDR_TRACE_XCD (read once here): 1 = the traversal kernel deals its ray chunks per XCD (trace_kernel.h), 0 = interleaved
-    if (const char *e = getenv("NVDR_TRACE_XCD")) c->trace_flags = atoi(e) ? NVDR_TRACE_XCD_PARTITION : 0u;
     if (const char *e = getenv("NVDR_STREAM_BUDGET_MB")) {
         const long long mb = atoll(e);
         if (mb >= 1) c->stream_budget = (int64_t)mb << 20;

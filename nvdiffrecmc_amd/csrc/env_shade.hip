@@ -860,7 +860,7 @@ static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_coun
     TraceLaunch L;
     L.bvh = bvh_view(c);
     L.rays = c->rays; L.pix_origin = c->pix_origin; L.live = c->live;
-    L.ray_count = ray_count; L.rays_per_pixel = rays_per_pixel; L.flags = c->trace_flags;
+    L.ray_count = ray_count; L.rays_per_pixel = rays_per_pixel;
     L.vis = c->vis; L.spill = c->spill; L.counters = counters; L.queues = c->queues;
     return L;
 }
@@ -875,13 +875,6 @@ static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t s
         env_trace_kernel<true><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
     else
         env_trace_kernel<false><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
-}
-
-extern "C" int nvdr_ctx_set_trace_flags(nvdr_ctx *c, unsigned flags)
-{
-    NVDR_REQUIRE(c && (flags & ~NVDR_TRACE_XCD_PARTITION) == 0u, "nvdr_ctx_set_trace_flags: unknown flag bits 0x%x", flags);
-    c->trace_flags = flags;
-    return 0;
 }
 
 // Scratch for the ray stream.  Round 1 sized it for the worst case -- every pixel of the launch covered -- which was

@@ -30,15 +30,6 @@
 #ifndef NVDR_TRACE_OCC
 #define NVDR_TRACE_OCC 8       // waves per SIMD the kernel is compiled for (= resident workgroups per CU of the persistent grid)
 #endif
-// experiment switches of the node step (tools/build_variants.sh + tools/ab_inproc.py), see below
-#ifndef NVDR_TRACE_PICK
-#define NVDR_TRACE_PICK 0      // which hit slot the walk continues with: 0 first, 1 first internal node, 2 first leaf
-#endif
-#ifndef NVDR_TRACE_LAZY_PEEK
-#define NVDR_TRACE_LAZY_PEEK 0 // 1: the stack top is read only by lanes that pop
-#endif
-
-// flags of TraceLaunch: NVDR_TRACE_XCD_PARTITION (nvdr_hip.h)
 
 struct TraceLaunch {
     BvhView bvh;
@@ -47,78 +38,39 @@ struct TraceLaunch {
     const uint32_t *live;          // the stream slots to traverse
     const unsigned *ray_count;     // their number (device counter)
     unsigned rays_per_pixel;
-    unsigned flags;
     uint8_t *vis;                  // stream slot -> 1 = unoccluded
     int *spill;                    // HBM part of the traversal stacks (bvh.h)
     unsigned long long *counters;  // counting build only (nvdr_hip.h NVDR_COUNTERS_*)
     unsigned *queues;              // [256][32] chunk counters, zeroed before every launch; the last line holds diagnostics
 };
 
-// Two ways of dealing the chunks to the wavefronts, both through the same 64 counters:
-//   interleaved (flags = 0): wave w uses counter w % 64 and receives the chunks q, q + 64, q + 128 ...: the whole chip
-//       works inside ONE window of the list, every XCD's L2 ends up holding the same subtrees;
-//   XCD partitions (NVDR_TRACE_XCD_PARTITION): the list is cut into 8 contiguous parts, part p is served by the 8
-//       counters 8p .. 8p+7, and a wave starts on the part of the XCD it runs on (HW_REG_XCC_ID).  Neighbouring pixels
-//       visit neighbouring subtrees, so the 8 L2s (4 MB each, not coherent, not shared) now cache 8 DIFFERENT regions of
-//       a tree that does not fit one of them.  A wave whose part is used up steals from the next part (a plain load of
-//       the counter first: used-up parts cost no atomic), so the load balance of the claiming scheme is kept.
-// Visibility does not depend on the dealing (each ray is traversed exactly once by somebody).
+// Chunk dealing: wave w uses counter w % 64 and receives the chunks q, q + 64, q + 128 ... of the list, so the whole chip works
+// inside ONE moving window of the list.  Every counter must be served by somebody: chunk c sits on counter c % 64 and the
+// launcher starts at least min(chunks, 2048) workgroups of 4 waves, so counter c % 64 < waves.
+// (Measured and dropped, interleaved in-process A/B, profiles/r02_ab_traversal_variants.md: one contiguous eighth of the list per
+// XCD with stealing -- each L2 caching another region of the tree -- is 4-7 % SLOWER on bob and +-2 % on 684 k triangles.)
 struct ChunkDealer {
-    unsigned *queues;
-    unsigned n_chunks, total;      // chunks of NVDR_TRACE_QCHUNK rays, rays
-    unsigned sub;                  // interleaved: this wave's counter; partitions: its counter inside a part
-    unsigned part, tried;          // partitions: current part, parts already found used up
-    bool partitioned;
+    unsigned *queue;               // this wave's counter
+    unsigned n_chunks, total, sub;
 
-    // Every counter must be served by somebody.  Interleaved: chunk c sits on counter c % 64 and the launcher starts at least
-    // min(chunks, 2048) workgroups of 4 waves, so counter c % 64 < waves.  Partitions: a wave only ever claims from the
-    // counters `sub` of the parts, so all 8 values of sub must exist: >= 64 waves, otherwise the launch is dealt interleaved.
-    __device__ __forceinline__ void init(unsigned *q, unsigned total_, unsigned wid, unsigned n_waves, unsigned flags)
+    __device__ __forceinline__ void init(unsigned *queues, unsigned total_, unsigned wid)
     {
-        queues = q;
         total = total_;
         n_chunks = (total_ + NVDR_TRACE_QCHUNK - 1u) / NVDR_TRACE_QCHUNK;
-        partitioned = (flags & NVDR_TRACE_XCD_PARTITION) != 0u && n_waves >= 64u;
-        part = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;     // HW_REG_XCC_ID
-        tried = 0;
-        sub = partitioned ? ((wid >> 3) & 7u) : (wid % NVDR_TRACE_QUEUES);
+        sub = wid % NVDR_TRACE_QUEUES;
+        queue = queues + sub * 32u;
     }
     // wave-uniform: claims the next chunk for the whole wave; false = the list is used up
     __device__ __forceinline__ bool claim(int lane, unsigned &next, unsigned &end)
     {
-        if (!partitioned) {
-            unsigned j = 0;
-            if (lane == 0) j = atomicAdd(queues + sub * 32u, 1u);
-            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-            const unsigned c = j * NVDR_TRACE_QUEUES + sub;
-            if (c >= n_chunks) return false;
-            next = c * NVDR_TRACE_QCHUNK;
-            end = min(next + NVDR_TRACE_QCHUNK, total);
-            return true;
-        }
-        while (tried < 8u) {
-            // part p covers the chunks [lo, hi); its counter `sub` hands out lo + sub, lo + sub + 8, ...
-            const unsigned lo = (unsigned)(((unsigned long long)part * n_chunks) >> 3);
-            const unsigned hi = (unsigned)(((unsigned long long)(part + 1u) * n_chunks) >> 3);
-            unsigned *q = queues + (part * 8u + sub) * 32u;
-            unsigned j = 0xffffffffu;
-            if (lane == 0) {
-                // a foreign part is looked at before it is claimed from: at the end of a launch every wave walks all parts
-                const bool look = tried > 0u;
-                const unsigned seen = look ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                if (!look || ((unsigned long long)seen * 8u + sub + lo < hi)) j = atomicAdd(q, 1u);
-            }
-            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-            const unsigned long long c = (unsigned long long)j * 8u + sub + lo;
-            if (j != 0xffffffffu && c < hi) {
-                next = (unsigned)c * NVDR_TRACE_QCHUNK;
-                end = min(next + NVDR_TRACE_QCHUNK, total);
-                return true;
-            }
-            part = (part + 1u) & 7u;
-            tried++;
-        }
-        return false;
+        unsigned j = 0;
+        if (lane == 0) j = atomicAdd(queue, 1u);
+        j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+        const unsigned c = j * NVDR_TRACE_QUEUES + sub;
+        if (c >= n_chunks) return false;
+        next = c * NVDR_TRACE_QCHUNK;
+        end = min(next + NVDR_TRACE_QCHUNK, total);
+        return true;
     }
 };
 
@@ -138,7 +90,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     const unsigned total = *a.ray_count;
     const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     ChunkDealer dealer;
-    dealer.init(a.queues, total, wid, gridDim.x * (blockDim.x >> 6), a.flags);
+    dealer.init(a.queues, total, wid);
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
     bool more = total > 0;
     unsigned n_box = 0, n_tri = 0, n_ray = 0;
@@ -200,9 +152,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             if (COUNT) n_tri++;
             nxt = tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz) ? HIT : POP;
         }
-#if !NVDR_TRACE_LAZY_PEEK
         const int popv = stack.peek(sp);                // value a pop would return (unused when sp == 0)
-#endif
         if (node_turn && ray >= 0 && cur >= 0) {
             // one step = the four grandchildren of `cur` (bvh.h "wide"): test all, continue with ONE hit slot, push the other
             // hits.  Any-hit needs no order at all, and ordering does not pay here: continuing with the FIRST hit slot instead
@@ -217,38 +167,22 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             (void)t0; (void)t1; (void)t2; (void)t3;
             const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
             if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
-#if NVDR_TRACE_PICK == 0
             // continue with the first hit slot; a later hit slot is pushed iff an earlier one was hit (slot 0 is never pushed)
             nxt = h0 ? c0 : h1 ? c1 : h2 ? c2 : h3 ? c3 : POP;
             const bool b01 = h0 | h1, b012 = b01 | h2;
             if (h1 & h0) sp = stack.push(sp, c1);
             if (h2 & b01) sp = stack.push(sp, c2);
             if (h3 & b012) sp = stack.push(sp, c3);
-#else
-            // experiment: prefer an internal node (leaves wait on the stack and are tested in larger batches) or a leaf (a hit
-            // triangle ends the ray at once)
-            const bool any = h0 | h1 | h2 | h3;
-            const bool want_leaf = NVDR_TRACE_PICK == 2;
-            const bool a0 = h0 & ((c0 < 0) == want_leaf), a1 = h1 & ((c1 < 0) == want_leaf), a2 = h2 & ((c2 < 0) == want_leaf),
-                       a3 = h3 & ((c3 < 0) == want_leaf);
-            const int best = (a0 | a1 | a2 | a3) ? (a0 ? 0 : a1 ? 1 : a2 ? 2 : 3) : (h0 ? 0 : h1 ? 1 : h2 ? 2 : 3);
-            nxt = any ? (best == 0 ? c0 : best == 1 ? c1 : best == 2 ? c2 : c3) : POP;
-            if (h0 & (best != 0)) sp = stack.push(sp, c0);
-            if (h1 & (best != 1)) sp = stack.push(sp, c1);
-            if (h2 & (best != 2)) sp = stack.push(sp, c2);
-            if (h3 & (best != 3)) sp = stack.push(sp, c3);
-#endif
-            // (unconditional LDS writes at the running depth + one rare spill branch instead of these branches: 0.70 vs 0.67 ms;
-            // a wave-uniform "nobody can leave the LDS part of the stack" fast path: no gain either)
+            // Measured and dropped (same A/B runs): preferring an internal node (+6..11 %) or a leaf (+9..10 %) over the first hit
+            // slot; unconditional LDS writes at the running depth + one rare spill branch (0.70 vs 0.67 ms); a wave-uniform
+            // "nobody leaves the LDS part of the stack" fast path (+-0 %); reading the stack top only in lanes that pop (+-1 %);
+            // leaf batches of 12 / 16 instead of 8 (+-1 %); refill thresholds 8 / 24 (+5 % / +-0 %); 6 waves per SIMD (+3..7 %);
+            // a 16-entry LDS stack (+-1 %).
         }
         bool finished = false;
         if (nxt != WAIT) {
             const bool pop = nxt == POP;
             finished = (nxt == HIT) | (pop & (sp == 0));
-#if NVDR_TRACE_LAZY_PEEK
-            int popv = nxt;
-            if (pop & (sp > 0)) popv = stack.pop(sp - 1);
-#endif
             sp -= (pop & (sp > 0)) ? 1 : 0;
             cur = pop ? popv : nxt;
         }

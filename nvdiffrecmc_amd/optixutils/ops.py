@@ -67,12 +67,6 @@ class OptiXContext:
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')
 
-    def set_trace_xcd_partition(self, on=True):
-        """Chunk dealing of the traversal kernel: one contiguous eighth of the ray list per XCD (True) or interleaved (False,
-        the default; csrc/trace_kernel.h).  Results are identical."""
-        w = self.cpp_wrapper
-        _lib.check(w.lib.nvdr_ctx_set_trace_flags(w.handle, _lib.TRACE_XCD_PARTITION if on else 0), 'nvdr_ctx_set_trace_flags')
-
     def check(self):
         """Synchronise and raise if any traversal launch on this context ever overflowed its stack (never silent)."""
         w = self.cpp_wrapper

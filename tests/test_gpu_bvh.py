@@ -268,10 +268,10 @@ def test_canonical_counters_equal_cpu_walk_of_exported_tree(dev):
     assert 5 < n_node / ro.shape[0] < 60
 
 
-def test_both_chunk_dealings_give_the_same_bits(dev):
-    """The production shadow-ray kernel deals its ray chunks either interleaved over the chip or one contiguous eighth of the
-    list per XCD with stealing (csrc/trace_kernel.h): both must answer like the binary walk, bit for bit -- also when the list
-    is shorter than the 64 counters serve and when it does not divide by the chunk size."""
+def test_production_kernel_equals_binary_walk_at_odd_list_lengths(dev):
+    """The production shadow-ray kernel claims chunks of 256 rays from 64 counters (csrc/trace_kernel.h): it must answer like
+    the binary walk, bit for bit, also when the list is shorter than the counters serve and when it does not divide by the
+    chunk size."""
     from nvdiffrecmc_amd import optixutils as ou
     mesh = sc.load_mesh('bob')
     ctx = make_ctx(mesh, dev)
@@ -279,9 +279,6 @@ def test_both_chunk_dealings_give_the_same_bits(dev):
         ro, rd = _rays(n, 31 + n)
         ro, rd = ro.to(dev), rd.to(dev)
         ref = ou.trace_visibility(ctx, ro, rd)
-        for part in (False, True):
-            ctx.set_trace_xcd_partition(part)
-            got = ou.trace_visibility_wide(ctx, ro, rd)
-            assert torch.equal(got, ref), 'xcd partition %s, %d rays: %d differ' % (part, n, int((got != ref).sum()))
-    ctx.set_trace_xcd_partition(False)
+        got = ou.trace_visibility_wide(ctx, ro, rd)
+        assert torch.equal(got, ref), '%d rays: %d differ' % (n, int((got != ref).sum()))
     ctx.check()

@@ -225,54 +225,31 @@ def test_render_layer_restatement_interpolates_like_nvdiffrast():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # chunk dealing of the traversal kernel (csrc/trace_kernel.h ChunkDealer): a sequential model of claim() under random
-# wave interleavings -- every chunk of the list must be handed out exactly once, whatever XCD a wave reports
+# wave interleavings -- every chunk of the list must be handed out exactly once for every grid the launcher can start
 
-def _deal(n_rays, n_waves, partitioned, rng, xcd_of=lambda wid: (wid // 4) % 8):
+def _deal(n_rays, n_waves, rng):
     QC, Q = 256, 64
     n_chunks = (n_rays + QC - 1) // QC
-    partitioned = partitioned and n_waves >= 64
-    counters = [0] * 64
-    waves = [{'wid': w, 'sub': ((w >> 3) & 7) if partitioned else (w % Q), 'part': xcd_of(w) & 7, 'tried': 0, 'done': False}
-             for w in range(n_waves)]
+    counters = [0] * Q
+    live = list(range(n_waves))
     claimed = []
-
-    def claim(w):
-        if not partitioned:
-            j = counters[w['sub']]
-            counters[w['sub']] += 1
-            c = j * Q + w['sub']
-            return c if c < n_chunks else None
-        while w['tried'] < 8:
-            p = w['part']
-            lo, hi = (p * n_chunks) >> 3, ((p + 1) * n_chunks) >> 3
-            q = p * 8 + w['sub']
-            j = None
-            if w['tried'] == 0 or counters[q] * 8 + w['sub'] + lo < hi:
-                j = counters[q]
-                counters[q] += 1
-            if j is not None and j * 8 + w['sub'] + lo < hi:
-                return j * 8 + w['sub'] + lo
-            w['part'] = (p + 1) & 7
-            w['tried'] += 1
-        return None
-
-    live = list(waves)
     while live:
         w = live[rng.randrange(len(live))]
-        c = claim(w)
-        if c is None:
-            live.remove(w)
-        else:
+        sub = w % Q
+        j = counters[sub]
+        counters[sub] += 1
+        c = j * Q + sub
+        if c < n_chunks:
             claimed.append(c)
+        else:
+            live.remove(w)
     return n_chunks, claimed
 
 
-@pytest.mark.parametrize('partitioned', [False, True])
-def test_chunk_dealing_hands_out_every_chunk_exactly_once(partitioned):
+def test_chunk_dealing_hands_out_every_chunk_exactly_once():
     import random
     rng = random.Random(7)
     for n_rays in (0, 1, 255, 256, 257, 4095, 4096, 4097, 70001, 2_000_003):
         blocks = max(1, min(2048, (n_rays + 255) // 256))            # the launcher's grid (env_shade.hip)
-        for xcd_of in (lambda w: (w // 4) % 8, lambda w: 3, lambda w: rng.randrange(8)):
-            n_chunks, claimed = _deal(n_rays, 4 * blocks, partitioned, rng, xcd_of)
-            assert sorted(claimed) == list(range(n_chunks)), (n_rays, partitioned)
+        n_chunks, claimed = _deal(n_rays, 4 * blocks, rng)
+        assert sorted(claimed) == list(range(n_chunks)), n_rays

@@ -19,10 +19,7 @@ paths = [('current', base)] + [(p.split('.so.')[-1], p) for p in sorted(glob.glo
 only = os.environ.get('AB_ONLY')
 if only:
     paths = [pp for pp in paths if pp[0] in only.split(',') or pp[0] == 'current']
-want_xcd = not only or 'xcdpart' in only.split(',')
 
-if want_xcd:
-    paths.append(('xcdpart', base))            # the current build with the per-XCD chunk dealing switched on
 steps = {}
 for tag, path in paths:
     _lib._lib = None
@@ -30,8 +27,6 @@ for tag, path in paths:
     lib = _lib.load()
     st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
     assert st.ctx.cpp_wrapper.lib is lib
-    if tag == 'xcdpart':
-        st.ctx.set_trace_xcd_partition(True)
     with torch.no_grad():
         m = st.mask[..., None]
         kd = (st.kd_tex[st.texel].view(st.nv, res, res, 3) * m).contiguous()

@@ -37,7 +37,7 @@ for tag, path in paths:
 _build.LIB = base
 
 
-def run(tag, iters=4):
+def run(tag, iters=int(os.environ.get('AB_ITERS', '4'))):
     """Average stage times (gen, trace, shade forward; trace, shade backward) over iters - 1 forward + backward passes."""
     st, kd, ks, nrm, ro = steps[tag]
     L = st.light
@@ -69,4 +69,7 @@ print('env-shade stage times, %d views, %d rounds interleaved in one process: me
 print('  %-10s %s' % ('', '  '.join('%-18s' % n for n in names)))
 for tag in steps:
     print('  %-10s %s' % (tag, '  '.join('%7.3f (%+5.1f %%)  ' % (med[tag][k], 100.0 * (med[tag][k] / med['current'][k] - 1.0)) for k in range(5))))
+print('traversal ms of every measured pass (forward | backward):')
+for tag in steps:
+    print('  %-10s %s | %s' % (tag, ' '.join('%.1f' % v[1] for v in times[tag]), ' '.join('%.1f' % v[3] for v in times[tag])))
 print('tenancy at the end: ' + snapshot())

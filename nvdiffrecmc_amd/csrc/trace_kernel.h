@@ -48,36 +48,26 @@ struct TraceLaunch {
 // inside ONE moving window of the list.  Every counter must be served by somebody: chunk c sits on counter c % 64 and the
 // launcher starts at least min(chunks, 2048) workgroups of 4 waves, so counter c % 64 < waves.
 // (Measured and dropped, interleaved in-process A/B, profiles/r02_ab_traversal_variants.md: one contiguous eighth of the list per
-// XCD with stealing -- each L2 caching another region of the tree -- is 4-7 % SLOWER on bob and +-2 % on 684 k triangles.)
-#ifndef NVDR_TRACE_STATIC
-#define NVDR_TRACE_STATIC 0    // experiment: 1 = no atomics, wave w walks the chunks w, w + waves, w + 2 waves ...
-#endif
+// XCD with stealing -- each L2 caching another region of the tree -- is 4-7 % SLOWER on bob and +-2 % on 684 k triangles; static
+// dealing without atomics (wave w walks the chunks w, w + waves, ...) is within 1 % of the claiming on 684 k triangles.)
 struct ChunkDealer {
     unsigned *queue;               // this wave's counter
     unsigned n_chunks, total, sub;
-    unsigned wid, n_waves, k;      // (static dealing)
 
-    __device__ __forceinline__ void init(unsigned *queues, unsigned total_, unsigned wid_)
+    __device__ __forceinline__ void init(unsigned *queues, unsigned total_, unsigned wid)
     {
         total = total_;
         n_chunks = (total_ + NVDR_TRACE_QCHUNK - 1u) / NVDR_TRACE_QCHUNK;
-        sub = wid_ % NVDR_TRACE_QUEUES;
+        sub = wid % NVDR_TRACE_QUEUES;
         queue = queues + sub * 32u;
-        wid = wid_; n_waves = gridDim.x * (blockDim.x >> 6); k = 0;
     }
     // wave-uniform: claims the next chunk for the whole wave; false = the list is used up
     __device__ __forceinline__ bool claim(int lane, unsigned &next, unsigned &end)
     {
-#if NVDR_TRACE_STATIC
-        (void)lane;
-        const unsigned c = k * n_waves + wid;
-        k++;
-#else
         unsigned j = 0;
         if (lane == 0) j = atomicAdd(queue, 1u);
         j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
         const unsigned c = j * NVDR_TRACE_QUEUES + sub;
-#endif
         if (c >= n_chunks) return false;
         next = c * NVDR_TRACE_QCHUNK;
         end = min(next + NVDR_TRACE_QCHUNK, total);

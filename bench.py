@@ -127,6 +127,8 @@ PMC_PASSES = [
      'SQ_WAVES', 'GRBM_GUI_ACTIVE'],
     ['FETCH_SIZE'],
     ['TCC_REQ_sum', 'WRITE_SIZE', 'TCC_MISS_sum'],
+    # the instruction mix of the traversal loop: how many issue slots go to scalar / branch / memory instructions beside VALU
+    ['SQ_INSTS_SALU', 'SQ_INSTS_SMEM', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR', 'SQ_WAIT_ANY'],
 ]
 
 
@@ -233,6 +235,14 @@ def valu_figures(c, kernel_ms):
         out['valu_busy_counter'] = active * 4.0 / (N_CUS * SIMDS_PER_CU * cycles)
     if c.get('SQ_WAVE_CYCLES') and c.get('SQ_WAIT_INST_ANY'):
         out['wave_time_waiting_on_issue_or_memory'] = c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']
+    mix = {k: c.get(k) for k in ('SQ_INSTS_SALU', 'SQ_INSTS_SMEM', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_VMEM_WR') if c.get(k) is not None}
+    if mix:
+        # wave-instructions of every kind per SIMD and cycle: the traversal loop spends about as many issue slots on scalar
+        # (exec-mask / branch) instructions as on VALU ones
+        total = insts + sum(mix.values())
+        out['instruction_mix_per_launch'] = dict(mix, SQ_INSTS_VALU=insts)
+        out['valu_share_of_instructions'] = insts / total
+        out['instructions_per_cycle_per_simd'] = total / (N_CUS * SIMDS_PER_CU * CLOCK_GHZ * 1e9 * kernel_ms * 1e-3)
     return out
 
 
@@ -540,6 +550,10 @@ def run(args):
             'ms_per_step': dt / args.steps * 1e3,
             'median_ms_per_step': med, 'median_over_steps': len(ext_ms) if ext_ms else len(step_ms),
             'min_ms_per_step': min(ext_ms or step_ms), 'max_ms_per_step': max(ext_ms or step_ms),
+            # steps that took more than twice the median: the traversal kernel of this pool's GPUs occasionally stalls for
+            # 0.3-0.4 s inside one dispatch (profiles/r02_slow_mode.md); `value` is the mean over the timed steps and includes them
+            'steps_over_twice_the_median': sum(1 for v in (ext_ms or step_ms) if v > 2.0 * med),
+            'timed_steps_over_twice_the_median': sum(1 for v in step_ms if v > 2.0 * med),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%s, batch of %d views per iteration (%s), LBVH + HIP traversal + GGX shading + bilateral denoiser + log-sRGB L1 loss, fwd+bwd+Adam'

@@ -378,7 +378,8 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         if (mb >= 1) c->stream_budget = (int64_t)mb << 20;
     }
     // NVDR_DEBUG (experiments only: 1 skip tracing, 2 skip the light gradient, 8 trace dead samples, 16 light-gradient
-    // atomics instead of the band gather) is read ONCE here, not per launch, and announced when set
+    // atomics instead of the band gather, 32 pretend the traversal stack holds 13 entries, 64 no reset kernel in front of
+    // the traversal kernel) is read ONCE here, not per launch, and announced when set
     if (const char *dbg = getenv("NVDR_DEBUG")) {
         c->debug = (unsigned)atoi(dbg);
         if (c->debug) fprintf(stderr, "[nvdr] NVDR_DEBUG=%u is active on this context (experiment switches; not for production)\n", c->debug);

@@ -219,52 +219,19 @@ __device__ __forceinline__ unsigned cdf_iterations(unsigned hi)
     // int(ceil(log2(float(hi)))) + 1  (kernel.cu:147), in integers
     return hi >= 2u ? (unsigned)(32 - __clz((int)(hi - 1u))) + 1u : hi;
 }
-// CDF inversion, kernel.cu:141-166: m steps of the reference's bisection.  The steps are dependent loads (~L2 latency each, 2 x 9
-// of them per light sample at 256^2), so NVDR_CDF_UNROLL > 1 runs k steps per round trip by loading the mid of the step AND the
-// mids of the following steps for either outcome (3 loads for k = 2, 7 for k = 3) before deciding: same comparisons on the same
-// table entries in the same order, hence the same (lo, hi) after every step -- also for NaN entries, which leave both unchanged.
-#ifndef NVDR_CDF_UNROLL
-#define NVDR_CDF_UNROLL 1
-#endif
-__device__ __forceinline__ void cdf_step(float x, float c, unsigned mid, unsigned &lo, unsigned &hi)
-{
-    const unsigned l = x >= c ? mid : lo, h = x < c ? mid : hi;
-    lo = l; hi = h;
-}
+// CDF inversion, kernel.cu:141-166: m steps of the reference's bisection.  (Measured and dropped, session V of round 2: running 2 or
+// 3 steps per round trip by loading the mids of the following steps for either outcome -- same comparisons, bit-identical, parity
+// tests green -- makes the kernel 1.4 % / 10 % SLOWER: the kernel is not waiting for these loads, the extra lookups cost more.)
 __device__ __forceinline__ float sample_cdf(const float *__restrict__ cdf, int stride, int size, float x, unsigned &idx)
 {
     x = fminf(x, 0.99999994f);
     unsigned lo = 0, hi = (unsigned)(size - 1);
     const unsigned m = cdf_iterations(hi);
-    unsigned i = 0;
-#if NVDR_CDF_UNROLL == 3
-    for (; i + 2 < m; i += 3) {
-        const unsigned mid = (lo + hi) >> 1, mL = (lo + mid) >> 1, mR = (mid + hi) >> 1;
-        const unsigned mLL = (lo + mL) >> 1, mLR = (mL + mid) >> 1, mRL = (mid + mR) >> 1, mRR = (mR + hi) >> 1;
-        const float c = cdf[mid * stride], cL = cdf[mL * stride], cR = cdf[mR * stride];
-        const float cLL = cdf[mLL * stride], cLR = cdf[mLR * stride], cRL = cdf[mRL * stride], cRR = cdf[mRR * stride];
-        cdf_step(x, c, mid, lo, hi);
-        const unsigned mid2 = (lo + hi) >> 1;
-        const float c2 = mid2 == mL ? cL : mid2 == mR ? cR : c;        // (equal indices hold equal values)
-        cdf_step(x, c2, mid2, lo, hi);
-        const unsigned mid3 = (lo + hi) >> 1;
-        const float c3 = mid3 == mLL ? cLL : mid3 == mLR ? cLR : mid3 == mRL ? cRL : mid3 == mRR ? cRR : mid3 == mid2 ? c2 : c;
-        cdf_step(x, c3, mid3, lo, hi);
-    }
-#endif
-#if NVDR_CDF_UNROLL >= 2
-    for (; i + 1 < m; i += 2) {
-        const unsigned mid = (lo + hi) >> 1, mL = (lo + mid) >> 1, mR = (mid + hi) >> 1;
-        const float c = cdf[mid * stride], cL = cdf[mL * stride], cR = cdf[mR * stride];
-        cdf_step(x, c, mid, lo, hi);
-        const unsigned mid2 = (lo + hi) >> 1;
-        const float c2 = mid2 == mL ? cL : mid2 == mR ? cR : c;
-        cdf_step(x, c2, mid2, lo, hi);
-    }
-#endif
-    for (; i < m; ++i) {
+    for (unsigned i = 0; i < m; ++i) {
         const unsigned mid = (lo + hi) >> 1;
-        cdf_step(x, cdf[mid * stride], mid, lo, hi);
+        const float c = cdf[mid * stride];
+        lo = x >= c ? mid : lo;
+        hi = x < c ? mid : hi;
     }
     idx = hi;
     float pdf, sample;

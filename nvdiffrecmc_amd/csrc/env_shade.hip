@@ -13,13 +13,13 @@
 //                            stratum, kernel.cu:513-524): bit-identical random sequence to the serial loop.  Samples
 //                            under the shading horizon contribute exactly zero and are left out of the LIVE-RAY LIST
 //                            the next stage walks;
-//       2. env_trace_kernel  PERSISTENT wavefronts over the live-ray list (round-robin chunks of 64): a lane that
-//                            finishes its ray immediately takes the next one of its wave (wave-uniform cursor, no
-//                            atomics), so lanes never idle behind the slowest ray of a pixel; four-slot wide nodes,
-//                            the traversal stack in LDS, one bank per lane;
+//       2. env_trace_kernel  (trace_kernel.h) PERSISTENT wavefronts over the live-ray list, chunks of 256 rays claimed from 64
+//                            device counters: a lane that finishes its ray immediately takes the next one of its wave
+//                            (wave-uniform cursor), so lanes never idle behind the slowest ray of a pixel; four-slot wide
+//                            nodes, unordered any-hit descent, the traversal stack in LDS, one bank per lane;
 //       3. env_shade_kernel  BSDF evaluation (forward) or hand-derived gradients (backward) per live sample, reduced
-//                            across the L lanes with shuffle butterflies; only the light gradient needs global
-//                            atomics (kernel.cu:208-210).
+//                            across the L lanes with shuffle butterflies; the light gradient leaves (texel, rgb) records
+//                            in the stream that an LDS band gather reduces (no global atomics; kernel.cu:208-210).
 //     Why not one fused kernel (the first version, 2.1 ms forward): rocprofv3 showed the traversal VALU-bound at ~40 %
 //     active lanes and the fused kernel spilling 67 VGPRs + 146 SGPRs; the split keeps each stage in registers and
 //     lets the traversal refill lanes across pixel boundaries.

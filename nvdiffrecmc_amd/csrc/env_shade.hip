@@ -1087,13 +1087,16 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (pb[k] * waves_per_block > max_groups) pb[k] = (max_groups + waves_per_block - 1) / waves_per_block;
         if (pb[k] < 1) pb[k] = 1;
     }
+#ifndef NVDR_TRACE_BLOCKS_PER_CU
+#define NVDR_TRACE_BLOCKS_PER_CU 8
+#endif
     int64_t tblocks = (int64_t)c->n_cus * NVDR_TRACE_BLOCKS_PER_CU;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     {
         const int64_t need = (cap * 2 * S + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
         if (tblocks > need) tblocks = need < 1 ? 1 : need;
     }
-    const size_t trace_lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK) * (NVDR_TRACE_DUAL ? 2 : 1);
+    const size_t trace_lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
     const bool replay = backward && p.vis_cache != nullptr;   // forward bits handed back by the caller: no traversal
 
     c->stream_id = 0; // invalid while being rewritten
@@ -1178,11 +1181,11 @@ extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const fl
     if (r) return r;
     c->stream_id = 0;
     pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts, c->queues);
-    int64_t tblocks = (int64_t)c->n_cus * NVDR_TRACE_BLOCKS_PER_CU;
+    int64_t tblocks = (int64_t)c->n_cus * 8;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
     if (tblocks > need) tblocks = need;
-    launch_trace(c, (unsigned)tblocks, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK) * (NVDR_TRACE_DUAL ? 2 : 1), stream, c->chunk_counts, 1u, nullptr);
+    launch_trace(c, (unsigned)tblocks, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u, nullptr);
     NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
     NVDR_LAUNCH_CHECK();
     return 0;

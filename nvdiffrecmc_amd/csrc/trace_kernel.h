@@ -30,15 +30,6 @@
 #ifndef NVDR_TRACE_OCC
 #define NVDR_TRACE_OCC 8       // waves per SIMD the kernel is compiled for (= resident workgroups per CU of the persistent grid)
 #endif
-#ifndef NVDR_TRACE_BLOCKS_PER_CU
-#define NVDR_TRACE_BLOCKS_PER_CU NVDR_TRACE_OCC
-#endif
-
-// experiment: 1 = every lane works on TWO rays, software-pipelined (the node fetch of one ray is in flight while the other ray's
-// node is tested); 5 workgroups per CU (NVDR_TRACE_OCC = NVDR_TRACE_BLOCKS_PER_CU = 5), two LDS stacks per lane
-#ifndef NVDR_TRACE_DUAL
-#define NVDR_TRACE_DUAL 0
-#endif
 
 struct TraceLaunch {
     BvhView bvh;
@@ -84,108 +75,6 @@ struct ChunkDealer {
     }
 };
 
-
-#if NVDR_TRACE_DUAL
-// the second ray's stack: its own LDS columns behind those of the first rays, its own spill region behind the launch's regions
-// (EXPERIMENT: the context's spill buffer holds NVDR_QUERY_MAX_BLOCKS regions, so 2 x gridDim.x must stay below that for meshes
-// whose stacks outgrow the LDS part)
-__device__ __forceinline__ TravStack make_stack2(int *smem, int *spill, int stack_max, int *overflow)
-{
-    TravStack s = make_stack(smem, spill, stack_max, overflow);
-    s.lds += (blockDim.x >> 6) * NVDR_STACK_LDS * 64;
-    s.glb += (int64_t)gridDim.x * blockDim.x * max(stack_max - NVDR_STACK_LDS, 0);
-    return s;
-}
-
-// One of the two rays a lane works on.  q0..q3 = the wide node of `cur`, fetched at the END of the ray's previous turn, i.e. in
-// flight during the other ray's turn.
-struct TraceRay {
-    int ray, cur, sp;
-    float ox, oy, oz, dx, dy, dz;
-    float nx, ny, nz, ix, iy, iz;      // GridRay without its three byte-permute selectors (recomputed per node step: 6 VGPRs less)
-    uint4 q0, q1, q2, q3;
-};
-
-// One turn of one ray state: leaf step / node step (gated like the single-ray loop), pop, refill, fetch of the next node.
-// Returns false when the state has no ray in any lane and the list is used up.
-template <bool COUNT>
-__device__ __forceinline__ bool trace_turn(TraceRay &s, const TravStack &stack, const TraceLaunch &a, ChunkDealer &dealer, unsigned &next,
-                                           unsigned &end, bool &more, int lane, bool single, unsigned &n_box, unsigned &n_tri, unsigned &n_ray)
-{
-    const BvhView &bvh = a.bvh;
-    const int POP = NVDR_TRAV_DONE, HIT = NVDR_TRAV_DONE - 1, WAIT = NVDR_TRAV_DONE - 2;
-    const int n_leaf = __popcll(__ballot(s.ray >= 0 && s.cur < 0));
-    const int n_node = __popcll(__ballot(s.ray >= 0 && s.cur >= 0));
-    const bool leaf_turn = n_leaf >= NVDR_LEAF_MIN || n_node == 0;
-    int nxt = WAIT;
-    if (leaf_turn && s.ray >= 0 && s.cur < 0) {
-        if (COUNT) n_tri++;
-        nxt = tri_any_hit(bvh.tris, ~s.cur, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz) ? HIT : POP;
-    }
-    const int popv = stack.peek(s.sp);
-    if (n_node > 0 && s.ray >= 0 && s.cur >= 0) {
-        GridRay g;
-        g.nx = s.nx; g.ny = s.ny; g.nz = s.nz; g.ix = s.ix; g.iy = s.iy; g.iz = s.iz;
-        g.px = g.ix >= 0.0f ? 0x03020504u : 0x05040302u;      // as make_grid_ray (bvh.h)
-        g.py = g.iy >= 0.0f ? 0x01000706u : 0x07060100u;
-        g.pz = g.iz >= 0.0f ? 0x03020504u : 0x05040302u;
-        float t0, t1, t2, t3;
-        const bool h0 = slot_hit(s.q0, g, NVDR_RAY_TMAX, t0), h1 = slot_hit(s.q1, g, NVDR_RAY_TMAX, t1);
-        const bool h2 = slot_hit(s.q2, g, NVDR_RAY_TMAX, t2), h3 = slot_hit(s.q3, g, NVDR_RAY_TMAX, t3);
-        (void)t0; (void)t1; (void)t2; (void)t3;
-        const int c0 = (int)s.q0.w, c1 = (int)s.q1.w, c2 = (int)s.q2.w, c3 = (int)s.q3.w;
-        if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
-        nxt = h0 ? c0 : h1 ? c1 : h2 ? c2 : h3 ? c3 : POP;
-        const bool b01 = h0 | h1, b012 = b01 | h2;
-        if (h1 & h0) s.sp = stack.push(s.sp, c1);
-        if (h2 & b01) s.sp = stack.push(s.sp, c2);
-        if (h3 & b012) s.sp = stack.push(s.sp, c3);
-    }
-    if (nxt != WAIT) {
-        const bool pop = nxt == POP;
-        const bool finished = (nxt == HIT) | (pop & (s.sp == 0));
-        s.sp -= (pop & (s.sp > 0)) ? 1 : 0;
-        s.cur = pop ? popv : nxt;
-        if (finished) {
-            a.vis[s.ray] = nxt == HIT ? 0 : 1;
-            s.ray = -1;
-        }
-    }
-    // refill the idle lanes of this state from the wave's chunk
-    const unsigned long long idle = __ballot(s.ray < 0);
-    const int n_idle = __popcll(idle);
-    if (n_idle >= NVDR_REFILL_MIN && next >= end && more) {
-        more = dealer.claim(lane, next, end);
-        if (!more) next = end = 0u;
-    }
-    bool refilled = false;
-    if (next < end && n_idle >= NVDR_REFILL_MIN) {
-        const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-        if (s.ray < 0 && take < end) {
-            const unsigned slot = a.live[take];
-            s.ray = (int)slot;
-            if (COUNT) n_ray++;
-            const float4 rd = a.rays[slot];
-            const float4 ro = a.pix_origin[slot / a.rays_per_pixel];
-            s.ox = ro.x; s.oy = ro.y; s.oz = ro.z;
-            s.dx = rd.x; s.dy = rd.y; s.dz = rd.z;
-            const GridRay g = make_grid_ray(bvh.info, s.ox, s.oy, s.oz, s.dx, s.dy, s.dz);
-            s.nx = g.nx; s.ny = g.ny; s.nz = g.nz; s.ix = g.ix; s.iy = g.iy; s.iz = g.iz;
-            s.cur = single ? ~0 : 0;
-            s.sp = 0;
-        }
-        next += (unsigned)n_idle;
-        refilled = true;
-    }
-    // the node this ray tests in its NEXT turn: in flight while the other ray has its turn
-    if (s.ray >= 0 && s.cur >= 0) {
-        const uint4 *w4 = bvh.wide + 4 * (int64_t)s.cur;
-        s.q0 = w4[0]; s.q1 = w4[1]; s.q2 = w4[2]; s.q3 = w4[3];
-    }
-    return refilled || n_idle < 64 || more;
-}
-#endif
-
 // COUNT: the counting build (box / triangle tests, per-wave clocks)
 template <bool COUNT>
 __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
@@ -210,23 +99,6 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
     const unsigned long long c_begin = COUNT ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
 
-#if NVDR_TRACE_DUAL
-    const TravStack stack1 = make_stack2(smem, a.spill, bvh.stack_max, bvh.overflow);
-    TraceRay s0, s1;
-    s0.ray = s1.ray = -1; s0.cur = s1.cur = 0; s0.sp = s1.sp = 0;
-    s0.ox = s0.oy = s0.oz = s0.dx = s0.dy = s0.dz = 0.0f;
-    s1.ox = s1.oy = s1.oz = s1.dx = s1.dy = s1.dz = 0.0f;
-    s0.nx = s0.ny = s0.nz = s0.ix = s0.iy = s0.iz = 0.0f;
-    s1.nx = s1.ny = s1.nz = s1.ix = s1.iy = s1.iz = 0.0f;
-    s0.q0 = s0.q1 = s0.q2 = s0.q3 = make_uint4(0u, 0u, 0u, (unsigned)NVDR_TRAV_EMPTY);
-    s1.q0 = s1.q1 = s1.q2 = s1.q3 = s0.q0;
-    (void)rays; (void)pix_origin; (void)live; (void)vis; (void)rays_per_pixel;
-    while (true) {
-        const bool a0 = trace_turn<COUNT>(s0, stack, a, dealer, next, end, more, lane, single, n_box, n_tri, n_ray);
-        const bool a1 = trace_turn<COUNT>(s1, stack1, a, dealer, next, end, more, lane, single, n_box, n_tri, n_ray);
-        if (!a0 && !a1) break;
-    }
-#else
     int ray = -1, cur = 0, sp = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
     GridRay g;
@@ -306,7 +178,10 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             // slot; unconditional LDS writes at the running depth + one rare spill branch (0.70 vs 0.67 ms); a wave-uniform
             // "nobody leaves the LDS part of the stack" fast path (+-0 %); reading the stack top only in lanes that pop (+-1 %);
             // leaf batches of 12 / 16 instead of 8 (+-1 %); refill thresholds 8 / 24 (+5 % / +-0 %); 6 waves per SIMD (+3..7 %);
-            // a 16-entry LDS stack (+-1 %).
+            // a 16-entry LDS stack (+-1 %).  Also measured and dropped (session Y): TWO rays per lane, software-pipelined so that the
+            // node fetch of one ray is in flight while the other ray's node is tested (112 VGPRs, 4 waves per SIMD, two LDS stacks
+            // per lane; bit-exact on the first run) -- +30 % (one view) / +37 % (8 views): eight hardware-interleaved waves hide
+            // the fetch better than four waves that interleave two rays in software.
         }
         bool finished = false;
         if (nxt != WAIT) {
@@ -320,7 +195,6 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             ray = -1;
         }
     }
-#endif
     if (COUNT) {
         for (int o = 32; o >= 1; o >>= 1) {
             n_box += __shfl_xor(n_box, o);

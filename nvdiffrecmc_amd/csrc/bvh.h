@@ -227,9 +227,20 @@ __device__ __forceinline__ GridRay make_grid_ray(const BvhDeviceInfo *__restrict
 {
     GridRay g;
     const float sx = info->g_scale[0], sy = info->g_scale[1], sz = info->g_scale[2];
-    g.ix = 1.0f / (dx * sx);
-    g.iy = 1.0f / (dy * sy);
-    g.iz = 1.0f / (dz * sz);
+    // An axis the ray does not move along has 1 / (d * s) = +-inf, and in the fused form below b * inf + (-o * inf) is NaN for EVERY
+    // plane (grid coordinates are positive), so fminf / fmaxf would drop that axis from every box test: correct, but an exactly
+    // axis-parallel ray -- two such axes; a light sample at the pole of the probe is (0, 1, -0) once in ~1e8 samples -- would cull
+    // along ONE axis only and visit a large part of the tree: hundreds of thousands of steps for one lane on a 684 k-triangle
+    // mesh, 0.3-0.4 s during which the whole launch waits for it (the "slow mode" / "stalls" of rounds 1-2,
+    // profiles/r02_slow_mode.md).  With |inv| capped at 1e30 the planes of such an axis evaluate to (b - o) * 1e30, i.e. to
+    // -huge / +huge when the origin lies between them (no constraint, as it must be) and to +-huge on the same side when it does
+    // not (culled): still conservative -- o is at least 0.99 cells inside the padded box of any triangle the exact predicate can
+    // hit, the rounding of b * 1e30 - o * 1e30 is worth 0.004 cells, and a ray with |inv| >= 1e30 moves < 1e-14 cells over the
+    // whole parameter range [0, 1e16] anyway.
+    const float INV_MAX = 1.0e30f;
+    g.ix = fminf(fmaxf(1.0f / (dx * sx), -INV_MAX), INV_MAX);
+    g.iy = fminf(fmaxf(1.0f / (dy * sy), -INV_MAX), INV_MAX);
+    g.iz = fminf(fmaxf(1.0f / (dz * sz), -INV_MAX), INV_MAX);
     g.nx = -((ox - info->g_lo[0]) * sx + 2.0f) * g.ix;
     g.ny = -((oy - info->g_lo[1]) * sy + 2.0f) * g.iy;
     g.nz = -((oz - info->g_lo[2]) * sz + 2.0f) * g.iz;
@@ -244,7 +255,8 @@ __device__ __forceinline__ GridRay make_grid_ray(const BvhDeviceInfo *__restrict
 
 // Slab test of one child box against the ray interval [0, tmax].  The traversal is VALU-issue bound, so every plane
 // distance is ONE fma (pairs of them pack into v_pk_fma_f32).  An axis-parallel ray gives inv = +-inf and NaN plane
-// distances; fminf/fmaxf drop NaNs, i.e. that axis simply stops culling: conservative.  The fma rounds differently
+// distances; fminf/fmaxf drop NaNs, i.e. that axis simply stops culling: conservative (make_grid_ray caps |inv| so that this
+// only happens for NaN inputs).  The fma rounds differently
 // from (b - o) * inv by < 0.01 grid cells, far inside the one-cell slack every box carries.
 __device__ __forceinline__ bool box_hit(float minx, float miny, float minz, float maxx, float maxy, float maxz,
                                         const GridRay &r, float tmax, float &tnear)

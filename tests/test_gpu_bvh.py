@@ -282,3 +282,28 @@ def test_production_kernel_equals_binary_walk_at_odd_list_lengths(dev):
         got = ou.trace_visibility_wide(ctx, ro, rd)
         assert torch.equal(got, ref), '%d rays: %d differ' % (n, int((got != ref).sum()))
     ctx.check()
+
+
+def test_axis_parallel_rays_cost_what_other_rays_cost(dev):
+    """A ray that does not move along an axis has an infinite inverse direction there; round 2 found that the fused slab test then
+    stopped culling on that axis (NaN planes), so an EXACTLY axis-parallel ray -- the light sample at the pole of the probe is
+    (0, 1, -0) once in ~1e8 samples -- walked a large part of the tree: hundreds of thousands of steps for one lane on a big mesh
+    (the "slow mode" of rounds 1-2).  make_grid_ray caps |1/d|: such rays must answer like brute force AND visit about as many
+    boxes as other rays (counted by the binary walk: this is a deterministic check, not a timing)."""
+    from nvdiffrecmc_amd import optixutils as ou
+    mesh = sc.load_mesh('bob')
+    ctx = make_ctx(mesh, dev)
+    g = torch.Generator().manual_seed(11)
+    v = mesh['v_pos']
+    n = 6000
+    ro = (v[torch.randint(0, v.shape[0], (n,), generator=g)] * 0.999).contiguous()      # just inside the surface: long walks
+    dirs = torch.tensor([[0.0, 1.0, -0.0], [-0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [-1.0, -0.0, 0.0], [0.0, -0.0, 1.0], [-0.0, 0.0, -1.0]])
+    rd = dirs.repeat(n // 6, 1).contiguous()
+    ref = orc.visibility(mesh['v_pos'], mesh['t_pos_idx'], ro, rd, n_threads=NT)
+    got, cnt = ou.trace_visibility(ctx, ro.to(dev), rd.to(dev), count=True)
+    assert torch.equal(got.cpu(), ref), '%d of %d axis-parallel rays differ' % (int((got.cpu() != ref).sum()), n)
+    assert torch.equal(ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev)).cpu(), ref)
+    ro2, rd2 = _rays(n, 12)
+    _, cnt2 = ou.trace_visibility(ctx, ro2.to(dev), rd2.to(dev), count=True)
+    per_ray, per_ray2 = cnt[0].item() / n, cnt2[0].item() / n
+    assert per_ray < 4.0 * per_ray2 + 50.0, 'axis-parallel rays test %.0f boxes each, random rays %.0f' % (per_ray, per_ray2)

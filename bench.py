@@ -550,8 +550,8 @@ def run(args):
             'ms_per_step': dt / args.steps * 1e3,
             'median_ms_per_step': med, 'median_over_steps': len(ext_ms) if ext_ms else len(step_ms),
             'min_ms_per_step': min(ext_ms or step_ms), 'max_ms_per_step': max(ext_ms or step_ms),
-            # steps that took more than twice the median: the traversal kernel of this pool's GPUs occasionally stalls for
-            # 0.3-0.4 s inside one dispatch (profiles/r02_slow_mode.md); `value` is the mean over the timed steps and includes them
+            # steps that took more than twice the median (straggler flag: until the end of round 2 an exactly axis-parallel ray
+            # could hold a launch for 0.3-0.4 s, profiles/r02_slow_mode.md); `value` is the mean over the timed steps and includes them
             'steps_over_twice_the_median': sum(1 for v in (ext_ms or step_ms) if v > 2.0 * med),
             'timed_steps_over_twice_the_median': sum(1 for v in step_ms if v > 2.0 * med),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,

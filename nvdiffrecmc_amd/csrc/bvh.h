@@ -237,7 +237,11 @@ __device__ __forceinline__ GridRay make_grid_ray(const BvhDeviceInfo *__restrict
     // not (culled): still conservative -- o is at least 0.99 cells inside the padded box of any triangle the exact predicate can
     // hit, the rounding of b * 1e30 - o * 1e30 is worth 0.004 cells, and a ray with |inv| >= 1e30 moves < 1e-14 cells over the
     // whole parameter range [0, 1e16] anyway.
-    const float INV_MAX = 1.0e30f;
+    // (NVDR_INV_CAP=0 builds the uncapped form again: tools/axis_ray_probe.py compares the two)
+#ifndef NVDR_INV_CAP
+#define NVDR_INV_CAP 1
+#endif
+    const float INV_MAX = NVDR_INV_CAP ? 1.0e30f : __builtin_inff();
     g.ix = fminf(fmaxf(1.0f / (dx * sx), -INV_MAX), INV_MAX);
     g.iy = fminf(fmaxf(1.0f / (dy * sy), -INV_MAX), INV_MAX);
     g.iz = fminf(fmaxf(1.0f / (dz * sz), -INV_MAX), INV_MAX);

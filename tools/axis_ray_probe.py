@@ -1,6 +1,8 @@
-"""Box tests per ray of EXACTLY axis-parallel rays vs random rays (binary walk, counting build), for the current library and for
-every variant under csrc/build/variants (e.g. a build without the |1/d| cap of make_grid_ray), plus the time of the production
-kernel on the axis-parallel rays.  Evidence for profiles/r02_slow_mode.md, section "Root cause"."""
+"""Box tests per ray of EXACTLY axis-parallel rays vs random rays (binary walk of the library in csrc/build, counting build) and the
+time of the production kernel on the axis-parallel rays, for the current library and for every variant under csrc/build/variants --
+e.g. the uncapped inverse direction of rounds 1-2:  tools/build_variants.sh "nocap:-DNVDR_INV_CAP=0"  (a variant rebuilds
+env_shade.hip only, i.e. the production kernel; the binary walk of bvh.hip stays the default build).
+profiles/r02_slow_mode.md, section "Root cause"."""
 import glob, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

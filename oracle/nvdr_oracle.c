@@ -906,9 +906,10 @@ void oracle_bvh2_walk(const uint32_t *nodes, const float *trirec, long n_tris, c
             continue;
         }
         grid_ray g;
-        g.ix = 1.0f / (dx * g_scale[0]);
-        g.iy = 1.0f / (dy * g_scale[1]);
-        g.iz = 1.0f / (dz * g_scale[2]);
+        /* |inv| capped like make_grid_ray (csrc/bvh.h): an axis the ray does not move along must keep culling */
+        g.ix = fminf(fmaxf(1.0f / (dx * g_scale[0]), -1.0e30f), 1.0e30f);
+        g.iy = fminf(fmaxf(1.0f / (dy * g_scale[1]), -1.0e30f), 1.0e30f);
+        g.iz = fminf(fmaxf(1.0f / (dz * g_scale[2]), -1.0e30f), 1.0e30f);
         g.nx = -((ox - g_lo[0]) * g_scale[0] + 2.0f) * g.ix;
         g.ny = -((oy - g_lo[1]) * g_scale[1] + 2.0f) * g.iy;
         g.nz = -((oz - g_lo[2]) * g_scale[2] + 2.0f) * g.iz;

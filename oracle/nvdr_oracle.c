@@ -625,8 +625,22 @@ static void process_sample(const shade_env *e, int backward, f3 ro, f3 dir, f3 p
  *   vis_out    : optional uint8 [N*H*W, 2S] visibility that was used
  *   dbg        : optional f32 [N*H*W, 2S, 4] (dir.xyz, pdf_light + pdf_bsdf) per sample
  * Outputs are zero-filled first, like torch::zeros in the reference.  Returns the number of covered pixels. */
+long oracle_env_shade_frozen(const nvdr_env_shade_args *a, const nvdr_env_shade_args *samp, const float *verts, const int32_t *tris,
+                             long n_tris, int backward, int n_threads, const uint8_t *vis_in, uint8_t *vis_out, float *dbg);
+
 long oracle_env_shade(const nvdr_env_shade_args *a, const float *verts, const int32_t *tris, long n_tris, int backward,
                       int n_threads, const uint8_t *vis_in, uint8_t *vis_out, float *dbg)
+{
+    return oracle_env_shade_frozen(a, a, verts, tris, n_tris, backward, n_threads, vis_in, vis_out, dbg);
+}
+
+/* The same program with FROZEN SAMPLES: everything that decides where the samples go and what their pdfs are (normal,
+ * view vector, roughness, lobe probabilities -- kernel.cu:490-526) is taken from `samp`'s G-buffer, everything that is
+ * EVALUATED at a sample (process_sample, kernel.cu:403-461) from `a`'s.  With samp == a this is the reference program.  The
+ * backward pass of the reference differentiates the evaluation only, so a finite-difference check of its gradients
+ * must hold the samples fixed while the evaluated inputs move: tests/test_oracle_selfconsistency.py. */
+long oracle_env_shade_frozen(const nvdr_env_shade_args *a, const nvdr_env_shade_args *samp, const float *verts, const int32_t *tris,
+                             long n_tris, int backward, int n_threads, const uint8_t *vis_in, uint8_t *vis_out, float *dbg)
 {
     const long N = a->ro.size[0], H = a->ro.size[1], W = a->ro.size[2];
     shade_env e;
@@ -672,12 +686,15 @@ long oracle_env_shade(const nvdr_env_shade_args *a, const float *verts, const in
         memset(&po, 0, sizeof(po));
         const float strata_frac = 1.0f / (float)n;
         const float sample_frac = 1.0f / (float)(n * n);
-        const float alpha = ks.y * ks.y;
-        f3 wo = safe_normalize(sub3(view_pos, pos));
-        const float metallic = ks.z;
-        f3 specColor = add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - metallic), scale3(kd, metallic));
-        float diffuseWeight = (1.f - metallic) * luminance(kd);
-        float specularWeight = albedo(specColor, wo, nrm);
+        /* sampling-side copies of the G-buffer (the same values unless the caller froze the samples) */
+        const f3 s_pos = fetch3v(&samp->gb_pos, z, y, x), s_nrm = fetch3v(&samp->gb_normal, z, y, x);
+        const f3 s_view_pos = fetch3v(&samp->gb_view_pos, z, y, x), s_kd = fetch3v(&samp->gb_kd, z, y, x), s_ks = fetch3v(&samp->gb_ks, z, y, x);
+        const float alpha = s_ks.y * s_ks.y;
+        f3 wo = safe_normalize(sub3(s_view_pos, s_pos));
+        const float metallic = s_ks.z;
+        f3 specColor = add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - metallic), scale3(s_kd, metallic));
+        float diffuseWeight = (1.f - metallic) * luminance(s_kd);
+        float specularWeight = albedo(specColor, wo, s_nrm);
         float pDiffuse = (diffuseWeight + specularWeight) > 0.f ? diffuseWeight / (diffuseWeight + specularWeight) : 1.f;
         float pSpecular = 1.0f - pDiffuse;
 
@@ -696,7 +713,7 @@ long oracle_env_shade(const nvdr_env_shade_args *a, const float *verts, const in
             sx = ((float)(pl % n) + uniform_pcg(&rng)) * strata_frac;
             sy = ((float)(pl / n) + uniform_pcg(&rng)) * strata_frac;
             dir = lightSample(&e, sx, sy, &pdf_light);
-            pdf_bsdf = bsdf_pdf(pDiffuse, pSpecular, nrm, wo, dir, alpha);
+            pdf_bsdf = bsdf_pdf(pDiffuse, pSpecular, s_nrm, wo, dir, alpha);
             vis = vis_in ? (float)vis_in[lin * 2 * S + 2 * i] : shadow_test(&e, ro, dir);
             if (vis_out) vis_out[lin * 2 * S + 2 * i] = vis > 0.5f;
             if (dbg) { float *q = dbg + (lin * 2 * S + 2 * i) * 4; q[0] = dir.x; q[1] = dir.y; q[2] = dir.z; q[3] = pdf_light + pdf_bsdf; }
@@ -708,7 +725,7 @@ long oracle_env_shade(const nvdr_env_shade_args *a, const float *verts, const in
             sx = ((float)(pb % n) + uniform_pcg(&rng)) * strata_frac;
             sy = ((float)(pb / n) + uniform_pcg(&rng)) * strata_frac;
             sz = uniform_pcg(&rng);
-            dir = bsdf_sample(pDiffuse, pSpecular, nrm, wo, mk3(sx, sy, sz), alpha, &pdf_bsdf);
+            dir = bsdf_sample(pDiffuse, pSpecular, s_nrm, wo, mk3(sx, sy, sz), alpha, &pdf_bsdf);
             pdf_light = lightPDF(&e, dir);
             vis = vis_in ? (float)vis_in[lin * 2 * S + 2 * i + 1] : shadow_test(&e, ro, dir);
             if (vis_out) vis_out[lin * 2 * S + 2 * i + 1] = vis > 0.5f;

@@ -121,10 +121,12 @@ def _shade_args(mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, p
 
 def env_shade(verts, tris, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
               bsdf='pbr', n_samples_x=8, rnd_seed=0, shadow_scale=1.0, diff_grad=None, spec_grad=None,
-              n_threads=1, vis_in=None, want_vis=False, want_dbg=False, pixel_index_offset=0, impl='oracle'):
+              n_threads=1, vis_in=None, want_vis=False, want_dbg=False, pixel_index_offset=0, impl='oracle', frozen=None):
     """Forward (diff_grad is None) or backward pass.  impl: 'oracle' | 'ref' | 'ref_detmath'.
     Returns a dict: fwd {diff, spec}, bwd {gb_pos_grad, gb_normal_grad, gb_kd_grad, gb_ks_grad, light_grad};
-    plus 'covered', optionally 'vis' [N*H*W, 2S] uint8 and 'dbg' [N*H*W, 2S, 4]."""
+    plus 'covered', optionally 'vis' [N*H*W, 2S] uint8 and 'dbg' [N*H*W, 2S, 4].
+    frozen (impl 'oracle' only): dict with any of gb_pos / gb_normal / gb_view_pos / gb_kd / gb_ks -- the G-buffer the SAMPLES
+    are generated from (directions, pdfs, lobe choice), while the arguments proper are what is evaluated at the samples."""
     a = _shade_args(mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms, bsdf,
                     n_samples_x, rnd_seed, shadow_scale, pixel_index_offset)
     N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
@@ -156,11 +158,18 @@ def env_shade(verts, tris, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_k
     P = lambda t: c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
     if impl == 'oracle':
         lib = _load(LIB)
-        lib.oracle_env_shade.restype = c_long
-        cov = lib.oracle_env_shade(ctypes.byref(a), P(verts), P(tris), c_long(tris.shape[0]), c_int(int(backward)),
-                                   c_int(n_threads), P(vin), P(vout), P(dbg))
+        lib.oracle_env_shade_frozen.restype = c_long
+        sa = a
+        if frozen:
+            g = dict(gb_pos=gb_pos, gb_normal=gb_normal, gb_view_pos=gb_view_pos, gb_kd=gb_kd, gb_ks=gb_ks)
+            g.update(frozen)
+            sa = _shade_args(mask, ro, g['gb_pos'], g['gb_normal'], g['gb_view_pos'], g['gb_kd'], g['gb_ks'], light, pdf, rows, cols,
+                             perms, bsdf, n_samples_x, rnd_seed, shadow_scale, pixel_index_offset)
+            keep += list(g.values())
+        cov = lib.oracle_env_shade_frozen(ctypes.byref(a), ctypes.byref(sa), P(verts), P(tris), c_long(tris.shape[0]), c_int(int(backward)),
+                                          c_int(n_threads), P(vin), P(vout), P(dbg))
     else:
-        assert not want_dbg
+        assert not want_dbg and not frozen
         lib = _load(REF_LIB if impl == 'ref' else REF_DM_LIB)
         lib.ref_env_shade.restype = c_long
         cov = lib.ref_env_shade(ctypes.byref(a), P(verts), P(tris), c_long(tris.shape[0]), c_int(int(backward)),

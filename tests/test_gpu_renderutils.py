@@ -126,6 +126,25 @@ def test_light_update_pdf_vs_oracle(dev):
         assert L.rows.shape == (res, res)
 
 
+def test_light_update_pdf_vs_reference_vectors(dev):
+    """SURVEY a18 pin on the GPU: nvdr_light_update_pdf (through EnvironmentLight) against the tables the REFERENCE's own
+    update_pdf produced (tests/golden/light_reference.npz, tools/make_golden.py gen_light)."""
+    import numpy as np
+    from nvdiffrecmc_amd.light import EnvironmentLight
+    from tests.util import load_npz, checksum
+    from tools import make_golden as mg
+    gold_all = load_npz('light_reference.npz')
+    for name, kind, res in mg.LIGHT_CASES:
+        gold = gold_all[name]
+        base = mg.light_case_base(kind, res, name)
+        assert checksum(base) == str(gold['base_sha256'])
+        L = EnvironmentLight(base.to(dev))
+        assert_close(L._pdf, gold['pdf'], 1e-5, floor=1e-9, what=name + ' pdf')
+        assert_close(L.cols, gold['cols'], 1e-5, floor=1e-6, what=name + ' cols')
+        assert_close(L.rows, gold['rows'], 1e-5, floor=1e-6, what=name + ' rows')
+        assert L.rows.shape == (res, res)
+
+
 @pytest.mark.parametrize('cd,cs,bsdf', [(4, 4, 'pbr'), (3, 3, 'pbr'), (4, 3, 'diffuse')])
 def test_shade_composite_vs_torch(cd, cs, bsdf, dev):
     """The fused final-colour op (render.py:119-127 + the division of optixutils/ops.py:139-141) against the torch

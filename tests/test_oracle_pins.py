@@ -174,6 +174,30 @@ def test_light_tables_oracle_vs_torch_restatement():
     assert (cols[:, 1:] >= cols[:, :-1]).all() and (rows[1:] >= rows[:-1]).all()
 
 
+@pytest.mark.parametrize('case', mg.LIGHT_CASES, ids=[c[0] for c in mg.LIGHT_CASES])
+def test_light_tables_oracle_vs_reference_vectors(case):
+    """SURVEY a18 pin: oracle.light_update_pdf against _pdf / cols / rows produced by the REFERENCE's own
+    EnvironmentLight.update_pdf (render/light.py:46-59, imported from /root/reference by tools/make_golden.py with its
+    CUDA-only imports stubbed); also the repo's torch transcription scene.light_tables, which feeds every other test."""
+    from nvdiffrecmc_amd import scene as sc
+    name, kind, res = case
+    gold = load_npz('light_reference.npz')[name]
+    base = mg.light_case_base(kind, res, name)
+    assert checksum(base) == str(gold['base_sha256']), 'regenerated probe differs'
+    assert np.array_equal(gold['rows'], np.repeat(gold['rows'][:, :1], res, axis=1))   # identical columns: rows[:, 0] is the row CDF
+    pdf, cols, rows = orc.light_update_pdf(base)
+    # float32 prefix sums in another association than torch.cumsum: 1e-5 relative (floor: the smallest table entries)
+    assert_close(pdf, gold['pdf'], 1e-5, floor=1e-9, what=name + ' pdf')
+    assert_close(cols, gold['cols'], 1e-5, floor=1e-6, what=name + ' cols')
+    assert_close(rows, gold['rows'][:, 0], 1e-5, floor=1e-6, what=name + ' rows')
+    tp, tr, tc = sc.light_tables(base)
+    assert_close(tp, gold['pdf'], 1e-6, floor=1e-9)
+    assert_close(tc, gold['cols'], 1e-6, floor=1e-6)
+    assert_close(tr, gold['rows'], 1e-6, floor=1e-6)
+    if name.endswith('zero_rows'):
+        assert float(cols[5].abs().max()) == 0.0 and float(np.abs(gold['cols'][5]).max()) == 0.0   # light.py:58: 0 / 1, not 0 / 0
+
+
 # ---------------------------------------------------------------------------------------------- dead samples
 @pytest.mark.parametrize('impl', ['oracle', 'ref'])
 @pytest.mark.parametrize('mesh,bsdf', [('bob', 'pbr'), ('spot', 'pbr'), ('bob', 'diffuse')])

@@ -9,6 +9,10 @@
                       for the CPU by oracle/Makefile `ref` (two builds: libm transcendentals, and the
                       detmath build whose discrete decisions our kernels must reproduce bit for bit).
   denoiser_*.npz    : forward + backward of the reference's denoising.cu kernels, same route.
+  light_reference.npz : _pdf / cols / rows of the reference's own EnvironmentLight.update_pdf (render/light.py:46-59),
+                      imported from /root/reference with its two CUDA-only imports (nvdiffrast, imageio) stubbed in
+                      sys.modules and torch.arange stripped of device="cuda" (render/util.py:62-66 builds the pixel
+                      grid on 'cuda'); probes E0 / E1 at 256x256 and 48x48, plus a probe with an all-zero row.
 
 Inputs of the env-shade / denoiser cases are NOT stored (they are regenerated from seeds by
 oracle/scene_cpu.py); a checksum of them is stored and re-checked by the tests.
@@ -157,9 +161,56 @@ def gen_denoiser():
     print('denoiser: %d cases' % len(DN_CASES))
 
 
+LIGHT_CASES = [('E0_256', 'E0', 256), ('E1_256', 'E1', 256), ('E0_48', 'E0', 48), ('E1_48', 'E1', 48), ('E1_64_zero_rows', 'E1', 64)]
+
+
+def light_case_base(kind, res, name):
+    from nvdiffrecmc_amd import scene as sc
+    base = sc.env_map(kind, res).clone()
+    if name.endswith('zero_rows'):
+        base[5] = 0.0           # a row without light: its column CDF keeps the un-normalised zeros (light.py:58 `where`)
+        base[-1] = 0.0
+    return base
+
+
+def gen_light():
+    """The reference's EnvironmentLight.update_pdf itself: 12 lines of torch behind CUDA-only imports."""
+    import types
+    import importlib
+    for mod in ('nvdiffrast', 'nvdiffrast.torch', 'imageio'):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules['nvdiffrast'].torch = sys.modules['nvdiffrast.torch']
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    real_arange = torch.arange
+
+    def cpu_arange(*a, **k):
+        k.pop('device', None)
+        return real_arange(*a, **k)
+    torch.arange = cpu_arange
+    try:
+        light = importlib.import_module('render.light')     # /root/reference/render/light.py, unmodified
+        flat = {}
+        for name, kind, res in LIGHT_CASES:
+            base = light_case_base(kind, res, name)
+            lgt = light.EnvironmentLight(base)               # __init__ calls update_pdf (light.py:31-32)
+            flat[name + '/base_sha256'] = np.array(checksum(base))
+            flat[name + '/pdf'] = lgt._pdf.numpy()
+            flat[name + '/cols'] = lgt.cols.numpy()
+            flat[name + '/rows'] = lgt.rows.numpy()          # [H,W] with identical columns; render.py:114 passes rows[:,0]
+            print('light', name, tuple(lgt._pdf.shape), float(lgt._pdf.sum()))
+    finally:
+        torch.arange = real_arange
+    np.savez_compressed(os.path.join(OUT, 'light_reference.npz'), **flat)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'light':
+        gen_light()
+        sys.exit(0)
     gen_renderutils()
+    gen_light()
     gen_env_shade()
     gen_denoiser()
     for f in sorted(os.listdir(OUT)):

@@ -54,6 +54,10 @@ int nvdr_ctx_check(nvdr_ctx *ctx, void *stream);
  * exceed the chunk is processed chunk by chunk with identical results.  The reference needs no scratch (one thread per
  * pixel keeps its rays in registers); a worst-case allocation would be N*H*W*2S*25 B (16 GB for 8 x 800^2 x 64 spp). */
 int nvdr_ctx_set_stream_budget(nvdr_ctx *ctx, int64_t bytes);
+/* Shadow-ray kernel of this context: 1 (default) = round 3 (eight-wide compressed nodes, deferred triangle tests), 0 = the
+ * round-2 kernel (four-slot nodes), kept for in-process A/B timing and bit-for-bit cross-checks.  Must be selected before the
+ * first nvdr_bvh_build on the context. */
+int nvdr_ctx_set_trace_variant(nvdr_ctx *ctx, int variant);
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
  * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);
  * rebuild == 0: refit the bounds of the existing hierarchy to moved vertices (OPTIX_BUILD_OPERATION_UPDATE). */
@@ -85,9 +89,17 @@ int nvdr_bvh_export(nvdr_ctx *ctx, float *nodes_host, float *tri_records_host, v
 int nvdr_trace_visibility(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis,
                           unsigned long long *counters, void *stream);
 
-/* Same answer through the PRODUCTION shadow-ray kernel of env-shade (persistent wavefronts over the four-slot wide nodes):
- * a test hook that lets arbitrary rays -- grazing, degenerate meshes -- reach the kernel the renderer actually runs. */
+/* Same answer through the PRODUCTION shadow-ray kernel of env-shade (persistent wavefronts over the eight-wide compressed nodes,
+ * deferred triangle tests): a test hook that lets arbitrary rays -- grazing, degenerate meshes -- reach the kernel the renderer
+ * actually runs.  The _counted form runs the counting build of that kernel; counters: uint64[NVDR_COUNTERS_LEN] zeroed by the
+ * caller, laid out as nvdr_env_shade_args.counters. */
 int nvdr_trace_visibility_wide(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis, void *stream);
+int nvdr_trace_visibility_wide_counted(nvdr_ctx *ctx, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis,
+                                       unsigned long long *counters, void *stream);
+/* copy the eight-wide tree the shadow rays walk to host buffers: oct = counts[0] * 16 uint32 (64-B records, layout in
+ * nvdiffrecmc_amd/csrc/bvh.h), tris8 = n_tris * 12 floats (the triangle records in the order the oct nodes refer to them);
+ * counts_host int64[3] = {oct nodes, triangles placed, nodes finished}.  oct / tris8 may be NULL (counts only). */
+int nvdr_bvh_export_oct(nvdr_ctx *ctx, uint32_t *oct_host, float *tris8_host, int64_t *counts_host, void *stream);
 
 /* Closest hit of R rays: out_t f32[R] (<0 = miss), out_tri i32[R] (original triangle index, -1 = miss),
  * out_uv f32[R,2] barycentrics of v1, v2.  G-buffer producer building block. */
@@ -159,13 +171,15 @@ typedef struct nvdr_env_shade_args {
     uint32_t *vis_cache;
     /* optional device accumulators uint64[NVDR_COUNTERS_LEN], zeroed by the caller (a COUNTING build of the traversal
        kernel runs instead of the production one; feeds the roofline figures):
-         [0] box tests of the wide walk (non-empty slots only)   [1] its triangle tests   [2] rays traversed
+         [0] box tests of the production (oct) walk (non-empty slots only)   [1] its triangle tests   [2] rays traversed
          [3] sum and [4] max of the per-wavefront busy time in 100 MHz ticks   [5] wavefronts
          [6] sum of the per-wavefront shader-clock cycles   [7] bit mask of the XCDs that ran wavefronts
          [8 .. 8+2*8192) (begin, end) ticks of every wavefront
          [NVDR_COUNTERS_BVH2 + 0] node visits, [+1] triangle tests, [+2] rays of the CANONICAL binary any-hit walk over
          the same live rays (reference accounting layout: 32-B BVH2 node, 36-B triangle) -- invariant to how speculative
          the production walk is, checked against a CPU walk of the exported tree in tests/test_gpu_bvh.py.
+         [NVDR_COUNTERS_BVH2 + 3] node steps of the production walk (one 64-byte node fetch + eight box tests each),
+         [+4] triangle-test batches, [+5] lanes those batches filled (= triangle tests; / 64 / batches = their occupancy).
        Rays traversed < 2*S*pixels: samples with dot(n, wi) <= 0 contribute exactly zero through the BSDF's own
        gates whatever their visibility and are not traced (NVDR_DEBUG bit 8 traces them anyway). */
     unsigned long long *counters;

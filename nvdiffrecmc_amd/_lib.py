@@ -58,11 +58,14 @@ _SIGNATURES = {
     'nvdr_ctx_destroy': [c_void_p],
     'nvdr_ctx_check': [c_void_p, c_void_p],
     'nvdr_ctx_set_stream_budget': [c_void_p, c_int64],
+    'nvdr_ctx_set_trace_variant': [c_void_p, c_int],
     'nvdr_bvh_build': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
     'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
     'nvdr_bvh_export': [c_void_p, c_void_p, c_void_p, c_void_p],
+    'nvdr_bvh_export_oct': [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_void_p],
     'nvdr_trace_visibility': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     'nvdr_trace_visibility_wide': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+    'nvdr_trace_visibility_wide_counted': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     'nvdr_trace_closest': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_render_gbuffer': [c_void_p, ctypes.POINTER(NvdrGbufferArgs), c_void_p],
     'nvdr_env_shade_fwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],

@@ -17,11 +17,22 @@
 //       lines twice as often costs +65 %.  Two lookups per node instead of four is the lever.
 //       The ray is transformed into grid space once (o' = (o - g_lo) * g_scale, d' = d * g_scale), which
 //       leaves the ray parameter t unchanged, so the slab test runs directly on the decoded integers.
-//   wide[n]   : 4 x uint4 = 64 B per internal node: the node's up to four GRANDCHILDREN (both children expanded one
-//       level; a leaf child stays one slot), one uint4 per slot = the slot's quantised box (3 words as above) +
-//       its child reference (>= 0 internal node, < 0 leaf, NVDR_TRAV_EMPTY unused slot).  Derived from nodes[] by
-//       one kernel after the fit; the shadow-ray traversal of env-shade walks THESE (half the dependent steps:
-//       the step's fixed cost -- ballots, stack, loop -- is paid once per four box tests instead of per two).
+//   oct[m]    : 4 x uint4 = 64 B per EIGHT-WIDE node (what the shadow-ray traversal of env-shade walks; csrc/trace_kernel.h).  Built from
+//       nodes[] after the fit by a top-down collapse (bvh_oct_build_kernel: a node's slots start as its two children and the
+//       internal slot with the largest surface area is replaced by ITS two children until eight slots are taken).  Slots are
+//       ordered internal children first (n_int of them, stored CONTIGUOUSLY in oct[] from child_base: no per-child index), then
+//       leaves (n_leaf triangles, stored contiguously in tris8[] from tri_base), then empty slots.  Child boxes are re-quantised
+//       to 8 bits in the NODE'S OWN frame -- origin = the node's lower corner on the 16-bit grid, one power-of-two cell size
+//       per axis -- rounded outward, so they contain the 16-bit boxes, which contain the exact ones:
+//         w0.x = org.x | org.y << 16      w0.y = org.z | ex << 16 | ey << 20 | ez << 24       (plane = org + q << e)
+//         w0.z = child_base | n_int << 28 w0.w = tri_base | n_leaf << 28
+//         w1 = lo.x[0..7], lo.y[0..7]     w2 = lo.z[0..7], hi.x[0..7]      w3 = hi.y[0..7], hi.z[0..7]   (one byte per slot)
+//       8 B per child instead of 16 B (four-slot nodes of round 2) and ~n/5 nodes instead of n: bob 0.15 MB instead of 0.68 MB,
+//       684 k triangles 9 MB instead of 44 MB; one dependent 64-B fetch per THREE tree levels.
+//   tris8[k]  : the triangle records in the order the oct nodes refer to them (a node's leaf children are adjacent).
+//   wide[n]   : 4 x uint4 = 64 B per internal node, the four-slot nodes of the ROUND-2 kernel (the node's up to four grandchildren,
+//       one uint4 per slot = 16-bit box + child reference).  Only built when that kernel is selected (nvdr_ctx_set_trace_variant(0):
+//       in-process A/B and cross-checks, csrc/trace_kernel_r2.h).
 //   tris[k]   : 3 x float4 = 48 B per triangle in Morton order, world space, full precision:
 //       (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, orig_index_bits, 0, 0) -- the hit predicate itself
 //       (include/nvdr_raytri.h) never sees quantised data.
@@ -30,23 +41,21 @@
 #include "common.h"
 #include "nvdr_raytri.h"
 
-// Traversal stack: the first NVDR_STACK_LDS entries of every lane live in LDS (entry k of lane l at
-// word k*64 + l: one bank per lane, conflict-free); deeper entries -- rare: a Karras tree over 30-bit
-// Morton codes + index tie-break can be up to ~64 levels deep, typical meshes use < 24 -- spill to a
-// per-lane column of an HBM scratch buffer owned by the context.  Sizing for the worst case this way
-// needs no read-back of the tree height, so nothing on the query path synchronises the host.
-// 12 entries = 12 KB of LDS per 256-thread workgroup (8 workgroups per CU leave slack in the 160 KB); deeper entries go to
-// the HBM spill columns.  Same speed as 16 on bob, faster on a 171 k-triangle mesh (27.5 vs 30.1 ms).
+// Traversal stacks.  The BINARY walk (test hooks, closest hit, counting) keeps the first NVDR_STACK_LDS entries of every lane in
+// LDS (entry k of lane l at word k*64 + l: one bank per lane, conflict-free); deeper entries spill to a per-lane column of an
+// HBM scratch buffer owned by the context.  The OCT walk (shadow rays) keeps (child group, remaining hit bits) PAIRS: one 8-byte
+// entry per visited node that still has unvisited internal children, NVDR_OSTACK_LDS of them in LDS (ds_write_b64 / ds_read_b64,
+// conflict-free at 8 B per lane), the rest in the same spill buffer.
 //
-// WHY THE STACK CANNOT OVERFLOW.  A Karras node is identified by the common-prefix length delta of its key range and
+// WHY THE STACKS CANNOT OVERFLOW.  A Karras node is identified by the common-prefix length delta of its key range and
 // delta strictly grows from parent to child.  Distinct 30-bit keys give delta = clz(a ^ b) in [2, 31] (30 values), equal
 // keys give delta = 32 + clz(i ^ j) with i, j < n (at most ceil(log2 n) values): a root-to-leaf path holds at most
 // h_max = 30 + ceil(log2 n) <= 60 internal nodes whatever the mesh (100 k triangles on one centroid: a balanced tree over
-// the index bits).  The binary walk holds <= h_max entries; the wide walk pushes <= 3 entries per step and a step
-// descends two levels (or ends in a leaf), so it holds <= 3 * (ceil(h_max / 2) + 1) <= 93 < NVDR_STACK_MAX entries.
-// nvdr_bvh_build sizes the spill columns from this bound (nvdr_stack_bound); a push beyond it -- unreachable unless the
-// bound is wrong -- raises the context's overflow flag (host-mapped memory), which every later call on the context and
-// nvdr_ctx_check() turn into an error instead of a silently wrong visibility (tests/test_gpu_bvh.py feeds degenerate meshes).
+// the index bits).  The binary walk holds <= h_max entries.  Every level of the oct tree descends at least one binary level, and
+// the oct walk pushes at most one entry per level of its path, so it holds <= h_max entries too.  nvdr_bvh_build sizes the spill
+// columns from this bound (nvdr_stack_bound); a push beyond it -- unreachable unless the bound is wrong -- raises the context's
+// overflow flag (host-mapped memory), which every later call on the context and nvdr_ctx_check() turn into an error instead
+// of a silently wrong visibility (tests/test_gpu_bvh.py feeds degenerate meshes).
 #ifndef NVDR_STACK_LDS
 #define NVDR_STACK_LDS 12
 #endif
@@ -58,7 +67,8 @@
 #define NVDR_PROF_RING 512
 #define NVDR_MAX_CHUNKS 1024                 // chunks of the env-shade ray stream one launch may be cut into
 #define NVDR_TRAV_DONE 0x7fffffff            // traversal marker: nothing left (never a valid node / leaf id)
-#define NVDR_TRAV_EMPTY 0x7ffffff0           // child reference of an unused slot of a wide node
+#define NVDR_OSTACK_LDS 6                    // oct walk: (child group, hit bits) entries per lane kept in LDS (8 B each); deeper ones spill
+#define NVDR_OCT_MAX_INDEX (1 << 28)         // child_base / tri_base share their word with a 4-bit count
 #define NVDR_GRID_MAX 65531.0f               // usable span of the 16-bit box grid (2 cells of slack on both ends)
 
 struct BvhDeviceInfo {
@@ -72,15 +82,13 @@ struct BvhDeviceInfo {
     unsigned int ray_count; // (unused since the chunked ray stream: the per-chunk counters live in nvdr_ctx::chunk_counts)
 };
 
-// upper bound of the traversal stack depth for a tree over n triangles (see the note at NVDR_STACK_MAX)
+// upper bound of the traversal stack depth (binary and oct walk alike) for a tree over n triangles (see the note above)
 static inline int nvdr_stack_bound(int64_t n_tris)
 {
     int lg = 0;
     while ((1ll << lg) < n_tris) ++lg;
     const int h_max = 30 + lg;
-    const int wide = 3 * ((h_max + 1) / 2 + 1);
-    const int b = wide > h_max ? wide : h_max;
-    return b < NVDR_STACK_MAX ? b : NVDR_STACK_MAX;
+    return h_max < NVDR_STACK_MAX ? h_max : NVDR_STACK_MAX;
 }
 
 struct nvdr_ctx {
@@ -90,7 +98,11 @@ struct nvdr_ctx {
     int64_t n_tris = 0;
     int64_t n_verts = 0;
     uint4 *nodes = nullptr;        // [2 * cap]
-    uint4 *wide = nullptr;         // [4 * cap] four-slot nodes derived from nodes[]
+    uint4 *wide = nullptr;         // [4 * cap] four-slot nodes of the round-2 kernel (traversal variant 0; built only when selected)
+    uint4 *oct = nullptr;          // [4 * cap] eight-wide nodes collapsed from nodes[] (bvh_oct_build_kernel)
+    float4 *tris8 = nullptr;       // [3 * cap] triangle records in oct-leaf order
+    int *oct_task = nullptr;       // [cap] build queue: binary node id of every oct node, -1 until published
+    unsigned *oct_ctl = nullptr;   // [8] build counters: ticket head, nodes allocated, nodes done, triangles placed
     float4 *tris = nullptr;        // [3 * cap]
     uint32_t *keys[2] = {nullptr, nullptr};
     uint32_t *vals[2] = {nullptr, nullptr};
@@ -102,10 +114,12 @@ struct nvdr_ctx {
     BvhDeviceInfo *dinfo = nullptr;
     int *spill = nullptr;          // [NVDR_QUERY_MAX_BLOCKS][stack_max - NVDR_STACK_LDS][NVDR_QUERY_BLOCK]
     int stack_max = 0;             // entries per lane the current spill allocation supports (LDS part included)
+    int oct_stack_max = 0;         // the same for the oct walk's (group, bits) entries
     int spill_cap = 0;             // stack_max the spill buffer was allocated for (grow-only)
     int *ovf_host = nullptr;       // host-mapped overflow flag (a push beyond stack_max sets it)
     int *ovf_dev = nullptr;        // its device address
     unsigned debug = 0;            // NVDR_DEBUG, read ONCE when the context is created
+    int trace_variant = 1;         // shadow-ray kernel: 1 = round 3 (oct nodes, deferred triangle tests), 0 = round 2 (four-slot nodes)
     // env-shade scratch
     int *pix_list = nullptr;       // [N*H*W] compacted indices of the covered pixels of the whole launch
     int64_t pix_cap = 0;
@@ -134,6 +148,9 @@ struct nvdr_ctx {
 struct BvhView {
     const uint4 *nodes;
     const uint4 *wide;
+    const uint4 *oct;
+    const float4 *tris8;
+    int oct_stack_max;
     const float4 *tris;
     const BvhDeviceInfo *info;
     int n_tris;
@@ -148,6 +165,9 @@ static inline BvhView bvh_view(const nvdr_ctx *c)
     BvhView v;
     v.nodes = c->nodes;
     v.wide = c->wide;
+    v.oct = c->oct;
+    v.tris8 = c->tris8;
+    v.oct_stack_max = c->oct_stack_max;
     v.tris = c->tris;
     v.info = c->dinfo;
     v.n_tris = (int)c->n_tris;
@@ -176,7 +196,7 @@ struct TravStack {
     {
         if (sp < NVDR_STACK_LDS) { lds[sp * 64] = v; return sp + 1; }
         if (sp < smax) { glb[(int64_t)(sp - NVDR_STACK_LDS) * gstride] = v; return sp + 1; }
-        *ovf = 1;
+        atomicOr(ovf, 1);
         return sp;
     }
     // peek returns what a pop at depth sp would yield without changing anything (branch-free loops read it every step)
@@ -292,22 +312,6 @@ __device__ __forceinline__ NodeHit visit_node(const uint4 *__restrict__ nodes, i
     h.cl = (int)b.z;
     h.cr = (int)b.w;
     return h;
-}
-
-// one slot of a wide node: box (x, y, z words) + child reference (w).  The (lo, hi) pair of every axis is ordered
-// (near, far) for this ray by one byte permute with a per-ray selector, which replaces the min/max pair of the
-// generic slab test: 3 perm + 6 cvt + 6 fma + 4 instead of 6 cvt + 6 fma + 6 min/max + 4.
-__device__ __forceinline__ bool slot_hit(const uint4 &q, const GridRay &r, float tmax, float &tnear)
-{
-    const unsigned X = __builtin_amdgcn_perm(q.x, q.y, r.px), Y = __builtin_amdgcn_perm(q.x, q.z, r.py),
-                   Z = __builtin_amdgcn_perm(q.y, q.z, r.pz);
-    const float nx = fmaf(lo16(X), r.ix, r.nx), fx = fmaf(hi16(X), r.ix, r.nx);
-    const float ny = fmaf(lo16(Y), r.iy, r.ny), fy = fmaf(hi16(Y), r.iy, r.ny);
-    const float nz = fmaf(lo16(Z), r.iz, r.nz), fz = fmaf(hi16(Z), r.iz, r.nz);
-    const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
-    const float tf = fminf(fminf(fx, fy), fminf(fz, tmax));
-    tnear = tn;
-    return (tn <= tf) & ((int)q.w != NVDR_TRAV_EMPTY);
 }
 
 // ---------------------------------------------------------------------------------------------

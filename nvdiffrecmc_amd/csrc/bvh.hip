@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_closest_kernel(BvhView
     }
 }
 
-// wide[i] = the (up to four) grandchildren of internal node i, see bvh.h
+// round-2 kernel only (traversal variant 0): wide[i] = the (up to four) grandchildren of internal node i, see bvh.h
 __global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal, uint4 *__restrict__ wide)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -299,9 +299,160 @@ __global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal
             slot[k++] = own[s];                 // leaf child: box from this node
         }
     }
-    for (; k < 4; ++k) slot[k] = make_uint4(0u, 0u, 0u, (unsigned)NVDR_TRAV_EMPTY);
+    for (; k < 4; ++k) slot[k] = make_uint4(0u, 0u, 0u, 0x7ffffff0u);
 #pragma unroll
     for (int q = 0; q < 4; ++q) wide[4 * (int64_t)i + q] = slot[q];
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Eight-wide nodes (layout: bvh.h "oct").  Top-down collapse of the fitted binary tree, one THREAD per oct node, driven by a
+// ticket queue so that the whole tree is built by ONE launch whatever its depth:
+//   * oct node m is described by task[m] = the binary node it is rooted at; task[0] = 0 (the root), every other entry is -1 until
+//     the thread that builds the parent publishes it (relaxed agent-scope store; the only cross-thread payload is that one int:
+//     the binary tree itself was written by earlier kernels);
+//   * a thread draws tickets m = 0, 1, 2, ... from one counter and polls task[m].  A ticket's parent always has a smaller ticket,
+//     drawn earlier by a thread that is running (it holds the ticket), so every wait ends: no assumption about residency or
+//     dispatch order.  Polling and building are the two arms of ONE loop iteration, never a nested spin: lanes of one wavefront
+//     may wait for each other's output;
+//   * done == allocated (read in this order) <=> nothing is in flight and nothing more will be published: everybody leaves.
+// Collapse rule: the slots start as the two children; the internal slot with the largest (world-space) surface area is replaced by
+// its two children until eight slots are taken or only leaves remain.  Slots are then ordered internal-first (so the children
+// sit contiguously in oct[] and need no per-slot index) and their 16-bit boxes re-quantised to 8 bits in the node's own frame.
+
+struct OctBuildArgs {
+    const uint4 *nodes;     // fitted binary nodes
+    const float4 *tris;     // triangle records in Morton order
+    uint4 *oct;
+    float4 *tris8;
+    int *task;
+    int *fault;             // the context's host-mapped flag word: bit 1 is raised if the build gives up waiting
+    unsigned *ctl;          // [0] next ticket, [1] oct nodes allocated, [2] oct nodes finished, [3] triangles placed
+    const BvhDeviceInfo *info;
+    int cap;                // entries of task[] / oct nodes that fit (>= n_tris)
+};
+
+__global__ void bvh_oct_init_kernel(OctBuildArgs a, int n_tris)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.cap; i += gridDim.x * blockDim.x) a.task[i] = i == 0 && n_tris > 1 ? 0 : -1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.ctl[0] = 0u;
+        a.ctl[1] = 1u;
+        a.ctl[2] = n_tris > 1 ? 0u : 1u;
+        a.ctl[3] = n_tris > 1 ? 0u : 1u;
+        if (n_tris == 1) {
+            // one triangle, no binary node: a root with a single leaf slot that spans the whole grid (org 0, cell 2^9)
+            a.oct[0] = make_uint4(0u, (9u << 16) | (9u << 20) | (9u << 24), 0u, 1u << 28);
+            a.oct[1] = make_uint4(0u, 0u, 0u, 0u);
+            a.oct[2] = make_uint4(0u, 0u, 0xffu, 0u);
+            a.oct[3] = make_uint4(0xffu, 0u, 0xffu, 0u);
+            a.tris8[0] = a.tris[0]; a.tris8[1] = a.tris[1]; a.tris8[2] = a.tris[2];
+        }
+    }
+}
+
+struct OctSlot {
+    int ref;            // >= 0 binary internal node, < 0: ~triangle slot (Morton order)
+    int lo[3], hi[3];   // 16-bit grid box
+};
+
+__device__ __forceinline__ void oct_child_slots(const uint4 *__restrict__ nodes, int b, OctSlot &l, OctSlot &r)
+{
+    const uint4 p = nodes[2 * (int64_t)b], q = nodes[2 * (int64_t)b + 1];
+    l.lo[0] = p.x & 0xffff; l.lo[1] = p.x >> 16; l.lo[2] = p.y & 0xffff; l.hi[0] = p.y >> 16; l.hi[1] = p.z & 0xffff; l.hi[2] = p.z >> 16;
+    r.lo[0] = p.w & 0xffff; r.lo[1] = p.w >> 16; r.lo[2] = q.x & 0xffff; r.hi[0] = q.x >> 16; r.hi[1] = q.y & 0xffff; r.hi[2] = q.y >> 16;
+    l.ref = (int)q.z;
+    r.ref = (int)q.w;
+}
+
+__device__ void oct_build_node(const OctBuildArgs &a, int b, int m)
+{
+    OctSlot s[8];
+    int n = 2;
+    oct_child_slots(a.nodes, b, s[0], s[1]);
+    const float wx = 1.0f / a.info->g_scale[0], wy = 1.0f / a.info->g_scale[1], wz = 1.0f / a.info->g_scale[2];
+    while (n < 8) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int k = 0; k < n; ++k) {
+            if (s[k].ref < 0) continue;
+            const float ex = (float)(s[k].hi[0] - s[k].lo[0]) * wx, ey = (float)(s[k].hi[1] - s[k].lo[1]) * wy, ez = (float)(s[k].hi[2] - s[k].lo[2]) * wz;
+            const float area = ex * ey + ey * ez + ez * ex;
+            if (area > best_area) { best_area = area; best = k; }
+        }
+        if (best < 0) break;
+        OctSlot l, r;
+        oct_child_slots(a.nodes, s[best].ref, l, r);
+        s[best] = l;
+        s[n++] = r;
+    }
+    // order: internal children first (stable), then leaves
+    OctSlot t[8];
+    int n_int = 0, n_leaf = 0;
+    for (int k = 0; k < n; ++k) if (s[k].ref >= 0) t[n_int++] = s[k];
+    for (int k = 0; k < n; ++k) if (s[k].ref < 0) t[n_int + n_leaf++] = s[k];
+    // the node's frame: lower corner + one power-of-two cell per axis such that the extent fits 8 bits
+    int org[3], e[3];
+    for (int ax = 0; ax < 3; ++ax) {
+        int lo = 65535, hi = 0;
+        for (int k = 0; k < n; ++k) { lo = min(lo, t[k].lo[ax]); hi = max(hi, t[k].hi[ax]); }
+        org[ax] = lo;
+        int ee = 0;
+        while ((((hi - lo) + (1 << ee) - 1) >> ee) > 255) ++ee;
+        e[ax] = ee;
+    }
+    unsigned planes[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // lo.x[2], lo.y[2], lo.z[2], hi.x[2], hi.y[2], hi.z[2]
+    for (int k = 0; k < n; ++k) {
+        for (int ax = 0; ax < 3; ++ax) {
+            const unsigned qlo = (unsigned)((t[k].lo[ax] - org[ax]) >> e[ax]);                              // floor
+            const unsigned qhi = (unsigned)(((t[k].hi[ax] - org[ax]) + (1 << e[ax]) - 1) >> e[ax]);          // ceil
+            planes[2 * ax + (k >> 2)] |= qlo << (8 * (k & 3));
+            planes[6 + 2 * ax + (k >> 2)] |= qhi << (8 * (k & 3));
+        }
+    }
+    unsigned cb = 0, tb = 0;
+    if (n_int) cb = atomicAdd(&a.ctl[1], (unsigned)n_int);
+    if (n_leaf) tb = atomicAdd(&a.ctl[3], (unsigned)n_leaf);
+    uint4 *o = a.oct + 4 * (int64_t)m;
+    o[0] = make_uint4((unsigned)org[0] | ((unsigned)org[1] << 16),
+                      (unsigned)org[2] | ((unsigned)e[0] << 16) | ((unsigned)e[1] << 20) | ((unsigned)e[2] << 24),
+                      cb | ((unsigned)n_int << 28), tb | ((unsigned)n_leaf << 28));
+    o[1] = make_uint4(planes[0], planes[1], planes[2], planes[3]);
+    o[2] = make_uint4(planes[4], planes[5], planes[6], planes[7]);
+    o[3] = make_uint4(planes[8], planes[9], planes[10], planes[11]);
+    for (int k = 0; k < n_leaf; ++k) {
+        const int64_t src = 3 * (int64_t)(~t[n_int + k].ref), dst = 3 * (int64_t)(tb + k);
+        a.tris8[dst] = a.tris[src]; a.tris8[dst + 1] = a.tris[src + 1]; a.tris8[dst + 2] = a.tris[src + 2];
+    }
+    for (int k = 0; k < n_int; ++k)
+        if ((int)(cb + k) < a.cap) __hip_atomic_store(&a.task[cb + k], t[k].ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256) bvh_oct_build_kernel(OctBuildArgs a)
+{
+    int ticket = -1;
+    unsigned waited = 0;
+    while (true) {
+        if (ticket < 0) ticket = (int)atomicAdd(&a.ctl[0], 1u);
+        const int b = ticket < a.cap ? __hip_atomic_load(&a.task[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        if (b >= 0) {
+            oct_build_node(a, b, ticket);
+            atomicAdd(&a.ctl[2], 1u);
+            ticket = -1;
+        } else {
+            // `done` first, `allocated` second: equal values then mean they were equal when `done` was read (both only grow,
+            // done <= allocated), i.e. every published node is finished and nobody can publish another one
+            const unsigned done = __hip_atomic_load(&a.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned alloc = __hip_atomic_load(&a.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == alloc) break;
+            // every wait ends (see above); the bound only turns a bug into an error report instead of a hung GPU (~1 s of polling)
+            if (++waited > (1u << 22)) {
+                atomicOr(a.fault, 2);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -311,10 +462,16 @@ __global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal
 // were not trustworthy.  The flag lives in host-mapped memory, so this costs no synchronisation.
 int ctx_check_overflow(nvdr_ctx *c, const char *who)
 {
-    if (c->ovf_host && *(volatile int *)c->ovf_host != 0) {
+    const int f = c->ovf_host ? *(volatile int *)c->ovf_host : 0;
+    if (f & 1) {
         nvdr_set_error("%s: a traversal launch on this context overflowed its %d-entry stack (degenerate BVH); "
-                       "the visibility it produced is invalid", who, c->stack_max);
+                       "the visibility it produced is invalid; the context must be destroyed", who, c->stack_max);
         return -2;
+    }
+    if (f & 6) {
+        nvdr_set_error("%s: %s on this context did not terminate within its iteration bound (internal error); "
+                       "results are invalid; the context must be destroyed", who, (f & 2) ? "the eight-wide BVH build" : "a shadow-ray launch");
+        return -3;
     }
     return 0;
 }
@@ -329,11 +486,14 @@ extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
 
 static int ctx_free_bvh(nvdr_ctx *c)
 {
-    hipFree(c->nodes); hipFree(c->wide); hipFree(c->tris);
+    hipFree(c->nodes); hipFree(c->wide); hipFree(c->oct); hipFree(c->tris8); hipFree(c->oct_task); hipFree(c->tris);
     hipFree(c->keys[0]); hipFree(c->keys[1]); hipFree(c->vals[0]); hipFree(c->vals[1]);
     hipFree(c->parent); hipFree(c->flags); hipFree(c->heights); hipFree(c->sort_tmp);
     c->nodes = nullptr;
+    c->oct = nullptr;
     c->wide = nullptr;
+    c->tris8 = nullptr;
+    c->oct_task = nullptr;
     c->tris = nullptr;
     c->keys[0] = c->keys[1] = c->vals[0] = c->vals[1] = nullptr;
     c->parent = c->flags = c->heights = nullptr;
@@ -364,6 +524,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     }
     if (e == hipSuccess) e = hipMalloc((void **)&c->chunk_counts, sizeof(unsigned) * NVDR_MAX_CHUNKS);
     if (e == hipSuccess) e = hipMalloc((void **)&c->queues, sizeof(unsigned) * 32 * 256);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->oct_ctl, sizeof(unsigned) * 8);
     if (e != hipSuccess) {
         hipFree(c->dinfo);
         if (c->ovf_host) hipHostFree(c->ovf_host);
@@ -384,6 +545,13 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         c->debug = (unsigned)atoi(dbg);
         if (c->debug) fprintf(stderr, "[nvdr] NVDR_DEBUG=%u is active on this context (experiment switches; not for production)\n", c->debug);
     }
+    // NVDR_TRACE_VARIANT=0 selects the round-2 shadow-ray kernel for contexts created while it is set (A/B tools)
+    if (const char *tv = getenv("NVDR_TRACE_VARIANT")) {
+        if (atoi(tv) == 0) {
+            c->trace_variant = 0;
+            fprintf(stderr, "[nvdr] NVDR_TRACE_VARIANT=0: this context runs the round-2 shadow-ray kernel (A/B only)\n");
+        }
+    }
     (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (c->n_cus <= 0) c->n_cus = 256;
     *out = c;
@@ -403,6 +571,7 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     hipFree(c->pix_list);
     hipFree(c->chunk_counts);
     hipFree(c->queues);
+    hipFree(c->oct_ctl);
     hipFree(c->rays); hipFree(c->texel); hipFree(c->vis); hipFree(c->live); hipFree(c->pix_origin); hipFree(c->lg_part);
     if (c->ovf_host) hipHostFree(c->ovf_host);
     delete c;
@@ -418,7 +587,9 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     ctx_free_bvh(c);
     const int64_t cap = n_tris + n_tris / 2 + 64;
     NVDR_HIP_TRY(hipMalloc((void **)&c->nodes, sizeof(uint4) * 2 * cap));
-    NVDR_HIP_TRY(hipMalloc((void **)&c->wide, sizeof(uint4) * 4 * cap));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->oct, sizeof(uint4) * 4 * cap));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->tris8, sizeof(float4) * 3 * cap));
+    NVDR_HIP_TRY(hipMalloc((void **)&c->oct_task, sizeof(int) * cap));
     NVDR_HIP_TRY(hipMalloc((void **)&c->tris, sizeof(float4) * 3 * cap));
     for (int i = 0; i < 2; ++i) {
         NVDR_HIP_TRY(hipMalloc((void **)&c->keys[i], sizeof(uint32_t) * cap));
@@ -441,10 +612,12 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     NVDR_REQUIRE(c != nullptr, "nvdr_bvh_build: ctx is NULL");
     // same message as the Python asserts of the reference (render/optixutils/ops.py:131-132)
     NVDR_REQUIRE(n_tris > 0 && n_verts > 0, "Got empty training triangle mesh (unrecoverable discontinuity)");
-    NVDR_REQUIRE(n_tris < (1ll << 30), "nvdr_bvh_build: too many triangles (%lld)", (long long)n_tris);
+    NVDR_REQUIRE(n_tris < (long long)NVDR_OCT_MAX_INDEX, "nvdr_bvh_build: too many triangles (%lld, the limit is 2^28)", (long long)n_tris);
     NVDR_REQUIRE(verts && tris, "nvdr_bvh_build: NULL geometry pointer");
     hipStream_t stream = (hipStream_t)stream_;
     NVDR_HIP_TRY(hipSetDevice(c->device));
+    // a context whose traversal stack overflowed (or whose build / walk gave up) is unusable: say so before touching any buffer
+    if (int r0 = ctx_check_overflow(c, "nvdr_bvh_build")) return r0;
     if (rebuild == 0) {
         NVDR_REQUIRE(c->n_tris == n_tris && c->n_verts == n_verts,
                      "nvdr_bvh_build: refit (rebuild=0) needs the topology of the last full build "
@@ -454,21 +627,23 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         int r = ctx_reserve(c, n_tris);
         if (r) return r;
     }
-    int r0 = ctx_check_overflow(c, "nvdr_bvh_build");
-    if (r0) return r0;
-    // spill columns for the proven stack bound of a tree over n_tris triangles (bvh.h); grow-only
+    // spill columns for the proven stack bound of a tree over n_tris triangles (bvh.h); grow-only.  The binary walks keep 4-byte
+    // entries beyond their NVDR_STACK_LDS, the oct walk 8-byte entries beyond its NVDR_OSTACK_LDS: sized for the larger of the two
     const int smax = nvdr_stack_bound(n_tris);
     if (smax > c->spill_cap) {
         NVDR_HIP_TRY(hipStreamSynchronize(stream));
         (void)hipFree(c->spill);
         c->spill = nullptr;
         c->spill_cap = 0;
-        const size_t depth = (size_t)(smax > NVDR_STACK_LDS ? smax - NVDR_STACK_LDS : 0);
-        NVDR_HIP_TRY(hipMalloc((void **)&c->spill, sizeof(int) * (depth > 0 ? depth : 1) * NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK));
+        const size_t d_bin = (size_t)(smax > NVDR_STACK_LDS ? smax - NVDR_STACK_LDS : 0) * sizeof(int);
+        const size_t d_oct = (size_t)(smax > NVDR_OSTACK_LDS ? smax - NVDR_OSTACK_LDS : 0) * sizeof(uint2);
+        const size_t per_lane = d_bin > d_oct ? d_bin : d_oct;
+        NVDR_HIP_TRY(hipMalloc((void **)&c->spill, (per_lane > 0 ? per_lane : sizeof(uint2)) * NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK));
         c->spill_cap = smax;
     }
-    // NVDR_DEBUG bit 32 (tests only): pretend the stack is one entry deeper than its LDS part, to exercise the overflow report
+    // NVDR_DEBUG bit 32 (tests only): pretend the stacks are one entry deeper than their LDS part, to exercise the overflow report
     c->stack_max = (c->debug & 32u) ? NVDR_STACK_LDS + 1 : c->spill_cap;
+    c->oct_stack_max = (c->debug & 32u) ? 2 : c->spill_cap;
     const int n = (int)n_tris;
     bvh_init_info_kernel<<<1, 64, 0, stream>>>(c->dinfo);
     bvh_bounds_kernel<<<min(div_up(n_verts, 256), 1024u), 256, 0, stream>>>(verts, n_verts, c->dinfo);
@@ -484,7 +659,21 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
     bvh_fit_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->parent,
                                                         c->flags, c->heights, c->dinfo);
-    if (n > 1) bvh_widen_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->nodes, n - 1, c->wide);
+    if (c->trace_variant == 0 && n > 1) {
+        if (!c->wide) NVDR_HIP_TRY(hipMalloc((void **)&c->wide, sizeof(uint4) * 4 * c->cap_tris));
+        bvh_widen_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->nodes, n - 1, c->wide);
+    }
+    {
+        // eight-wide nodes for the shadow-ray walk: one launch, ticket-driven (see bvh_oct_build_kernel)
+        OctBuildArgs oa;
+        oa.nodes = c->nodes; oa.tris = c->tris; oa.oct = c->oct; oa.tris8 = c->tris8; oa.task = c->oct_task; oa.ctl = c->oct_ctl;
+        oa.info = c->dinfo; oa.cap = n; oa.fault = c->ovf_dev;
+        bvh_oct_init_kernel<<<min(div_up(n, 256), 1024u), 256, 0, stream>>>(oa, n);
+        if (n > 1) {
+            const unsigned blocks = min(div_up((n + 3) / 4, 256), (unsigned)c->n_cus * 4u);
+            bvh_oct_build_kernel<<<blocks < 1u ? 1u : blocks, 256, 0, stream>>>(oa);
+        }
+    }
     NVDR_LAUNCH_CHECK();
     c->n_tris = n_tris;
     c->n_verts = n_verts;
@@ -531,6 +720,33 @@ extern "C" int nvdr_bvh_export(nvdr_ctx *c, float *nodes_host, float *tri_host, 
         NVDR_HIP_TRY(hipMemcpyAsync(nodes_host, c->nodes, sizeof(uint32_t) * 8 * (c->n_tris - 1), hipMemcpyDeviceToHost, stream));
     if (tri_host)
         NVDR_HIP_TRY(hipMemcpyAsync(tri_host, c->tris, sizeof(float) * 12 * c->n_tris, hipMemcpyDeviceToHost, stream));
+    NVDR_HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
+extern "C" int nvdr_ctx_set_trace_variant(nvdr_ctx *c, int variant)
+{
+    NVDR_REQUIRE(c, "nvdr_ctx_set_trace_variant: NULL ctx");
+    NVDR_REQUIRE(variant == 0 || variant == 1, "nvdr_ctx_set_trace_variant: variant %d (0 = round-2 kernel, 1 = round-3 kernel)", variant);
+    NVDR_REQUIRE(variant == 1 || c->n_tris == 0, "nvdr_ctx_set_trace_variant: select the round-2 kernel BEFORE the first nvdr_bvh_build "
+                 "(its four-slot nodes are only built when it is selected)");
+    c->trace_variant = variant;
+    return 0;
+}
+
+extern "C" int nvdr_bvh_export_oct(nvdr_ctx *c, uint32_t *oct_host, float *tris8_host, int64_t *counts_host, void *stream_)
+{
+    NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_bvh_export_oct: no BVH built");
+    NVDR_REQUIRE(counts_host != nullptr, "nvdr_bvh_export_oct: counts_host is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    unsigned ctl[4] = {0, 0, 0, 0};
+    NVDR_HIP_TRY(hipMemcpyAsync(ctl, c->oct_ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
+    NVDR_HIP_TRY(hipStreamSynchronize(stream));
+    counts_host[0] = ctl[1];    // oct nodes
+    counts_host[1] = ctl[3];    // triangles placed (== n_tris)
+    counts_host[2] = ctl[2];    // nodes finished (== nodes)
+    if (oct_host) NVDR_HIP_TRY(hipMemcpyAsync(oct_host, c->oct, sizeof(uint4) * 4 * (size_t)ctl[1], hipMemcpyDeviceToHost, stream));
+    if (tris8_host) NVDR_HIP_TRY(hipMemcpyAsync(tris8_host, c->tris8, sizeof(float) * 12 * c->n_tris, hipMemcpyDeviceToHost, stream));
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
     return 0;
 }

@@ -14,9 +14,10 @@
 //                            under the shading horizon contribute exactly zero and are left out of the LIVE-RAY LIST
 //                            the next stage walks;
 //       2. env_trace_kernel  (trace_kernel.h) PERSISTENT wavefronts over the live-ray list, chunks of 256 rays claimed from 64
-//                            device counters: a lane that finishes its ray immediately takes the next one of its wave
-//                            (wave-uniform cursor), so lanes never idle behind the slowest ray of a pixel; four-slot wide
-//                            nodes, unordered any-hit descent, the traversal stack in LDS, one bank per lane;
+//                            device counters: a lane that finishes its ray takes the next one of its wave (wave-uniform
+//                            cursor), so lanes never idle behind the slowest ray of a pixel; eight-wide compressed nodes,
+//                            unordered any-hit descent over (child group, hit mask) pairs stacked in LDS, triangle tests
+//                            deferred to a per-wavefront queue and run 64 at a time;
 //       3. env_shade_kernel  BSDF evaluation (forward) or hand-derived gradients (backward) per live sample, reduced
 //                            across the L lanes with shuffle butterflies; the light gradient leaves (texel, rgb) records
 //                            in the stream that an LDS band gather reduces (no global atomics; kernel.cu:208-210).
@@ -27,6 +28,7 @@
 // source and uses include/nvdr_detmath.h for sin/cos/acos/atan2, which makes every
 // discrete decision (texel, lobe, visibility) bit-identical to the CPU oracle.
 #include "trace_kernel.h"
+#include "trace_kernel_r2.h"
 #include "bsdf_device.h"
 
 #define NVDR_PI_DBL 3.14159265358979323846
@@ -529,6 +531,13 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
     extern __shared__ __attribute__((aligned(16))) int smem[];
     env_trace_body<COUNT>(a, smem);
 }
+// the round-2 kernel (trace_kernel_r2.h), traversal variant 0: A/B and cross-checks only
+template <bool COUNT>
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_kernel_r2(TraceLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    env_trace_body_r2<COUNT>(a, smem);
+}
 
 // ---------------------------------------------------------------------------------------------
 // stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
@@ -874,6 +883,14 @@ static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t s
     // experiment (NVDR_DEBUG bit 64): no tiny kernel in front of the persistent one; the counters were left zeroed by the stage-1 /
     // stage-3 kernel that ran before on this stream
     if (!(c->debug & 64u)) zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
+    if (c->trace_variant == 0) {
+        const size_t lds2 = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
+        if (counters)
+            env_trace_kernel_r2<true><<<blocks, NVDR_QUERY_BLOCK, lds2, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
+        else
+            env_trace_kernel_r2<false><<<blocks, NVDR_QUERY_BLOCK, lds2, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
+        return;
+    }
     if (counters)
         env_trace_kernel<true><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
     else
@@ -981,6 +998,11 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     NVDR_HIP_TRY(hipSetDevice(c->device));
     const int64_t cap = stream_chunk_pixels(c, npix, S);
     const int n_chunks = (int)((npix + cap - 1) / cap);
+    // the chunk is raised to npix / NVDR_MAX_CHUNKS when the byte budget asks for more chunks than that; chunk-local slot numbers
+    // must still fit 31 bits (they are stored as unsigned / int in the live list, the light-gradient keys and the band gather)
+    NVDR_REQUIRE(cap * 2 * (int64_t)S <= (1ll << 31) - 64,
+                 "env_shade: %lld pixels x %u rays per pixel cannot be cut into %d chunks of < 2^31 rays; raise the stream budget "
+                 "(nvdr_ctx_set_stream_budget) or launch fewer views at once", (long long)npix, 2 * S, NVDR_MAX_CHUNKS);
 
     ShadeParams p;
     memset(&p, 0, sizeof(p));
@@ -1096,7 +1118,8 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         const int64_t need = (cap * 2 * S + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
         if (tblocks > need) tblocks = need < 1 ? 1 : need;
     }
-    const size_t trace_lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
+    const size_t trace_lds = NVDR_TRACE_LDS_BYTES(NVDR_QUERY_BLOCK);
+    const size_t count_lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
     const bool replay = backward && p.vis_cache != nullptr;   // forward bits handed back by the caller: no traversal
 
     c->stream_id = 0; // invalid while being rewritten
@@ -1126,7 +1149,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             } else {
                 launch_trace(c, (unsigned)tblocks, trace_lds, stream, p.ray_count, 2 * S, a->counters);
                 if (a->counters)
-                    bvh2_count_kernel<<<(unsigned)tblocks, NVDR_QUERY_BLOCK, trace_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, p.ray_count,
+                    bvh2_count_kernel<<<(unsigned)tblocks, NVDR_QUERY_BLOCK, count_lds, stream>>>(bvh_view(c), c->rays, c->pix_origin, c->live, p.ray_count,
                                                                                                 2 * S, c->spill, a->counters + NVDR_COUNTERS_BVH2);
             }
         }
@@ -1169,13 +1192,13 @@ __global__ void pack_rays_kernel(const float *__restrict__ ro, const float *__re
     live[i] = i;
 }
 
-extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis, void *stream_)
+static int trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis, unsigned long long *counters,
+                                 hipStream_t stream, const char *who)
 {
-    NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_trace_visibility_wide: no BVH built");
-    NVDR_REQUIRE(n_rays < (1ll << 30), "nvdr_trace_visibility_wide: too many rays");
-    if (int r0 = ctx_check_overflow(c, "nvdr_trace_visibility_wide")) return r0;
+    NVDR_REQUIRE(c && c->n_tris > 0, "%s: no BVH built", who);
+    NVDR_REQUIRE(n_rays < (1ll << 30), "%s: too many rays", who);
+    if (int r0 = ctx_check_overflow(c, who)) return r0;
     if (n_rays <= 0) return 0;
-    hipStream_t stream = (hipStream_t)stream_;
     NVDR_HIP_TRY(hipSetDevice(c->device));
     int r = reserve_stream(c, n_rays, n_rays, 1, stream);
     if (r) return r;
@@ -1185,10 +1208,23 @@ extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const fl
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
     if (tblocks > need) tblocks = need;
-    launch_trace(c, (unsigned)tblocks, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u, nullptr);
+    launch_trace(c, (unsigned)tblocks, NVDR_TRACE_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u, counters);
     NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
     NVDR_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int nvdr_trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis, void *stream_)
+{
+    return trace_visibility_wide(c, ro, rd, n_rays, out_vis, nullptr, (hipStream_t)stream_, "nvdr_trace_visibility_wide");
+}
+
+// the same through the COUNTING build of the production kernel: counters as nvdr_env_shade_args.counters
+extern "C" int nvdr_trace_visibility_wide_counted(nvdr_ctx *c, const float *ro, const float *rd, int64_t n_rays, uint8_t *out_vis,
+                                                  unsigned long long *counters, void *stream_)
+{
+    NVDR_REQUIRE(counters != nullptr, "nvdr_trace_visibility_wide_counted: counters is NULL");
+    return trace_visibility_wide(c, ro, rd, n_rays, out_vis, counters, (hipStream_t)stream_, "nvdr_trace_visibility_wide_counted");
 }
 
 extern "C" int nvdr_ctx_set_stream_budget(nvdr_ctx *c, int64_t bytes)

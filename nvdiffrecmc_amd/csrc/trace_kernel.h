@@ -1,15 +1,24 @@
 // trace_kernel.h -- stage 2 of env-shade: persistent-wavefront any-hit traversal of the ray stream.
 //
-// Replaces optixTrace inside __raygen__rg (render/optixutils/c_src/envsampling/kernel.cu:101-118).
+// Replaces optixTrace inside __raygen__rg (render/optixutils/c_src/envsampling/kernel.cu:101-118: tmin 0, tmax 1e16, terminate on
+// the first hit, no culling).
+//
+// Round 3 design (round 2 walked four-slot nodes and tested a leaf in the lane that reached it):
+//   * EIGHT-WIDE COMPRESSED NODES (bvh.h "oct"): one dependent 64-byte fetch covers three levels of the binary tree; the children
+//     of a node are contiguous, so the traversal state is a (first child, 8-bit hit mask) GROUP, and the stack holds one 8-byte
+//     group per visited node that still has unvisited internal children -- not one entry per child;
+//   * DEFERRED, COMPACTED TRIANGLE TESTS: a lane that hits a leaf box does not test the triangle itself (round 2: ~10 of 64
+//     lanes active in that arm, a third of the kernel's VALU work).  It appends (lane, triangle) to a per-wavefront LDS queue and
+//     keeps walking as if the triangle had been missed -- any-hit visibility does not depend on the order of the tests.  When 64
+//     entries have gathered the WHOLE wavefront tests one triangle per lane (the owner's ray is fetched with ds_bpermute), and a
+//     hit ends the owner's walk.  A ray whose walk ends with tests still queued is undecided ("draining") until the queue is
+//     flushed; lanes are only refilled right after a complete flush, so a queue entry never outlives the ray it belongs to.
 #pragma once
 
 #include "bvh.h"
 
 #ifndef NVDR_REFILL_MIN
-#define NVDR_REFILL_MIN 16
-#endif
-#ifndef NVDR_LEAF_MIN
-#define NVDR_LEAF_MIN 8
+#define NVDR_REFILL_MIN 16      // refill (and flush) when this many lanes have no node to visit
 #endif
 // Chunks of NVDR_TRACE_QCHUNK rays are CLAIMED from device counters, one 128-B line each, instead of being dealt
 // round-robin: all waves then work inside a moving window of the list (neighbouring pixels -> the same subtrees stay in
@@ -21,15 +30,10 @@
 #ifndef NVDR_TRACE_QCHUNK
 #define NVDR_TRACE_QCHUNK 256
 #endif
-#ifndef NVDR_TRACE_ALIGN
-#define NVDR_TRACE_ALIGN 8
-#endif
-#ifndef NVDR_TRACE_PAD
-#define NVDR_TRACE_PAD 10
-#endif
 #ifndef NVDR_TRACE_OCC
 #define NVDR_TRACE_OCC 8       // waves per SIMD the kernel is compiled for (= resident workgroups per CU of the persistent grid)
 #endif
+#define NVDR_LEAFQ_CAP 128     // entries of a wavefront's triangle-test queue (< 64 before an append round, <= 64 appended per round)
 
 struct TraceLaunch {
     BvhView bvh;
@@ -43,6 +47,11 @@ struct TraceLaunch {
     unsigned long long *counters;  // counting build only (nvdr_hip.h NVDR_COUNTERS_*)
     unsigned *queues;              // [256][32] chunk counters, zeroed before every launch; the last line holds diagnostics
 };
+
+// LDS of one workgroup of the traversal kernel: per wavefront the oct stack (NVDR_OSTACK_LDS x 64 lanes x 8 B) and the
+// triangle-test queue (NVDR_LEAFQ_CAP x 8 B)
+#define NVDR_TRACE_LDS_PER_WAVE (NVDR_OSTACK_LDS * 64 * 8 + NVDR_LEAFQ_CAP * 8)
+#define NVDR_TRACE_LDS_BYTES(threads) ((size_t)((threads) / 64) * NVDR_TRACE_LDS_PER_WAVE)
 
 // Chunk dealing: wave w uses counter w % 64 and receives the chunks q, q + 64, q + 128 ... of the list, so the whole chip works
 // inside ONE moving window of the list.  Every counter must be served by somebody: chunk c sits on counter c % 64 and the
@@ -75,7 +84,44 @@ struct ChunkDealer {
     }
 };
 
-// COUNT: the counting build (box / triangle tests, per-wave clocks)
+// 8-byte entries (low word, high word) in explicit address spaces: ds_write_b64 / global_store_dwordx2, no flat accesses
+typedef __attribute__((address_space(3))) unsigned long long lds_pair_t;
+typedef __attribute__((address_space(1))) unsigned long long glb_pair_t;
+__device__ __forceinline__ unsigned long long pack2(unsigned lo, unsigned hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); }
+
+// the oct walk's stack of one lane: entry k at LDS word pair (k * 64 + lane), deeper entries in the HBM spill columns
+struct OctStack {
+    lds_pair_t *lds;
+    glb_pair_t *glb;
+    int gstride, smax;
+    int *ovf;
+    __device__ __forceinline__ int push(int sp, unsigned long long v) const
+    {
+        if (sp >= smax) {    // unreachable unless the depth bound is wrong (bvh.h): the group is dropped, the context flagged
+            atomicOr(ovf, 1);
+            return sp;
+        }
+        if (sp < NVDR_OSTACK_LDS) lds[sp * 64] = v;
+        else glb[(int64_t)(sp - NVDR_OSTACK_LDS) * gstride] = v;
+        return sp + 1;
+    }
+    __device__ __forceinline__ unsigned long long pop(int sp) const      // entry at depth sp (the caller has already decremented)
+    {
+        if (sp < NVDR_OSTACK_LDS) return lds[sp * 64];
+        return glb[(int64_t)(min(sp, smax - 1) - NVDR_OSTACK_LDS) * gstride];
+    }
+};
+
+__device__ __forceinline__ float ubyte_f32(unsigned w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
+
+// A ray prepared for the oct walk: plane distance t(p) = p * inv + noi in grid space (as bvh.h make_grid_ray; the reciprocal is
+// v_rcp_f32 here: 1 ulp, i.e. < 0.01 grid cells on a plane coordinate, inside the one-cell slack of every box; |inv| capped for the
+// reason given there).
+struct OctRay {
+    float ix, iy, iz, nx, ny, nz;
+};
+
+// COUNT: the counting build (box / triangle tests, node steps, per-wave clocks)
 template <bool COUNT>
 __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
 {
@@ -83,116 +129,193 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     const float4 *__restrict__ rays = a.rays;
     const float4 *__restrict__ pix_origin = a.pix_origin;
     const uint32_t *__restrict__ live = a.live;
+    const uint4 *__restrict__ oct = bvh.oct;
+    const float4 *__restrict__ tris8 = bvh.tris8;
     uint8_t *__restrict__ vis = a.vis;
     unsigned long long *counters = a.counters;
     const unsigned rays_per_pixel = a.rays_per_pixel;
-    const TravStack stack = make_stack(smem, a.spill, bvh.stack_max, bvh.overflow);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char *wbase = (char *)smem + wave * NVDR_TRACE_LDS_PER_WAVE;
+    OctStack stack;
+    stack.lds = (lds_pair_t *)wbase + lane;
+    stack.gstride = blockDim.x;
+    stack.smax = bvh.oct_stack_max;
+    stack.ovf = bvh.overflow;
+    stack.glb = (glb_pair_t *)a.spill + (int64_t)blockIdx.x * blockDim.x * max(bvh.oct_stack_max - NVDR_OSTACK_LDS, 0) + threadIdx.x;
+    lds_pair_t *leafq = (lds_pair_t *)(wbase + NVDR_OSTACK_LDS * 64 * 8);      // (triangle, owner lane) entries, used as a stack
+    // the grid transform, wave-uniform (scalar registers)
+    const BvhDeviceInfo *__restrict__ info = bvh.info;
+    const float gsx = info->g_scale[0], gsy = info->g_scale[1], gsz = info->g_scale[2];
+    const float glx = info->g_lo[0], gly = info->g_lo[1], glz = info->g_lo[2];
+
     const unsigned total = *a.ray_count;
-    const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned wid = blockIdx.x * (blockDim.x >> 6) + wave;
     ChunkDealer dealer;
     dealer.init(a.queues, total, wid);
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
     bool more = total > 0;
-    unsigned n_box = 0, n_tri = 0, n_ray = 0;
-    const bool single = bvh.n_tris == 1;
+    unsigned n_box = 0, n_tri = 0, n_ray = 0, n_step = 0, n_batch = 0;
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
     const unsigned long long c_begin = COUNT ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
 
-    int ray = -1, cur = 0, sp = 0;
+    // per-lane walk state.  ray < 0: idle.  ray >= 0 and (gbits | sp) == 0: the walk is over, queued tests decide ("draining").
+    int ray = -1, sp = 0;
+    unsigned gbase = 0, gbits = 0;                          // current group: first child, hit bits of the children still to visit
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
-    GridRay g;
-    g.nx = g.ny = g.nz = g.ix = g.iy = g.iz = 0.0f;
-    g.px = g.py = g.pz = 0u;
-    // The three arms of an iteration -- refill, leaf step, node step -- are gated by WAVE-UNIFORM lane counts so that
-    // the two expensive rare ones are never issued for a handful of lanes:
-    //   refill : when >= NVDR_REFILL_MIN lanes are idle (or nobody can step) and the range still has rays;
-    //   leaf   : when >= NVDR_LEAF_MIN lanes are parked on a leaf, or no lane has a node to visit;
-    //   node   : whenever some lane has one.
-    // Measured (same GPU session, bob 512^2 x 64 spp): ungated 1.36 ms, (16, 8) 1.23-1.31 ms, one-arm-per-iteration
-    // (16, 16) 1.30 ms, (32, 16) 1.68 ms.  The loop has ONE back edge (refill falls through into the step): with a
-    // `continue` after the refill the compiler kept two copies of the ray state and moved ~27 registers per iteration.
-    // The loop is placed at a fixed offset from a 256-byte boundary so that edits elsewhere cannot move it relative to the
-    // instruction-cache lines.
-    asm volatile(".p2align %0" ::"n"(NVDR_TRACE_ALIGN));
-    asm volatile(".rept %0\n s_nop 0\n .endr" ::"n"(NVDR_TRACE_PAD));
+    OctRay g;
+    g.ix = g.iy = g.iz = g.nx = g.ny = g.nz = 0.0f;
+    unsigned q_count = 0;                                   // wave-uniform fill of the triangle-test queue
+
+    // One batch of triangle tests: the top n entries of the queue, one per lane.  Returns nothing; a hit ends the owner's walk
+    // (visibility 0) whatever the owner is doing.  Entries of rays that have ended meanwhile test against the owner's stale
+    // registers and can only "kill" an idle lane: harmless, because lanes are refilled only when the queue is empty.
+    auto test_batch = [&](unsigned n) {
+        __builtin_amdgcn_wave_barrier();                    // the entries were written by other lanes of this wavefront
+        const unsigned first = q_count - n;
+        const bool valid = (unsigned)lane < n;
+        unsigned long long e = pack2(0u, (unsigned)lane);
+        if (valid) e = leafq[first + lane];
+        const unsigned e_tri = (unsigned)e, e_own = (unsigned)(e >> 32);
+        const int src = (int)(e_own << 2);
+        // the owner's ray (all lanes execute the permutes: a source lane must be active to be read)
+        const float rox = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(ox)));
+        const float roy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(oy)));
+        const float roz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(oz)));
+        const float rdx = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dx)));
+        const float rdy = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dy)));
+        const float rdz = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(dz)));
+        bool hit = false;
+        if (valid) hit = tri_any_hit(tris8, (int)e_tri, rox, roy, roz, rdx, rdy, rdz);
+        if (COUNT) { n_tri += valid ? 1u : 0u; n_batch += lane == 0 ? 1u : 0u; }
+        // owners of the hits, gathered on the scalar unit (hits are rare: one per occluded ray)
+        unsigned long long hm = __ballot(hit), kill = 0ull;
+        while (hm) {
+            const int l = __builtin_ctzll(hm);
+            hm &= hm - 1ull;
+            kill |= 1ull << (unsigned)__builtin_amdgcn_readlane((int)e_own, l);
+        }
+        q_count = first;
+        if (((kill >> lane) & 1ull) && ray >= 0) {
+            vis[ray] = 0;
+            ray = -1;
+            sp = 0;
+            gbits = 0u;
+        }
+    };
+
+    unsigned iters = 0;
     while (true) {
-        const unsigned long long idle = __ballot(ray < 0);
-        const int n_idle = __popcll(idle);
-        if (n_idle >= NVDR_REFILL_MIN && next >= end && more) {
+        // every iteration retires work, so the loop ends by itself; the bound (far above any real launch: 2^26 node steps of one
+        // wavefront) only turns a bug into an error report instead of a hung GPU
+        if (++iters > (1u << 26)) {
+            if (lane == 0) atomicOr(bvh.overflow, 4);
+            break;
+        }
+        // ---- refill: when enough lanes have no node to visit, decide the undecided rays and hand out new ones
+        const unsigned long long busy = __ballot(ray >= 0 && (gbits | (unsigned)sp) != 0u);
+        const int n_free = 64 - __popcll(busy);
+        if (n_free >= NVDR_REFILL_MIN && next >= end && more) {
             more = dealer.claim(lane, next, end);
             if (!more) next = end = 0u;
         }
-        if (next < end && n_idle >= NVDR_REFILL_MIN) {
-            // refill every idle lane from the wave's chunk (no atomics: the cursor is wave-uniform)
-            const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-            if (ray < 0 && take < end) {
-                const unsigned slot = live[take];
-                ray = (int)slot;
-                if (COUNT) n_ray++;
-                const float4 rd = rays[slot];
-                const float4 ro = pix_origin[slot / rays_per_pixel];
-                ox = ro.x; oy = ro.y; oz = ro.z;
-                dx = rd.x; dy = rd.y; dz = rd.z;
-                g = make_grid_ray(bvh.info, ox, oy, oz, dx, dy, dz);
-                cur = single ? ~0 : 0;
-                sp = 0;
+        if ((n_free >= NVDR_REFILL_MIN && next < end) || busy == 0ull) {
+            while (q_count > 0u) test_batch(min(q_count, 64u));
+            if (ray >= 0 && (gbits | (unsigned)sp) == 0u) {         // walk over, every queued test missed: unoccluded
+                vis[ray] = 1;
+                ray = -1;
             }
-            next += (unsigned)n_idle;
-        } else if (n_idle == 64) {
-            if (!more) break;
+            if (next < end) {
+                const unsigned long long idle = __ballot(ray < 0);
+                const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                if (ray < 0 && take < end) {
+                    const unsigned slot = live[take];
+                    ray = (int)slot;
+                    if (COUNT) n_ray++;
+                    const float4 rd = rays[slot];
+                    const float4 ro = pix_origin[slot / rays_per_pixel];
+                    ox = ro.x; oy = ro.y; oz = ro.z;
+                    dx = rd.x; dy = rd.y; dz = rd.z;
+                    g.ix = fminf(fmaxf(__builtin_amdgcn_rcpf(dx * gsx), -1.0e30f), 1.0e30f);
+                    g.iy = fminf(fmaxf(__builtin_amdgcn_rcpf(dy * gsy), -1.0e30f), 1.0e30f);
+                    g.iz = fminf(fmaxf(__builtin_amdgcn_rcpf(dz * gsz), -1.0e30f), 1.0e30f);
+                    g.nx = -((ox - glx) * gsx + 2.0f) * g.ix;
+                    g.ny = -((oy - gly) * gsy + 2.0f) * g.iy;
+                    g.nz = -((oz - glz) * gsz + 2.0f) * g.iz;
+                    gbase = 0u;                             // the root is "child 0 of group 0"
+                    gbits = 1u;
+                    sp = 0;
+                }
+                next += (unsigned)__popcll(idle);
+            } else if (__ballot(ray >= 0) == 0ull) {
+                if (!more) break;
+                continue;                                   // nothing to do until the next claim
+            }
         }
-        const unsigned long long on_leaf = __ballot(ray >= 0 && cur < 0);
-        const int n_leaf = __popcll(on_leaf);
-        const int n_node = __popcll(__ballot(ray >= 0 && cur >= 0));
-        const int POP = NVDR_TRAV_DONE, HIT = NVDR_TRAV_DONE - 1, WAIT = NVDR_TRAV_DONE - 2;
-        const bool leaf_turn = n_leaf >= NVDR_LEAF_MIN || n_node == 0;   // parked leaves are tested in batches
-        const bool node_turn = n_node > 0;
-        int nxt = WAIT;                                 // next node / leaf, or one of the markers
-        if (leaf_turn && ray >= 0 && cur < 0) {
-            if (COUNT) n_tri++;
-            nxt = tri_any_hit(bvh.tris, ~cur, ox, oy, oz, dx, dy, dz) ? HIT : POP;
+
+        // ---- node step of every lane that has one
+        unsigned leaf_bits = 0u, leaf_base = 0u;
+        if (ray >= 0 && (gbits | (unsigned)sp) != 0u) {
+            if (gbits == 0u) {
+                sp--;
+                const unsigned long long top = stack.pop(sp);
+                gbase = (unsigned)top;
+                gbits = (unsigned)(top >> 32);
+            }
+            const int k = __builtin_ctz(gbits);
+            gbits &= gbits - 1u;
+            const uint4 *nd = oct + 4 * (int64_t)(gbase + (unsigned)k);
+            const uint4 h = nd[0], p1 = nd[1], p2 = nd[2], p3 = nd[3];
+            if (COUNT) n_step++;
+            // the node's frame: plane = org + q * 2^e  ->  t = q * (inv * 2^e) + (org * inv + noi)
+            const float ax = __builtin_ldexpf(g.ix, (int)((h.y >> 16) & 15u)), bx = fmaf((float)(h.x & 0xffffu), g.ix, g.nx);
+            const float ay = __builtin_ldexpf(g.iy, (int)((h.y >> 20) & 15u)), by = fmaf((float)(h.x >> 16), g.iy, g.ny);
+            const float az = __builtin_ldexpf(g.iz, (int)((h.y >> 24) & 15u)), bz = fmaf((float)(h.y & 0xffffu), g.iz, g.nz);
+            // (near, far) byte planes of each axis for this ray's direction: lo.x = p1.xy, lo.y = p1.zw, lo.z = p2.xy, hi.x = p2.zw, hi.y = p3.xy, hi.z = p3.zw
+            const bool sx = g.ix < 0.0f, sy = g.iy < 0.0f, sz = g.iz < 0.0f;
+            const unsigned nx0 = sx ? p2.z : p1.x, nx1 = sx ? p2.w : p1.y, fx0 = sx ? p1.x : p2.z, fx1 = sx ? p1.y : p2.w;
+            const unsigned ny0 = sy ? p3.x : p1.z, ny1 = sy ? p3.y : p1.w, fy0 = sy ? p1.z : p3.x, fy1 = sy ? p1.w : p3.y;
+            const unsigned nz0 = sz ? p3.z : p2.x, nz1 = sz ? p3.w : p2.y, fz0 = sz ? p2.x : p3.z, fz1 = sz ? p2.y : p3.w;
+            unsigned miss = 0u;                             // bit j = slot j is missed, shifted in from slot 7 down to slot 0
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {
+                const unsigned wnx = j < 4 ? nx0 : nx1, wny = j < 4 ? ny0 : ny1, wnz = j < 4 ? nz0 : nz1;
+                const unsigned wfx = j < 4 ? fx0 : fx1, wfy = j < 4 ? fy0 : fy1, wfz = j < 4 ? fz0 : fz1;
+                const float tnx = fmaf(ubyte_f32(wnx, j & 3), ax, bx), tfx = fmaf(ubyte_f32(wfx, j & 3), ax, bx);
+                const float tny = fmaf(ubyte_f32(wny, j & 3), ay, by), tfy = fmaf(ubyte_f32(wfy, j & 3), ay, by);
+                const float tnz = fmaf(ubyte_f32(wnz, j & 3), az, bz), tfz = fmaf(ubyte_f32(wfz, j & 3), az, bz);
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+                const float tf = fminf(fminf(tfx, tfy), tfz);
+                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);     // (miss << 1) | sign(tf - tn)
+            }
+            const unsigned n_int = h.z >> 28, n_leaf = h.w >> 28;
+            const unsigned hits = ~miss & ((1u << (n_int + n_leaf)) - 1u);
+            if (COUNT) n_box += n_int + n_leaf;
+            const unsigned hi = hits & ((1u << n_int) - 1u);
+            leaf_bits = hits >> n_int;
+            leaf_base = h.w & (NVDR_OCT_MAX_INDEX - 1u);
+            if (hi != 0u) {
+                // descend into the new group; the old one waits on the stack if it still has children to visit
+                if (gbits != 0u) sp = stack.push(sp, pack2(gbase, gbits));
+                gbase = h.z & (NVDR_OCT_MAX_INDEX - 1u);
+                gbits = hi;
+            }
         }
-        const int popv = stack.peek(sp);                // value a pop would return (unused when sp == 0)
-        if (node_turn && ray >= 0 && cur >= 0) {
-            // one step = the four grandchildren of `cur` (bvh.h "wide"): test all, continue with ONE hit slot, push the other
-            // hits.  Any-hit needs no order at all, and ordering does not pay here: continuing with the FIRST hit slot instead
-            // of the nearest one (4 selects + min3 + 3 compares + 3 selects less per step) also visits 3 % FEWER boxes on the
-            // benchmark's shadow rays (44.5 vs 46.0 per ray) -- measured -5 % (8 views), -8 % (one view), -9 % (684 k
-            // triangles) in interleaved in-process A/B runs (profiles/r02_ab_traversal_variants.md).
-            const uint4 *w4 = bvh.wide + 4 * (int64_t)cur;
-            const uint4 q0 = w4[0], q1 = w4[1], q2 = w4[2], q3 = w4[3];
-            float t0, t1, t2, t3;
-            const bool h0 = slot_hit(q0, g, NVDR_RAY_TMAX, t0), h1 = slot_hit(q1, g, NVDR_RAY_TMAX, t1);
-            const bool h2 = slot_hit(q2, g, NVDR_RAY_TMAX, t2), h3 = slot_hit(q3, g, NVDR_RAY_TMAX, t3);
-            (void)t0; (void)t1; (void)t2; (void)t3;
-            const int c0 = (int)q0.w, c1 = (int)q1.w, c2 = (int)q2.w, c3 = (int)q3.w;
-            if (COUNT) n_box += (c0 != NVDR_TRAV_EMPTY) + (c1 != NVDR_TRAV_EMPTY) + (c2 != NVDR_TRAV_EMPTY) + (c3 != NVDR_TRAV_EMPTY);
-            // continue with the first hit slot; a later hit slot is pushed iff an earlier one was hit (slot 0 is never pushed)
-            nxt = h0 ? c0 : h1 ? c1 : h2 ? c2 : h3 ? c3 : POP;
-            const bool b01 = h0 | h1, b012 = b01 | h2;
-            if (h1 & h0) sp = stack.push(sp, c1);
-            if (h2 & b01) sp = stack.push(sp, c2);
-            if (h3 & b012) sp = stack.push(sp, c3);
-            // Measured and dropped (same A/B runs): preferring an internal node (+6..11 %) or a leaf (+9..10 %) over the first hit
-            // slot; unconditional LDS writes at the running depth + one rare spill branch (0.70 vs 0.67 ms); a wave-uniform
-            // "nobody leaves the LDS part of the stack" fast path (+-0 %); reading the stack top only in lanes that pop (+-1 %);
-            // leaf batches of 12 / 16 instead of 8 (+-1 %); refill thresholds 8 / 24 (+5 % / +-0 %); 6 waves per SIMD (+3..7 %);
-            // a 16-entry LDS stack (+-1 %).  Also measured and dropped (session Y): TWO rays per lane, software-pipelined so that the
-            // node fetch of one ray is in flight while the other ray's node is tested (112 VGPRs, 4 waves per SIMD, two LDS stacks
-            // per lane; bit-exact on the first run) -- +30 % (one view) / +37 % (8 views): eight hardware-interleaved waves hide
-            // the fetch better than four waves that interleave two rays in software.
-        }
-        bool finished = false;
-        if (nxt != WAIT) {
-            const bool pop = nxt == POP;
-            finished = (nxt == HIT) | (pop & (sp == 0));
-            sp -= (pop & (sp > 0)) ? 1 : 0;
-            cur = pop ? popv : nxt;
-        }
-        if (finished) {
-            vis[ray] = nxt == HIT ? 0 : 1;
-            ray = -1;
+
+        // ---- queue the hit leaves: one entry per lane and round, ranks by ballot; a full queue is tested at once
+        while (true) {
+            const unsigned long long has = __ballot(leaf_bits != 0u);
+            if (has == 0ull) break;
+            if (leaf_bits != 0u) {
+                const unsigned pos = q_count + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(has >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)has, 0u));
+                const int j = __builtin_ctz(leaf_bits);
+                leaf_bits &= leaf_bits - 1u;
+                leafq[pos] = pack2(leaf_base + (unsigned)j, (unsigned)lane);
+            }
+            q_count += (unsigned)__popcll(has);
+            if (q_count >= 64u) {
+                test_batch(64u);
+                if (ray < 0) leaf_bits = 0u;                // the owner was just found occluded: its other leaves do not matter
+            }
         }
     }
     if (COUNT) {
@@ -200,11 +323,16 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             n_box += __shfl_xor(n_box, o);
             n_tri += __shfl_xor(n_tri, o);
             n_ray += __shfl_xor(n_ray, o);
+            n_step += __shfl_xor(n_step, o);
+            n_batch += __shfl_xor(n_batch, o);
         }
         if (lane == 0) {
             atomicAdd(&counters[0], (unsigned long long)n_box);
             atomicAdd(&counters[1], (unsigned long long)n_tri);
             atomicAdd(&counters[2], (unsigned long long)n_ray);
+            atomicAdd(&counters[NVDR_COUNTERS_BVH2 + 3], (unsigned long long)n_step);
+            atomicAdd(&counters[NVDR_COUNTERS_BVH2 + 4], (unsigned long long)n_batch);
+            atomicAdd(&counters[NVDR_COUNTERS_BVH2 + 5], (unsigned long long)n_tri);
             // load balance: sum and maximum of the per-wave busy time (100 MHz ticks), wave count
             const unsigned long long dt = wall_clock64() - t_begin;
             atomicAdd(&counters[3], dt);
@@ -214,8 +342,10 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             // actually ran at) and the set of XCDs that ran waves
             atomicAdd(&counters[6], (unsigned long long)__builtin_readcyclecounter() - c_begin);
             atomicOr(&counters[7], 1ull << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
-            counters[8 + 2 * wid] = t_begin;                 // per-wave begin / end ticks (wid < 8192); the XCD it ran on in the top byte
-            counters[9 + 2 * wid] = (t_begin + dt) | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 56);
+            if (wid < 8192u) {
+                counters[8 + 2 * wid] = t_begin;                 // per-wave begin / end ticks; the XCD it ran on in the top byte
+                counters[9 + 2 * wid] = (t_begin + dt) | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 56);
+            }
         }
     }
 }

@@ -67,6 +67,12 @@ class OptiXContext:
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')
 
+    def set_trace_variant(self, variant):
+        """Shadow-ray kernel: 1 (default) = eight-wide nodes + deferred triangle tests, 0 = the round-2 kernel (A/B and
+        cross-checks).  Before the first optix_build_bvh on this context."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_ctx_set_trace_variant(w.handle, int(variant)), 'nvdr_ctx_set_trace_variant')
+
     def check(self):
         """Synchronise and raise if any traversal launch on this context ever overflowed its stack (never silent)."""
         w = self.cpp_wrapper
@@ -104,6 +110,23 @@ class OptiXContext:
         _lib.check(w.lib.nvdr_bvh_export(w.handle, nodes.ctypes.data_as(ctypes.c_void_p), tris.ctypes.data_as(ctypes.c_void_p),
                                          _lib.stream_ptr()), 'nvdr_bvh_export')
         return nodes[:info['n_nodes']], tris
+
+
+def _bvh_export_oct(self):
+    """Host copies of the eight-wide tree the shadow rays walk: oct uint32 [n_oct, 16] (64-B records, csrc/bvh.h) and the
+    triangle records float32 [n_tris, 12] in the order the oct nodes refer to them; plus the builder's counters."""
+    w = self.cpp_wrapper
+    cnt = (ctypes.c_int64 * 3)()
+    _lib.check(w.lib.nvdr_bvh_export_oct(w.handle, None, None, cnt, _lib.stream_ptr()), 'nvdr_bvh_export_oct')
+    n_oct, n_tri = int(cnt[0]), int(cnt[1])
+    oct = np.zeros((max(n_oct, 1), 16), dtype=np.uint32)
+    tris8 = np.zeros((self.bvh_info()['n_tris'], 12), dtype=np.float32)
+    _lib.check(w.lib.nvdr_bvh_export_oct(w.handle, oct.ctypes.data_as(ctypes.c_void_p), tris8.ctypes.data_as(ctypes.c_void_p), cnt,
+                                         _lib.stream_ptr()), 'nvdr_bvh_export_oct')
+    return oct[:n_oct], tris8, {'nodes': n_oct, 'triangles_placed': n_tri, 'nodes_finished': int(cnt[2])}
+
+
+OptiXContext.bvh_export_oct = _bvh_export_oct
 
 
 def optix_build_bvh(optix_ctx, verts, tris, rebuild):
@@ -317,16 +340,23 @@ def trace_visibility(optix_ctx, ro, rd, count=False):
     return (vis, cnt) if count else vis
 
 
-def trace_visibility_wide(optix_ctx, ro, rd):
-    """trace_visibility through the PRODUCTION shadow-ray kernel (wide nodes, persistent wavefronts); test hook."""
+def trace_visibility_wide(optix_ctx, ro, rd, count=False):
+    """trace_visibility through the PRODUCTION shadow-ray kernel (wide nodes, persistent wavefronts); test hook.
+    With count=True the counting build of the same kernel runs and (box tests, triangle tests, rays, node steps) are returned too."""
     w = optix_ctx.cpp_wrapper
     _lib.require_cuda_f32(ro, 'ro')
     _lib.require_cuda_f32(rd, 'rd')
     ro, rd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous()
     vis = torch.empty(ro.shape[0], dtype=torch.uint8, device=ro.device)
-    _lib.check(w.lib.nvdr_trace_visibility_wide(w.handle, _lib.ptr(ro), _lib.ptr(rd), ro.shape[0], _lib.ptr(vis), _lib.stream_ptr()),
-               'trace_visibility_wide')
-    return vis
+    if not count:
+        _lib.check(w.lib.nvdr_trace_visibility_wide(w.handle, _lib.ptr(ro), _lib.ptr(rd), ro.shape[0], _lib.ptr(vis), _lib.stream_ptr()),
+                   'trace_visibility_wide')
+        return vis
+    cnt = torch.zeros(_lib.COUNTERS_LEN, dtype=torch.int64, device=ro.device)
+    _lib.check(w.lib.nvdr_trace_visibility_wide_counted(w.handle, _lib.ptr(ro), _lib.ptr(rd), ro.shape[0], _lib.ptr(vis), _lib.ptr(cnt),
+                                                        _lib.stream_ptr()), 'trace_visibility_wide_counted')
+    c = cnt.cpu()
+    return vis, (int(c[0]), int(c[1]), int(c[2]), int(c[_lib.COUNTERS_BVH2 + 3]))
 
 
 def trace_closest(optix_ctx, ro, rd):
@@ -384,6 +414,25 @@ def render_gbuffer(optix_ctx, mesh, mvp, cam, resolution):
     return out
 
 
+def env_shade_forward_with_bits(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols,
+                                BSDF='pbr', n_samples_x=8, rnd_seed=0, shadow_scale=1.0):
+    """Test hook: one forward launch that also returns the visibility bits the kernels used -- int32 [N*H*W, 2, ceil(S/32)],
+    bit s of plane 0 / 1 = the light- / BSDF-sampled shadow ray of STRATUM s is occluded (nvdr_env_shade_args.vis_cache)."""
+    perms = _perms_for(n_samples_x, ro.device)
+    w = optix_ctx.cpp_wrapper
+    a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
+                   ['pbr', 'diffuse', 'white'].index(BSDF), n_samples_x, rnd_seed, shadow_scale,
+                   _optix_env_shade_func._switches(optix_ctx)[1], getattr(optix_ctx, 'seed_offset', None))
+    N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
+    diff = torch.empty(N, H, W, 3, dtype=torch.float32, device=ro.device)
+    spec = torch.empty_like(diff)
+    words = (n_samples_x * n_samples_x + 31) // 32
+    bits = torch.zeros(N * H * W, 2, words, dtype=torch.int32, device=ro.device)
+    a.diff, a.spec, a.vis_cache = diff.data_ptr(), spec.data_ptr(), bits.data_ptr()
+    _lib.check(w.lib.nvdr_env_shade_fwd(w.handle, ctypes.byref(a), _lib.stream_ptr()), 'env_shade_fwd(bits)')
+    return diff, spec, bits
+
+
 def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols,
                                BSDF='pbr', n_samples_x=8, rnd_seed=0, shadow_scale=1.0):
     """Run the COUNTING build of the forward kernel once: returns (covered pixels, box tests, triangle tests,
@@ -411,4 +460,6 @@ def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_p
     env_shade_traversal_counts.clock_mhz = 100.0 * int(c[6]) / max(int(c[3]), 1)     # shader clock the waves ran at
     env_shade_traversal_counts.xcd_mask = int(c[7])
     env_shade_traversal_counts.bvh2 = tuple(int(v) for v in c[_lib.COUNTERS_BVH2:_lib.COUNTERS_BVH2 + 3])
+    env_shade_traversal_counts.node_steps = int(c[_lib.COUNTERS_BVH2 + 3])      # node visits of the production walk
+    env_shade_traversal_counts.leaf_batches = (int(c[_lib.COUNTERS_BVH2 + 4]), int(c[_lib.COUNTERS_BVH2 + 5]))   # triangle-test batches, lanes they filled
     return int(npx.value), int(c[0]), int(c[1]), int(c[2])

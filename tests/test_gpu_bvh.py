@@ -307,3 +307,186 @@ def test_axis_parallel_rays_cost_what_other_rays_cost(dev):
     _, cnt2 = ou.trace_visibility(ctx, ro2.to(dev), rd2.to(dev), count=True)
     per_ray, per_ray2 = cnt[0].item() / n, cnt2[0].item() / n
     assert per_ray < 4.0 * per_ray2 + 50.0, 'axis-parallel rays test %.0f boxes each, random rays %.0f' % (per_ray, per_ray2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: the large-mesh preset and the production walk's own cost counters
+
+def test_684k_triangle_mesh_real_shadow_rays_vs_bruteforce(dev):
+    """bench.py --config dmtet800 (bob subdivided three times, 684 032 triangles -- the tree does not fit the L2s): >= 50 k shadow
+    rays of a REAL env-shade launch (the samples the raygen program draws for ~420 pixels of the 800x800 view, from the oracle's
+    sample generator: bit-identical directions) plus exact pole rays (0, 1, -0) through the PRODUCTION kernel and the binary
+    walk == the oracle's brute force over all 684 k triangles; then the same pixels through the whole env-shade launch."""
+    from nvdiffrecmc_amd import optixutils as ou
+    from tests.test_gpu_fullsize import _gpu_scene, _shade
+    res, n, seed = 800, 8, 4
+    S = n * n
+    mesh, ctx, kw, perms = _gpu_scene('bob', res, n, dev, view=5, subdiv=3)
+    assert ctx.bvh_info()['n_tris'] == 684032
+    sub = torch.zeros_like(kw['mask'])
+    sub[:, 9::27, 4::29] = kw['mask'][:, 9::27, 4::29]
+    kws = dict(kw, mask=sub)
+    cpu = {k: v.detach().cpu().contiguous() for k, v in kws.items()}
+    P = res * res
+    ones = torch.ones(P, 2 * S, dtype=torch.uint8)
+    smp = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT, vis_in=ones, want_dbg=True)
+    pix = (cpu['mask'].view(-1) > 0).nonzero().view(-1)
+    assert 380 < pix.numel() < 480 and smp['covered'] == pix.numel()
+    rd = smp['dbg'][pix][:, :, 0:3].reshape(-1, 3).contiguous()                      # [pixels * 2S, 3] in the oracle's sample order
+    ro = cpu['ro'].view(-1, 3)[pix][:, None, :].expand(-1, 2 * S, -1).reshape(-1, 3).contiguous()
+    assert rd.shape[0] >= 50000
+    # exact pole rays: the light sample of stratum row 0 with a uniform draw of 0 (round 2's stragglers), one per 256 rays
+    pole = torch.tensor([[0.0, 1.0, -0.0], [0.0, -1.0, 0.0]])
+    rd[::256] = pole[0]
+    rd[128::256] = pole[1]
+    ref = orc.visibility(mesh['v_pos'], mesh['t_pos_idx'], ro, rd, n_threads=NT)
+    got_w, (n_box, n_tri, n_ray, n_step) = ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev), count=True)
+    assert torch.equal(got_w.cpu(), ref), '%d of %d rays differ (production kernel)' % (int((got_w.cpu() != ref).sum()), ref.numel())
+    assert torch.equal(ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev)).cpu(), ref)
+    assert torch.equal(ou.trace_visibility(ctx, ro.to(dev), rd.to(dev)).cpu(), ref)
+    assert n_ray == ref.numel() and 0.02 < 1.0 - ref.float().mean().item() < 0.9
+    ctx.check()
+    # the launch itself on these pixels: the oracle with the brute-force visibility of the un-poled rays
+    rd0 = smp['dbg'][pix][:, :, 0:3].reshape(-1, 3).contiguous()
+    vis_pix = orc.visibility(mesh['v_pos'], mesh['t_pos_idx'], ro, rd0, n_threads=NT).view(-1, 2 * S)
+    vis = ones.clone()
+    vis[pix] = vis_pix
+    f = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT, vis_in=vis)
+    d, s = _shade(ctx, kws, n, seed)
+    from tests.util import assert_close
+    assert_close(d, f['diff'], 2e-6, what='diff')
+    assert_close(s, f['spec'], 2e-6, what='spec')
+    ctx.check()
+
+
+def test_production_walk_cost_of_axis_parallel_rays(dev):
+    """Round 2's straggler rays, counted through the PRODUCTION walk (the counting build of env_trace_kernel, not the binary
+    walk): a ray list salted with exactly axis-parallel rays must cost about what the same list costs without them, and an
+    axis-parallel ray about what any other ray costs -- on bob and on a 171 k-triangle mesh."""
+    from nvdiffrecmc_amd import optixutils as ou
+    for subdiv in (0, 2):
+        mesh = sc.load_mesh('bob')
+        v, t = (mesh['v_pos'], mesh['t_pos_idx']) if subdiv == 0 else sc.subdivide(mesh['v_pos'], mesh['t_pos_idx'], subdiv)
+        ctx = ou.OptiXContext()
+        ou.optix_build_bvh(ctx, v.to(dev), t.to(dev), rebuild=1)
+        g = torch.Generator().manual_seed(11)
+        n = 60000
+        ro = (v[torch.randint(0, v.shape[0], (n,), generator=g)] * 0.999).contiguous()     # just inside the surface: long walks
+        rd = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).contiguous()
+        dirs = torch.tensor([[0.0, 1.0, -0.0], [-0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [-1.0, -0.0, 0.0], [0.0, -0.0, 1.0], [-0.0, 0.0, -1.0]])
+        rd_ax = rd.clone()
+        rd_ax[::10] = dirs.repeat(n // 60, 1)                                              # every 10th ray exactly axis-parallel
+        vis0, c0 = ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev), count=True)
+        vis1, c1 = ou.trace_visibility_wide(ctx, ro.to(dev), rd_ax.to(dev), count=True)
+        assert torch.equal(vis0, ou.trace_visibility(ctx, ro.to(dev), rd.to(dev)))
+        assert torch.equal(vis1, ou.trace_visibility(ctx, ro.to(dev), rd_ax.to(dev)))
+        only_ax = rd_ax[::10].contiguous()
+        _, c2 = ou.trace_visibility_wide(ctx, ro[::10].contiguous().to(dev), only_ax.to(dev), count=True)
+        per0, per1, per2 = c0[0] / n, c1[0] / n, c2[0] / (n // 10)
+        print('\n[subdiv %d, %d triangles] production walk box tests per ray: random %.1f, salted %.1f, axis-parallel only %.1f; node steps %.2f'
+              % (subdiv, t.shape[0], per0, per1, per2, c0[3] / n))
+        assert c0[2] == n and c1[2] == n
+        assert per1 < 2.0 * per0 and per2 < 2.0 * per0, (per0, per1, per2)
+        ctx.check()
+
+
+def _check_oct_tree(ctx, v, t):
+    """Structural invariants of the eight-wide tree (csrc/bvh.h "oct"), checked on the host copy."""
+    import numpy as np
+    info = ctx.bvh_info()
+    oct, tris8, cnt = ctx.bvh_export_oct()
+    n = info['n_tris']
+    assert cnt['triangles_placed'] == n and cnt['nodes_finished'] == cnt['nodes'] >= 1
+    # every triangle exactly once (the original index travels in the record)
+    orig = tris8[:, 9].view(np.int32)
+    assert np.array_equal(np.sort(orig), np.arange(n))
+    w0 = oct[:, 0:4]
+    org = np.stack([w0[:, 0] & 0xffff, w0[:, 0] >> 16, w0[:, 1] & 0xffff], -1).astype(np.int64)
+    ex = np.stack([(w0[:, 1] >> 16) & 15, (w0[:, 1] >> 20) & 15, (w0[:, 1] >> 24) & 15], -1).astype(np.int64)
+    cbase, n_int = (w0[:, 2] & 0xfffffff).astype(np.int64), (w0[:, 2] >> 28).astype(np.int64)
+    tbase, n_leaf = (w0[:, 3] & 0xfffffff).astype(np.int64), (w0[:, 3] >> 28).astype(np.int64)
+    assert ((n_int + n_leaf >= 1) & (n_int + n_leaf <= 8)).all()
+
+    def tiles(base, cnt_, lo, hi):              # the non-empty ranges, sorted, tile [lo, hi)
+        m = cnt_ > 0
+        o = np.argsort(base[m])
+        b, c = base[m][o], cnt_[m][o]
+        return b[0] == lo and (b[1:] == b[:-1] + c[:-1]).all() and b[-1] + c[-1] == hi
+    assert cnt['nodes'] == 1 or tiles(cbase, n_int, 1, cnt['nodes'])
+    assert tiles(tbase, n_leaf, 0, n)
+    planes = oct[:, 4:16].copy().view(np.uint8).reshape(-1, 6, 8).astype(np.int64)   # lo.x, lo.y, lo.z, hi.x, hi.y, hi.z per slot
+    lo = org[:, :, None] + (planes[:, 0:3, :] << ex[:, :, None])                   # [nodes, axis, slot] on the 16-bit grid
+    hi = org[:, :, None] + (planes[:, 3:6, :] << ex[:, :, None])
+    # leaf slots contain their triangle (exact vertices mapped to the grid)
+    gl, gs = np.array(info['grid_lo']), np.array(info['grid_scale'])
+    v0, e1, e2 = tris8[:, 0:3].astype(np.float64), tris8[:, 3:6].astype(np.float64), tris8[:, 6:9].astype(np.float64)
+    pts = np.stack([v0, v0 + e1, v0 + e2], 1)
+    g = (pts - gl) * gs + 2.0
+    tmin, tmax = g.min(1), g.max(1)
+    for node in np.nonzero(n_leaf > 0)[0]:
+        for j in range(n_leaf[node]):
+            k, tri = n_int[node] + j, tbase[node] + j
+            assert (lo[node, :, k] <= tmin[tri] + 1e-3).all() and (hi[node, :, k] >= tmax[tri] - 1e-3).all(), (node, j)
+    # an internal slot contains every slot of the child node it points to
+    used = np.arange(8)[None, :] < (n_int + n_leaf)[:, None]
+    nlo = np.where(used[:, None, :], lo, 1 << 30).min(2)
+    nhi = np.where(used[:, None, :], hi, -1).max(2)
+    for node in np.nonzero(n_int > 0)[0]:
+        for k in range(n_int[node]):
+            c = cbase[node] + k
+            assert (lo[node, :, k] <= nlo[c]).all() and (hi[node, :, k] >= nhi[c]).all(), (node, k, c)
+    return cnt['nodes'], float((n_int + n_leaf).mean())
+
+
+@pytest.mark.parametrize('kind', ['bob', 'spot', 'single', 'pair', 'fan', 'subdiv1'])
+def test_oct_tree_invariants(kind, dev):
+    """The eight-wide tree built by the ticket-driven collapse (bvh_oct_build_kernel): every triangle placed once, children and
+    leaves stored contiguously, every 8-bit box contains what it stands for -- on regular meshes, degenerate ones, and after a refit."""
+    from nvdiffrecmc_amd import optixutils as ou
+    if kind in ('bob', 'spot'):
+        m = sc.load_mesh(kind)
+        v, t = m['v_pos'], m['t_pos_idx']
+    elif kind == 'subdiv1':
+        m = sc.load_mesh('bob')
+        v, t = sc.subdivide(m['v_pos'], m['t_pos_idx'], 1)
+    elif kind == 'fan':
+        v, t = _degenerate_fan(20000, 3)
+    else:
+        v = torch.tensor([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.0]])
+        t = torch.tensor([[0, 1, 2], [0, 2, 3]], dtype=torch.int32)[:1 if kind == 'single' else 2].contiguous()
+    ctx = ou.OptiXContext()
+    ou.optix_build_bvh(ctx, v.to(dev), t.to(dev), rebuild=1)
+    nodes, fill = _check_oct_tree(ctx, v, t)
+    print('\n[%s] %d triangles -> %d oct nodes, %.2f slots used per node' % (kind, t.shape[0], nodes, fill))
+    if t.shape[0] > 8:
+        assert nodes < t.shape[0] / 3 and fill > 4.0
+    g = torch.Generator().manual_seed(1)
+    v2 = (v * 1.05 + 0.01 * torch.randn(v.shape, generator=g)).contiguous()
+    ou.optix_build_bvh(ctx, v2.to(dev), t.to(dev), rebuild=0)                   # refit: the oct tree is rebuilt over the new boxes
+    _check_oct_tree(ctx, v2, t)
+    ctx.check()
+
+
+def test_round2_and_round3_kernels_agree(dev):
+    """The round-2 shadow-ray kernel (four-slot nodes, kept as traversal variant 0 for A/B timing) and the round-3 kernel
+    (eight-wide compressed nodes, deferred triangle tests) answer identically, ray for ray and image for image."""
+    from nvdiffrecmc_amd import optixutils as ou
+    from tests.test_gpu_fullsize import _gpu_scene, _shade
+    mesh = sc.load_mesh('bob')
+    ctx3 = make_ctx(mesh, dev)
+    ctx2 = ou.OptiXContext()
+    ctx2.set_trace_variant(0)
+    ou.optix_build_bvh(ctx2, mesh['v_pos'].to(dev), mesh['t_pos_idx'].to(dev), rebuild=1)
+    ro, rd = _rays(300000, 5, 0.35)
+    ro, rd = ro.to(dev), rd.to(dev)
+    a, b = ou.trace_visibility_wide(ctx3, ro, rd), ou.trace_visibility_wide(ctx2, ro, rd)
+    assert torch.equal(a, b) and 0.05 < a.float().mean().item() < 0.95
+    with pytest.raises(RuntimeError, match='BEFORE'):
+        ctx3.set_trace_variant(0)
+    res, n = 160, 8
+    _, c3, kw, perms = _gpu_scene('bob', res, n, dev, view=3)
+    d3, s3 = _shade(c3, kw, n, 7)
+    d2, s2 = _shade(ctx2, kw, n, 7)
+    assert torch.equal(d3, d2) and torch.equal(s3, s2)
+    ctx2.check()
+    ctx3.check()

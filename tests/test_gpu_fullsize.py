@@ -5,7 +5,7 @@ import torch
 
 from oracle import oracle as orc
 from nvdiffrecmc_amd import scene as sc
-from tests.util import assert_close
+from tests.util import assert_close, vis_by_sample_from_stratum_bits
 
 pytestmark = pytest.mark.gpu
 NT = orc.max_threads()
@@ -89,8 +89,9 @@ def test_fullsize_sparse_subset_vs_oracle(dev):
     assert 50 < f['covered'] < 200
     assert_close(d, f['diff'], 2e-6)
     assert_close(s, f['spec'], 2e-6)
-    assert_close(leaves['gb_normal'].grad, b['gb_normal_grad'], 2e-4, floor=1e-3 * b['gb_normal_grad'].abs().max().item())
-    assert_close(leaves['gb_ks'].grad, b['gb_ks_grad'], 2e-4, floor=1e-3 * b['gb_ks_grad'].abs().max().item())
+    for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks'):
+        ref = b[k + '_grad']
+        assert_close(leaves[k].grad, ref, 2e-4, floor=1e-3 * max(ref.abs().max().item(), 1e-6), what=k)
     assert_close(leaves['light'].grad, b['light_grad'], 1e-4, floor=1e-3 * b['light_grad'].abs().max().item())
     # the same benchmark-sized launch against the REFERENCE's own raygen program (oracle/_ref: kernel.cu compiled for the CPU,
     # travels to the GPU box prebuilt): with this library's transcendentals tightly, with libm on >= 99.8 % of the values
@@ -105,6 +106,81 @@ def test_fullsize_sparse_subset_vs_oracle(dev):
                          frac_outliers=outl, what=impl + ' gb_normal_grad')
             assert_close(leaves['light'].grad, rb['light_grad'], 1e-3, floor=1e-3 * rb['light_grad'].abs().max().item(),
                          frac_outliers=outl, what=impl + ' light_grad')
+
+
+def test_whole_frame_vs_oracle_with_gpu_visibility(dev):
+    """BASELINE configs[1], ONE WHOLE VIEW: bob 512x512, n_samples_x = 8, EVERY covered pixel (~56 k pixels, 7.2 M samples) against
+    the oracle, forward and all five gradients.  Brute-force visibility of 7.2 M rays is out of reach of the CPU, so the oracle
+    is handed the visibility the GPU traced (the kernels' own bit planes, converted from stratum order to sample order through
+    the pixel's permutation rows); everything else -- sample generation, pdfs, texels, BSDF, adjoints -- is the oracle's own.
+    The visibility itself is pinned separately: bit-exact vs brute force on random, grazing and real shadow rays (test_gpu_bvh.py)
+    and on the sparse subset of this very frame (test_fullsize_sparse_subset_vs_oracle)."""
+    from nvdiffrecmc_amd import optixutils as ou
+    res, n, seed = 512, 8, 3
+    S = n * n
+    mesh, ctx, kw, perms = _gpu_scene('bob', res, n, dev)
+    g = torch.Generator().manual_seed(1)
+    dg, sg = torch.rand(1, res, res, 3, generator=g), torch.rand(1, res, res, 3, generator=g)
+    leaves = {k: kw[k].clone().requires_grad_(True) for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')}
+    kq = dict(kw, **leaves)
+    ctx.cache_visibility = False                                     # the backward pass re-traces, as the benchmark does
+    d, s = _shade(ctx, kq, n, seed)
+    ((d * dg.to(dev)).sum() + (s * sg.to(dev)).sum()).backward()
+    d2, s2, bits = ou.ops.env_shade_forward_with_bits(ctx, kw['mask'], kw['ro'], kw['gb_pos'], kw['gb_normal'], kw['gb_view_pos'], kw['gb_kd'],
+                                                     kw['gb_ks'], kw['light'], kw['pdf'], kw['rows'], kw['cols'], n_samples_x=n, rnd_seed=seed)
+    assert torch.equal(d2, d.detach()) and torch.equal(s2, s.detach())
+    vis = torch.from_numpy(vis_by_sample_from_stratum_bits(bits.cpu().numpy(), perms.numpy(), seed, S))
+    cpu = {k: v.detach().cpu().contiguous() for k, v in kw.items()}
+    covered = int((cpu['mask'] > 0).sum())
+    occluded = 1.0 - vis.view(-1, 2 * S)[(cpu['mask'] > 0).view(-1)].float().mean().item()
+    assert covered > 40000 and 0.02 < occluded < 0.6, (covered, occluded)
+    f = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT, vis_in=vis)
+    b = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, diff_grad=dg, spec_grad=sg,
+                      n_threads=NT, vis_in=vis)
+    assert f['covered'] == covered
+    assert_close(d, f['diff'], 2e-6, what='diff')
+    assert_close(s, f['spec'], 2e-6, what='spec')
+    for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks'):
+        ref = b[k + '_grad']
+        assert_close(leaves[k].grad, ref, 2e-4, floor=1e-3 * max(ref.abs().max().item(), 1e-6), what=k)
+    assert_close(leaves['light'].grad, b['light_grad'], 2e-4, floor=1e-3 * b['light_grad'].abs().max().item(), what='light')
+    ctx.check()
+
+
+def test_batched_views_equal_single_view_launches(dev):
+    """The benchmarked launch shape -- N = 8 views in ONE launch (configs/bob.json:8) -- against eight one-view launches whose
+    pixel index is offset by view * H * W (the data-parallel split, kernel.cu:504): images and per-pixel gradients bit for bit,
+    the light gradient (a sum over all views) up to addition order."""
+    from nvdiffrecmc_amd import optixutils as ou
+    res, n, seed, nv = 128, 8, 6, 8
+    views = [_gpu_scene('bob', res, n, dev, view=v) for v in range(nv)]
+    mesh, ctx = views[0][0], views[0][1]
+    cat = {k: torch.cat([v[2][k] for v in views], 0).contiguous() for k in ('mask', 'ro', 'gb_pos', 'gb_normal', 'gb_view_pos', 'gb_kd', 'gb_ks')}
+    shared = {k: views[0][2][k] for k in ('light', 'pdf', 'rows', 'cols')}
+    g = torch.Generator().manual_seed(2)
+    dg, sg = torch.rand(nv, res, res, 3, generator=g).to(dev), torch.rand(nv, res, res, 3, generator=g).to(dev)
+    names = ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')
+
+    def run(kw, dgv, sgv, offset):
+        leaves = {k: kw[k].clone().requires_grad_(True) for k in names}
+        ctx.pixel_index_offset = offset
+        ctx.cache_visibility = False
+        d, s = _shade(ctx, dict(kw, **leaves), n, seed)
+        ((d * dgv).sum() + (s * sgv).sum()).backward()
+        ctx.pixel_index_offset = None
+        return d.detach(), s.detach(), {k: leaves[k].grad for k in names}
+
+    D, Sp, G = run(dict(cat, **shared), dg, sg, 0)
+    light_sum = torch.zeros_like(G['light'])
+    for v in range(nv):
+        kw1 = dict({k: cat[k][v:v + 1].contiguous() for k in cat}, **shared)
+        d1, s1, g1 = run(kw1, dg[v:v + 1], sg[v:v + 1], v * res * res)
+        assert torch.equal(d1[0], D[v]) and torch.equal(s1[0], Sp[v]), 'view %d' % v
+        for k in names[:4]:
+            assert torch.equal(g1[k][0], G[k][v]), 'view %d %s' % (v, k)
+        light_sum += g1['light']
+    assert_close(G['light'], light_sum, 1e-4, floor=1e-3 * light_sum.abs().max().item())
+    ctx.check()
 
 
 @pytest.mark.parametrize('cache_vis', [False, True], ids=['retrace', 'cached_visibility'])

@@ -16,6 +16,8 @@ nviews = int(os.environ.get('PROBE_VIEWS', '8'))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 base = _build.LIB
 paths = [('current', base)] + [(p.split('.so.')[-1], p) for p in sorted(glob.glob(os.path.join(_build.BUILD, 'variants', 'libnvdr_hip.so.*')))]
+if os.environ.get('AB_R2', '1') != '0':
+    paths.append(('r2kernel', base))       # the same library with the round-2 shadow-ray kernel selected (NVDR_TRACE_VARIANT=0)
 only = os.environ.get('AB_ONLY')
 if only:
     paths = [pp for pp in paths if pp[0] in only.split(',') or pp[0] == 'current']
@@ -25,7 +27,12 @@ for tag, path in paths:
     _lib._lib = None
     _build.LIB = path                      # _lib.load() binds the signatures of whatever this points to
     lib = _lib.load()
+    if tag == 'r2kernel':
+        os.environ['NVDR_TRACE_VARIANT'] = '0'
+    else:
+        os.environ.pop('NVDR_TRACE_VARIANT', None)
     st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
+    os.environ.pop('NVDR_TRACE_VARIANT', None)
     assert st.ctx.cpp_wrapper.lib is lib
     with torch.no_grad():
         m = st.mask[..., None]

@@ -67,6 +67,9 @@ print('counting launch, event brackets: gen %.3f trace+binary-walk %.3f shade %.
 tot, mx, nw = ou.ops.env_shade_traversal_counts.balance
 print('counting build: %d rays traversed of %d, %.1f box %.2f tri tests/ray; per-wave busy time mean %.1f us max %.1f us over %d waves'
       % (nr, 2 * n * n * P, nb / nr, nt / nr, tot / max(nw, 1) / 100.0, mx / 100.0, nw))
+_lb = ou.ops.env_shade_traversal_counts.leaf_batches
+print('production walk: %.2f node steps per ray; %d triangle-test batches, %.1f of 64 lanes filled on average'
+      % (ou.ops.env_shade_traversal_counts.node_steps / max(nr, 1), _lb[0], _lb[1] / max(_lb[0], 1)))
 wt = ou.ops.env_shade_traversal_counts.wave_ticks.double()
 t0 = wt[:, 0].min()
 b, e = (wt[:, 0] - t0) / 100.0, (wt[:, 1] - t0) / 100.0

@@ -119,6 +119,7 @@ struct nvdr_ctx {
     int *ovf_host = nullptr;       // host-mapped overflow flag (a push beyond stack_max sets it)
     int *ovf_dev = nullptr;        // its device address
     unsigned debug = 0;            // NVDR_DEBUG, read ONCE when the context is created
+    int per_cu[3] = {8, 6, 6};     // workgroups per CU of the sample-generation, forward- and backward-shading kernels (NVDR_PBLOCKS="g,f,b")
     int trace_variant = 1;         // shadow-ray kernel: 1 = round 3 (oct nodes, deferred triangle tests), 0 = round 2 (four-slot nodes)
     // env-shade scratch
     int *pix_list = nullptr;       // [N*H*W] compacted indices of the covered pixels of the whole launch

@@ -539,11 +539,15 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         if (mb >= 1) c->stream_budget = (int64_t)mb << 20;
     }
     // NVDR_DEBUG (experiments only: 1 skip tracing, 2 skip the light gradient, 8 trace dead samples, 16 light-gradient
-    // atomics instead of the band gather, 32 pretend the traversal stack holds 13 entries, 64 no reset kernel in front of
-    // the traversal kernel) is read ONCE here, not per launch, and announced when set
+    // atomics instead of the band gather, 32 pretend the traversal stacks hold 13 / 2 entries, 64 an explicit reset kernel in
+    // front of the traversal kernel) is read ONCE here, not per launch, and announced when set
     if (const char *dbg = getenv("NVDR_DEBUG")) {
         c->debug = (unsigned)atoi(dbg);
         if (c->debug) fprintf(stderr, "[nvdr] NVDR_DEBUG=%u is active on this context (experiment switches; not for production)\n", c->debug);
+    }
+    if (const char *pb = getenv("NVDR_PBLOCKS")) {
+        sscanf(pb, "%d,%d,%d", &c->per_cu[0], &c->per_cu[1], &c->per_cu[2]);
+        for (int k = 0; k < 3; ++k) c->per_cu[k] = c->per_cu[k] < 1 ? 1 : (c->per_cu[k] > 16 ? 16 : c->per_cu[k]);
     }
     // NVDR_TRACE_VARIANT=0 selects the round-2 shadow-ray kernel for contexts created while it is set (A/B tools)
     if (const char *tv = getenv("NVDR_TRACE_VARIANT")) {

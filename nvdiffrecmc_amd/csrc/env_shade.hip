@@ -84,6 +84,7 @@ struct ShadeParams {
     const unsigned *seed_dev; // optional: a seed offset read from device memory (captured HIP graphs replay with fresh seeds)
     int reuse;                // backward: the forward's stream is still in the context IF the whole launch fitted one chunk
     int lg_records;           // backward: 1 = write (texel, rgb) records for the band gather, 0 = global atomics
+    int lg_shift;             // band of a texel = texel >> lg_shift (bands hold a power-of-two number of texels)
     unsigned *queues;         // chunk counters of the traversal kernel: stages 1 and 3 leave them zeroed for the next stage-2 launch
 };
 
@@ -508,6 +509,10 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 // texel < 0 marks a slot without light-gradient record (dead here; occluded / zero after the backward pass)
                 p.texel[rA] = deadA ? -1 : tyA * p.light.n1 + txA;
                 p.texel[rB] = deadB ? -1 : tyB * p.light.n1 + txB;
+                // the visibility byte of a dead slot is never written by stage 2; the light-gradient gather reads that byte as
+                // the slot's BAND after the backward pass (255 = no record), so dead slots say so from the start
+                if (deadA) p.vis[rA] = 255;
+                if (deadB) p.vis[rB] = 255;
             }
             // append the live slots to this wavefront's LDS staging buffer (ballot ranks; `staged` is wave-uniform)
             const unsigned long long mA = __ballot(deadA == 0u), mB = __ballot(deadB == 0u);
@@ -633,9 +638,15 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     // Band gather (light_grad_band_kernel): the addend REPLACES the sample's ray in the stream -- this
                     // lane read it above and nobody needs it again -- and a slot without addend gets texel -1.
                     // No atomic leaves the workgroup: 21 M addends per 8-view launch were 63 M memory-side fp32 atomics.
+                    // and its visibility byte -- consumed above as well -- becomes the record's BAND (255: no record), the
+                    // one-byte key the gather scans: 8 bands x 58 MB instead of 8 x 233 MB of 4-byte texel keys (round 2)
                     const int64_t ri = r == 0 ? rA : rB;
-                    if (nz) p.rays[ri] = make_float4(lg.x, lg.y, lg.z, 0.0f);
-                    else p.texel[ri] = -1;
+                    if (nz) {
+                        p.rays[ri] = make_float4(lg.x, lg.y, lg.z, 0.0f);
+                        p.vis[ri] = (uint8_t)(at >> p.lg_shift);
+                    } else {
+                        p.vis[ri] = 255;
+                    }
                 } else if (nz) {
                     float *g = xcd_light + (int64_t)at * 3;
                     __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -742,19 +753,19 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 // has just consumed; texel = -1 marks slots without addend) and this kernel reduces the records by key:
 //   * the probe is cut into `n_bands` bands of consecutive texels whose fp32 accumulators (band_texels * 12 B) fit the LDS
 //     of one workgroup (96 KB -> 8 bands at 256x256);
-//   * workgroup (g, band) scans the g-th slice of the key array (coalesced int4 loads, 4 B per slot) and fetches the 16-byte
-//     record only of keys inside its band, adding it into LDS with ds_add_f32 (hot sun texels serialise inside the LDS
-//     atomic unit, not on the fabric);
+//   * workgroup (g, band) scans the g-th slice of the one-byte BAND keys (coalesced 16-byte loads = 16 slots; the byte is the
+//     slot's old visibility flag, rewritten by the backward shading kernel) and fetches texel + 16-byte record only of keys of
+//     its band, adding the record into LDS with ds_add_f32 (hot sun texels serialise inside the LDS atomic unit, not on the fabric);
 //   * it then writes its band as ONE plain partial row; light_grad_reduce_kernel sums the partial rows.
-// Cost model per 8-view launch (58 M slots, 21 M records): keys 8 bands x 233 MB = 1.9 GB (mostly Infinity-Cache hits, the
-// key array is 233 MB), records 21 M x 64-B sectors = 1.3 GB, partials 25 MB: ~0.5 ms instead of ~3 ms.
+// Cost model per 8-view launch (58 M slots, 21 M records): keys 8 bands x 58 MB = 0.47 GB, texels + records 21 M x (4 + 16) B =
+// 0.42 GB, partials 25 MB.  (Round 2 scanned the 4-byte texel keys: 8 x 233 MB, counter-measured 3.4 GB per launch, 1.31 ms.)
 
 #define NVDR_LG_THREADS 1024
 
-__global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const int *__restrict__ texel, const float4 *__restrict__ recs,
-                                                                          const unsigned *__restrict__ pix_count, unsigned pix_begin,
-                                                                          unsigned pix_cap, unsigned rays_per_pixel, int band_texels,
-                                                                          int n_texels, float *__restrict__ partials)
+__global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const uint8_t *__restrict__ band_of, const int *__restrict__ texel,
+                                                                          const float4 *__restrict__ recs, const unsigned *__restrict__ pix_count,
+                                                                          unsigned pix_begin, unsigned pix_cap, unsigned rays_per_pixel,
+                                                                          int band_texels, int n_texels, float *__restrict__ partials)
 {
     extern __shared__ __attribute__((aligned(16))) float lg_acc[];
     const unsigned Ptot = *pix_count;
@@ -766,18 +777,25 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
     for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) lg_acc[i] = 0.0f;
     __syncthreads();
     const unsigned total = P * rays_per_pixel;              // < 2^31 by the chunk size
-    const unsigned n4 = (total + 3u) >> 2;
-    const unsigned per = (n4 + G - 1) / G;
-    const unsigned b4 = g * per, e4 = min(b4 + per, n4);
-    const int4 *__restrict__ keys = (const int4 *)texel;    // the allocation is padded to a multiple of 4 entries
-    for (unsigned q = b4 + threadIdx.x; q < e4; q += NVDR_LG_THREADS) {
-        const int4 k4 = keys[q];
-        const int kk[4] = {k4.x, k4.y, k4.z, k4.w};
+    const unsigned n16 = (total + 15u) >> 4;
+    const unsigned per = (n16 + G - 1) / G;
+    const unsigned b16 = g * per, e16 = min(b16 + per, n16);
+    const uint4 *__restrict__ keys = (const uint4 *)band_of;   // 16 one-byte keys per load; the allocation is padded to a multiple of 16
+    const unsigned want = (unsigned)band * 0x01010101u;
+    for (unsigned q = b16 + threadIdx.x; q < e16; q += NVDR_LG_THREADS) {
+        const uint4 k16 = keys[q];
+        const unsigned kw[4] = {k16.x, k16.y, k16.z, k16.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned slot = 4u * q + j;
-            const int t = kk[j];
-            if (slot < total && t >= t_lo && t < t_hi) {
+        for (int w = 0; w < 4; ++w) {
+            const unsigned x = kw[w] ^ want;                                    // a zero byte = a slot of this band
+            if (((x - 0x01010101u) & ~x & 0x80808080u) == 0u) continue;        // none of the four (exact zero-byte test)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (((x >> (8 * j)) & 0xffu) != 0u) continue;
+                const unsigned slot = 16u * q + 4u * w + j;
+                if (slot >= total) continue;
+                const int t = texel[slot];
+                if (t < t_lo || t >= t_hi) continue;                            // (a stale byte of a slot nobody wrote in this launch)
                 const float4 v = recs[slot];
                 float *a = lg_acc + (t - t_lo) * 3;
                 __hip_atomic_fetch_add(a + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -864,7 +882,7 @@ static int check_gb(const nvdr_tensor &t, int64_t N, int64_t H, int64_t W, const
 // ---------------------------------------------------------------------------------------------
 // the production traversal launch
 
-// The 64 chunk counters of the traversal kernel must read zero when it starts: a 64-thread kernel on the launch stream.
+// explicit reset of the 64 chunk counters of the traversal kernel (NVDR_DEBUG bit 64 only; see launch_trace)
 __global__ void zero_queues_kernel(unsigned *queues) { queues[threadIdx.x * 32u] = 0u; }
 
 static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_count, unsigned rays_per_pixel, unsigned long long *counters)
@@ -880,9 +898,10 @@ static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_coun
 static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t stream, const unsigned *ray_count, unsigned rays_per_pixel,
                          unsigned long long *counters)
 {
-    // experiment (NVDR_DEBUG bit 64): no tiny kernel in front of the persistent one; the counters were left zeroed by the stage-1 /
-    // stage-3 kernel that ran before on this stream
-    if (!(c->debug & 64u)) zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
+    // The 64 chunk counters read zero here: the stage-1 / stage-3 kernel (or pack_rays_kernel) that ran before on this stream
+    // reset them -- every traversal launch follows one of those (a backward pass that re-traces the forward's stream follows the
+    // forward's stage 3; any other launch in between invalidates that stream).  NVDR_DEBUG bit 64 adds an explicit reset kernel.
+    if (c->debug & 64u) zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
     if (c->trace_variant == 0) {
         const size_t lds2 = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
         if (counters)
@@ -919,7 +938,7 @@ static int64_t stream_chunk_pixels(const nvdr_ctx *c, int64_t npix, unsigned S)
 
 static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, unsigned S, hipStream_t stream)
 {
-    const size_t rays = ((size_t)cap * 2 * S + 3) & ~(size_t)3;   // the band gather reads the keys as int4
+    const size_t rays = ((size_t)cap * 2 * S + 15) & ~(size_t)15;   // the band gather reads 16 one-byte keys per load
     if (c->stream_cap_rays >= rays && c->pix_cap >= npix && c->stream_cap_pixels >= cap) return 0;
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
     if (c->pix_cap < npix) {
@@ -1035,11 +1054,15 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     size_t lg_lds = 0;
     if (backward) {
         const size_t lds_budget = lg_lds_budget();
-        const int max_band = (int)(lds_budget / 12);
-        n_bands = (n_texels + max_band - 1) / max_band;
+        // a band = the largest power-of-two number of texels whose fp32 accumulators fit the LDS budget (band = texel >> shift)
+        int shift = 0;
+        while ((size_t)(2 << shift) * 12 <= lds_budget) ++shift;
+        band_texels = 1 << shift;
+        n_bands = (n_texels + band_texels - 1) / band_texels;
         p.lg_records = (n_bands <= 16 && !(c->debug & 16u)) ? 1 : 0;
+        p.lg_shift = shift;
         if (p.lg_records) {
-            band_texels = (n_texels + n_bands - 1) / n_bands;
+            if (band_texels > n_texels) band_texels = n_texels;
             lg_lds = (size_t)band_texels * 12;
             lg_rows = c->n_cus / n_bands < 1 ? 1 : c->n_cus / n_bands;
         }
@@ -1101,8 +1124,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     const int64_t max_groups = (cap + (64 / L) - 1) / (64 / L);
     // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading); NVDR_PBLOCKS="g,f,b"
     // overrides them for tuning
-    int per_cu[3] = {8, 6, 6};   // measured (bob 512^2 x 64 spp, 1 and 8 views per launch): within 3 % of the best for each kernel
-    if (const char *e = getenv("NVDR_PBLOCKS")) sscanf(e, "%d,%d,%d", &per_cu[0], &per_cu[1], &per_cu[2]);
+    const int *per_cu = c->per_cu;   // {8, 6, 6}: measured within 3 % of the best for each kernel; NVDR_PBLOCKS is read once per context
     int64_t pb[3];
     for (int k = 0; k < 3; ++k) {
         pb[k] = (int64_t)c->n_cus * (per_cu[k] < 1 ? 1 : per_cu[k]);
@@ -1159,7 +1181,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
             if (p.lg_records && !(c->debug & 2u)) {
                 light_grad_band_kernel<<<dim3((unsigned)lg_rows, (unsigned)n_bands), NVDR_LG_THREADS, lg_lds, stream>>>(
-                    c->texel, c->rays, p.pix_count, p.pix_begin, p.pix_cap, 2 * S, band_texels, n_texels, c->lg_part);
+                    c->vis, c->texel, c->rays, p.pix_count, p.pix_begin, p.pix_cap, 2 * S, 1 << p.lg_shift, n_texels, c->lg_part);
                 light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, lg_rows, p.g_light,
                                                                                          k > 0 ? 1 : 0, p.pix_count, p.pix_begin);
             }

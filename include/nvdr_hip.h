@@ -21,6 +21,7 @@
 #ifndef NVDR_HIP_H
 #define NVDR_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -54,6 +55,14 @@ int nvdr_ctx_check(nvdr_ctx *ctx, void *stream);
  * exceed the chunk is processed chunk by chunk with identical results.  The reference needs no scratch (one thread per
  * pixel keeps its rays in registers); a worst-case allocation would be N*H*W*2S*25 B (16 GB for 8 x 800^2 x 64 spp). */
 int nvdr_ctx_set_stream_budget(nvdr_ctx *ctx, int64_t bytes);
+/* Optional device allocator for everything the context owns beyond a few control words (BVH buffers, ray stream, stack spill:
+ * hundreds of MB).  Without it the library calls hipMalloc / hipFree.  The Python shim passes torch's caching allocator, so the
+ * scratch is visible to -- and recycled by -- the framework that owns the GPU's memory (the reference allocates its GAS with
+ * cudaMalloc, torch_bindings.cpp:84-95, and leaks a launch-parameter block per call, :174-180).  alloc returns NULL on failure;
+ * `stream` is the stream of the call that needs the memory.  Must be set before the context allocates anything. */
+typedef void *(*nvdr_alloc_fn)(size_t bytes, int device, void *stream, void *user);
+typedef void (*nvdr_free_fn)(void *ptr, void *user);
+int nvdr_ctx_set_allocator(nvdr_ctx *ctx, nvdr_alloc_fn alloc_fn, nvdr_free_fn free_fn, void *user);
 /* Shadow-ray kernel of this context: 1 (default) = round 3 (eight-wide compressed nodes, deferred triangle tests), 0 = the
  * round-2 kernel (four-slot nodes), kept for in-process A/B timing and bit-for-bit cross-checks.  Must be selected before the
  * first nvdr_bvh_build on the context. */

@@ -48,6 +48,26 @@ class NvdrGbufferArgs(ctypes.Structure):
                                 'gb_texc_deriv', 'gb_depth')]
 
 
+ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p)     # nvdr_alloc_fn
+FREE_FN = ctypes.CFUNCTYPE(None, c_void_p, c_void_p)                                    # nvdr_free_fn
+
+
+def torch_allocator():
+    """(alloc, free) callbacks that serve the library's scratch from torch's caching allocator (nvdr_ctx_set_allocator)."""
+    def _alloc(nbytes, device, stream, user):
+        try:
+            return torch.cuda.caching_allocator_alloc(int(nbytes), int(device), int(stream or 0))
+        except Exception:           # out of memory etc.: NULL -> the library reports the failed allocation
+            return 0
+
+    def _free(ptr, user):
+        try:
+            torch.cuda.caching_allocator_delete(int(ptr))
+        except Exception:           # interpreter shutdown: the process is going away anyway
+            pass
+    return ALLOC_FN(_alloc), FREE_FN(_free)
+
+
 _T = ctypes.POINTER(NvdrTensor)
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -59,6 +79,7 @@ _SIGNATURES = {
     'nvdr_ctx_check': [c_void_p, c_void_p],
     'nvdr_ctx_set_stream_budget': [c_void_p, c_int64],
     'nvdr_ctx_set_trace_variant': [c_void_p, c_int],
+    'nvdr_ctx_set_allocator': [c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_bvh_build': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
     'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
     'nvdr_bvh_export': [c_void_p, c_void_p, c_void_p, c_void_p],

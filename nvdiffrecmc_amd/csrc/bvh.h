@@ -91,8 +91,17 @@ static inline int nvdr_stack_bound(int64_t n_tris)
     return h_max < NVDR_STACK_MAX ? h_max : NVDR_STACK_MAX;
 }
 
+// optional caller-provided device allocator (nvdr_ctx_set_allocator): the Python shim hands over torch's caching allocator, so the
+// context's scratch (ray stream, stack spill, BVH buffers) shows up in torch's memory accounting and is recycled by it
+typedef void *(*nvdr_alloc_fn)(size_t bytes, int device, void *stream, void *user);
+typedef void (*nvdr_free_fn)(void *ptr, void *user);
+
 struct nvdr_ctx {
     int device = 0;
+    nvdr_alloc_fn alloc_fn = nullptr;
+    nvdr_free_fn free_fn = nullptr;
+    void *alloc_user = nullptr;
+    int64_t n_allocs = 0;          // live allocations made through ctx_malloc
     int n_cus = 256;
     int64_t cap_tris = 0;
     int64_t n_tris = 0;
@@ -160,6 +169,36 @@ struct BvhView {
 };
 
 int ctx_check_overflow(nvdr_ctx *c, const char *who);   // bvh.hip
+
+// every device buffer the context owns beyond its few fixed control words goes through these two
+static inline hipError_t ctx_malloc_raw(nvdr_ctx *c, void **p, size_t bytes, hipStream_t stream)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (c->alloc_fn) {
+        *p = c->alloc_fn(bytes, c->device, (void *)stream, c->alloc_user);
+        if (!*p) return hipErrorOutOfMemory;
+    } else {
+        const hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    c->n_allocs++;
+    return hipSuccess;
+}
+template <typename T>
+static inline hipError_t ctx_malloc(nvdr_ctx *c, T **p, size_t bytes, hipStream_t stream = nullptr)
+{
+    return ctx_malloc_raw(c, (void **)p, bytes, stream);
+}
+template <typename T>
+static inline void ctx_free(nvdr_ctx *c, T *&p)
+{
+    if (!p) return;
+    if (c->free_fn) c->free_fn((void *)p, c->alloc_user);
+    else (void)hipFree((void *)p);
+    c->n_allocs--;
+    p = nullptr;
+}
 
 static inline BvhView bvh_view(const nvdr_ctx *c)
 {

@@ -320,6 +320,12 @@ __global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal
 // its two children until eight slots are taken or only leaves remain.  Slots are then ordered internal-first (so the children
 // sit contiguously in oct[] and need no per-slot index) and their 16-bit boxes re-quantised to 8 bits in the node's own frame.
 
+#define OCT_CTL_TICKET 0
+#define OCT_CTL_ALLOC 32
+#define OCT_CTL_DONE 64
+#define OCT_CTL_TRIS 96
+#define OCT_CTL_WORDS 128
+
 struct OctBuildArgs {
     const uint4 *nodes;     // fitted binary nodes
     const float4 *tris;     // triangle records in Morton order
@@ -327,7 +333,7 @@ struct OctBuildArgs {
     float4 *tris8;
     int *task;
     int *fault;             // the context's host-mapped flag word: bit 1 is raised if the build gives up waiting
-    unsigned *ctl;          // [0] next ticket, [1] oct nodes allocated, [2] oct nodes finished, [3] triangles placed
+    unsigned *ctl;          // four counters, one 128-byte line each (OCT_CTL_*): next ticket, oct nodes allocated, oct nodes finished, triangles placed
     const BvhDeviceInfo *info;
     int cap;                // entries of task[] / oct nodes that fit (>= n_tris)
 };
@@ -336,10 +342,10 @@ __global__ void bvh_oct_init_kernel(OctBuildArgs a, int n_tris)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.cap; i += gridDim.x * blockDim.x) a.task[i] = i == 0 && n_tris > 1 ? 0 : -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.ctl[0] = 0u;
-        a.ctl[1] = 1u;
-        a.ctl[2] = n_tris > 1 ? 0u : 1u;
-        a.ctl[3] = n_tris > 1 ? 0u : 1u;
+        a.ctl[OCT_CTL_TICKET] = 0u;
+        a.ctl[OCT_CTL_ALLOC] = 1u;
+        a.ctl[OCT_CTL_DONE] = n_tris > 1 ? 0u : 1u;
+        a.ctl[OCT_CTL_TRIS] = n_tris > 1 ? 0u : 1u;
         if (n_tris == 1) {
             // one triangle, no binary node: a root with a single leaf slot that spans the whole grid (org 0, cell 2^9)
             a.oct[0] = make_uint4(0u, (9u << 16) | (9u << 20) | (9u << 24), 0u, 1u << 28);
@@ -351,68 +357,85 @@ __global__ void bvh_oct_init_kernel(OctBuildArgs a, int n_tris)
     }
 }
 
-struct OctSlot {
-    int ref;            // >= 0 binary internal node, < 0: ~triangle slot (Morton order)
-    int lo[3], hi[3];   // 16-bit grid box
-};
+// A thread's eight slots live in LDS, field-major (field f of slot k of thread t at ((k * 7 + f) * 256 + t): consecutive threads hit
+// consecutive banks).  Private arrays with run-time indices would live in scratch memory: the first version did, and spent
+// 0.3 ms on bob's 3 300 nodes (~30 us per node, ten levels deep).
+#define OCT_SLOT_FIELDS 7       // ref, lo.xyz, hi.xyz
+#define OCT_SL(k, f) sl[((k) * OCT_SLOT_FIELDS + (f)) * 256]
 
-__device__ __forceinline__ void oct_child_slots(const uint4 *__restrict__ nodes, int b, OctSlot &l, OctSlot &r)
+__device__ __forceinline__ void oct_load_children(const uint4 *__restrict__ nodes, int b, int *sl, int kl, int kr)
 {
     const uint4 p = nodes[2 * (int64_t)b], q = nodes[2 * (int64_t)b + 1];
-    l.lo[0] = p.x & 0xffff; l.lo[1] = p.x >> 16; l.lo[2] = p.y & 0xffff; l.hi[0] = p.y >> 16; l.hi[1] = p.z & 0xffff; l.hi[2] = p.z >> 16;
-    r.lo[0] = p.w & 0xffff; r.lo[1] = p.w >> 16; r.lo[2] = q.x & 0xffff; r.hi[0] = q.x >> 16; r.hi[1] = q.y & 0xffff; r.hi[2] = q.y >> 16;
-    l.ref = (int)q.z;
-    r.ref = (int)q.w;
+    OCT_SL(kl, 0) = (int)q.z;
+    OCT_SL(kl, 1) = p.x & 0xffff; OCT_SL(kl, 2) = p.x >> 16; OCT_SL(kl, 3) = p.y & 0xffff;
+    OCT_SL(kl, 4) = p.y >> 16; OCT_SL(kl, 5) = p.z & 0xffff; OCT_SL(kl, 6) = p.z >> 16;
+    OCT_SL(kr, 0) = (int)q.w;
+    OCT_SL(kr, 1) = p.w & 0xffff; OCT_SL(kr, 2) = p.w >> 16; OCT_SL(kr, 3) = q.x & 0xffff;
+    OCT_SL(kr, 4) = q.x >> 16; OCT_SL(kr, 5) = q.y & 0xffff; OCT_SL(kr, 6) = q.y >> 16;
 }
 
-__device__ void oct_build_node(const OctBuildArgs &a, int b, int m)
+__device__ void oct_build_node(const OctBuildArgs &a, int b, int m, int *sl)
 {
-    OctSlot s[8];
     int n = 2;
-    oct_child_slots(a.nodes, b, s[0], s[1]);
+    oct_load_children(a.nodes, b, sl, 0, 1);
     const float wx = 1.0f / a.info->g_scale[0], wy = 1.0f / a.info->g_scale[1], wz = 1.0f / a.info->g_scale[2];
     while (n < 8) {
         int best = -1;
         float best_area = -1.0f;
-        for (int k = 0; k < n; ++k) {
-            if (s[k].ref < 0) continue;
-            const float ex = (float)(s[k].hi[0] - s[k].lo[0]) * wx, ey = (float)(s[k].hi[1] - s[k].lo[1]) * wy, ez = (float)(s[k].hi[2] - s[k].lo[2]) * wz;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= n || OCT_SL(k, 0) < 0) continue;
+            const float ex = (float)(OCT_SL(k, 4) - OCT_SL(k, 1)) * wx, ey = (float)(OCT_SL(k, 5) - OCT_SL(k, 2)) * wy,
+                        ez = (float)(OCT_SL(k, 6) - OCT_SL(k, 3)) * wz;
             const float area = ex * ey + ey * ez + ez * ex;
             if (area > best_area) { best_area = area; best = k; }
         }
         if (best < 0) break;
-        OctSlot l, r;
-        oct_child_slots(a.nodes, s[best].ref, l, r);
-        s[best] = l;
-        s[n++] = r;
+        oct_load_children(a.nodes, OCT_SL(best, 0), sl, best, n);
+        n++;
     }
-    // order: internal children first (stable), then leaves
-    OctSlot t[8];
+    // order: internal children first (stable), then leaves -- as a 4-bit-per-position permutation of the slots
+    unsigned perm = 0u;
     int n_int = 0, n_leaf = 0;
-    for (int k = 0; k < n; ++k) if (s[k].ref >= 0) t[n_int++] = s[k];
-    for (int k = 0; k < n; ++k) if (s[k].ref < 0) t[n_int + n_leaf++] = s[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < n && OCT_SL(k, 0) >= 0) perm |= (unsigned)k << (4 * n_int++);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < n && OCT_SL(k, 0) < 0) perm |= (unsigned)k << (4 * (n_int + n_leaf++));
+    // the children first: they are what the next level is waiting for
+    unsigned cb = 0, tb = 0;
+    if (n_int) cb = atomicAdd(&a.ctl[OCT_CTL_ALLOC], (unsigned)n_int);
+    if (n_leaf) tb = atomicAdd(&a.ctl[OCT_CTL_TRIS], (unsigned)n_leaf);
+    for (int p = 0; p < n_int; ++p)
+        if ((int)(cb + p) < a.cap)
+            __hip_atomic_store(&a.task[cb + p], OCT_SL((perm >> (4 * p)) & 15u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the node's frame: lower corner + one power-of-two cell per axis such that the extent fits 8 bits
     int org[3], e[3];
+#pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         int lo = 65535, hi = 0;
-        for (int k = 0; k < n; ++k) { lo = min(lo, t[k].lo[ax]); hi = max(hi, t[k].hi[ax]); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < n) { lo = min(lo, OCT_SL(k, 1 + ax)); hi = max(hi, OCT_SL(k, 4 + ax)); }
         org[ax] = lo;
         int ee = 0;
         while ((((hi - lo) + (1 << ee) - 1) >> ee) > 255) ++ee;
         e[ax] = ee;
     }
     unsigned planes[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // lo.x[2], lo.y[2], lo.z[2], hi.x[2], hi.y[2], hi.z[2]
-    for (int k = 0; k < n; ++k) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p >= n) continue;
+        const int k = (int)((perm >> (4 * p)) & 15u);
+#pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            const unsigned qlo = (unsigned)((t[k].lo[ax] - org[ax]) >> e[ax]);                              // floor
-            const unsigned qhi = (unsigned)(((t[k].hi[ax] - org[ax]) + (1 << e[ax]) - 1) >> e[ax]);          // ceil
-            planes[2 * ax + (k >> 2)] |= qlo << (8 * (k & 3));
-            planes[6 + 2 * ax + (k >> 2)] |= qhi << (8 * (k & 3));
+            const unsigned qlo = (unsigned)((OCT_SL(k, 1 + ax) - org[ax]) >> e[ax]);                              // floor
+            const unsigned qhi = (unsigned)(((OCT_SL(k, 4 + ax) - org[ax]) + (1 << e[ax]) - 1) >> e[ax]);          // ceil
+            planes[2 * ax + (p >> 2)] |= qlo << (8 * (p & 3));
+            planes[6 + 2 * ax + (p >> 2)] |= qhi << (8 * (p & 3));
         }
     }
-    unsigned cb = 0, tb = 0;
-    if (n_int) cb = atomicAdd(&a.ctl[1], (unsigned)n_int);
-    if (n_leaf) tb = atomicAdd(&a.ctl[3], (unsigned)n_leaf);
     uint4 *o = a.oct + 4 * (int64_t)m;
     o[0] = make_uint4((unsigned)org[0] | ((unsigned)org[1] << 16),
                       (unsigned)org[2] | ((unsigned)e[0] << 16) | ((unsigned)e[1] << 20) | ((unsigned)e[2] << 24),
@@ -420,33 +443,37 @@ __device__ void oct_build_node(const OctBuildArgs &a, int b, int m)
     o[1] = make_uint4(planes[0], planes[1], planes[2], planes[3]);
     o[2] = make_uint4(planes[4], planes[5], planes[6], planes[7]);
     o[3] = make_uint4(planes[8], planes[9], planes[10], planes[11]);
-    for (int k = 0; k < n_leaf; ++k) {
-        const int64_t src = 3 * (int64_t)(~t[n_int + k].ref), dst = 3 * (int64_t)(tb + k);
+    for (int j = 0; j < n_leaf; ++j) {
+        const int k = (int)((perm >> (4 * (n_int + j))) & 15u);
+        const int64_t src = 3 * (int64_t)(~OCT_SL(k, 0)), dst = 3 * (int64_t)(tb + j);
         a.tris8[dst] = a.tris[src]; a.tris8[dst + 1] = a.tris[src + 1]; a.tris8[dst + 2] = a.tris[src + 2];
     }
-    for (int k = 0; k < n_int; ++k)
-        if ((int)(cb + k) < a.cap) __hip_atomic_store(&a.task[cb + k], t[k].ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void __launch_bounds__(256) bvh_oct_build_kernel(OctBuildArgs a)
 {
+    __shared__ int slots[8 * OCT_SLOT_FIELDS * 256];
+    int *sl = slots + threadIdx.x;
     int ticket = -1;
     unsigned waited = 0;
     while (true) {
-        if (ticket < 0) ticket = (int)atomicAdd(&a.ctl[0], 1u);
+        if (ticket < 0) ticket = (int)atomicAdd(&a.ctl[OCT_CTL_TICKET], 1u);
         const int b = ticket < a.cap ? __hip_atomic_load(&a.task[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
         if (b >= 0) {
-            oct_build_node(a, b, ticket);
-            atomicAdd(&a.ctl[2], 1u);
+            oct_build_node(a, b, ticket, sl);
+            atomicAdd(&a.ctl[OCT_CTL_DONE], 1u);
             ticket = -1;
         } else {
-            // `done` first, `allocated` second: equal values then mean they were equal when `done` was read (both only grow,
-            // done <= allocated), i.e. every published node is finished and nobody can publish another one
-            const unsigned done = __hip_atomic_load(&a.ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned alloc = __hip_atomic_load(&a.ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (done == alloc) break;
+            // The waiting threads poll their OWN task word; the shared counters only every 8th time (they sit on the lines the
+            // builders' atomics go to).  `done` first, `allocated` second: equal values then mean they were equal when `done` was
+            // read (both only grow, done <= allocated), i.e. every published node is finished and nobody can publish another one
+            if ((++waited & 7u) == 0u) {
+                const unsigned done = __hip_atomic_load(&a.ctl[OCT_CTL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned alloc = __hip_atomic_load(&a.ctl[OCT_CTL_ALLOC], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (done == alloc) break;
+            }
             // every wait ends (see above); the bound only turns a bug into an error report instead of a hung GPU (~1 s of polling)
-            if (++waited > (1u << 22)) {
+            if (waited > (1u << 22)) {
                 atomicOr(a.fault, 2);
                 break;
             }
@@ -486,18 +513,9 @@ extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
 
 static int ctx_free_bvh(nvdr_ctx *c)
 {
-    hipFree(c->nodes); hipFree(c->wide); hipFree(c->oct); hipFree(c->tris8); hipFree(c->oct_task); hipFree(c->tris);
-    hipFree(c->keys[0]); hipFree(c->keys[1]); hipFree(c->vals[0]); hipFree(c->vals[1]);
-    hipFree(c->parent); hipFree(c->flags); hipFree(c->heights); hipFree(c->sort_tmp);
-    c->nodes = nullptr;
-    c->oct = nullptr;
-    c->wide = nullptr;
-    c->tris8 = nullptr;
-    c->oct_task = nullptr;
-    c->tris = nullptr;
-    c->keys[0] = c->keys[1] = c->vals[0] = c->vals[1] = nullptr;
-    c->parent = c->flags = c->heights = nullptr;
-    c->sort_tmp = nullptr;
+    ctx_free(c, c->nodes); ctx_free(c, c->wide); ctx_free(c, c->oct); ctx_free(c, c->tris8); ctx_free(c, c->oct_task); ctx_free(c, c->tris);
+    ctx_free(c, c->keys[0]); ctx_free(c, c->keys[1]); ctx_free(c, c->vals[0]); ctx_free(c, c->vals[1]);
+    ctx_free(c, c->parent); ctx_free(c, c->flags); ctx_free(c, c->heights); ctx_free(c, c->sort_tmp);
     c->sort_tmp_bytes = 0;
     c->cap_tris = 0;
     return 0;
@@ -524,7 +542,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     }
     if (e == hipSuccess) e = hipMalloc((void **)&c->chunk_counts, sizeof(unsigned) * NVDR_MAX_CHUNKS);
     if (e == hipSuccess) e = hipMalloc((void **)&c->queues, sizeof(unsigned) * 32 * 256);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->oct_ctl, sizeof(unsigned) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->oct_ctl, sizeof(unsigned) * OCT_CTL_WORDS);
     if (e != hipSuccess) {
         hipFree(c->dinfo);
         if (c->ovf_host) hipHostFree(c->ovf_host);
@@ -571,12 +589,12 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
         for (int i = 0; i < NVDR_PROF_RING; ++i)
             for (int k = 0; k < 4; ++k) hipEventDestroy(c->prof_ev[i][k]);
     hipFree(c->dinfo);
-    hipFree(c->spill);
-    hipFree(c->pix_list);
     hipFree(c->chunk_counts);
     hipFree(c->queues);
     hipFree(c->oct_ctl);
-    hipFree(c->rays); hipFree(c->texel); hipFree(c->vis); hipFree(c->live); hipFree(c->pix_origin); hipFree(c->lg_part);
+    ctx_free(c, c->spill);
+    ctx_free(c, c->pix_list);
+    ctx_free(c, c->rays); ctx_free(c, c->texel); ctx_free(c, c->vis); ctx_free(c, c->live); ctx_free(c, c->pix_origin); ctx_free(c, c->lg_part);
     if (c->ovf_host) hipHostFree(c->ovf_host);
     delete c;
     return 0;
@@ -590,21 +608,21 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     NVDR_HIP_TRY(hipDeviceSynchronize());
     ctx_free_bvh(c);
     const int64_t cap = n_tris + n_tris / 2 + 64;
-    NVDR_HIP_TRY(hipMalloc((void **)&c->nodes, sizeof(uint4) * 2 * cap));
-    NVDR_HIP_TRY(hipMalloc((void **)&c->oct, sizeof(uint4) * 4 * cap));
-    NVDR_HIP_TRY(hipMalloc((void **)&c->tris8, sizeof(float4) * 3 * cap));
-    NVDR_HIP_TRY(hipMalloc((void **)&c->oct_task, sizeof(int) * cap));
-    NVDR_HIP_TRY(hipMalloc((void **)&c->tris, sizeof(float4) * 3 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->nodes, sizeof(uint4) * 2 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct, sizeof(uint4) * 4 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->tris8, sizeof(float4) * 3 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_task, sizeof(int) * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->tris, sizeof(float4) * 3 * cap));
     for (int i = 0; i < 2; ++i) {
-        NVDR_HIP_TRY(hipMalloc((void **)&c->keys[i], sizeof(uint32_t) * cap));
-        NVDR_HIP_TRY(hipMalloc((void **)&c->vals[i], sizeof(uint32_t) * cap));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->keys[i], sizeof(uint32_t) * cap));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->vals[i], sizeof(uint32_t) * cap));
     }
-    NVDR_HIP_TRY(hipMalloc((void **)&c->parent, sizeof(int) * 2 * cap));
-    NVDR_HIP_TRY(hipMalloc((void **)&c->flags, sizeof(int) * cap));
-    NVDR_HIP_TRY(hipMalloc((void **)&c->heights, sizeof(int) * 2 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->parent, sizeof(int) * 2 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->flags, sizeof(int) * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->heights, sizeof(int) * 2 * cap));
     size_t bytes = 0;
     NVDR_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1], (size_t)cap, 0, 30));
-    NVDR_HIP_TRY(hipMalloc(&c->sort_tmp, bytes + 256));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->sort_tmp, bytes + 256));
     c->sort_tmp_bytes = bytes + 256;
     c->cap_tris = cap;
     return 0;
@@ -636,13 +654,12 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     const int smax = nvdr_stack_bound(n_tris);
     if (smax > c->spill_cap) {
         NVDR_HIP_TRY(hipStreamSynchronize(stream));
-        (void)hipFree(c->spill);
-        c->spill = nullptr;
+        ctx_free(c, c->spill);
         c->spill_cap = 0;
         const size_t d_bin = (size_t)(smax > NVDR_STACK_LDS ? smax - NVDR_STACK_LDS : 0) * sizeof(int);
         const size_t d_oct = (size_t)(smax > NVDR_OSTACK_LDS ? smax - NVDR_OSTACK_LDS : 0) * sizeof(uint2);
         const size_t per_lane = d_bin > d_oct ? d_bin : d_oct;
-        NVDR_HIP_TRY(hipMalloc((void **)&c->spill, (per_lane > 0 ? per_lane : sizeof(uint2)) * NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->spill, (per_lane > 0 ? per_lane : sizeof(uint2)) * NVDR_QUERY_MAX_BLOCKS * NVDR_QUERY_BLOCK, stream));
         c->spill_cap = smax;
     }
     // NVDR_DEBUG bit 32 (tests only): pretend the stacks are one entry deeper than their LDS part, to exercise the overflow report
@@ -664,7 +681,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     bvh_fit_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->parent,
                                                         c->flags, c->heights, c->dinfo);
     if (c->trace_variant == 0 && n > 1) {
-        if (!c->wide) NVDR_HIP_TRY(hipMalloc((void **)&c->wide, sizeof(uint4) * 4 * c->cap_tris));
+        if (!c->wide) NVDR_HIP_TRY(ctx_malloc(c, &c->wide, sizeof(uint4) * 4 * c->cap_tris, stream));
         bvh_widen_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->nodes, n - 1, c->wide);
     }
     {
@@ -728,6 +745,18 @@ extern "C" int nvdr_bvh_export(nvdr_ctx *c, float *nodes_host, float *tri_host, 
     return 0;
 }
 
+extern "C" int nvdr_ctx_set_allocator(nvdr_ctx *c, nvdr_alloc_fn alloc_fn, nvdr_free_fn free_fn, void *user)
+{
+    NVDR_REQUIRE(c, "nvdr_ctx_set_allocator: NULL ctx");
+    NVDR_REQUIRE((alloc_fn == nullptr) == (free_fn == nullptr), "nvdr_ctx_set_allocator: give both functions or neither");
+    NVDR_REQUIRE(c->n_allocs == 0, "nvdr_ctx_set_allocator: the context already owns %lld buffers from the previous allocator; "
+                 "set the allocator right after nvdr_ctx_create", (long long)c->n_allocs);
+    c->alloc_fn = alloc_fn;
+    c->free_fn = free_fn;
+    c->alloc_user = user;
+    return 0;
+}
+
 extern "C" int nvdr_ctx_set_trace_variant(nvdr_ctx *c, int variant)
 {
     NVDR_REQUIRE(c, "nvdr_ctx_set_trace_variant: NULL ctx");
@@ -743,13 +772,13 @@ extern "C" int nvdr_bvh_export_oct(nvdr_ctx *c, uint32_t *oct_host, float *tris8
     NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_bvh_export_oct: no BVH built");
     NVDR_REQUIRE(counts_host != nullptr, "nvdr_bvh_export_oct: counts_host is NULL");
     hipStream_t stream = (hipStream_t)stream_;
-    unsigned ctl[4] = {0, 0, 0, 0};
+    unsigned ctl[OCT_CTL_WORDS];
     NVDR_HIP_TRY(hipMemcpyAsync(ctl, c->oct_ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
-    counts_host[0] = ctl[1];    // oct nodes
-    counts_host[1] = ctl[3];    // triangles placed (== n_tris)
-    counts_host[2] = ctl[2];    // nodes finished (== nodes)
-    if (oct_host) NVDR_HIP_TRY(hipMemcpyAsync(oct_host, c->oct, sizeof(uint4) * 4 * (size_t)ctl[1], hipMemcpyDeviceToHost, stream));
+    counts_host[0] = ctl[OCT_CTL_ALLOC];    // oct nodes
+    counts_host[1] = ctl[OCT_CTL_TRIS];     // triangles placed (== n_tris)
+    counts_host[2] = ctl[OCT_CTL_DONE];     // nodes finished (== nodes)
+    if (oct_host) NVDR_HIP_TRY(hipMemcpyAsync(oct_host, c->oct, sizeof(uint4) * 4 * (size_t)ctl[OCT_CTL_ALLOC], hipMemcpyDeviceToHost, stream));
     if (tris8_host) NVDR_HIP_TRY(hipMemcpyAsync(tris8_host, c->tris8, sizeof(float) * 12 * c->n_tris, hipMemcpyDeviceToHost, stream));
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
     return 0;

@@ -782,9 +782,23 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
     const unsigned b16 = g * per, e16 = min(b16 + per, n16);
     const uint4 *__restrict__ keys = (const uint4 *)band_of;   // 16 one-byte keys per load; the allocation is padded to a multiple of 16
     const unsigned want = (unsigned)band * 0x01010101u;
+    // A lane walks 16 CONSECUTIVE slots.  Stage 1 orders a pixel's samples by stratum, i.e. neighbouring slots are neighbouring
+    // cells of the CDF grid: where the probe has a sun, dozens of consecutive records hit the SAME texel -- and the same LDS
+    // address, which the atomic unit serialises (first version of this kernel: 1.3-1.5 ms per 8-view launch whatever the key
+    // traffic was).  Runs of equal texels are therefore summed in registers and leave the lane as ONE atomic triple.
     for (unsigned q = b16 + threadIdx.x; q < e16; q += NVDR_LG_THREADS) {
         const uint4 k16 = keys[q];
         const unsigned kw[4] = {k16.x, k16.y, k16.z, k16.w};
+        int run_t = -1;
+        float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+        auto flush = [&]() {
+            if (run_t >= 0) {
+                float *a = lg_acc + (run_t - t_lo) * 3;
+                __hip_atomic_fetch_add(a + 0, rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 1, ry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 2, rz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const unsigned x = kw[w] ^ want;                                    // a zero byte = a slot of this band
@@ -797,12 +811,16 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
                 const int t = texel[slot];
                 if (t < t_lo || t >= t_hi) continue;                            // (a stale byte of a slot nobody wrote in this launch)
                 const float4 v = recs[slot];
-                float *a = lg_acc + (t - t_lo) * 3;
-                __hip_atomic_fetch_add(a + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(a + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(a + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (t != run_t) {
+                    flush();
+                    run_t = t;
+                    rx = v.x; ry = v.y; rz = v.z;
+                } else {
+                    rx += v.x; ry += v.y; rz += v.z;
+                }
             }
         }
+        flush();
     }
     __syncthreads();
     float *out = partials + (int64_t)g * n_texels * 3 + (int64_t)t_lo * 3;
@@ -942,28 +960,27 @@ static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, unsigned S, hi
     if (c->stream_cap_rays >= rays && c->pix_cap >= npix && c->stream_cap_pixels >= cap) return 0;
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
     if (c->pix_cap < npix) {
-        (void)hipFree(c->pix_list);
-        c->pix_list = nullptr;
-        NVDR_HIP_TRY(hipMalloc((void **)&c->pix_list, sizeof(int) * npix));
+        ctx_free(c, c->pix_list);
+        c->pix_cap = 0;
+        NVDR_HIP_TRY(ctx_malloc(c, &c->pix_list, sizeof(int) * npix, stream));
         c->pix_cap = npix;
     }
     if (c->stream_cap_pixels < cap) {
-        (void)hipFree(c->pix_origin);
-        c->pix_origin = nullptr;
-        NVDR_HIP_TRY(hipMalloc((void **)&c->pix_origin, sizeof(float4) * cap));
+        ctx_free(c, c->pix_origin);
+        c->stream_cap_pixels = 0;
+        NVDR_HIP_TRY(ctx_malloc(c, &c->pix_origin, sizeof(float4) * cap, stream));
         c->stream_cap_pixels = cap;
     }
     if (c->stream_cap_rays < rays) {
-        (void)hipFree(c->rays);
-        (void)hipFree(c->texel);
-        (void)hipFree(c->vis);
-        (void)hipFree(c->live);
-        c->rays = nullptr; c->texel = nullptr; c->vis = nullptr; c->live = nullptr;
+        ctx_free(c, c->rays);
+        ctx_free(c, c->texel);
+        ctx_free(c, c->vis);
+        ctx_free(c, c->live);
         c->stream_cap_rays = 0;
-        NVDR_HIP_TRY(hipMalloc((void **)&c->rays, sizeof(float4) * rays));
-        NVDR_HIP_TRY(hipMalloc((void **)&c->texel, sizeof(int) * rays));
-        NVDR_HIP_TRY(hipMalloc((void **)&c->vis, rays));
-        NVDR_HIP_TRY(hipMalloc((void **)&c->live, sizeof(uint32_t) * rays));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->rays, sizeof(float4) * rays, stream));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->texel, sizeof(int) * rays, stream));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->vis, rays, stream));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->live, sizeof(uint32_t) * rays, stream));
         c->stream_cap_rays = rays;
     }
     c->stream_id = 0;
@@ -1097,10 +1114,9 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         const size_t need = (size_t)p.light_elems * (size_t)(lg_rows > 8 ? lg_rows : 8);
         if (c->lg_cap < need) {
             NVDR_HIP_TRY(hipStreamSynchronize(stream));
-            (void)hipFree(c->lg_part);
-            c->lg_part = nullptr;
+            ctx_free(c, c->lg_part);
             c->lg_cap = 0;
-            NVDR_HIP_TRY(hipMalloc((void **)&c->lg_part, sizeof(float) * need));
+            NVDR_HIP_TRY(ctx_malloc(c, &c->lg_part, sizeof(float) * need, stream));
             c->lg_cap = need;
         }
         p.g_light_xcd = c->lg_part;

@@ -14,6 +14,7 @@ kernels are hand-written HIP for gfx950 (nvdiffrecmc_amd/csrc).  There is no CPU
 tensors must live on the GPU and the HIP library must be built, otherwise RuntimeError.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -34,6 +35,13 @@ class _HipContext:
         h = ctypes.c_void_p()
         _lib.check(self.lib.nvdr_ctx_create(ctypes.byref(h), self.device), 'nvdr_ctx_create')
         self.handle = h
+        # scratch (ray stream, stack spill, BVH buffers) comes from torch's caching allocator: visible in torch.cuda.memory_*
+        # and returned to its pool when the context dies.  NVDR_RAW_ALLOC=1 keeps the library on hipMalloc (A/B, debugging).
+        self._alloc_cb = None
+        if not os.environ.get('NVDR_RAW_ALLOC'):
+            self._alloc_cb = _lib.torch_allocator()
+            _lib.check(self.lib.nvdr_ctx_set_allocator(h, ctypes.cast(self._alloc_cb[0], ctypes.c_void_p),
+                                                       ctypes.cast(self._alloc_cb[1], ctypes.c_void_p), None), 'nvdr_ctx_set_allocator')
         self._geom = None  # keeps the verts/tris tensors alive while the device may still read them
 
     def __del__(self):

@@ -427,14 +427,23 @@ def _check_oct_tree(ctx, v, t):
         for j in range(n_leaf[node]):
             k, tri = n_int[node] + j, tbase[node] + j
             assert (lo[node, :, k] <= tmin[tri] + 1e-3).all() and (hi[node, :, k] >= tmax[tri] - 1e-3).all(), (node, j)
-    # an internal slot contains every slot of the child node it points to
-    used = np.arange(8)[None, :] < (n_int + n_leaf)[:, None]
-    nlo = np.where(used[:, None, :], lo, 1 << 30).min(2)
-    nhi = np.where(used[:, None, :], hi, -1).max(2)
-    for node in np.nonzero(n_int > 0)[0]:
+    # an internal slot contains every TRIANGLE below the child node it points to (children are allocated after their parents, so
+    # one sweep from the last node to the first sees every child before its parent).  Note that it need not contain the child's
+    # own 8-bit slots: those are rounded outward in the child's frame, which may be coarser than what the parent's slot shows.
+    big = 1 << 30
+    sub_lo = np.full((cnt['nodes'], 3), float(big))
+    sub_hi = np.full((cnt['nodes'], 3), -float(big))
+    for node in range(cnt['nodes'] - 1, -1, -1):
+        for j in range(n_leaf[node]):
+            tri = tbase[node] + j
+            sub_lo[node] = np.minimum(sub_lo[node], tmin[tri])
+            sub_hi[node] = np.maximum(sub_hi[node], tmax[tri])
         for k in range(n_int[node]):
             c = cbase[node] + k
-            assert (lo[node, :, k] <= nlo[c]).all() and (hi[node, :, k] >= nhi[c]).all(), (node, k, c)
+            assert c > node
+            assert (lo[node, :, k] <= sub_lo[c] + 1e-3).all() and (hi[node, :, k] >= sub_hi[c] - 1e-3).all(), (node, k, c)
+            sub_lo[node] = np.minimum(sub_lo[node], sub_lo[c])
+            sub_hi[node] = np.maximum(sub_hi[node], sub_hi[c])
     return cnt['nodes'], float((n_int + n_leaf).mean())
 
 

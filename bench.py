@@ -29,6 +29,8 @@ steps, then EXACTLY K steps between barriers (`value`, `ms_per_step`), then an e
 and >= 3 s) whose per-step HIP-event times give `median_ms_per_step`.
 
 Extra objects on the JSON line:
+  large_mesh   -- (default preset, N = 1) the same iteration on the `dmtet800` preset for a few steps: ms/step, the traversal kernel's
+                  rays/s, and its counter-measured HBM traffic / L2 hit rate -- the workload whose tree does not fit the L2s.
   roofline     -- the dominant kernel, env_trace_kernel<false> (persistent-wavefront shadow-ray traversal).  It is
                   VALU-issue bound on cache-resident data (counters below), so `bound` is "valu": `achieved` =
                   active-lane VALU operations per second (SQ_INSTS_VALU x active-lane fraction, rocprofv3 PMC pass of
@@ -159,21 +161,25 @@ def _pmc_read(db_path, lead):
     return out, disp
 
 
-def collect_pmc(args, keep_dir=None):
-    """Run the PMC passes; returns (counters per kernel, note) -- counters is None when rocprofv3 is unavailable or failed."""
+def collect_pmc(args, keep_dir=None, config=None, passes=None):
+    """Run the PMC passes; returns (counters per kernel, note) -- counters is None when rocprofv3 is unavailable or failed.
+    config / passes: another preset (the large-mesh object runs `dmtet800` with the two memory passes only)."""
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return None, 'rocprofv3 not found'
     merged, notes = {}, []
-    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child', '--config', args.config, '--steps', '2', '--warmup', '1',
+    own = config is None
+    config = config or args.config
+    passes = passes or PMC_PASSES
+    child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child', '--config', config, '--steps', '2', '--warmup', '1',
              '--scaling', args.scaling]
     for flag, v in (('--res', args.res), ('--n-samples-x', args.n_samples_x), ('--mesh', args.mesh), ('--subdiv', args.subdiv), ('--batch', args.batch)):
-        if v is not None:
+        if v is not None and own:
             child += [flag, str(v)]
     env = dict(os.environ, TMPDIR='/tmp')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
-    for i, group in enumerate(PMC_PASSES):
+    for i, group in enumerate(passes):
         d = tempfile.mkdtemp(prefix='nvdr_pmc%d_' % i, dir='/tmp')
         cmd = [exe, '--kernel-trace', '--pmc'] + group + ['-d', d, '-o', 'r', '--'] + child
         try:
@@ -193,17 +199,17 @@ def collect_pmc(args, keep_dir=None):
     if keep_dir and merged:
         # the raw per-launch counter sums behind the roofline object, as a small table (the rocpd databases are ~30 MB each)
         os.makedirs(keep_dir, exist_ok=True)
-        with open(os.path.join(keep_dir, 'pmc_counters_%s.md' % args.config), 'w') as f:
+        with open(os.path.join(keep_dir, 'pmc_counters_%s.md' % config), 'w') as f:
             f.write('rocprofv3 --kernel-trace --pmc <group> -- python bench.py --pmc-child --config %s --steps 2 --warmup 1 (one pass per group: %s); '
                     'per-launch sums over the non-empty dispatches\n\n| kernel | counter | per launch | launches |\n|---|---|---|---|\n'
-                    % (args.config, ' / '.join(' '.join(g) for g in PMC_PASSES)))
+                    % (config, ' / '.join(' '.join(g) for g in passes)))
             for kname in sorted(merged):
                 if not any(t in kname for t in ('env_', 'light_grad', 'bilateral', 'bvh_', 'gbuffer', 'image_loss', 'compact')):
                     continue
                 for ctr in sorted(merged[kname]):
                     if ctr.startswith('dispatches_pass'):
                         continue
-                    n = max(merged[kname].get('dispatches_pass%d' % i, 0) for i in range(len(PMC_PASSES)))
+                    n = max(merged[kname].get('dispatches_pass%d' % i, 0) for i in range(len(passes)))
                     f.write('| %s | %s | %.6g | %d |\n' % (kname[:90], ctr, merged[kname][ctr], n))
     return (merged or None), '; '.join(notes)
 
@@ -266,6 +272,72 @@ def mem_figures(c, kernel_ms):
     return out
 
 
+def large_mesh_object(args, dev):
+    """The L2-spilling workload on the SAME bench line (rank 0, N = 1): `dmtet800` -- bob subdivided three times, 684 032 triangles
+    (9 MB of eight-wide nodes + 33 MB of triangle records against 4 MB of L2 per XCD), 800x800, 64 spp, 8 views -- a few timed
+    iterations, the traversal kernel's HIP-event time and ray count, and two memory-side PMC passes (FETCH_SIZE; TCC_REQ /
+    WRITE_SIZE / TCC_MISS).  This is where "fraction of the HBM roofline" is a physical question (on bob the tree is L2 resident)."""
+    import torch
+    from nvdiffrecmc_amd.trainer import DirectLightingStep
+    from nvdiffrecmc_amd import optixutils as ou, renderutils as ru
+    pre = PRESETS['dmtet800']
+    t0 = time.perf_counter()
+    H, n, nv = pre['res'], pre['n'], pre['batch']
+    step = DirectLightingStep(pre['mesh'], H, n, view=list(range(nv)), n_views=nv, device=dev, retrace_backward=True, subdiv=pre['subdiv'])
+    for _ in range(4):
+        step.step(1)
+    step.ctx.set_profiling(True)
+    K = 8
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step.step(1)
+        b.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - w0
+    ms = [a.elapsed_time(b) for a, b in ev]
+    n_f, (gen_ms, trace_ms, shade_ms) = step.ctx.stage_times(backward=False)
+    step.ctx.set_profiling(False)
+    with torch.no_grad():
+        m = step.mask[..., None]
+        kd = step.kd_tex[step.texel].view(step.nv, H, H, 3) * m
+        ks = step.ks.view(1, 1, 1, 3) * m
+        nrm = ru.prepare_shading_normal(step.gb_pos, step.view_pos, None, step.gb_smooth_nrm, step.gb_tangent, step.gb_geom_nrm)
+        ro = step.gb_pos + nrm * 0.001
+        L = step.light
+        P, n_box, n_tri, n_traced = ou.ops.env_shade_traversal_counts(step.ctx, step.mask, ro, step.gb_pos, nrm, step.view_pos, kd, ks, L.base, L._pdf,
+                                                                     L.rows[:, 0], L.cols, n_samples_x=n, rnd_seed=0)
+        steps_per_ray = ou.ops.env_shade_traversal_counts.node_steps / max(n_traced, 1)
+    n_tris = int(step.mesh['t_pos_idx'].shape[0])
+    med = statistics.median(ms)
+    out = {'preset': 'dmtet800', 'workload': pre['what'] + ', batch of %d views' % nv, 'mesh_triangles': n_tris, 'covered_pixels': P,
+           'rays_traversed_per_pass': n_traced, 'steps': K, 'ms_per_step': dt / K * 1e3, 'median_ms_per_step': med,
+           'steps_over_twice_the_median': sum(1 for v in ms if v > 2.0 * med),
+           'rays_per_sec': 2.0 * n_traced * K / dt, 'kernel': DOMINANT, 'kernel_ms_hip_events': trace_ms, 'launches_timed': n_f,
+           'kernel_rays_per_sec': n_traced / (trace_ms * 1e-3), 'node_steps_per_ray': steps_per_ray, 'box_tests_per_ray': n_box / max(n_traced, 1),
+           'triangle_tests_per_ray': n_tri / max(n_traced, 1),
+           'tree_bytes': {'oct_nodes_64B': None, 'triangle_records_48B': 48 * n_tris}}
+    try:
+        out['tree_bytes']['oct_nodes_64B'] = 64 * int(step.ctx.bvh_export_oct()[2]['nodes'])
+    except Exception:
+        pass
+    del step
+    torch.cuda.empty_cache()
+    if not args.no_pmc:
+        counters, note = collect_pmc(args, keep_dir=args.pmc_keep, config='dmtet800', passes=[['FETCH_SIZE'], ['TCC_REQ_sum', 'WRITE_SIZE', 'TCC_MISS_sum']])
+        c = find_kernel(counters, DOMINANT) if counters else None
+        if c:
+            mem = mem_figures(c, trace_ms)
+            out['hbm'] = {k: mem[k] for k in ('hbm_bytes', 'fetch_bytes_corrected', 'write_bytes', 'hbm_GBs', 'hbm_frac') if k in mem}
+            out['l2'] = {k: mem[k] for k in ('l2_requests', 'l2_hit', 'l2_GBs_at_64B_per_request', 'l2_frac') if k in mem}
+        if note:
+            out['pmc_note'] = note
+    out['seconds'] = time.perf_counter() - t0
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 
 def parse_args():
@@ -285,6 +357,7 @@ def parse_args():
     ap.add_argument('--pmc-timeout', type=int, default=240)
     ap.add_argument('--pmc-keep', default=None, help='directory to write the per-kernel counter table of the PMC passes to')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-large-mesh', action='store_true', help='skip the `large_mesh` object (dmtet800: 684 k triangles) of the default N = 1 line')
     ap.add_argument('--no-extended', action='store_true', help='skip the extended median phase and the cached-visibility loop')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
                     help='capture the iteration in HIP graphs (auto: when a rank renders <= 2 views, the launch-bound regime)')
@@ -498,6 +571,9 @@ def run(args):
                                 'bytes_per_launch': bytes_trace, 'traversal_bytes_per_launch': b_trav,
                                 'bvh2_node_visits_per_ray': bvh2_nodes / max(bvh2_rays, 1), 'bvh2_tri_tests_per_ray': bvh2_tris / max(bvh2_rays, 1),
                                 'wide_walk_box_tests_per_ray': n_box / max(n_traced, 1), 'wide_walk_tri_tests_per_ray': n_tri / max(n_traced, 1),
+                                'oct_walk_node_steps_per_ray': ou.ops.env_shade_traversal_counts.node_steps / max(n_traced, 1),
+                                'triangle_test_batch_fill': (ou.ops.env_shade_traversal_counts.leaf_batches[1]
+                                                             / max(64 * ou.ops.env_shade_traversal_counts.leaf_batches[0], 1)),
                                 'GBs': bytes_trace / (trace_ms * 1e-3) / 1e9,
                                 'frac_of_hbm_peak_if_it_were_hbm_traffic': bytes_trace / (trace_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 'forward_pass': {'gen_ms': gen_ms, 'trace_ms': trace_ms, 'shade_ms': shade_ms, 'algorithmic_bytes': bytes_fwd,
@@ -572,6 +648,17 @@ def run(args):
             out['cpu_baseline'] = cpu_baseline(preset['mesh'], H, n, 0, n_views, stride=stride)
         else:
             out['cpu_baseline'] = None   # N > 1, --no-cpu-baseline, or a subdivided mesh (brute force over 684 k triangles is not a bounded sample)
+        if out['cpu_baseline'] is not None:
+            out['cpu_baseline']['note'] = ('this is the reference\'s own CUDA raygen program compiled for the host and run under OpenMP on every core '
+                                           '(kind "reference"), NOT the brute-force PyTorch-CPU path BASELINE.json sketches: the same arithmetic, a '
+                                           'faster CPU implementation of it than torch ops would be')
+        if world == 1 and args.config == 'bob512' and not args.no_large_mesh and not args.pmc_child and args.res is None and args.subdiv is None:
+            try:
+                step = None
+                torch.cuda.empty_cache()
+                out['large_mesh'] = large_mesh_object(args, dev)
+            except Exception as e:      # never lose the headline line to the extra object
+                out['large_mesh'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -782,10 +782,13 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
     const unsigned b16 = g * per, e16 = min(b16 + per, n16);
     const uint4 *__restrict__ keys = (const uint4 *)band_of;   // 16 one-byte keys per load; the allocation is padded to a multiple of 16
     const unsigned want = (unsigned)band * 0x01010101u;
-    // A lane walks 16 CONSECUTIVE slots.  Stage 1 orders a pixel's samples by stratum, i.e. neighbouring slots are neighbouring
-    // cells of the CDF grid: where the probe has a sun, dozens of consecutive records hit the SAME texel -- and the same LDS
-    // address, which the atomic unit serialises (first version of this kernel: 1.3-1.5 ms per 8-view launch whatever the key
-    // traffic was).  Runs of equal texels are therefore summed in registers and leave the lane as ONE atomic triple.
+    // A lane walks 16 CONSECUTIVE slots, eight at a time in THREE PHASES -- the texels of the matching slots, then the records of
+    // the texels that really are in this band, then the additions -- so that eight loads are in flight per lane and phase.  (The
+    // first versions fetched texel and record slot by slot inside one divergent branch per slot: 32 dependent memory round trips
+    // per 16 slots, and almost every branch is taken by SOME lane of the wavefront -- 1.3-1.5 ms per 8-view launch whatever the
+    // key traffic was; the run-length sum alone changed nothing.)  Neighbouring slots are neighbouring cells of the CDF grid
+    // (stage 1 orders a pixel's samples by stratum): where the probe has a sun, consecutive records hit the SAME texel, so runs of
+    // equal texels are summed in registers and leave the lane as one atomic triple.
     for (unsigned q = b16 + threadIdx.x; q < e16; q += NVDR_LG_THREADS) {
         const uint4 k16 = keys[q];
         const unsigned kw[4] = {k16.x, k16.y, k16.z, k16.w};
@@ -800,23 +803,34 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
             }
         };
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned x = kw[w] ^ want;                                    // a zero byte = a slot of this band
-            if (((x - 0x01010101u) & ~x & 0x80808080u) == 0u) continue;        // none of the four (exact zero-byte test)
+        for (int half = 0; half < 2; ++half) {
+            const unsigned x0 = kw[2 * half] ^ want, x1 = kw[2 * half + 1] ^ want;      // a zero byte = a slot of this band
+            const bool any0 = ((x0 - 0x01010101u) & ~x0 & 0x80808080u) != 0u, any1 = ((x1 - 0x01010101u) & ~x1 & 0x80808080u) != 0u;
+            if (!(any0 | any1)) continue;                                       // (exact zero-byte test)
+            const unsigned slot0 = 16u * q + 8u * half;
+            int t[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (((x >> (8 * j)) & 0xffu) != 0u) continue;
-                const unsigned slot = 16u * q + 4u * w + j;
-                if (slot >= total) continue;
-                const int t = texel[slot];
-                if (t < t_lo || t >= t_hi) continue;                            // (a stale byte of a slot nobody wrote in this launch)
-                const float4 v = recs[slot];
-                if (t != run_t) {
+            for (int j = 0; j < 8; ++j) {
+                const unsigned x = j < 4 ? x0 : x1;
+                t[j] = -1;
+                if (((x >> (8 * (j & 3))) & 0xffu) == 0u && slot0 + j < total) t[j] = texel[slot0 + j];
+            }
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (t[j] < t_lo || t[j] >= t_hi) t[j] = -1;                     // (a stale byte of a slot nobody wrote in this launch)
+                v[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (t[j] >= 0) v[j] = recs[slot0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (t[j] < 0) continue;
+                if (t[j] != run_t) {
                     flush();
-                    run_t = t;
-                    rx = v.x; ry = v.y; rz = v.z;
+                    run_t = t[j];
+                    rx = v[j].x; ry = v[j].y; rz = v[j].z;
                 } else {
-                    rx += v.x; ry += v.y; rz += v.z;
+                    rx += v[j].x; ry += v[j].y; rz += v[j].z;
                 }
             }
         }

@@ -33,9 +33,6 @@
 #ifndef NVDR_TRACE_OCC
 #define NVDR_TRACE_OCC 8       // waves per SIMD the kernel is compiled for (= resident workgroups per CU of the persistent grid)
 #endif
-#ifndef NVDR_OCT_MIX
-#define NVDR_OCT_MIX 0         // 1: plane bytes reach the slab test through v_perm_b32 + v_fma_mix_f32 (3 VALU per byte pair instead of 4)
-#endif
 #define NVDR_LEAFQ_CAP 128     // entries of a wavefront's triangle-test queue (< 64 before an append round, <= 64 appended per round)
 
 struct TraceLaunch {
@@ -279,38 +276,6 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             const unsigned ny0 = sy ? p3.x : p1.z, ny1 = sy ? p3.y : p1.w, fy0 = sy ? p1.z : p3.x, fy1 = sy ? p1.w : p3.y;
             const unsigned nz0 = sz ? p3.z : p2.x, nz1 = sz ? p3.w : p2.y, fz0 = sz ? p2.x : p3.z, fz1 = sz ? p2.y : p3.w;
             unsigned miss = 0u;                             // bit j = slot j is missed, shifted in from slot 7 down to slot 0
-#if NVDR_OCT_MIX
-            // Plane bytes -> distances WITHOUT a conversion instruction per byte: v_perm_b32 pairs two bytes with the constant 0x64
-            // into two f16 values 1024 + q (0x6400 is 1024.0 in f16 and its low mantissa bits add q exactly), and v_fma_mix_f32
-            // consumes an f16 operand in an f32 fma: t = (1024 + q) * a + (b - 1024 a).  3 VALU per byte pair instead of 4; the
-            // two roundings differ from q * a + b by < 1.3e-4 quantisation steps (< 0.07 grid cells at the root's 2^9 cells).
-            const float cx = fmaf(-1024.0f, ax, bx), cy = fmaf(-1024.0f, ay, by), cz = fmaf(-1024.0f, az, bz);
-            auto pair_t = [](unsigned w, int odd, float a_, float c_, float &t0, float &t1) {
-                const unsigned pk = __builtin_amdgcn_perm(0x64646464u, w, odd ? 0x04030402u : 0x04010400u);
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(pk), "v"(a_), "v"(c_));
-                asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(pk), "v"(a_), "v"(c_));
-            };
-#pragma unroll
-            for (int jp = 3; jp >= 0; --jp) {               // slots 2 jp and 2 jp + 1 share the byte pair (jp & 1) of word jp >> 1
-                // (the reductions are written as instructions too: the compiler would canonicalise every asm result -- one more
-                // v_max_f32 x, x each -- before an IEEE fmaxf / fminf)
-                float x0, x1, y0, y1, z0, z1, tn0, tn1, tf0, tf1;
-                pair_t(jp < 2 ? nx0 : nx1, jp & 1, ax, cx, x0, x1);
-                pair_t(jp < 2 ? ny0 : ny1, jp & 1, ay, cy, y0, y1);
-                pair_t(jp < 2 ? nz0 : nz1, jp & 1, az, cz, z0, z1);
-                asm("v_max_f32 %0, 0, %1" : "=v"(z0) : "v"(z0));
-                asm("v_max_f32 %0, 0, %1" : "=v"(z1) : "v"(z1));
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn0) : "v"(x0), "v"(y0), "v"(z0));
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn1) : "v"(x1), "v"(y1), "v"(z1));
-                pair_t(jp < 2 ? fx0 : fx1, jp & 1, ax, cx, x0, x1);
-                pair_t(jp < 2 ? fy0 : fy1, jp & 1, ay, cy, y0, y1);
-                pair_t(jp < 2 ? fz0 : fz1, jp & 1, az, cz, z0, z1);
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf0) : "v"(x0), "v"(y0), "v"(z0));
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf1) : "v"(x1), "v"(y1), "v"(z1));
-                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf1 - tn1), 31u);
-                miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf0 - tn0), 31u);
-            }
-#else
 #pragma unroll
             for (int j = 7; j >= 0; --j) {
                 const unsigned wnx = j < 4 ? nx0 : nx1, wny = j < 4 ? ny0 : ny1, wnz = j < 4 ? nz0 : nz1;
@@ -322,7 +287,10 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 const float tf = fminf(fminf(tfx, tfy), tfz);
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);     // (miss << 1) | sign(tf - tn)
             }
-#endif
+            // (Measured and dropped, round 3: bytes -> distances through v_perm_b32 + v_fma_mix_f32 -- two bytes and the constant
+            // 0x64 make two f16 values 1024 + q, which an f32 fma consumes directly: 3 VALU per byte pair instead of 4, exact to 8e-5
+            // quantisation steps -- is NOT faster: v_fma_mix_f32 and v_perm_b32 issue at 2.6-2.7 cycles against 2.1 / 1.9 for the
+            // conversion and the fma; 2.501 vs 2.488 ms per 8-view launch.  tools/ubench/fma_mix.hip, profiles/r03_fma_mix_ubench.txt.)
             const unsigned n_int = h.z >> 28, n_leaf = h.w >> 28;
             const unsigned hits = ~miss & ((1u << (n_int + n_leaf)) - 1u);
             if (COUNT) n_box += n_int + n_leaf;

@@ -129,6 +129,17 @@ struct nvdr_ctx {
     int *ovf_dev = nullptr;        // its device address
     unsigned debug = 0;            // NVDR_DEBUG, read ONCE when the context is created
     int per_cu[3] = {8, 6, 6};     // workgroups per CU of the sample-generation, forward- and backward-shading kernels (NVDR_PBLOCKS="g,f,b")
+    // BVH builds run on the context's own side stream, overlapped with whatever the caller enqueues next that does not need the
+    // tree (pixel compaction and sample generation of env-shade: ~0.35-2.3 ms against a 0.25 ms build); consumers wait on `ev_built`
+    // (ctx_wait_built).  The reference builds on stream 0 while everything else runs on torch's stream (torch_bindings.cpp:99).
+    bool async_build = true;       // NVDR_ASYNC_BUILD=0: build on the caller's stream
+    hipStream_t build_stream = nullptr;
+    hipEvent_t ev_inputs = nullptr, ev_built = nullptr;
+    float *in_verts = nullptr;     // the build's own copy of the caller's geometry (taken on the caller's stream: the caller may
+    int32_t *in_tris = nullptr;    // overwrite or free its tensors as soon as nvdr_bvh_build has returned)
+    int64_t in_verts_cap = 0, in_tris_cap = 0;
+    bool built_pending = false;    // a build is (possibly) still in flight on build_stream
+    hipStream_t built_waited = nullptr;   // the caller stream that already waits on ev_built
     int trace_variant = 1;         // shadow-ray kernel: 1 = round 3 (oct nodes, deferred triangle tests), 0 = round 2 (four-slot nodes)
     // env-shade scratch
     int *pix_list = nullptr;       // [N*H*W] compacted indices of the covered pixels of the whole launch
@@ -169,6 +180,7 @@ struct BvhView {
 };
 
 int ctx_check_overflow(nvdr_ctx *c, const char *who);   // bvh.hip
+int ctx_wait_built(nvdr_ctx *c, hipStream_t stream);    // bvh.hip: make `stream` wait for the context's last BVH build
 
 // every device buffer the context owns beyond its few fixed control words goes through these two
 static inline hipError_t ctx_malloc_raw(nvdr_ctx *c, void **p, size_t bytes, hipStream_t stream)

@@ -503,10 +503,20 @@ int ctx_check_overflow(nvdr_ctx *c, const char *who)
     return 0;
 }
 
+// Every consumer of the tree calls this before its first launch that reads it: the build may still be running on the side stream.
+int ctx_wait_built(nvdr_ctx *c, hipStream_t stream)
+{
+    if (!c->built_pending || c->built_waited == stream) return 0;
+    NVDR_HIP_TRY(hipStreamWaitEvent(stream, c->ev_built, 0));
+    c->built_waited = stream;
+    return 0;
+}
+
 extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
 {
     NVDR_REQUIRE(c != nullptr, "nvdr_ctx_check: ctx is NULL");
     NVDR_HIP_TRY(hipSetDevice(c->device));
+    if (c->build_stream) NVDR_HIP_TRY(hipStreamSynchronize(c->build_stream));
     NVDR_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
     return ctx_check_overflow(c, "nvdr_ctx_check");
 }
@@ -567,6 +577,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         sscanf(pb, "%d,%d,%d", &c->per_cu[0], &c->per_cu[1], &c->per_cu[2]);
         for (int k = 0; k < 3; ++k) c->per_cu[k] = c->per_cu[k] < 1 ? 1 : (c->per_cu[k] > 16 ? 16 : c->per_cu[k]);
     }
+    if (const char *ab = getenv("NVDR_ASYNC_BUILD")) c->async_build = atoi(ab) != 0;
     // NVDR_TRACE_VARIANT=0 selects the round-2 shadow-ray kernel for contexts created while it is set (A/B tools)
     if (const char *tv = getenv("NVDR_TRACE_VARIANT")) {
         if (atoi(tv) == 0) {
@@ -584,6 +595,14 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
 {
     if (!c) return 0;
     hipSetDevice(c->device);
+    if (c->build_stream) {
+        (void)hipStreamSynchronize(c->build_stream);
+        (void)hipEventDestroy(c->ev_inputs);
+        (void)hipEventDestroy(c->ev_built);
+        (void)hipStreamDestroy(c->build_stream);
+    }
+    ctx_free(c, c->in_verts);
+    ctx_free(c, c->in_tris);
     ctx_free_bvh(c);
     if (c->prof_ev[0][0])
         for (int i = 0; i < NVDR_PROF_RING; ++i)
@@ -654,6 +673,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     const int smax = nvdr_stack_bound(n_tris);
     if (smax > c->spill_cap) {
         NVDR_HIP_TRY(hipStreamSynchronize(stream));
+        if (c->build_stream) NVDR_HIP_TRY(hipStreamSynchronize(c->build_stream));
         ctx_free(c, c->spill);
         c->spill_cap = 0;
         const size_t d_bin = (size_t)(smax > NVDR_STACK_LDS ? smax - NVDR_STACK_LDS : 0) * sizeof(int);
@@ -666,6 +686,41 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     c->stack_max = (c->debug & 32u) ? NVDR_STACK_LDS + 1 : c->spill_cap;
     c->oct_stack_max = (c->debug & 32u) ? 2 : c->spill_cap;
     const int n = (int)n_tris;
+    // the build runs on the context's side stream: it starts when everything enqueued so far on the caller's stream is done (the
+    // vertices are ready, earlier traversals have finished with the old tree) and consumers wait for it (ctx_wait_built)
+    hipStream_t caller = stream;
+    if (c->async_build) {
+        if (!c->build_stream) {
+            NVDR_HIP_TRY(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
+            NVDR_HIP_TRY(hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming));
+            NVDR_HIP_TRY(hipEventCreateWithFlags(&c->ev_built, hipEventDisableTiming));
+        }
+        // the geometry is copied on the caller's stream first (36 B per triangle-ish: microseconds), so that the side stream never
+        // reads caller memory: stream-ordered use of verts / tris by the caller stays correct without knowing about the side stream
+        if (c->in_verts_cap < n_verts || c->in_tris_cap < n_tris) {
+            NVDR_HIP_TRY(hipStreamSynchronize(caller));
+            NVDR_HIP_TRY(hipStreamSynchronize(c->build_stream));
+            if (c->in_verts_cap < n_verts) {
+                ctx_free(c, c->in_verts);
+                c->in_verts_cap = 0;
+                NVDR_HIP_TRY(ctx_malloc(c, &c->in_verts, sizeof(float) * 3 * (n_verts + n_verts / 2 + 64), caller));
+                c->in_verts_cap = n_verts + n_verts / 2 + 64;
+            }
+            if (c->in_tris_cap < n_tris) {
+                ctx_free(c, c->in_tris);
+                c->in_tris_cap = 0;
+                NVDR_HIP_TRY(ctx_malloc(c, &c->in_tris, sizeof(int32_t) * 3 * (n_tris + n_tris / 2 + 64), caller));
+                c->in_tris_cap = n_tris + n_tris / 2 + 64;
+            }
+        }
+        NVDR_HIP_TRY(hipMemcpyAsync(c->in_verts, verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, caller));
+        NVDR_HIP_TRY(hipMemcpyAsync(c->in_tris, tris, sizeof(int32_t) * 3 * n_tris, hipMemcpyDeviceToDevice, caller));
+        verts = c->in_verts;
+        tris = c->in_tris;
+        NVDR_HIP_TRY(hipEventRecord(c->ev_inputs, caller));
+        NVDR_HIP_TRY(hipStreamWaitEvent(c->build_stream, c->ev_inputs, 0));
+        stream = c->build_stream;
+    }
     bvh_init_info_kernel<<<1, 64, 0, stream>>>(c->dinfo);
     bvh_bounds_kernel<<<min(div_up(n_verts, 256), 1024u), 256, 0, stream>>>(verts, n_verts, c->dinfo);
     bvh_grid_kernel<<<1, 1, 0, stream>>>(c->dinfo);
@@ -696,6 +751,11 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         }
     }
     NVDR_LAUNCH_CHECK();
+    if (c->async_build) {
+        NVDR_HIP_TRY(hipEventRecord(c->ev_built, c->build_stream));
+        c->built_pending = true;
+        c->built_waited = nullptr;
+    }
     c->n_tris = n_tris;
     c->n_verts = n_verts;
     c->stream_id = 0; // a ray stream traced against the old geometry must not be reused
@@ -716,6 +776,7 @@ extern "C" int nvdr_bvh_info_get(nvdr_ctx *c, nvdr_bvh_info *out, void *stream_)
     NVDR_REQUIRE(c && out, "nvdr_bvh_info_get: NULL argument");
     NVDR_REQUIRE(c->n_tris > 0, "nvdr_bvh_info_get: no BVH built");
     hipStream_t stream = (hipStream_t)stream_;
+    if (int rw = ctx_wait_built(c, stream)) return rw;
     BvhDeviceInfo h;
     NVDR_HIP_TRY(hipMemcpyAsync(&h, c->dinfo, sizeof(h), hipMemcpyDeviceToHost, stream));
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
@@ -737,6 +798,7 @@ extern "C" int nvdr_bvh_export(nvdr_ctx *c, float *nodes_host, float *tri_host, 
 {
     NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_bvh_export: no BVH built");
     hipStream_t stream = (hipStream_t)stream_;
+    if (int rw = ctx_wait_built(c, stream)) return rw;
     if (nodes_host && c->n_tris > 1)
         NVDR_HIP_TRY(hipMemcpyAsync(nodes_host, c->nodes, sizeof(uint32_t) * 8 * (c->n_tris - 1), hipMemcpyDeviceToHost, stream));
     if (tri_host)
@@ -772,6 +834,7 @@ extern "C" int nvdr_bvh_export_oct(nvdr_ctx *c, uint32_t *oct_host, float *tris8
     NVDR_REQUIRE(c && c->n_tris > 0, "nvdr_bvh_export_oct: no BVH built");
     NVDR_REQUIRE(counts_host != nullptr, "nvdr_bvh_export_oct: counts_host is NULL");
     hipStream_t stream = (hipStream_t)stream_;
+    if (int rw = ctx_wait_built(c, stream)) return rw;
     unsigned ctl[OCT_CTL_WORDS];
     NVDR_HIP_TRY(hipMemcpyAsync(ctl, c->oct_ctl, sizeof(ctl), hipMemcpyDeviceToHost, stream));
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
@@ -791,6 +854,7 @@ extern "C" int nvdr_trace_visibility(nvdr_ctx *c, const float *ro, const float *
     if (int r0 = ctx_check_overflow(c, "nvdr_trace_visibility")) return r0;
     if (n_rays <= 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
+    if (int rw = ctx_wait_built(c, stream)) return rw;
     const size_t lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
     const unsigned grid = query_grid(c, n_rays);
     if (counters)
@@ -808,6 +872,7 @@ extern "C" int nvdr_trace_closest(nvdr_ctx *c, const float *ro, const float *rd,
     if (int r0 = ctx_check_overflow(c, "nvdr_trace_closest")) return r0;
     if (n_rays <= 0) return 0;
     hipStream_t stream = (hipStream_t)stream_;
+    if (int rw = ctx_wait_built(c, stream)) return rw;
     trace_closest_kernel<<<query_grid(c, n_rays), NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), stream>>>(
         bvh_view(c), ro, rd, n_rays, out_t, out_tri, out_uv, c->spill);
     NVDR_LAUNCH_CHECK();

@@ -16,6 +16,10 @@
 // (Tried: one kernel for the diffuse and the specular image -- same guides, so one weight evaluation -- with the second
 // image's taps read from global memory because two colour planes do not fit the 64 KB tile budget: forward 0.75 ms
 // instead of 2 x 0.47, but backward 1.33 ms instead of 2 x 0.43 at 8 x 512^2; dropped.)
+// (Tried in round 3 and dropped: the radius as a template parameter + TWO vertically adjacent pixels per thread, so that every
+// tile element read from LDS serves two (pixel, tap) pairs -- half the LDS reads per tap, bit-identical output: 0.474 / 0.451 ms
+// instead of 0.468 / 0.434 ms per 8-view launch.  The filter is bound by its ~28 VALU instructions per tap, not by LDS reads,
+// and the coarser four-row background early-out costs more than the reads saved.)
 // The per-tap constants exp(-d^2/2s^2) and d are wave-uniform; gfx950 has no scalar float unit, so they are tabulated
 // once per workgroup in LDS and fetched as broadcast reads instead of being recomputed (v_sqrt + v_exp per tap).
 //   forward : w = w_xy * w_n * exp(-|z_t - z_c| / max(dz_c * dist, 1e-4)),  out = (sum w*col_t, max(sum w, 1e-4))
@@ -147,125 +151,6 @@ __global__ void __launch_bounds__(DN_BX * DN_BY) bilateral_kernel(DnView v, floa
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// The benchmark's filter (sigma = 2 -> radius 11, 529 taps) specialised: the radius is a template parameter (the tap loops
-// unroll, LDS reads are issued ahead of their use) and every thread filters TWO vertically adjacent pixels: tile row r is tap
-// row r - ly2 - RAD of the upper pixel and one row less of the lower one, so each element read from LDS serves two
-// (pixel, tap) pairs -- (2 RAD + 2)(2 RAD + 1) reads for 2 (2 RAD + 1)^2 taps.  A workgroup of 32 x 8 threads covers 32 x 16
-// pixels; its halo tile (54 x 38 pixels x 32 B = 66 KB at RAD 11) needs the large-LDS attribute, two workgroups per CU as before.
-// Same arithmetic per tap, same order of the additions per pixel (tap rows top to bottom, left to right) as bilateral_kernel.
-#define DN_ROWS 2
-
-template <bool BACKWARD, int RAD>
-__global__ void __launch_bounds__(DN_BX * DN_BY) bilateral_kernel_2row(DnView v, float sigma, float *__restrict__ out)
-{
-    extern __shared__ __attribute__((aligned(16))) float4 tile[];
-    constexpr int TW = DN_BX + 2 * RAD, TH = DN_BY * DN_ROWS + 2 * RAD, SIDE = 2 * RAD + 1;
-    float4 *tA = tile, *tB = tile + TW * TH;
-    float2 *tap_tab = (float2 *)(tile + 2 * TW * TH);   // (w_xy, dist) per tap
-    const int n = blockIdx.z;
-    const int x0 = blockIdx.x * DN_BX, y0 = blockIdx.y * DN_BY * DN_ROWS;
-    const int lx = threadIdx.x & (DN_BX - 1), ly = threadIdx.x / DN_BX;
-    const int x = x0 + lx, ya = y0 + DN_ROWS * ly, yb = ya + 1;
-    const bool in_a = x < v.W && ya < v.H, in_b = x < v.W && yb < v.H;
-    const int64_t oa = ((int64_t)n * v.H + ya) * v.W + x, ob = oa + v.W;
-    F3 na = f3(0.0f), nb = f3(0.0f);
-    if (in_a) na = fetch3(v.nrm, n, ya, x);
-    if (in_b) nb = fetch3(v.nrm, n, yb, x);
-    const bool live_a = na.x != 0.0f || na.y != 0.0f || na.z != 0.0f, live_b = nb.x != 0.0f || nb.y != 0.0f || nb.z != 0.0f;
-    auto write_empty = [&](bool inside, int64_t o) {
-        if (!inside) return;
-        if (BACKWARD) {
-            out[3 * o + 0] = 0.f; out[3 * o + 1] = 0.f; out[3 * o + 2] = 0.f;
-        } else {
-            out[4 * o + 0] = 0.f; out[4 * o + 1] = 0.f; out[4 * o + 2] = 0.f; out[4 * o + 3] = DN_EPS;
-        }
-    };
-    // background early-out, workgroup level (before the tile is staged)
-    if (!__syncthreads_or(live_a | live_b)) {
-        write_empty(in_a, oa);
-        write_empty(in_b, ob);
-        return;
-    }
-    const float inv2var = 1.0f / (2.0f * sigma * sigma);
-    for (int t = threadIdx.x; t < SIDE * SIDE; t += DN_BX * DN_BY) {
-        const int fx = t % SIDE - RAD, fy = t / SIDE - RAD;
-        const float dist_sqr = (float)(fx * fx + fy * fy);
-        tap_tab[t] = make_float2(__expf(-dist_sqr * inv2var), sqrtf(dist_sqr));
-    }
-    for (int t = threadIdx.x; t < TW * TH; t += DN_BX * DN_BY) {
-        const int tx = t % TW, ty = t / TW;
-        const int gx = x0 + tx - RAD, gy = y0 + ty - RAD;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (gx >= 0 && gy >= 0 && gx < v.W && gy < v.H) {
-            const F3 c = fetch3(v.col, n, gy, gx), nn = fetch3(v.nrm, n, gy, gx);
-            const float *zp = v.zdz.p + n * v.zdz.s0 + gy * v.zdz.s1 + gx * v.zdz.s2;
-            a = make_float4(c.x, c.y, c.z, zp[0]);
-            b = make_float4(nn.x, nn.y, nn.z, zp[v.zdz.s3]);
-        }
-        tA[t] = a;
-        tB[t] = b;
-    }
-    __syncthreads();
-    // wavefront-level early-out (four rows of 32 pixels)
-    if (__ballot(live_a | live_b) == 0ull) {
-        write_empty(in_a, oa);
-        write_empty(in_b, ob);
-        return;
-    }
-    const int ra = DN_ROWS * ly + RAD;                         // tile row of the upper pixel's centre
-    const float4 cAa = tA[ra * TW + lx + RAD], cBa = tB[ra * TW + lx + RAD];
-    const float4 cAb = tA[(ra + 1) * TW + lx + RAD], cBb = tB[(ra + 1) * TW + lx + RAD];
-    float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f, bx = 0.f, by = 0.f, bz = 0.f, bw = 0.f;
-    auto tap = [&](const float4 &tAv, const float4 &tBv, const float2 tt, const float4 &cA, const float4 &cB, float &sx, float &sy, float &sz, float &sw) {
-        const float w_xy = tt.x, dist = tt.y;
-        const float d = tBv.x * cB.x + tBv.y * cB.y + tBv.z * cB.z;
-        const float w_normal = pow128(fminf(fmaxf(d, DN_EPS), 1.0f));
-        const float dz = BACKWARD ? tBv.w : cB.w;
-        const float w_depth = __expf(-(fabsf(tAv.w - cA.w) * __builtin_amdgcn_rcpf(fmaxf(dz * dist, DN_EPS))));
-        const float w = w_xy * w_normal * w_depth;
-        sx += tAv.x * w;
-        sy += tAv.y * w;
-        sz += tAv.z * w;
-        sw += w;
-    };
-    for (int r = 0; r < SIDE + 1; ++r) {                       // tile rows ra - RAD + r: tap row r of the upper pixel, r - 1 of the lower
-        const int row = (ra - RAD + r) * TW + lx;
-#pragma unroll
-        for (int c = 0; c < SIDE; ++c) {
-            const float4 tAv = tA[row + c], tBv = tB[row + c];
-            if (r < SIDE) tap(tAv, tBv, tap_tab[r * SIDE + c], cAa, cBa, ax, ay, az, aw);
-            if (r > 0) tap(tAv, tBv, tap_tab[(r - 1) * SIDE + c], cAb, cBb, bx, by, bz, bw);
-        }
-    }
-    if (in_a) {
-        if (BACKWARD) {
-            out[3 * oa + 0] = ax; out[3 * oa + 1] = ay; out[3 * oa + 2] = az;
-        } else {
-            out[4 * oa + 0] = ax; out[4 * oa + 1] = ay; out[4 * oa + 2] = az; out[4 * oa + 3] = fmaxf(aw, DN_EPS);
-        }
-    }
-    if (in_b) {
-        if (BACKWARD) {
-            out[3 * ob + 0] = bx; out[3 * ob + 1] = by; out[3 * ob + 2] = bz;
-        } else {
-            out[4 * ob + 0] = bx; out[4 * ob + 1] = by; out[4 * ob + 2] = bz; out[4 * ob + 3] = fmaxf(bw, DN_EPS);
-        }
-    }
-}
-
-// dynamic LDS beyond 64 KB needs the attribute once per kernel
-template <typename K>
-static bool dn_allow_lds(K kernel, size_t bytes)
-{
-    if (bytes <= 64 * 1024) return true;
-    if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return true;
-}
-
 static int check_dn(const nvdr_tensor *t, int64_t N, int64_t H, int64_t W, int c, const char *op, const char *name)
 {
     NVDR_REQUIRE(t && t->data, "%s: %s is NULL", op, name);
@@ -297,19 +182,6 @@ static int launch_bilateral(const nvdr_tensor *col_or_grad, const nvdr_tensor *c
     const size_t lds_tab = (size_t)(2 * rad + 1) * (2 * rad + 1) * sizeof(float2);
     const size_t lds_tile = (size_t)(DN_BX + 2 * rad) * (DN_BY + 2 * rad) * 2 * sizeof(float4);
     dim3 grid(div_up(W, DN_BX), div_up(H, DN_BY), (unsigned)N);
-    // the benchmark's radius: two pixels per thread (bilateral_kernel_2row); NVDR_DN_2ROW=0 keeps the one-pixel kernel (A/B)
-    static const bool two_row = !(getenv("NVDR_DN_2ROW") && atoi(getenv("NVDR_DN_2ROW")) == 0);
-    if (rad == 11 && two_row) {
-        const size_t lds2 = (size_t)(DN_BX + 2 * rad) * (DN_BY * DN_ROWS + 2 * rad) * 2 * sizeof(float4) + lds_tab;
-        dim3 grid2(div_up(W, DN_BX), div_up(H, DN_BY * DN_ROWS), (unsigned)N);
-        static const bool ok_f = dn_allow_lds(bilateral_kernel_2row<false, 11>, lds2), ok_b = dn_allow_lds(bilateral_kernel_2row<true, 11>, lds2);
-        if (backward ? ok_b : ok_f) {
-            if (backward) bilateral_kernel_2row<true, 11><<<grid2, DN_BX * DN_BY, lds2, stream>>>(v, sigma, out);
-            else bilateral_kernel_2row<false, 11><<<grid2, DN_BX * DN_BY, lds2, stream>>>(v, sigma, out);
-            NVDR_LAUNCH_CHECK();
-            return 0;
-        }
-    }
     const bool tiled = lds_tile + lds_tab <= 64 * 1024;
     NVDR_REQUIRE(lds_tab <= 64 * 1024, "%s: sigma %g needs a %d-wide window, more than fits", op, (double)sigma, 2 * rad + 1);
     const size_t lds = (tiled ? lds_tile : 0) + lds_tab;

@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     // one-byte key the gather scans: 8 bands x 58 MB instead of 8 x 233 MB of 4-byte texel keys (round 2)
                     const int64_t ri = r == 0 ? rA : rB;
                     if (nz) {
-                        p.rays[ri] = make_float4(lg.x, lg.y, lg.z, 0.0f);
+                        p.rays[ri] = make_float4(lg.x, lg.y, lg.z, __int_as_float(at));     // the record carries its texel
                         p.vis[ri] = (uint8_t)(at >> p.lg_shift);
                     } else {
                         p.vis[ri] = 255;
@@ -754,16 +754,15 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 //   * the probe is cut into `n_bands` bands of consecutive texels whose fp32 accumulators (band_texels * 12 B) fit the LDS
 //     of one workgroup (96 KB -> 8 bands at 256x256);
 //   * workgroup (g, band) scans the g-th slice of the one-byte BAND keys (coalesced 16-byte loads = 16 slots; the byte is the
-//     slot's old visibility flag, rewritten by the backward shading kernel) and fetches texel + 16-byte record only of keys of
-//     its band, adding the record into LDS with ds_add_f32 (hot sun texels serialise inside the LDS atomic unit, not on the fabric);
+//     slot's old visibility flag, rewritten by the backward shading kernel) and fetches the 16-byte record (rgb + texel) only of
+//     keys of its band, adding it into LDS with ds_add_f32 (hot sun texels serialise inside the LDS atomic unit, not on the fabric);
 //   * it then writes its band as ONE plain partial row; light_grad_reduce_kernel sums the partial rows.
 // Cost model per 8-view launch (58 M slots, 21 M records): keys 8 bands x 58 MB = 0.47 GB, texels + records 21 M x (4 + 16) B =
 // 0.42 GB, partials 25 MB.  (Round 2 scanned the 4-byte texel keys: 8 x 233 MB, counter-measured 3.4 GB per launch, 1.31 ms.)
 
 #define NVDR_LG_THREADS 1024
 
-__global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const uint8_t *__restrict__ band_of, const int *__restrict__ texel,
-                                                                          const float4 *__restrict__ recs, const unsigned *__restrict__ pix_count,
+__global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const uint8_t *__restrict__ band_of, const float4 *__restrict__ recs, const unsigned *__restrict__ pix_count,
                                                                           unsigned pix_begin, unsigned pix_cap, unsigned rays_per_pixel,
                                                                           int band_texels, int n_texels, float *__restrict__ partials)
 {
@@ -782,16 +781,30 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
     const unsigned b16 = g * per, e16 = min(b16 + per, n16);
     const uint4 *__restrict__ keys = (const uint4 *)band_of;   // 16 one-byte keys per load; the allocation is padded to a multiple of 16
     const unsigned want = (unsigned)band * 0x01010101u;
-    // A lane walks 16 CONSECUTIVE slots, eight at a time in THREE PHASES -- the texels of the matching slots, then the records of
-    // the texels that really are in this band, then the additions -- so that eight loads are in flight per lane and phase.  (The
-    // first versions fetched texel and record slot by slot inside one divergent branch per slot: 32 dependent memory round trips
-    // per 16 slots, and almost every branch is taken by SOME lane of the wavefront -- 1.3-1.5 ms per 8-view launch whatever the
-    // key traffic was; the run-length sum alone changed nothing.)  Neighbouring slots are neighbouring cells of the CDF grid
-    // (stage 1 orders a pixel's samples by stratum): where the probe has a sun, consecutive records hit the SAME texel, so runs of
-    // equal texels are summed in registers and leave the lane as one atomic triple.
-    for (unsigned q = b16 + threadIdx.x; q < e16; q += NVDR_LG_THREADS) {
-        const uint4 k16 = keys[q];
+    // A lane walks 16 CONSECUTIVE slots: ONE round of predicated 16-byte record loads for the slots whose key byte names this band
+    // (the record carries its texel in .w, so there is no second dependent fetch), the next iteration's keys already in flight,
+    // then the additions.  The kernel is bound by the LATENCY of dependent memory stages, not by traffic: the first versions
+    // fetched texel and then record slot by slot inside one divergent branch per slot (32 dependent round trips per 16 slots,
+    // almost every branch taken by SOME lane of the wavefront): 1.3-1.5 ms per 8-view launch whatever the key traffic was.
+    // Neighbouring slots are neighbouring cells of the CDF grid (stage 1 orders a pixel's samples by stratum): where the probe has
+    // a sun, consecutive records hit the SAME texel, so runs of equal texels are summed in registers and leave the lane as one
+    // atomic triple.
+    unsigned q = b16 + threadIdx.x;
+    uint4 k16 = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    if (q < e16) k16 = keys[q];
+    while (q < e16) {
         const unsigned kw[4] = {k16.x, k16.y, k16.z, k16.w};
+        const unsigned qn = q + NVDR_LG_THREADS;
+        if (qn < e16) k16 = keys[qn];                                           // prefetch
+        float4 v[16];
+        bool m[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const unsigned x = kw[j >> 2] ^ want;                               // a zero byte = a slot of this band
+            m[j] = ((x >> (8 * (j & 3))) & 0xffu) == 0u && 16u * q + j < total;
+            v[j] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+            if (m[j]) v[j] = recs[16u * q + j];
+        }
         int run_t = -1;
         float rx = 0.0f, ry = 0.0f, rz = 0.0f;
         auto flush = [&]() {
@@ -803,38 +816,19 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
             }
         };
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const unsigned x0 = kw[2 * half] ^ want, x1 = kw[2 * half + 1] ^ want;      // a zero byte = a slot of this band
-            const bool any0 = ((x0 - 0x01010101u) & ~x0 & 0x80808080u) != 0u, any1 = ((x1 - 0x01010101u) & ~x1 & 0x80808080u) != 0u;
-            if (!(any0 | any1)) continue;                                       // (exact zero-byte test)
-            const unsigned slot0 = 16u * q + 8u * half;
-            int t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned x = j < 4 ? x0 : x1;
-                t[j] = -1;
-                if (((x >> (8 * (j & 3))) & 0xffu) == 0u && slot0 + j < total) t[j] = texel[slot0 + j];
-            }
-            float4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (t[j] < t_lo || t[j] >= t_hi) t[j] = -1;                     // (a stale byte of a slot nobody wrote in this launch)
-                v[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (t[j] >= 0) v[j] = recs[slot0 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (t[j] < 0) continue;
-                if (t[j] != run_t) {
-                    flush();
-                    run_t = t[j];
-                    rx = v[j].x; ry = v[j].y; rz = v[j].z;
-                } else {
-                    rx += v[j].x; ry += v[j].y; rz += v[j].z;
-                }
+        for (int j = 0; j < 16; ++j) {
+            const int t = __float_as_int(v[j].w);
+            if (!m[j] || t < t_lo || t >= t_hi) continue;                       // (a stale byte of a slot nobody wrote in this launch)
+            if (t != run_t) {
+                flush();
+                run_t = t;
+                rx = v[j].x; ry = v[j].y; rz = v[j].z;
+            } else {
+                rx += v[j].x; ry += v[j].y; rz += v[j].z;
             }
         }
         flush();
+        q = qn;
     }
     __syncthreads();
     float *out = partials + (int64_t)g * n_texels * 3 + (int64_t)t_lo * 3;
@@ -1194,8 +1188,9 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         // otherwise the kernel itself decides from the device-side pixel count)
         if (!(reuse && n_chunks == 1)) env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
-        // stage 2
+        // stage 2 (the first launch of this call that needs the tree: a build may still be running on the context's side stream)
         if (!replay) {
+            if (int rw = ctx_wait_built(c, stream)) return rw;
             if (c->debug & 1u) {
                 NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)cap * 2 * S, stream));
             } else {
@@ -1211,7 +1206,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
             if (p.lg_records && !(c->debug & 2u)) {
                 light_grad_band_kernel<<<dim3((unsigned)lg_rows, (unsigned)n_bands), NVDR_LG_THREADS, lg_lds, stream>>>(
-                    c->vis, c->texel, c->rays, p.pix_count, p.pix_begin, p.pix_cap, 2 * S, 1 << p.lg_shift, n_texels, c->lg_part);
+                    c->vis, c->rays, p.pix_count, p.pix_begin, p.pix_cap, 2 * S, 1 << p.lg_shift, n_texels, c->lg_part);
                 light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, lg_rows, p.g_light,
                                                                                          k > 0 ? 1 : 0, p.pix_count, p.pix_begin);
             }
@@ -1255,6 +1250,7 @@ static int trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, 
     int r = reserve_stream(c, n_rays, n_rays, 1, stream);
     if (r) return r;
     c->stream_id = 0;
+    if (int rw = ctx_wait_built(c, stream)) return rw;
     pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts, c->queues);
     int64_t tblocks = (int64_t)c->n_cus * 8;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;

@@ -139,6 +139,7 @@ extern "C" int nvdr_render_gbuffer(nvdr_ctx *c, const nvdr_gbuffer_args *a, void
     p.rast = a->rast; p.rast_db = a->rast_db; p.gb_pos = a->gb_pos; p.gb_gnrm = a->gb_geometric_normal; p.gb_nrm = a->gb_normal;
     p.gb_tng = a->gb_tangent; p.gb_texc = a->gb_texc; p.gb_texc_db = a->gb_texc_deriv; p.gb_depth = a->gb_depth;
     const int64_t total = (int64_t)p.N * p.H * p.W;
+    if (int rw = ctx_wait_built(c, (hipStream_t)stream_)) return rw;
     gbuffer_kernel<<<query_grid(c, total), NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), (hipStream_t)stream_>>>(bvh_view(c), p, c->spill);
     NVDR_LAUNCH_CHECK();
     return 0;

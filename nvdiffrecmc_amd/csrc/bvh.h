@@ -139,7 +139,8 @@ struct nvdr_ctx {
     int32_t *in_tris = nullptr;    // overwrite or free its tensors as soon as nvdr_bvh_build has returned)
     int64_t in_verts_cap = 0, in_tris_cap = 0;
     bool built_pending = false;    // a build is (possibly) still in flight on build_stream
-    hipStream_t built_waited = nullptr;   // the caller stream that already waits on ev_built
+    hipStream_t built_waited = nullptr;   // the caller stream that already waits on ev_built ...
+    bool built_waited_valid = false;      // ... if any (the default stream's handle IS the null pointer)
     int trace_variant = 1;         // shadow-ray kernel: 1 = round 3 (oct nodes, deferred triangle tests), 0 = round 2 (four-slot nodes)
     // env-shade scratch
     int *pix_list = nullptr;       // [N*H*W] compacted indices of the covered pixels of the whole launch

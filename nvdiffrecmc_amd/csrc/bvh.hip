@@ -506,9 +506,10 @@ int ctx_check_overflow(nvdr_ctx *c, const char *who)
 // Every consumer of the tree calls this before its first launch that reads it: the build may still be running on the side stream.
 int ctx_wait_built(nvdr_ctx *c, hipStream_t stream)
 {
-    if (!c->built_pending || c->built_waited == stream) return 0;
+    if (!c->built_pending || (c->built_waited_valid && c->built_waited == stream)) return 0;
     NVDR_HIP_TRY(hipStreamWaitEvent(stream, c->ev_built, 0));
     c->built_waited = stream;
+    c->built_waited_valid = true;
     return 0;
 }
 
@@ -754,7 +755,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     if (c->async_build) {
         NVDR_HIP_TRY(hipEventRecord(c->ev_built, c->build_stream));
         c->built_pending = true;
-        c->built_waited = nullptr;
+        c->built_waited_valid = false;
     }
     c->n_tris = n_tris;
     c->n_verts = n_verts;

@@ -805,14 +805,30 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
             v[j] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
             if (m[j]) v[j] = recs[16u * q + j];
         }
-        int run_t = -1;
+        // Runs of equal texels are summed in registers.  A finished run is BUFFERED (up to four per lane and iteration) and the
+        // buffered runs are added to LDS after the slot loop, in converged code: three LDS-atomic instructions per buffer level for
+        // the whole wavefront instead of three per slot and lane subset -- inside the divergent slot loop every `flush` site is its
+        // own instruction issue with a handful of active lanes, ~50 LDS atomics per iteration and wavefront, and THAT (not the
+        // memory traffic, not the latency of the loads) is what the first versions of this kernel spent their 1.2-1.5 ms on.
+        int run_t = -1, n_runs = 0;
         float rx = 0.0f, ry = 0.0f, rz = 0.0f;
-        auto flush = [&]() {
-            if (run_t >= 0) {
-                float *a = lg_acc + (run_t - t_lo) * 3;
-                __hip_atomic_fetch_add(a + 0, rx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(a + 1, ry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(a + 2, rz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int bt[4] = {-1, -1, -1, -1};
+        float bx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, by[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto add_run = [&](int t_, float x_, float y_, float z_) {
+            float *a = lg_acc + (t_ - t_lo) * 3;
+            __hip_atomic_fetch_add(a + 0, x_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(a + 1, y_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(a + 2, z_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        auto end_run = [&]() {
+            if (run_t < 0) return;
+            if (n_runs < 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k == n_runs) { bt[k] = run_t; bx[k] = rx; by[k] = ry; bz[k] = rz; }
+                n_runs++;
+            } else {
+                add_run(run_t, rx, ry, rz);                                       // a fifth run in 16 slots: rare
             }
         };
 #pragma unroll
@@ -820,14 +836,17 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
             const int t = __float_as_int(v[j].w);
             if (!m[j] || t < t_lo || t >= t_hi) continue;                       // (a stale byte of a slot nobody wrote in this launch)
             if (t != run_t) {
-                flush();
+                end_run();
                 run_t = t;
                 rx = v[j].x; ry = v[j].y; rz = v[j].z;
             } else {
                 rx += v[j].x; ry += v[j].y; rz += v[j].z;
             }
         }
-        flush();
+        end_run();
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (bt[k] >= 0) add_run(bt[k], bx[k], by[k], bz[k]);
         q = qn;
     }
     __syncthreads();

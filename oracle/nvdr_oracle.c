@@ -43,6 +43,32 @@
 
 typedef struct { float x, y, z; } f3;
 
+/* ---------------------------------------------------------------------------------------------
+ * EXPERIMENT SWITCH (tools/fast_value_math.py; never defined in the checker build): -DORACLE_FAST_VALUE_MATH evaluates the
+ * divisions whose result is only ever a VALUE -- BSDF evaluation and its adjoints, pdfs, the MIS weight -- the way a GPU fast path
+ * would: a * rcp(b) with a reciprocal that is off by up to one ulp (perturbed pseudo-randomly here), float instead of the
+ * fp64 islands of the reference.  Everything that feeds a DISCRETE decision (sample directions, texel indices, lobe choice, the
+ * dead-sample gate, CDF inversion) keeps IEEE arithmetic.  The question it answers: how far do images and gradients move? */
+#if ORACLE_FAST_VALUE_MATH
+static inline float vrcp_(float b)
+{
+    float r = 1.0f / b;
+    union { float f; uint32_t u; } x, y;
+    x.f = b;
+    y.f = r;
+    uint32_t h = x.u * 2654435761u;
+    h ^= h >> 15;
+    if ((h & 3u) == 1u) y.u += 1u;            /* one ulp up / down for half of the operands */
+    else if ((h & 3u) == 2u) y.u -= 1u;
+    return y.f;
+}
+#define VDIV(a, b) ((a) * vrcp_(b))
+#define VFAST 1
+#else
+#define VDIV(a, b) ((a) / (b))
+#define VFAST 0
+#endif
+
 static inline f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
 static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -70,12 +96,19 @@ static inline f3 safe_normalize(f3 v)                                           
     float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
     return l > 0.0f ? div3s(v, l) : mk3(0, 0, 0);
 }
+/* the same where the result is only evaluated (BSDF half vector, view vector of the evaluation, pdf of a given direction) */
+static inline f3 vdiv3s(f3 a, float s_) { return mk3(VDIV(a.x, s_), VDIV(a.y, s_), VDIV(a.z, s_)); }
+static inline f3 safe_normalize_v(f3 v)
+{
+    float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return l > 0.0f ? vdiv3s(v, l) : mk3(0, 0, 0);
+}
 static inline void bwd_safe_normalize(f3 v, f3 *d_v, f3 d_out)                              /* math_utils.h:140 */
 {
     float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
     if (l > 0.0f) {
         float l2 = v.x * v.x + v.y * v.y + v.z * v.z;
-        float fac = (float)(1.0 / (double)(l2 * sqrtf(l2))); /* 1.0 / powf(l2, 1.5f) */
+        float fac = VFAST ? VDIV(1.0f, l2 * sqrtf(l2)) : (float)(1.0 / (double)(l2 * sqrtf(l2))); /* 1.0 / powf(l2, 1.5f) */
         d_v->x += (d_out.x * (v.y * v.y + v.z * v.z) - d_out.y * (v.x * v.y) - d_out.z * (v.x * v.z)) * fac;
         d_v->y += (d_out.y * (v.x * v.x + v.z * v.z) - d_out.x * (v.y * v.x) - d_out.z * (v.y * v.z)) * fac;
         d_v->z += (d_out.z * (v.x * v.x + v.y * v.y) - d_out.x * (v.z * v.x) - d_out.y * (v.z * v.y)) * fac;
@@ -122,10 +155,10 @@ static inline float uniform_pcg(uint32_t *s) { return (float)(rand_pcg(s) & 0xFF
  * BSDF evaluation, forward and backward (bsdf.h) */
 #define SPECULAR_EPSILON 1e-4f
 
-static float fwdLambert(f3 nrm, f3 wi) { return fmaxf(dot3(nrm, wi) / PI_F, 0.0f); }         /* bsdf.h:21 */
+static float fwdLambert(f3 nrm, f3 wi) { return fmaxf(VDIV(dot3(nrm, wi), PI_F), 0.0f); }         /* bsdf.h:21 */
 static void bwdLambert(f3 nrm, f3 wi, f3 *d_nrm, f3 *d_wi, float d_out)                      /* bsdf.h:26 */
 {
-    if (dot3(nrm, wi) > 0.0f) bwd_dot(nrm, wi, d_nrm, d_wi, d_out / PI_F);
+    if (dot3(nrm, wi) > 0.0f) bwd_dot(nrm, wi, d_nrm, d_wi, VDIV(d_out, PI_F));
 }
 static f3 fwdFresnelSchlick3(f3 f0, f3 f90, float cosTheta)                                   /* bsdf.h:54 */
 {
@@ -137,7 +170,7 @@ static void bwdFresnelSchlick3(f3 f0, f3 f90, float cosTheta, f3 *d_f0, f3 *d_f9
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float scale = pow5f(fmaxf(1.0f - c, 0.0f));
-    float oms = (float)(1.0 - (double)scale);
+    float oms = VFAST ? 1.0f - scale : (float)(1.0 - (double)scale);
     *d_f0 = add3(*d_f0, scale3(d_out, oms));
     *d_f90 = add3(*d_f90, scale3(d_out, scale));
     if (cosTheta >= SPECULAR_EPSILON && cosTheta < 1.0f - SPECULAR_EPSILON) {
@@ -150,45 +183,47 @@ static float fwdNdfGGX(float alphaSqr, float cosTheta)                          
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float d = (c * alphaSqr - c) * c + 1.0f;
-    return alphaSqr / (d * d * PI_F);
+    return VDIV(alphaSqr, d * d * PI_F);
 }
 static void bwdNdfGGX(float alphaSqr, float cosTheta, float *d_alphaSqr, float *d_cos, float d_out) /* bsdf.h:83 */
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float c2 = c * c;
-    float base = (float)(((double)alphaSqr - 1.0) * (double)c2 + 1.0); /* (alphaSqr - 1.0) * cosThetaSqr + 1.0f */
+    float base = VFAST ? (alphaSqr - 1.0f) * c2 + 1.0f : (float)(((double)alphaSqr - 1.0) * (double)c2 + 1.0); /* (alphaSqr - 1.0) * cosThetaSqr + 1.0f */
     float cube = base * base * base;
-    *d_alphaSqr += d_out * (1.0f - (alphaSqr + 1.0f) * c2) / (PI_F * cube);
+    *d_alphaSqr += VDIV(d_out * (1.0f - (alphaSqr + 1.0f) * c2), PI_F * cube);
     if (cosTheta > SPECULAR_EPSILON && cosTheta < 1.0f - SPECULAR_EPSILON)
-        *d_cos += d_out * -(4.0f * (alphaSqr - 1.0f) * alphaSqr * cosTheta) / (PI_F * cube);
+        *d_cos += VDIV(d_out * -(4.0f * (alphaSqr - 1.0f) * alphaSqr * cosTheta), PI_F * cube);
 }
 static float fwdLambdaGGX(float alphaSqr, float cosTheta)                                     /* bsdf.h:98 */
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float c2 = c * c;
-    float tan2 = (float)((1.0 - (double)c2) / (double)c2);
+    float tan2 = VFAST ? VDIV(1.0f - c2, c2) : (float)((1.0 - (double)c2) / (double)c2);
     return 0.5f * (sqrtf(1.0f + alphaSqr * tan2) - 1.0f);
 }
 static void bwdLambdaGGX(float alphaSqr, float cosTheta, float *d_alphaSqr, float *d_cos, float d_out) /* bsdf.h:107 */
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float c2 = c * c;
-    float tan2 = (float)((1.0 - (double)c2) / (double)c2);
-    *d_alphaSqr += (float)((double)d_out * (0.25 * (double)tan2) / (double)sqrtf(alphaSqr * tan2 + 1.0f));
+    float tan2 = VFAST ? VDIV(1.0f - c2, c2) : (float)((1.0 - (double)c2) / (double)c2);
+    *d_alphaSqr += VFAST ? VDIV(d_out * (0.25f * tan2), sqrtf(alphaSqr * tan2 + 1.0f))
+                         : (float)((double)d_out * (0.25 * (double)tan2) / (double)sqrtf(alphaSqr * tan2 + 1.0f));
     if (cosTheta > SPECULAR_EPSILON && cosTheta < 1.0f - SPECULAR_EPSILON)
-        *d_cos += (float)((double)d_out * -(0.5 * (double)alphaSqr) /
-                          (double)((c * c * c) * sqrtf(alphaSqr / c2 - alphaSqr + 1.0f)));
+        *d_cos += VFAST ? VDIV(d_out * -(0.5f * alphaSqr), (c * c * c) * sqrtf(VDIV(alphaSqr, c2) - alphaSqr + 1.0f))
+                        : (float)((double)d_out * -(0.5 * (double)alphaSqr) /
+                                  (double)((c * c * c) * sqrtf(alphaSqr / c2 - alphaSqr + 1.0f)));
 }
 static float fwdMaskingSmith(float alphaSqr, float cosI, float cosO)                          /* bsdf.h:122 */
 {
-    return 1.0f / (1.0f + fwdLambdaGGX(alphaSqr, cosI) + fwdLambdaGGX(alphaSqr, cosO));
+    return VDIV(1.0f, 1.0f + fwdLambdaGGX(alphaSqr, cosI) + fwdLambdaGGX(alphaSqr, cosO));
 }
 static void bwdMaskingSmith(float alphaSqr, float cosI, float cosO, float *d_alphaSqr, float *d_cosI, float *d_cosO,
                             float d_out)                                                       /* bsdf.h:129 */
 {
     float lI = fwdLambdaGGX(alphaSqr, cosI), lO = fwdLambdaGGX(alphaSqr, cosO);
     float s = 1.0f + lI + lO;
-    float d_l = -d_out / (s * s);
+    float d_l = VDIV(-d_out, s * s);
     bwdLambdaGGX(alphaSqr, cosI, d_alphaSqr, d_cosI, d_l);
     bwdLambdaGGX(alphaSqr, cosO, d_alphaSqr, d_cosO, d_l);
 }
@@ -196,12 +231,12 @@ static f3 fwdPbrSpecular(f3 col, f3 nrm, f3 wo, f3 wi, float alpha, float min_ro
 {
     float _alpha = clampf(alpha, min_roughness * min_roughness, 1.0f);
     float alphaSqr = _alpha * _alpha;
-    f3 h = safe_normalize(add3(wo, wi));
+    f3 h = safe_normalize_v(add3(wo, wi));
     float woDotN = dot3(wo, nrm), wiDotN = dot3(wi, nrm), woDotH = dot3(wo, h), nDotH = dot3(nrm, h);
     float D = fwdNdfGGX(alphaSqr, nDotH);
     float G = fwdMaskingSmith(alphaSqr, woDotN, wiDotN);
     f3 F = fwdFresnelSchlick3(col, mk3(1, 1, 1), woDotH);
-    f3 w = div3s(scale3(scale3(scale3(F, D), G), 0.25f), woDotN);
+    f3 w = vdiv3s(scale3(scale3(scale3(F, D), G), 0.25f), woDotN);
     int front = (woDotN > SPECULAR_EPSILON) & (wiDotN > SPECULAR_EPSILON);
     return front ? w : mk3(0, 0, 0);
 }
@@ -210,17 +245,17 @@ static void bwdPbrSpecular(f3 col, f3 nrm, f3 wo, f3 wi, float alpha, float min_
 {
     float _alpha = clampf(alpha, min_roughness * min_roughness, 1.0f);
     float alphaSqr = _alpha * _alpha;
-    f3 h = safe_normalize(add3(wo, wi));
+    f3 h = safe_normalize_v(add3(wo, wi));
     float woDotN = dot3(wo, nrm), wiDotN = dot3(wi, nrm), woDotH = dot3(wo, h), nDotH = dot3(nrm, h);
     float D = fwdNdfGGX(alphaSqr, nDotH);
     float G = fwdMaskingSmith(alphaSqr, woDotN, wiDotN);
     f3 F = fwdFresnelSchlick3(col, mk3(1, 1, 1), woDotH);
     int front = (woDotN > SPECULAR_EPSILON) & (wiDotN > SPECULAR_EPSILON);
     if (!front) return;
-    f3 d_F = div3s(scale3(scale3(scale3(d_out, D), G), 0.25f), woDotN);
-    float d_D = sum3(div3s(scale3(scale3(mul3(d_out, F), G), 0.25f), woDotN));
-    float d_G = sum3(div3s(scale3(scale3(mul3(d_out, F), D), 0.25f), woDotN));
-    float d_woDotN = -sum3(div3s(scale3(scale3(scale3(mul3(d_out, F), D), G), 0.25f), woDotN * woDotN));
+    f3 d_F = vdiv3s(scale3(scale3(scale3(d_out, D), G), 0.25f), woDotN);
+    float d_D = sum3(vdiv3s(scale3(scale3(mul3(d_out, F), G), 0.25f), woDotN));
+    float d_G = sum3(vdiv3s(scale3(scale3(mul3(d_out, F), D), 0.25f), woDotN));
+    float d_woDotN = -sum3(vdiv3s(scale3(scale3(scale3(mul3(d_out, F), D), G), 0.25f), woDotN * woDotN));
     f3 d_f90 = mk3(0, 0, 0);
     float d_woDotH = 0, d_wiDotN = 0, d_nDotH = 0, d_alphaSqr = 0;
     bwdFresnelSchlick3(col, mk3(1, 1, 1), woDotH, d_col, &d_f90, &d_woDotH, d_F);
@@ -240,9 +275,9 @@ static void bwdPbrSpecular(f3 col, f3 nrm, f3 wo, f3 wi, float alpha, float min_
 /* demodulated-diffuse PBR BSDF of the shader (bsdf.h:222-236) */
 static void fwdPbrBSDF(f3 kd, f3 arm, f3 pos, f3 nrm, f3 view_pos, f3 wi, float min_roughness, f3 *diffuse, f3 *specular)
 {
-    f3 wo = safe_normalize(sub3(view_pos, pos));
+    f3 wo = safe_normalize_v(sub3(view_pos, pos));
     float alpha = arm.y * arm.y;
-    f3 spec_col = scale3(add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - arm.z), scale3(kd, arm.z)), (float)(1.0 - (double)arm.x));
+    f3 spec_col = scale3(add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - arm.z), scale3(kd, arm.z)), VFAST ? 1.0f - arm.x : (float)(1.0 - (double)arm.x));
     float diff = fwdLambert(nrm, wi);
     *diffuse = mk3(diff, diff, diff);
     *specular = fwdPbrSpecular(spec_col, nrm, wo, wi, alpha, min_roughness);
@@ -251,9 +286,9 @@ static void bwdPbrBSDF(f3 kd, f3 arm, f3 pos, f3 nrm, f3 view_pos, f3 wi, float 
                        f3 *d_pos, f3 *d_nrm, f3 *d_view_pos, f3 *d_wi, f3 d_diffuse, f3 d_specular) /* bsdf.h:238 */
 {
     f3 _wo = sub3(view_pos, pos);
-    f3 wo = safe_normalize(_wo);
+    f3 wo = safe_normalize_v(_wo);
     float alpha = arm.y * arm.y;
-    f3 spec_col = scale3(add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - arm.z), scale3(kd, arm.z)), (float)(1.0 - (double)arm.x));
+    f3 spec_col = scale3(add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - arm.z), scale3(kd, arm.z)), VFAST ? 1.0f - arm.x : (float)(1.0 - (double)arm.x));
     float d_alpha = 0;
     *d_wi = mk3(0, 0, 0);
     f3 d_spec_col = mk3(0, 0, 0), d_wo = mk3(0, 0, 0);
@@ -294,7 +329,7 @@ static f3 cosine_sample(f3 N, float u, float v, float *pdf)                     
     float sp, cp;
     nvdr_sincosf(phi, &sp, &cp);
     float x = cp * sintheta, y = sp * sintheta, z = costheta;
-    *pdf = (float)fmax((double)0.000001f, (double)costheta / PI_D);
+    *pdf = VFAST ? fmaxf(0.000001f, VDIV(costheta, PI_F)) : (float)fmax((double)0.000001f, (double)costheta / PI_D);
     f3 vec = add3(add3(scale3(dx, x), scale3(dy, y)), scale3(N, z));
     return safe_normalize(vec);
 }
@@ -352,7 +387,8 @@ static float lightPDF(const shade_env *e, f3 dir)                               
     int y = clampi((int)(cv * (float)e->Hl), 0, e->Hl - 1);
     float s, c;
     nvdr_sincosf((float)((double)cv * PI_D), &s, &c);
-    float pdf_weight = (float)((double)(e->Hl * e->Wl) / (2.0 * PI_D * PI_D * (double)fmaxf(s, 0.0001f)));
+    float pdf_weight = VFAST ? VDIV((float)(e->Hl * e->Wl), (2.0f * PI_F * PI_F) * fmaxf(s, 0.0001f))
+                             : (float)((double)(e->Hl * e->Wl) / (2.0 * PI_D * PI_D * (double)fmaxf(s, 0.0001f)));
     const nvdr_tensor *t = &e->a->pdf;
     return ((const float *)t->data)[y * t->stride[0] + x * t->stride[1]] * pdf_weight;
 }
@@ -381,20 +417,20 @@ static float evalNdfGGX(float alpha, float cosTheta)                            
 {
     float a2 = alpha * alpha;
     float d = ((cosTheta * a2 - cosTheta) * cosTheta + 1);
-    return (float)((double)a2 / ((double)(d * d) * PI_D));
+    return VFAST ? VDIV(a2, (d * d) * PI_F) : (float)((double)a2 / ((double)(d * d) * PI_D));
 }
 static float evalG1GGX(float alphaSqr, float cosTheta)                                        /* kernel.cu:224 */
 {
     if (cosTheta <= 0) return 0;
     float c2 = cosTheta * cosTheta;
-    float tan2 = fmaxf(1.0f - c2, 0.0f) / c2;
-    return 2 / (1 + sqrtf(1 + alphaSqr * tan2));
+    float tan2 = VDIV(fmaxf(1.0f - c2, 0.0f), c2);
+    return VDIV(2.0f, 1 + sqrtf(1 + alphaSqr * tan2));
 }
 static float evalPdfGGX_VNDF(float alpha, f3 wo, f3 h)                                        /* kernel.cu:232 */
 {
     float G1 = evalG1GGX(alpha * alpha, wo.z);
     float D = evalNdfGGX(alpha, h.z);
-    return G1 * D * fmaxf(0.f, dot3(wo, h)) / wo.z;
+    return VDIV(G1 * D * fmaxf(0.f, dot3(wo, h)), wo.z);
 }
 static f3 sampleGGX_VNDF(float alpha, f3 wo, float ux, float uy, float *pdf)                  /* kernel.cu:241 */
 {
@@ -427,7 +463,7 @@ static f3 ggx_sample(f3 N, f3 wo, float u, float v, float alpha, float *pdf)    
     f3 h = sampleGGX_VNDF(alpha, wo_l, u, v, pdf);
     float woDotH = dot3(wo_l, h);
     f3 wi_l = sub3(scale3(scale3(h, woDotH), 2.0f), wo_l);
-    *pdf /= (4.0f * woDotH);
+    *pdf = VDIV(*pdf, 4.0f * woDotH);
     f3 wi_o = toworld(wi_l, U, V, W);
     return safe_normalize(wi_o);
 }
@@ -439,12 +475,12 @@ static float ggx_pdf(f3 N, f3 wo, f3 wi, float alpha)                           
     f3 wi_l = tolocal(wi, U, V, W);
     float pdf = 0.0f;
     if (wo_l.z > 0 && wi_l.z > 0) {
-        f3 m = safe_normalize(add3(wi_l, wo_l));
+        f3 m = safe_normalize_v(add3(wi_l, wo_l));
         const float woDotH = dot3(m, wo_l);
         const float D = evalNdfGGX(alpha, m.z);
         float G1 = evalG1GGX(alpha * alpha, wo_l.z);
-        pdf = G1 * D * fmaxf(0.f, dot3(wo_l, m)) / wo_l.z;
-        pdf /= (4 * woDotH);
+        pdf = VDIV(G1 * D * fmaxf(0.f, dot3(wo_l, m)), wo_l.z);
+        pdf = VDIV(pdf, 4 * woDotH);
     }
     return pdf;
 }
@@ -474,7 +510,7 @@ static f3 bsdf_sample(float pDiffuse, float pSpecular, f3 N, f3 wo, f3 s, float 
         wi_o = ggx_sample(N, wo, s.x, s.y, alpha, pdf);
         *pdf *= 1.f - pDiffuse;
         if (pDiffuse > 0) {
-            float bp = (float)(fmax((double)dot3(N, wi_o), 0.0) / PI_D);
+            float bp = VFAST ? VDIV(fmaxf(dot3(N, wi_o), 0.0f), PI_F) : (float)(fmax((double)dot3(N, wi_o), 0.0) / PI_D);
             update_pdf(pdf, bp, pDiffuse);
         }
     }
@@ -486,7 +522,7 @@ static float bsdf_pdf(float pDiffuse, float pSpecular, f3 N, f3 wo, f3 wi, float
     float pdf = 0.0f;
     if (fminf(NdotV, NdotL) < 1e-6f) return 1.0f;
     if (pDiffuse > 0) {
-        float bp = (float)(fmax((double)dot3(N, wi), 0.0) / PI_D);
+        float bp = VFAST ? VDIV(fmaxf(dot3(N, wi), 0.0f), PI_F) : (float)(fmax((double)dot3(N, wi), 0.0) / PI_D);
         update_pdf(&pdf, bp, pDiffuse);
     }
     if (pSpecular > 0) {
@@ -588,7 +624,7 @@ static void process_sample(const shade_env *e, int backward, f3 ro, f3 dir, f3 p
     const nvdr_tensor *L = &a->light;
     const float *lp = (const float *)L->data + ty * L->stride[0] + tx * L->stride[1];
     f3 light_col = L->size[2] == 1 ? mk3(lp[0], lp[0], lp[0]) : mk3(lp[0], lp[L->stride[2]], lp[2 * L->stride[2]]);
-    float mis_weight = (float)(1.0 / (double)fmaxf(pdfSum, 0.0001f));
+    float mis_weight = VFAST ? VDIV(1.0f, fmaxf(pdfSum, 0.0001f)) : (float)(1.0 / (double)fmaxf(pdfSum, 0.0001f));
     f3 _diff = mk3(0, 0, 0), _spec = mk3(0, 0, 0);
     if (a->bsdf == 1 || a->bsdf == 2) {
         float l = fwdLambert(nrm, dir);

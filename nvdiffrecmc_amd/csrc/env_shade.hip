@@ -761,6 +761,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 // 0.42 GB, partials 25 MB.  (Round 2 scanned the 4-byte texel keys: 8 x 233 MB, counter-measured 3.4 GB per launch, 1.31 ms.)
 
 #define NVDR_LG_THREADS 1024
+#ifndef NVDR_LG_TEST
+#define NVDR_LG_TEST 0          // experiments (variants only): 1 no LDS atomics, 2 key scan only, 3 zero + copy-out only
+#endif
 
 __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const uint8_t *__restrict__ band_of, const float4 *__restrict__ recs, const unsigned *__restrict__ pix_count,
                                                                           unsigned pix_begin, unsigned pix_cap, unsigned rays_per_pixel,
@@ -793,11 +796,17 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
     uint4 k16 = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
     if (q < e16) k16 = keys[q];
     auto add_run = [&](int t_, float x_, float y_, float z_) {
+#if NVDR_LG_TEST >= 1
+        if (x_ != 12345.678f) return;               // experiment: no LDS atomics
+#endif
         float *a = lg_acc + (t_ - t_lo) * 3;
         __hip_atomic_fetch_add(a + 0, x_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(a + 1, y_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(a + 2, z_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+#if NVDR_LG_TEST >= 3
+    q = e16;                                        // experiment: zero + copy-out only
+#endif
     while (q < e16) {
         const unsigned kw[4] = {k16.x, k16.y, k16.z, k16.w};
         const unsigned qn = q + NVDR_LG_THREADS;
@@ -814,6 +823,9 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const 
         }
         const unsigned left = total - 16u * q;                                  // slots of this group that exist (>= 1)
         if (left < 16u) mask &= (1u << left) - 1u;
+#if NVDR_LG_TEST >= 2
+        mask &= (q == 0xffffffffu) ? 0xffffu : 0u;  // experiment: key scan only (no record fetched)
+#endif
         // Only ~4.5 % of the slots belong to one band: a lane holds 0.7 of them on average.  The first FOUR are fetched together
         // (predicated, all in flight at once), a fifth and later one -- one group in a thousand -- by the slow loop below.
         // (A version with 16 predicated fetches, one per slot position, executed ~560 VALU + ~300 scalar instructions per group

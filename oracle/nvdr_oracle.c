@@ -68,6 +68,14 @@ static inline float vrcp_(float b)
 #define VDIV(a, b) ((a) / (b))
 #define VFAST 0
 #endif
+/* level 1: the pdfs and the MIS weight only; level 2: also the BSDF evaluation and its adjoints (VDIV_E / VFAST_E) */
+#if ORACLE_FAST_VALUE_MATH >= 2
+#define VDIV_E(a, b) VDIV(a, b)
+#define VFAST_E 1
+#else
+#define VDIV_E(a, b) ((a) / (b))
+#define VFAST_E 0
+#endif
 
 static inline f3 mk3(float x, float y, float z) { f3 r = {x, y, z}; return r; }
 static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -103,12 +111,18 @@ static inline f3 safe_normalize_v(f3 v)
     float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
     return l > 0.0f ? vdiv3s(v, l) : mk3(0, 0, 0);
 }
+static inline f3 vdiv3s_e(f3 a, float s_) { return mk3(VDIV_E(a.x, s_), VDIV_E(a.y, s_), VDIV_E(a.z, s_)); }
+static inline f3 safe_normalize_e(f3 v)
+{
+    float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return l > 0.0f ? vdiv3s_e(v, l) : mk3(0, 0, 0);
+}
 static inline void bwd_safe_normalize(f3 v, f3 *d_v, f3 d_out)                              /* math_utils.h:140 */
 {
     float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
     if (l > 0.0f) {
         float l2 = v.x * v.x + v.y * v.y + v.z * v.z;
-        float fac = VFAST ? VDIV(1.0f, l2 * sqrtf(l2)) : (float)(1.0 / (double)(l2 * sqrtf(l2))); /* 1.0 / powf(l2, 1.5f) */
+        float fac = VFAST_E ? VDIV_E(1.0f, l2 * sqrtf(l2)) : (float)(1.0 / (double)(l2 * sqrtf(l2))); /* 1.0 / powf(l2, 1.5f) */
         d_v->x += (d_out.x * (v.y * v.y + v.z * v.z) - d_out.y * (v.x * v.y) - d_out.z * (v.x * v.z)) * fac;
         d_v->y += (d_out.y * (v.x * v.x + v.z * v.z) - d_out.x * (v.y * v.x) - d_out.z * (v.y * v.z)) * fac;
         d_v->z += (d_out.z * (v.x * v.x + v.y * v.y) - d_out.x * (v.z * v.x) - d_out.y * (v.z * v.y)) * fac;
@@ -155,10 +169,10 @@ static inline float uniform_pcg(uint32_t *s) { return (float)(rand_pcg(s) & 0xFF
  * BSDF evaluation, forward and backward (bsdf.h) */
 #define SPECULAR_EPSILON 1e-4f
 
-static float fwdLambert(f3 nrm, f3 wi) { return fmaxf(VDIV(dot3(nrm, wi), PI_F), 0.0f); }         /* bsdf.h:21 */
+static float fwdLambert(f3 nrm, f3 wi) { return fmaxf(VDIV_E(dot3(nrm, wi), PI_F), 0.0f); }         /* bsdf.h:21 */
 static void bwdLambert(f3 nrm, f3 wi, f3 *d_nrm, f3 *d_wi, float d_out)                      /* bsdf.h:26 */
 {
-    if (dot3(nrm, wi) > 0.0f) bwd_dot(nrm, wi, d_nrm, d_wi, VDIV(d_out, PI_F));
+    if (dot3(nrm, wi) > 0.0f) bwd_dot(nrm, wi, d_nrm, d_wi, VDIV_E(d_out, PI_F));
 }
 static f3 fwdFresnelSchlick3(f3 f0, f3 f90, float cosTheta)                                   /* bsdf.h:54 */
 {
@@ -170,7 +184,7 @@ static void bwdFresnelSchlick3(f3 f0, f3 f90, float cosTheta, f3 *d_f0, f3 *d_f9
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float scale = pow5f(fmaxf(1.0f - c, 0.0f));
-    float oms = VFAST ? 1.0f - scale : (float)(1.0 - (double)scale);
+    float oms = VFAST_E ? 1.0f - scale : (float)(1.0 - (double)scale);
     *d_f0 = add3(*d_f0, scale3(d_out, oms));
     *d_f90 = add3(*d_f90, scale3(d_out, scale));
     if (cosTheta >= SPECULAR_EPSILON && cosTheta < 1.0f - SPECULAR_EPSILON) {
@@ -183,47 +197,47 @@ static float fwdNdfGGX(float alphaSqr, float cosTheta)                          
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float d = (c * alphaSqr - c) * c + 1.0f;
-    return VDIV(alphaSqr, d * d * PI_F);
+    return VDIV_E(alphaSqr, d * d * PI_F);
 }
 static void bwdNdfGGX(float alphaSqr, float cosTheta, float *d_alphaSqr, float *d_cos, float d_out) /* bsdf.h:83 */
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float c2 = c * c;
-    float base = VFAST ? (alphaSqr - 1.0f) * c2 + 1.0f : (float)(((double)alphaSqr - 1.0) * (double)c2 + 1.0); /* (alphaSqr - 1.0) * cosThetaSqr + 1.0f */
+    float base = VFAST_E ? (alphaSqr - 1.0f) * c2 + 1.0f : (float)(((double)alphaSqr - 1.0) * (double)c2 + 1.0); /* (alphaSqr - 1.0) * cosThetaSqr + 1.0f */
     float cube = base * base * base;
-    *d_alphaSqr += VDIV(d_out * (1.0f - (alphaSqr + 1.0f) * c2), PI_F * cube);
+    *d_alphaSqr += VDIV_E(d_out * (1.0f - (alphaSqr + 1.0f) * c2), PI_F * cube);
     if (cosTheta > SPECULAR_EPSILON && cosTheta < 1.0f - SPECULAR_EPSILON)
-        *d_cos += VDIV(d_out * -(4.0f * (alphaSqr - 1.0f) * alphaSqr * cosTheta), PI_F * cube);
+        *d_cos += VDIV_E(d_out * -(4.0f * (alphaSqr - 1.0f) * alphaSqr * cosTheta), PI_F * cube);
 }
 static float fwdLambdaGGX(float alphaSqr, float cosTheta)                                     /* bsdf.h:98 */
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float c2 = c * c;
-    float tan2 = VFAST ? VDIV(1.0f - c2, c2) : (float)((1.0 - (double)c2) / (double)c2);
+    float tan2 = VFAST_E ? VDIV_E(1.0f - c2, c2) : (float)((1.0 - (double)c2) / (double)c2);
     return 0.5f * (sqrtf(1.0f + alphaSqr * tan2) - 1.0f);
 }
 static void bwdLambdaGGX(float alphaSqr, float cosTheta, float *d_alphaSqr, float *d_cos, float d_out) /* bsdf.h:107 */
 {
     float c = clampf(cosTheta, SPECULAR_EPSILON, 1.0f - SPECULAR_EPSILON);
     float c2 = c * c;
-    float tan2 = VFAST ? VDIV(1.0f - c2, c2) : (float)((1.0 - (double)c2) / (double)c2);
-    *d_alphaSqr += VFAST ? VDIV(d_out * (0.25f * tan2), sqrtf(alphaSqr * tan2 + 1.0f))
+    float tan2 = VFAST_E ? VDIV_E(1.0f - c2, c2) : (float)((1.0 - (double)c2) / (double)c2);
+    *d_alphaSqr += VFAST_E ? VDIV_E(d_out * (0.25f * tan2), sqrtf(alphaSqr * tan2 + 1.0f))
                          : (float)((double)d_out * (0.25 * (double)tan2) / (double)sqrtf(alphaSqr * tan2 + 1.0f));
     if (cosTheta > SPECULAR_EPSILON && cosTheta < 1.0f - SPECULAR_EPSILON)
-        *d_cos += VFAST ? VDIV(d_out * -(0.5f * alphaSqr), (c * c * c) * sqrtf(VDIV(alphaSqr, c2) - alphaSqr + 1.0f))
+        *d_cos += VFAST_E ? VDIV_E(d_out * -(0.5f * alphaSqr), (c * c * c) * sqrtf(VDIV_E(alphaSqr, c2) - alphaSqr + 1.0f))
                         : (float)((double)d_out * -(0.5 * (double)alphaSqr) /
                                   (double)((c * c * c) * sqrtf(alphaSqr / c2 - alphaSqr + 1.0f)));
 }
 static float fwdMaskingSmith(float alphaSqr, float cosI, float cosO)                          /* bsdf.h:122 */
 {
-    return VDIV(1.0f, 1.0f + fwdLambdaGGX(alphaSqr, cosI) + fwdLambdaGGX(alphaSqr, cosO));
+    return VDIV_E(1.0f, 1.0f + fwdLambdaGGX(alphaSqr, cosI) + fwdLambdaGGX(alphaSqr, cosO));
 }
 static void bwdMaskingSmith(float alphaSqr, float cosI, float cosO, float *d_alphaSqr, float *d_cosI, float *d_cosO,
                             float d_out)                                                       /* bsdf.h:129 */
 {
     float lI = fwdLambdaGGX(alphaSqr, cosI), lO = fwdLambdaGGX(alphaSqr, cosO);
     float s = 1.0f + lI + lO;
-    float d_l = VDIV(-d_out, s * s);
+    float d_l = VDIV_E(-d_out, s * s);
     bwdLambdaGGX(alphaSqr, cosI, d_alphaSqr, d_cosI, d_l);
     bwdLambdaGGX(alphaSqr, cosO, d_alphaSqr, d_cosO, d_l);
 }
@@ -231,12 +245,12 @@ static f3 fwdPbrSpecular(f3 col, f3 nrm, f3 wo, f3 wi, float alpha, float min_ro
 {
     float _alpha = clampf(alpha, min_roughness * min_roughness, 1.0f);
     float alphaSqr = _alpha * _alpha;
-    f3 h = safe_normalize_v(add3(wo, wi));
+    f3 h = safe_normalize_e(add3(wo, wi));
     float woDotN = dot3(wo, nrm), wiDotN = dot3(wi, nrm), woDotH = dot3(wo, h), nDotH = dot3(nrm, h);
     float D = fwdNdfGGX(alphaSqr, nDotH);
     float G = fwdMaskingSmith(alphaSqr, woDotN, wiDotN);
     f3 F = fwdFresnelSchlick3(col, mk3(1, 1, 1), woDotH);
-    f3 w = vdiv3s(scale3(scale3(scale3(F, D), G), 0.25f), woDotN);
+    f3 w = vdiv3s_e(scale3(scale3(scale3(F, D), G), 0.25f), woDotN);
     int front = (woDotN > SPECULAR_EPSILON) & (wiDotN > SPECULAR_EPSILON);
     return front ? w : mk3(0, 0, 0);
 }
@@ -245,17 +259,17 @@ static void bwdPbrSpecular(f3 col, f3 nrm, f3 wo, f3 wi, float alpha, float min_
 {
     float _alpha = clampf(alpha, min_roughness * min_roughness, 1.0f);
     float alphaSqr = _alpha * _alpha;
-    f3 h = safe_normalize_v(add3(wo, wi));
+    f3 h = safe_normalize_e(add3(wo, wi));
     float woDotN = dot3(wo, nrm), wiDotN = dot3(wi, nrm), woDotH = dot3(wo, h), nDotH = dot3(nrm, h);
     float D = fwdNdfGGX(alphaSqr, nDotH);
     float G = fwdMaskingSmith(alphaSqr, woDotN, wiDotN);
     f3 F = fwdFresnelSchlick3(col, mk3(1, 1, 1), woDotH);
     int front = (woDotN > SPECULAR_EPSILON) & (wiDotN > SPECULAR_EPSILON);
     if (!front) return;
-    f3 d_F = vdiv3s(scale3(scale3(scale3(d_out, D), G), 0.25f), woDotN);
-    float d_D = sum3(vdiv3s(scale3(scale3(mul3(d_out, F), G), 0.25f), woDotN));
-    float d_G = sum3(vdiv3s(scale3(scale3(mul3(d_out, F), D), 0.25f), woDotN));
-    float d_woDotN = -sum3(vdiv3s(scale3(scale3(scale3(mul3(d_out, F), D), G), 0.25f), woDotN * woDotN));
+    f3 d_F = vdiv3s_e(scale3(scale3(scale3(d_out, D), G), 0.25f), woDotN);
+    float d_D = sum3(vdiv3s_e(scale3(scale3(mul3(d_out, F), G), 0.25f), woDotN));
+    float d_G = sum3(vdiv3s_e(scale3(scale3(mul3(d_out, F), D), 0.25f), woDotN));
+    float d_woDotN = -sum3(vdiv3s_e(scale3(scale3(scale3(mul3(d_out, F), D), G), 0.25f), woDotN * woDotN));
     f3 d_f90 = mk3(0, 0, 0);
     float d_woDotH = 0, d_wiDotN = 0, d_nDotH = 0, d_alphaSqr = 0;
     bwdFresnelSchlick3(col, mk3(1, 1, 1), woDotH, d_col, &d_f90, &d_woDotH, d_F);
@@ -275,9 +289,9 @@ static void bwdPbrSpecular(f3 col, f3 nrm, f3 wo, f3 wi, float alpha, float min_
 /* demodulated-diffuse PBR BSDF of the shader (bsdf.h:222-236) */
 static void fwdPbrBSDF(f3 kd, f3 arm, f3 pos, f3 nrm, f3 view_pos, f3 wi, float min_roughness, f3 *diffuse, f3 *specular)
 {
-    f3 wo = safe_normalize_v(sub3(view_pos, pos));
+    f3 wo = safe_normalize_e(sub3(view_pos, pos));
     float alpha = arm.y * arm.y;
-    f3 spec_col = scale3(add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - arm.z), scale3(kd, arm.z)), VFAST ? 1.0f - arm.x : (float)(1.0 - (double)arm.x));
+    f3 spec_col = scale3(add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - arm.z), scale3(kd, arm.z)), VFAST_E ? 1.0f - arm.x : (float)(1.0 - (double)arm.x));
     float diff = fwdLambert(nrm, wi);
     *diffuse = mk3(diff, diff, diff);
     *specular = fwdPbrSpecular(spec_col, nrm, wo, wi, alpha, min_roughness);
@@ -286,9 +300,9 @@ static void bwdPbrBSDF(f3 kd, f3 arm, f3 pos, f3 nrm, f3 view_pos, f3 wi, float 
                        f3 *d_pos, f3 *d_nrm, f3 *d_view_pos, f3 *d_wi, f3 d_diffuse, f3 d_specular) /* bsdf.h:238 */
 {
     f3 _wo = sub3(view_pos, pos);
-    f3 wo = safe_normalize_v(_wo);
+    f3 wo = safe_normalize_e(_wo);
     float alpha = arm.y * arm.y;
-    f3 spec_col = scale3(add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - arm.z), scale3(kd, arm.z)), VFAST ? 1.0f - arm.x : (float)(1.0 - (double)arm.x));
+    f3 spec_col = scale3(add3(scale3(mk3(0.04f, 0.04f, 0.04f), 1.0f - arm.z), scale3(kd, arm.z)), VFAST_E ? 1.0f - arm.x : (float)(1.0 - (double)arm.x));
     float d_alpha = 0;
     *d_wi = mk3(0, 0, 0);
     f3 d_spec_col = mk3(0, 0, 0), d_wo = mk3(0, 0, 0);

@@ -15,14 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle as orc, scene_cpu  # noqa: E402
 
-FAST = os.path.join(ROOT, 'oracle', '_build', 'libnvdr_oracle_fast.so')
-
-
-def build_fast():
+def build_fast(level):
     src = os.path.join(ROOT, 'oracle', 'nvdr_oracle.c')
-    if not os.path.exists(FAST) or os.path.getmtime(FAST) < os.path.getmtime(src):
+    out = os.path.join(ROOT, 'oracle', '_build', 'libnvdr_oracle_fast%d.so' % level)
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         subprocess.check_call(['gcc', '-O2', '-mfma', '-mavx2', '-ffp-contract=off', '-fno-fast-math', '-fopenmp', '-fPIC', '-shared', '-Wno-unused-function',
-                               '-I' + os.path.join(ROOT, 'include'), '-std=gnu11', '-DORACLE_FAST_VALUE_MATH=1', src, '-o', FAST, '-lm'])
+                               '-I' + os.path.join(ROOT, 'include'), '-std=gnu11', '-DORACLE_FAST_VALUE_MATH=%d' % level, src, '-o', out, '-lm'])
+    return out
 
 
 def run(lib, m, kw, bsdf, n, seed, dg, sg, nt):
@@ -37,8 +36,13 @@ def run(lib, m, kw, bsdf, n, seed, dg, sg, nt):
 
 
 def main():
-    build_fast()
     orc.build()
+    for level, what in ((1, 'LEVEL 1: pdfs and the MIS weight only'), (2, 'LEVEL 2: + BSDF evaluation and its adjoints')):
+        print('\n### %s\n' % what)
+        table(build_fast(level))
+
+
+def table(FAST):
     nt = orc.max_threads()
     cases = [('bob', 64, 8, 'pbr', 0, 3), ('bob', 64, 8, 'pbr', 5, 4), ('spot', 64, 8, 'pbr', 2, 5), ('spot', 48, 16, 'pbr', 6, 6),
              ('bob', 64, 4, 'diffuse', 1, 7), ('bob', 96, 8, 'pbr', 3, 8)]

@@ -316,6 +316,26 @@ int nvdr_shade_composite_bwd(const nvdr_tensor *diff, const nvdr_tensor *spec, c
 int nvdr_light_update_pdf(const float *base, int64_t hl, int64_t wl, float *pdf, float *cols, float *rows,
                           void *stream);
 
+/* ---- the parameter update of an iteration in one launch (additive; train.py:439-476: light-gradient scale, torch.optim.Adam
+ * without weight decay / amsgrad, parameter clamps).  Per element: g = grad * grad_scale; Adam with bias correction at step
+ * state[0] + 1; p = max(min(p, hi), max(lo, lo_vec[e % lo_vec_n])).  state: 32 bytes of device memory, 8-byte aligned,
+ * zero-initialised by the caller once (int32 [0] = steps taken, [1] = scratch, then two doubles: beta1^step, beta2^step); the
+ * launch advances it, so it can be replayed from a HIP graph. */
+#define NVDR_ADAM_MAX_TENSORS 8
+typedef struct nvdr_adam_tensor {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t n;              /* elements (all four buffers contiguous f32) */
+    float grad_scale;       /* 1 for none */
+    float lo, hi;           /* -INFINITY / INFINITY for none */
+    const float *lo_vec;    /* optional per-channel lower bounds (device), NULL for none */
+    int64_t lo_vec_n;
+} nvdr_adam_tensor;
+int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps, int *state,
+                   void *stream);
+
 /* ---- test hook: evaluate include/nvdr_detmath.h on device.  op: 0 sin, 1 cos, 2 acos, 3 atan2(x,y). */
 int nvdr_test_detmath(int op, const float *x, const float *y, int64_t n, float *out, void *stream);
 

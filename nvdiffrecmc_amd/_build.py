@@ -25,6 +25,7 @@ SOURCES = [
     'renderutils.hip',
     'light.hip',
     'gbuffer.hip',
+    'optim.hip',
 ]
 
 # -ffp-contract=off: the sampling math must round exactly like the CPU oracle

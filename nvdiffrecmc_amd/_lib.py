@@ -70,6 +70,12 @@ def torch_allocator():
 
 _T = ctypes.POINTER(NvdrTensor)
 
+
+class NvdrAdamTensor(ctypes.Structure):     # include/nvdr_hip.h: nvdr_adam_tensor
+    _fields_ = [('param', c_void_p), ('grad', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p), ('n', c_int64),
+                ('grad_scale', c_float), ('lo', c_float), ('hi', c_float), ('lo_vec', c_void_p), ('lo_vec_n', c_int64)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 _SIGNATURES = {
     'nvdr_last_error': [],
@@ -123,6 +129,7 @@ _SIGNATURES = {
     'nvdr_shade_composite_fwd': [_T] * 4 + [c_int, c_void_p, c_void_p],
     'nvdr_shade_composite_bwd': [_T] * 4 + [c_int, _T] + [c_void_p] * 4 + [c_void_p],
     'nvdr_light_update_pdf': [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    'nvdr_adam_step': [ctypes.POINTER(NvdrAdamTensor), c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p],
     'nvdr_test_detmath': [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
 }
 _RESTYPES = {'nvdr_last_error': ctypes.c_char_p, 'nvdr_image_loss_num_partials': c_int64}

@@ -155,7 +155,11 @@ struct nvdr_ctx {
     uint32_t *live = nullptr;      // stream slots of the rays that need traversal (dead samples left out)
     unsigned *queues = nullptr;    // [256][32] chunk counters of the traversal kernel, one 128-B line each (NVDR_TRACE_QUEUES)
     float4 *pix_origin = nullptr;
-    size_t stream_cap_rays = 0;
+    size_t stream_cap_rays = 0;    // slots of texel / vis / live
+    size_t stream_cap_total = 0;   // slots of rays: the chunk's own + the spare blocks of the light-gradient records
+    uint16_t *lg_tags = nullptr;   // (band, fill) of every block of 128 slots of `rays` (0xFFFF: no records)
+    size_t lg_tags_cap = 0;
+    bool lg_tags_dirty = true;     // the array may hold tags nobody consumed (fresh allocation, a backward pass without gather)
     uint64_t stream_id = 0;        // id of the ray stream currently held in rays/texel/pix_origin/pix_list
     uint64_t stream_seq = 0;
     float *lg_part = nullptr;      // light-gradient partials: [chunks][Hl*Wl*3] of the band gather, or 8 per-XCD copies

@@ -27,7 +27,12 @@
 #include "common.h"
 
 #define DN_BX 32
-#define DN_BY 8
+#ifndef DN_BY
+#define DN_BY 16
+#endif
+#ifndef DN_LDS_KB
+#define DN_LDS_KB 80            // tile + tap table of one workgroup: two workgroups per CU (160 KB of LDS)
+#endif
 #define DN_EPS 0.0001f
 
 struct DnView {
@@ -182,7 +187,15 @@ static int launch_bilateral(const nvdr_tensor *col_or_grad, const nvdr_tensor *c
     const size_t lds_tab = (size_t)(2 * rad + 1) * (2 * rad + 1) * sizeof(float2);
     const size_t lds_tile = (size_t)(DN_BX + 2 * rad) * (DN_BY + 2 * rad) * 2 * sizeof(float4);
     dim3 grid(div_up(W, DN_BX), div_up(H, DN_BY), (unsigned)N);
-    const bool tiled = lds_tile + lds_tab <= 64 * 1024;
+    // beyond 64 KB of dynamic LDS a kernel needs the attribute
+    static bool big_lds = false, big_lds_tried = false;
+    if (!big_lds_tried) {
+        big_lds_tried = true;
+        big_lds = hipFuncSetAttribute((const void *)bilateral_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DN_LDS_KB * 1024) == hipSuccess &&
+                  hipFuncSetAttribute((const void *)bilateral_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DN_LDS_KB * 1024) == hipSuccess;
+        if (!big_lds) (void)hipGetLastError();
+    }
+    const bool tiled = lds_tile + lds_tab <= (size_t)(big_lds ? DN_LDS_KB : 64) * 1024;
     NVDR_REQUIRE(lds_tab <= 64 * 1024, "%s: sigma %g needs a %d-wide window, more than fits", op, (double)sigma, 2 * rad + 1);
     const size_t lds = (tiled ? lds_tile : 0) + lds_tab;
     if (backward) {

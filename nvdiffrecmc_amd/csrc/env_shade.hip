@@ -44,6 +44,10 @@
 #ifndef NVDR_BWD_ROLL
 #define NVDR_BWD_ROLL 1
 #endif
+// measurements only (variants): 1 = no light-gradient records at all, 2 = none + round-robin groups, 3 = unsorted in-place records + round-robin
+#ifndef NVDR_LG_EXPERIMENT
+#define NVDR_LG_EXPERIMENT 0
+#endif
 #ifndef NVDR_GEN_OCC
 #define NVDR_GEN_OCC 4   // 128 VGPRs (14 dwords spilled) instead of 150: 4 waves per SIMD, -3 % time
 #endif
@@ -85,6 +89,9 @@ struct ShadeParams {
     int reuse;                // backward: the forward's stream is still in the context IF the whole launch fitted one chunk
     int lg_records;           // backward: 1 = write (texel, rgb) records for the band gather, 0 = global atomics
     int lg_shift;             // band of a texel = texel >> lg_shift (bands hold a power-of-two number of texels)
+    uint16_t *lg_tags;        // per block of 128 stream slots: band | fill << 8 of the light-gradient records it holds (0xFFFF: none)
+    unsigned lg_spare_base;   // first spare block (behind the chunk's own slots); wavefront w owns lg_spw of them from lg_spare_base + w * lg_spw
+    unsigned lg_spw;
     unsigned *queues;         // chunk counters of the traversal kernel: stages 1 and 3 leave them zeroed for the next stage-2 launch
 };
 
@@ -111,22 +118,43 @@ __device__ __forceinline__ unsigned chunk_pixels(const ShadeParams &p) { return 
 // ---------------------------------------------------------------------------------------------
 // work-list compaction: covered pixels (mask > 0, kernel.cu:478) in raster order per wave
 
-__global__ void compact_pixels_kernel(const float *__restrict__ mask, int64_t ms0, int64_t ms1, int64_t ms2, int N, int H,
-                                      int W, int *__restrict__ list, unsigned *count)
+// A wavefront looks at NVDR_COMPACT_ROUNDS x 64 consecutive pixels and claims list space for all of them with ONE atomic (the
+// counter is a single address: with one claim per 64 pixels the 32 k claims of an 8-view launch serialised into 113 us).
+#define NVDR_COMPACT_ROUNDS 16
+__global__ void __launch_bounds__(256) compact_pixels_kernel(const float *__restrict__ mask, int64_t ms0, int64_t ms1, int64_t ms2, int N, int H,
+                                                             int W, int *__restrict__ list, unsigned *count)
 {
-    const int64_t total = (int64_t)N * H * W;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool on = false;
-    if (i < total) {
-        const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / ((int64_t)W * H));
-        on = mask[z * ms0 + y * ms1 + x * ms2] > 0.0f;
-    }
-    const unsigned long long b = __ballot(on);
+    const unsigned total = (unsigned)(N * H * W);           // < 2^31 (checked by the launcher)
     const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned first = wave * (64u * NVDR_COMPACT_ROUNDS);
+    const bool dense = ms2 == 1 && ms1 == W && ms0 == (int64_t)W * H;
+    unsigned long long bits[NVDR_COMPACT_ROUNDS];
+    unsigned n = 0;
+#pragma unroll
+    for (int k = 0; k < NVDR_COMPACT_ROUNDS; ++k) {
+        const unsigned i = first + k * 64 + lane;
+        bool on = false;
+        if (i < total) {
+            if (dense) {
+                on = mask[i] > 0.0f;
+            } else {
+                const unsigned x = i % (unsigned)W, y = (i / (unsigned)W) % (unsigned)H, z = i / ((unsigned)W * (unsigned)H);
+                on = mask[z * ms0 + y * ms1 + x * ms2] > 0.0f;
+            }
+        }
+        bits[k] = __ballot(on);
+        n += (unsigned)__popcll(bits[k]);
+    }
+    if (n == 0) return;
     unsigned base = 0;
-    if (lane == 0 && b) base = atomicAdd(count, (unsigned)__popcll(b));
-    base = __shfl(base, 0);
-    if (on) list[base + __popcll(b & ((1ull << lane) - 1ull))] = (int)i;
+    if (lane == 0) base = atomicAdd(count, n);
+    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+    for (int k = 0; k < NVDR_COMPACT_ROUNDS; ++k) {
+        if ((bits[k] >> lane) & 1ull) list[base + (unsigned)__popcll(bits[k] & ((1ull << lane) - 1ull))] = (int)(first + k * 64 + lane);
+        base += (unsigned)__popcll(bits[k]);
+    }
 }
 
 // start of an env-shade launch: reset the covered-pixel counter (not when the forward's work list is reused) and the
@@ -506,13 +534,8 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 deadB = (cull && !(dot3(nrm, dirB) > 0.0f)) ? 0x80000000u : 0u;
                 p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(__float_as_uint(pdfA_light + pdfA_bsdf) | deadA));
                 p.rays[rB] = make_float4(dirB.x, dirB.y, dirB.z, __uint_as_float(__float_as_uint(pdfB_light + pdfB_bsdf) | deadB));
-                // texel < 0 marks a slot without light-gradient record (dead here; occluded / zero after the backward pass)
-                p.texel[rA] = deadA ? -1 : tyA * p.light.n1 + txA;
-                p.texel[rB] = deadB ? -1 : tyB * p.light.n1 + txB;
-                // the visibility byte of a dead slot is never written by stage 2; the light-gradient gather reads that byte as
-                // the slot's BAND after the backward pass (255 = no record), so dead slots say so from the start
-                if (deadA) p.vis[rA] = 255;
-                if (deadB) p.vis[rB] = 255;
+                p.texel[rA] = tyA * p.light.n1 + txA;
+                p.texel[rB] = tyB * p.light.n1 + txB;
             }
             // append the live slots to this wavefront's LDS staging buffer (ballot ranks; `staged` is wave-uniform)
             const unsigned long long mA = __ballot(deadA == 0u), mB = __ballot(deadB == 0u);
@@ -570,7 +593,65 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     const bool use_bits = BACKWARD && p.vis_cache != nullptr;    // replay the caller's cached forward bits
     const bool save_bits = !BACKWARD && p.vis_cache != nullptr;
 
-    for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
+    // Work split.  Forward: groups of pixels dealt round-robin.  Backward: every wavefront takes ONE CONTIGUOUS run of groups, so
+    // that the stream slots it has consumed form one growing range -- the space its light-gradient records go to (below).
+    const unsigned wave_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wave));
+    unsigned grp_first = wave_id, grp_last = n_groups, grp_step = waves_total;
+    if (BACKWARD && NVDR_LG_EXPERIMENT != 2 && NVDR_LG_EXPERIMENT != 3) {
+        const unsigned per_wave = (n_groups + waves_total - 1) / waves_total;
+        grp_first = min(wave_id * per_wave, n_groups);
+        grp_last = min(grp_first + per_wave, n_groups);
+        grp_step = 1;
+    }
+    // Light-gradient records, sorted by band as they are written (light_grad_block_kernel reads them).  A record = (rgb addend, texel);
+    // records of one band are packed into BLOCKS of 128 stream slots, and a block is tagged with (band, fill) once it is complete.
+    // Where the blocks come from: the ray stream itself.  The rays of a group are dead once this wavefront has read them, and a
+    // group emits at most as many records as it has slots, so the wavefront carves blocks out of the range it has already consumed
+    // (free_ptr .. free_end); until enough is consumed -- the first group, the up to n_bands blocks that are open at any time, the
+    // alignment of the range to 128 slots -- it draws on lg_spw spare blocks of its own behind the chunk.  Per-band state lives in
+    // the lanes of two registers (lane b: next slot to write / slots left in the open block of band b).
+    const unsigned gs = (unsigned)G * 2u * S;                           // stream slots of one group
+    unsigned free_ptr = (grp_first * gs + 127u) & ~127u, free_end = grp_first * gs;
+    unsigned spare_next = p.lg_spare_base + wave_id * p.lg_spw;
+    unsigned bpos = 0xFFFFFFFFu, bleft = 0u;
+    // both samples of the lanes' strata at once (A: light-sampled, B: BSDF-sampled): one pass over the bands present in either
+    auto emit_records = [&](bool hasA, const float4 &recA, bool hasB, const float4 &recB) {      // called in converged control flow
+        const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : -1;
+        const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : -1;
+        unsigned long long remA = __ballot(hasA), remB = __ballot(hasB);
+        while (remA | remB) {
+            // the band of the first record still to place
+            const int b = remA ? __builtin_amdgcn_readlane(bandA, __builtin_ctzll(remA)) : __builtin_amdgcn_readlane(bandB, __builtin_ctzll(remB));
+            const unsigned long long mA = __ballot(bandA == b), mB = __ballot(bandB == b);
+            remA &= ~mA;
+            remB &= ~mB;
+            const unsigned nA = (unsigned)__popcll(mA), cnt = nA + (unsigned)__popcll(mB);
+            const unsigned at_slot = (unsigned)__builtin_amdgcn_readlane((int)bpos, b), left = (unsigned)__builtin_amdgcn_readlane((int)bleft, b);
+            unsigned fresh = 0u;
+            if (cnt > left) {                                           // the open block fills up: `left` records complete it, the rest open a new one
+                unsigned blk;
+                if (free_ptr + 128u <= free_end) { blk = free_ptr >> 7; free_ptr += 128u; }
+                else blk = spare_next++;
+                fresh = blk << 7;
+                if (at_slot != 0xFFFFFFFFu && lane == 0) p.lg_tags[(at_slot + left - 1u) >> 7] = (uint16_t)((unsigned)b | (128u << 8));
+            }
+            const unsigned to_fresh = fresh - left;                     // (wraps; only used by ranks >= left)
+            if (bandA == b) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recA;
+            }
+            if (bandB == b) {
+                const unsigned rank = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recB;
+            }
+            const unsigned at2 = cnt > left ? fresh + (cnt - left) : at_slot + cnt;
+            const unsigned left2 = cnt > left ? 128u - (cnt - left) : left - cnt;
+            bpos = lane == b ? at2 : bpos;
+            bleft = lane == b ? left2 : bleft;
+        }
+    };
+
+    for (unsigned grp = grp_first; grp < grp_last; grp += grp_step) {
         const unsigned pi = grp * G + slot;
         const bool valid = pi < P;
         const int lin = p.pix_list[p.pix_begin + (valid ? pi : 0u)];
@@ -627,40 +708,23 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     }
                 }
             }
-            if (!active) continue;
-            F3 lg_add[2] = {f3(0.0f), f3(0.0f)};
-            int lg_at[2] = {0, 0};
-            // light-gradient addend of one sample: a record for the band gather, or (fallback) three global atomics
-            auto emit_light_grad = [&](int r, F3 lg, int at) {
-                // adding +-0 never changes an accumulator that started at +0: occluded and dead samples are skipped
-                const bool nz = lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f;
-                if (p.lg_records) {
-                    // Band gather (light_grad_band_kernel): the addend REPLACES the sample's ray in the stream -- this
-                    // lane read it above and nobody needs it again -- and a slot without addend gets texel -1.
-                    // No atomic leaves the workgroup: 21 M addends per 8-view launch were 63 M memory-side fp32 atomics.
-                    // and its visibility byte -- consumed above as well -- becomes the record's BAND (255: no record), the
-                    // one-byte key the gather scans: 8 bands x 58 MB instead of 8 x 233 MB of 4-byte texel keys (round 2)
-                    const int64_t ri = r == 0 ? rA : rB;
-                    if (nz) {
-                        p.rays[ri] = make_float4(lg.x, lg.y, lg.z, __int_as_float(at));     // the record carries its texel
-                        p.vis[ri] = (uint8_t)(at >> p.lg_shift);
-                    } else {
-                        p.vis[ri] = 255;
-                    }
-                } else if (nz) {
-                    float *g = xcd_light + (int64_t)at * 3;
-                    __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            // (no `continue` for lanes without a sample: the record placement below votes across the whole wavefront)
+            // light-gradient addend of one sample, atomics mode (the fallback): three global atomics
+            auto emit_light_grad = [&](F3 lg, int at) {
+                float *g = xcd_light + (int64_t)at * 3;
+                __hip_atomic_fetch_add(g + 0, lg.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(g + 1, lg.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(g + 2, lg.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
+            float4 lg_recA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), lg_recB = lg_recA;
+            bool lg_hasA = false, lg_hasB = false;
 #if NVDR_BWD_ROLL
 #pragma unroll 1
 #else
 #pragma unroll
 #endif
             for (int r = 0; r < 2; ++r) {
-                if ((dead >> r) & 1u) continue;         // contributes exactly zero to every output
+              if (!((dead >> r) & 1u)) {                // a dead sample contributes exactly zero to every output
                 const int64_t ri = r == 0 ? rA : rB;
                 const float4 rd = r == 0 ? rdA : rdB;
                 const int texel = p.texel[ri];
@@ -685,12 +749,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     // issuing the zero addends.  The atomics of both samples are issued together after the loop over r
                     // (no effect on time, but it keeps them out of the way of the second sample's loads).
                     const int at = (p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel;   // bit 4: contention experiment
-#if NVDR_BWD_ROLL
-                    if (!(p.debug & 2u)) emit_light_grad(r, lg, at);
-#else
-                    lg_add[r] = lg;
-                    lg_at[r] = at;
-#endif
+                    // adding +-0 never changes an accumulator that started at +0: occluded samples leave no addend
+                    const bool lg_has = !(p.debug & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
+                    if (r == 0) { lg_hasA = lg_has; lg_recA = make_float4(lg.x, lg.y, lg.z, __int_as_float(at)); }
+                    else { lg_hasB = lg_has; lg_recB = make_float4(lg.x, lg.y, lg.z, __int_as_float(at)); }
+                    if (lg_has && !p.lg_records) emit_light_grad(lg, at);
                     const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
                     const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
                     if (p.bsdf == 1 || p.bsdf == 2) {
@@ -703,17 +766,20 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     diffAccum += (((_diff * light_col) * V) * mis_weight) * sample_frac;
                     specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
                 }
+              }
             }
-#if !NVDR_BWD_ROLL
-            if (BACKWARD && !(p.debug & 2u)) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    if (!((dead >> r) & 1u)) emit_light_grad(r, lg_add[r], lg_at[r]);      // dead: stage 1 already wrote texel -1
+            // No atomic leaves the workgroup in records mode (21 M addends per 8-view launch were 63 M memory-side fp32 atomics):
+            // the addends of this round go to the band blocks, light-sampled ones first, in lane order
+#if NVDR_LG_EXPERIMENT == 0
+            if (BACKWARD && p.lg_records) emit_records(lg_hasA, lg_recA, lg_hasB, lg_recB);
+#elif NVDR_LG_EXPERIMENT == 3           // records written in place, unsorted (what the shading kernel cost before the band blocks)
+            if (BACKWARD && p.lg_records) {
+                if (lg_hasA) p.rays[rA] = lg_recA;
+                if (lg_hasB) p.rays[rB] = lg_recB;
             }
-#else
-            (void)lg_add; (void)lg_at;
 #endif
         }
+        if (BACKWARD) free_end = (grp + 1u) * gs;       // the rays of this group have all been read: its slots may hold records now
 
         if (!BACKWARD) {
             diffAccum = group_sum3(diffAccum, L);
@@ -741,139 +807,131 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             }
         }
     }
+    // the blocks still open when the wavefront runs out of pixels: lane b tags the one of band b with its fill
+    if (BACKWARD && p.lg_records && bpos != 0xFFFFFFFFu)
+        p.lg_tags[(bpos + bleft - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - bleft) << 8));
 }
 
 // ---------------------------------------------------------------------------------------------
-// light gradient (eval_light_bwd, kernel.cu:203-211) without global atomics: BAND GATHER.
+// light gradient (eval_light_bwd, kernel.cu:203-211) without global atomics: BAND-SORTED RECORD BLOCKS + LDS GATHER.
 //
 // The reference adds every sample's addend to light_grad[texel] with three atomicAdds.  On MI355X fp32 atomics are
 // executed at the memory side (rocprofv3, round 1: one 64-byte fabric write per atomic, 63 M of them per 8-view launch,
-// WRITE_SIZE 3.75 GB against 0.5 GB of algorithmic addends) -- a third of the backward shading kernel's time.  Here the
-// backward kernel leaves a (texel, rgb) RECORD per non-zero addend in the ray stream (the rgb overwrites the ray the lane
-// has just consumed; texel = -1 marks slots without addend) and this kernel reduces the records by key:
+// WRITE_SIZE 3.75 GB against 0.5 GB of algorithmic addends) -- a third of the backward shading kernel's time.  Here:
 //   * the probe is cut into `n_bands` bands of consecutive texels whose fp32 accumulators (band_texels * 12 B) fit the LDS
 //     of one workgroup (96 KB -> 8 bands at 256x256);
-//   * workgroup (g, band) scans the g-th slice of the one-byte BAND keys (coalesced 16-byte loads = 16 slots; the byte is the
-//     slot's old visibility flag, rewritten by the backward shading kernel) and fetches the 16-byte record (rgb + texel) only of
-//     keys of its band, adding it into LDS with ds_add_f32 (hot sun texels serialise inside the LDS atomic unit, not on the fabric);
+//   * the backward shading kernel writes a 16-byte RECORD (rgb, texel) per non-zero addend, and it writes the records SORTED BY
+//     BAND: every wavefront keeps one open block of 128 stream slots per band (carved out of the part of the ray stream it has
+//     already consumed) and tags a block with (band, fill) when it is complete -- env_shade_kernel<true>, emit_records;
+//   * workgroup (g, band) of this kernel walks the tag array (2 B per 128 slots), reads the blocks of its band as plain
+//     coalesced 2 KB loads -- every lane a record, every fetched byte used -- and adds them into LDS with ds_add_f32 (hot sun
+//     texels serialise inside the LDS atomic unit, not on the fabric); it leaves the tags it consumed reset to 0xFFFF;
 //   * it then writes its band as ONE plain partial row; light_grad_reduce_kernel sums the partial rows.
-// Cost model per 8-view launch (58 M slots, 21 M records): keys 8 bands x 58 MB = 0.47 GB, texels + records 21 M x (4 + 16) B =
-// 0.42 GB, partials 25 MB.  (Round 2 scanned the 4-byte texel keys: 8 x 233 MB, counter-measured 3.4 GB per launch, 1.31 ms.)
+// History (8-view launch, 58 M slots, 21 M records): round 2 kept the records in place, one per slot, and every band scanned a 4-byte
+// key per slot: 1.31 ms.  Round 3 first shrank the keys to one byte and batched the fetches: still 1.26 ms -- 0.70 ms of it were
+// record fetches at cache-line granularity (a line held records of ~2.5 bands and was fetched by each of them: 2.3 GB for 0.34 GB
+// of records) and 0.55 ms LDS atomics issued from loops with 40 % of the lanes active (profiles/r03_gather_elimination.md).
+// Sorting at the source removes both: 0.34 GB of block reads, all lanes busy.
 
 #define NVDR_LG_THREADS 1024
-#ifndef NVDR_LG_TEST
-#define NVDR_LG_TEST 0          // experiments (variants only): 1 no LDS atomics, 2 key scan only, 3 zero + copy-out only
+#ifndef NVDR_LG_NATIVE_ATOMICS
+#define NVDR_LG_NATIVE_ATOMICS 0        // 1: ds_add_f32 (A/B only)
 #endif
 
-__global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_band_kernel(const uint8_t *__restrict__ band_of, const float4 *__restrict__ recs, const unsigned *__restrict__ pix_count,
-                                                                          unsigned pix_begin, unsigned pix_cap, unsigned rays_per_pixel,
-                                                                          int band_texels, int n_texels, float *__restrict__ partials)
+__global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint16_t *__restrict__ tags, const float4 *__restrict__ recs,
+                                                                           const unsigned *__restrict__ pix_count, unsigned pix_begin, unsigned pix_cap,
+                                                                           unsigned pixels_per_group, unsigned group_slots, unsigned spare_base,
+                                                                           unsigned spare_blocks, int band_texels, int n_bands, int n_texels,
+                                                                           float *__restrict__ partials)
 {
     extern __shared__ __attribute__((aligned(16))) float lg_acc[];
     const unsigned Ptot = *pix_count;
     if (Ptot <= pix_begin) return;                          // empty chunk (light_grad_reduce_kernel makes the same test)
     const unsigned P = chunk_span(Ptot, pix_begin, pix_cap);
-    const int g = blockIdx.x, G = gridDim.x, band = blockIdx.y;
-    const int t_lo = band * band_texels, t_hi = min(t_lo + band_texels, n_texels);
-    const int n_acc = (t_hi - t_lo) * 3;
-    for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) lg_acc[i] = 0.0f;
-    __syncthreads();
-    const unsigned total = P * rays_per_pixel;              // < 2^31 by the chunk size
-    const unsigned n16 = (total + 15u) >> 4;
-    const unsigned per = (n16 + G - 1) / G;
-    const unsigned b16 = g * per, e16 = min(b16 + per, n16);
-    const uint4 *__restrict__ keys = (const uint4 *)band_of;   // 16 one-byte keys per load; the allocation is padded to a multiple of 16
-    const unsigned want = (unsigned)band * 0x01010101u;
-    // A lane walks 16 CONSECUTIVE slots: ONE round of predicated 16-byte record loads for the slots whose key byte names this band
-    // (the record carries its texel in .w, so there is no second dependent fetch), the next iteration's keys already in flight,
-    // then the additions.  The kernel is bound by the LATENCY of dependent memory stages, not by traffic: the first versions
-    // fetched texel and then record slot by slot inside one divergent branch per slot (32 dependent round trips per 16 slots,
-    // almost every branch taken by SOME lane of the wavefront): 1.3-1.5 ms per 8-view launch whatever the key traffic was.
-    // Neighbouring slots are neighbouring cells of the CDF grid (stage 1 orders a pixel's samples by stratum): where the probe has
-    // a sun, consecutive records hit the SAME texel, so runs of equal texels are summed in registers and leave the lane as one
-    // atomic triple.
-    unsigned q = b16 + threadIdx.x;
-    uint4 k16 = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-    if (q < e16) k16 = keys[q];
-    auto add_run = [&](int t_, float x_, float y_, float z_) {
-#if NVDR_LG_TEST >= 1
-        if (x_ != 12345.678f) return;               // experiment: no LDS atomics
+    // Work split: workgroup g owns the g-th SLICE of the block list and walks it once per band (the tags of a slice are a few KB).
+    // Every band costs every workgroup the same, however unevenly the records are spread over the bands -- with one set of
+    // workgroups per band (the first version) the equatorial bands of a lat-long probe kept their 32 CUs busy four times longer than
+    // the polar ones kept theirs.
+    const int g = blockIdx.x, G = gridDim.x;
+    // blocks that may hold records: the chunk's own slots (whole groups of pixels) and the wavefronts' spare blocks behind them
+    const unsigned n_groups = (P + pixels_per_group - 1u) / pixels_per_group;
+    const unsigned n_own = (n_groups * group_slots + 127u) >> 7;
+    const unsigned n_all = n_own + spare_blocks;
+    const unsigned per = (n_all + (unsigned)G - 1u) / (unsigned)G;
+    const unsigned v_lo = min((unsigned)g * per, n_all), v_hi = min(v_lo + per, n_all);
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const float4 none = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    for (int band = 0; band < n_bands; ++band) {
+        const int t_lo = band * band_texels, t_hi = min(t_lo + band_texels, n_texels);
+        const int n_acc = (t_hi - t_lo) * 3;
+        for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) lg_acc[i] = 0.0f;
+        __syncthreads();
+        // fp32 add to LDS.  NOT ds_add_f32: gfx950 executes that at 0.8 lane-operations per CU and nanosecond, twenty times slower
+        // than its integer LDS atomics (tools/ubench/lds_atomic.hip, profiles/r03_lds_atomic_ubench.txt) -- it was 0.55 ms of the
+        // 1.26 ms of this gather.  A compare-and-swap loop on the bit pattern runs at the integer rate; a lane repeats only when
+        // another lane hit the same word in between.
+        auto add = [&](const float4 &r) {
+            const int t = __float_as_int(r.w);
+            if (t >= t_lo && t < t_hi) {
+#if NVDR_LG_NATIVE_ATOMICS
+                float *a = lg_acc + (t - t_lo) * 3;
+                __hip_atomic_fetch_add(a + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(a + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+                unsigned *a = (unsigned *)lg_acc + (t - t_lo) * 3;
+                unsigned o0 = __hip_atomic_load(a + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned o1 = __hip_atomic_load(a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned o2 = __hip_atomic_load(a + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                bool d0 = false, d1 = false, d2 = false;
+                do {
+                    if (!d0) d0 = __hip_atomic_compare_exchange_strong(a + 0, &o0, __float_as_uint(__uint_as_float(o0) + r.x), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!d1) d1 = __hip_atomic_compare_exchange_strong(a + 1, &o1, __float_as_uint(__uint_as_float(o1) + r.y), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!d2) d2 = __hip_atomic_compare_exchange_strong(a + 2, &o2, __float_as_uint(__uint_as_float(o2) + r.z), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } while (!(d0 && d1 && d2));
 #endif
-        float *a = lg_acc + (t_ - t_lo) * 3;
-        __hip_atomic_fetch_add(a + 0, x_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(a + 1, y_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(a + 2, z_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-#if NVDR_LG_TEST >= 3
-    q = e16;                                        // experiment: zero + copy-out only
-#endif
-    while (q < e16) {
-        const unsigned kw[4] = {k16.x, k16.y, k16.z, k16.w};
-        const unsigned qn = q + NVDR_LG_THREADS;
-        if (qn < e16) k16 = keys[qn];                                           // prefetch
-        // 16-bit mask of the slots whose key byte names this band: exact per-byte zero test of (key ^ band) -- the 7-bit add
-        // cannot carry across bytes -- and a multiply that gathers the four flag bits of a word
-        unsigned mask = 0u;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const unsigned x = kw[w] ^ want;
-            const unsigned nz = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;          // bit 7 of every byte: the byte is non-zero
-            const unsigned z = (~nz & 0x80808080u) >> 7;                        // bits 0, 8, 16, 24: the byte is zero
-            mask |= (((z * 0x00204081u) >> 21) & 0xfu) << (4 * w);
-        }
-        const unsigned left = total - 16u * q;                                  // slots of this group that exist (>= 1)
-        if (left < 16u) mask &= (1u << left) - 1u;
-#if NVDR_LG_TEST >= 2
-        mask &= (q == 0xffffffffu) ? 0xffffu : 0u;  // experiment: key scan only (no record fetched)
-#endif
-        // Only ~4.5 % of the slots belong to one band: a lane holds 0.7 of them on average.  The first FOUR are fetched together
-        // (predicated, all in flight at once), a fifth and later one -- one group in a thousand -- by the slow loop below.
-        // (A version with 16 predicated fetches, one per slot position, executed ~560 VALU + ~300 scalar instructions per group
-        // of 16 slots whether a slot matched or not: rocprofv3 counters of round 3, 1.2-1.3 ms per 8-view launch.)
-        int sj[4];
-        float4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sj[k] = mask ? __builtin_ctz(mask) : -1;
-            mask &= mask - 1u;
-            v[k] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-            if (sj[k] >= 0) v[k] = recs[16u * q + (unsigned)sj[k]];
-        }
-        // runs of equal texels (neighbouring slots are neighbouring cells of the CDF grid: under a sun they share the texel) are
-        // summed in registers; the additions to LDS happen in converged code, three atomic instructions per run level
-        int bt[4] = {-1, -1, -1, -1};
-        float bx[4] = {0.0f, 0.0f, 0.0f, 0.0f}, by[4] = {0.0f, 0.0f, 0.0f, 0.0f}, bz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int n_runs = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = __float_as_int(v[k].w);
-            if (!(sj[k] >= 0 && t >= t_lo && t < t_hi)) continue;               // (a stale byte of a slot nobody wrote in this launch)
-            bool merged = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r == n_runs - 1 && bt[r] == t) { bx[r] += v[k].x; by[r] += v[k].y; bz[r] += v[k].z; merged = true; }
-            if (!merged) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r == n_runs) { bt[r] = t; bx[r] = v[k].x; by[r] = v[k].y; bz[r] = v[k].z; }
-                n_runs++;
+            }
+        };
+        for (unsigned v0 = v_lo + wave * 64u; v0 < v_hi; v0 += NVDR_LG_THREADS) {
+            const unsigned v = v0 + lane;
+            unsigned blk = 0u, tag = 0xFFFFu;
+            if (v < v_hi) {
+                blk = v < n_own ? v : spare_base + (v - n_own);
+                tag = tags[blk];
+            }
+            const bool mine = tag != 0xFFFFu && (tag & 0xFFu) == (unsigned)band;
+            unsigned long long m = __ballot(mine);
+            if (mine) tags[blk] = 0xFFFFu;                  // consumed: the array reads "no records" again for the next launch
+            // one block per step, the next block's two loads in flight while this one's records are added
+            float4 c0 = none, c1 = none;
+            if (m) {
+                const int j = __builtin_ctzll(m);
+                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)blk, j), f = (unsigned)__builtin_amdgcn_readlane((int)tag, j) >> 8;
+                if (lane < f) c0 = recs[(b << 7) + lane];
+                if (lane + 64u < f) c1 = recs[(b << 7) + 64u + lane];
+                m &= m - 1ull;
+            }
+            for (;;) {
+                float4 n0 = none, n1 = none;
+                const bool more = m != 0ull;
+                if (more) {
+                    const int j = __builtin_ctzll(m);
+                    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)blk, j), f = (unsigned)__builtin_amdgcn_readlane((int)tag, j) >> 8;
+                    if (lane < f) n0 = recs[(b << 7) + lane];
+                    if (lane + 64u < f) n1 = recs[(b << 7) + 64u + lane];
+                    m &= m - 1ull;
+                }
+                add(c0);
+                add(c1);
+                if (!more) break;
+                c0 = n0; c1 = n1;
             }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (bt[k] >= 0) add_run(bt[k], bx[k], by[k], bz[k]);
-        while (mask) {                                                          // more than four matches in 16 slots: rare
-            const int j = __builtin_ctz(mask);
-            mask &= mask - 1u;
-            const float4 r = recs[16u * q + (unsigned)j];
-            const int t = __float_as_int(r.w);
-            if (t >= t_lo && t < t_hi) add_run(t, r.x, r.y, r.z);
-        }
-        q = qn;
+        __syncthreads();
+        float *out = partials + (int64_t)g * n_texels * 3 + (int64_t)t_lo * 3;
+        for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) out[i] = lg_acc[i];
+        __syncthreads();
     }
-    __syncthreads();
-    float *out = partials + (int64_t)g * n_texels * 3 + (int64_t)t_lo * 3;
-    for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) out[i] = lg_acc[i];
 }
 
 // light_grad (+)= sum over the `rows` partial rows (band gather: one row per slice of the key array; atomics mode: the 8
@@ -884,8 +942,17 @@ __global__ void __launch_bounds__(256) light_grad_reduce_kernel(const float *__r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float acc = 0.0f;
-    if (pix_count == nullptr || *pix_count > pix_begin)
-        for (int k = 0; k < rows; ++k) acc += parts[(int64_t)k * n + i];
+    if (pix_count == nullptr || *pix_count > pix_begin) {
+        int k = 0;
+        for (; k + 8 <= rows; k += 8) {                 // eight loads in flight (the gather leaves one row per CU)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = parts[(int64_t)(k + j) * n + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; k < rows; ++k) acc += parts[(int64_t)k * n + i];
+    }
     if (accumulate) out[i] += acc;
     else out[i] = acc;
 }
@@ -990,10 +1057,12 @@ static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t s
 // walks the compacted pixel list chunk by chunk: gen -> trace -> shade per chunk.  The host never learns the covered
 // count (no synchronisation): it issues ceil(N*H*W / cap) chunks and the ones behind the device-side count are empty
 // launches (~4 us each).  Slot numbers are chunk-local, so the 31-bit limit applies to cap * 2S only.
-static int64_t stream_chunk_pixels(const nvdr_ctx *c, int64_t npix, unsigned S)
+static int64_t stream_chunk_pixels(const nvdr_ctx *c, int64_t npix, unsigned S, int64_t spare_bytes)
 {
     const int64_t per_pixel = (int64_t)2 * S * (16 + 4 + 1 + 4) + 16;
-    int64_t cap = c->stream_budget / per_pixel;
+    // the spare blocks of the light-gradient records come out of the same budget (unless that would halve it)
+    const int64_t budget = c->stream_budget > 2 * spare_bytes ? c->stream_budget - spare_bytes : c->stream_budget;
+    int64_t cap = budget / per_pixel;
     const int64_t lim31 = ((1ll << 31) - 64) / (2ll * S);          // chunk-local slot numbers stay below 2^31
     if (cap > lim31) cap = lim31;
     const int64_t min_cap = (npix + NVDR_MAX_CHUNKS - 1) / NVDR_MAX_CHUNKS;
@@ -1003,10 +1072,22 @@ static int64_t stream_chunk_pixels(const nvdr_ctx *c, int64_t npix, unsigned S)
     return cap;
 }
 
-static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, unsigned S, hipStream_t stream)
+// `own_slots`: the chunk's stream slots (whole groups of pixels, rounded up to blocks of 128); `spare_slots`: the spare blocks of the
+// backward shading kernel's wavefronts behind them (light-gradient records, see env_shade_kernel<true>) -- only the 16-byte `rays`
+// array has them
+static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, size_t own_slots, size_t spare_slots, hipStream_t stream)
 {
-    const size_t rays = ((size_t)cap * 2 * S + 15) & ~(size_t)15;   // the band gather reads 16 one-byte keys per load
-    if (c->stream_cap_rays >= rays && c->pix_cap >= npix && c->stream_cap_pixels >= cap) return 0;
+    const size_t rays = own_slots;
+    const size_t n_tags = (own_slots + spare_slots) >> 7;
+    if (c->lg_tags_cap < n_tags) {
+        NVDR_HIP_TRY(hipStreamSynchronize(stream));
+        ctx_free(c, c->lg_tags);
+        c->lg_tags_cap = 0;
+        NVDR_HIP_TRY(ctx_malloc(c, &c->lg_tags, sizeof(uint16_t) * n_tags, stream));
+        c->lg_tags_cap = n_tags;
+        c->lg_tags_dirty = true;
+    }
+    if (c->stream_cap_rays >= rays && c->stream_cap_total >= rays + spare_slots && c->pix_cap >= npix && c->stream_cap_pixels >= cap) return 0;
     NVDR_HIP_TRY(hipStreamSynchronize(stream));
     if (c->pix_cap < npix) {
         ctx_free(c, c->pix_list);
@@ -1021,16 +1102,20 @@ static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, unsigned S, hi
         c->stream_cap_pixels = cap;
     }
     if (c->stream_cap_rays < rays) {
-        ctx_free(c, c->rays);
         ctx_free(c, c->texel);
         ctx_free(c, c->vis);
         ctx_free(c, c->live);
         c->stream_cap_rays = 0;
-        NVDR_HIP_TRY(ctx_malloc(c, &c->rays, sizeof(float4) * rays, stream));
         NVDR_HIP_TRY(ctx_malloc(c, &c->texel, sizeof(int) * rays, stream));
         NVDR_HIP_TRY(ctx_malloc(c, &c->vis, rays, stream));
         NVDR_HIP_TRY(ctx_malloc(c, &c->live, sizeof(uint32_t) * rays, stream));
         c->stream_cap_rays = rays;
+    }
+    if (c->stream_cap_total < rays + spare_slots) {
+        ctx_free(c, c->rays);
+        c->stream_cap_total = 0;
+        NVDR_HIP_TRY(ctx_malloc(c, &c->rays, sizeof(float4) * (rays + spare_slots), stream));
+        c->stream_cap_total = rays + spare_slots;
     }
     c->stream_id = 0;
     return 0;
@@ -1047,7 +1132,7 @@ static size_t lg_lds_budget()
     if (kb > 160) kb = 160;
     size_t want = kb * 1024;
     if (want > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)light_grad_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+        hipFuncSetAttribute((const void *)light_grad_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
         (void)hipGetLastError();
         want = 64 * 1024;
     }
@@ -1081,7 +1166,39 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
                  "env_shade: pdf/rows/cols shapes disagree");
     const int64_t npix = N * H * W;
     NVDR_HIP_TRY(hipSetDevice(c->device));
-    const int64_t cap = stream_chunk_pixels(c, npix, S);
+    int L = 1, lg = 0;
+    while (L < (int)S && L < 64) { L <<= 1; lg++; }
+    const int G = 64 / L;                                       // pixels per wavefront round (a "group")
+    const int64_t group_slots = (int64_t)G * 2 * S;
+    const int *per_cu = c->per_cu;   // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading): {8, 6, 6},
+                                     // measured within 3 % of the best for each kernel; NVDR_PBLOCKS="g,f,b" is read once per context
+    const int waves_per_block = 4;
+
+    // Light gradient: records + LDS gather when the probe's accumulators fit <= 16 LDS bands (and a group of pixels <= 16 blocks of
+    // 128 slots: n_samples_x <= 32), memory-side atomics otherwise.  Decided the same way by the forward and the backward launch: the
+    // forward already reserves the spare blocks the backward shading kernel's wavefronts will need (a reallocation in between
+    // would lose the forward's stream).
+    const int n_texels = (int)(a->light.size[0] * a->light.size[1]);
+    int n_bands = 0, band_texels = 0, lg_rows = 8, lg_shift = 0, lg_records = 0;
+    size_t lg_lds = 0;
+    {
+        const size_t lds_budget = lg_lds_budget();
+        // a band = the largest power-of-two number of texels whose fp32 accumulators fit the LDS budget (band = texel >> shift)
+        while ((size_t)(2 << lg_shift) * 12 <= lds_budget) ++lg_shift;
+        band_texels = 1 << lg_shift;
+        n_bands = (n_texels + band_texels - 1) / band_texels;
+        lg_records = (n_bands <= 16 && group_slots <= 16 * 128 && !(c->debug & 16u)) ? 1 : 0;
+        if (lg_records) {
+            if (band_texels > n_texels) band_texels = n_texels;
+            lg_lds = (size_t)band_texels * 12;
+            lg_rows = c->n_cus;             // one gather workgroup per CU (its accumulators take most of the CU's LDS)
+        }
+    }
+    // spare blocks per wavefront of the backward shading kernel: one open block per band + the records of the first group (nothing
+    // consumed yet) + the alignment of its range to 128 slots + the round in flight (env_shade_kernel<true>)
+    const unsigned lg_spw = lg_records ? (unsigned)(n_bands + (group_slots + 127) / 128 + 2) : 0u;
+    const int64_t bwd_waves_max = (int64_t)c->n_cus * (per_cu[2] < 1 ? 1 : per_cu[2]) * waves_per_block;
+    const int64_t cap = stream_chunk_pixels(c, npix, S, bwd_waves_max * lg_spw * 128 * 16);
     const int n_chunks = (int)((npix + cap - 1) / cap);
     // the chunk is raised to npix / NVDR_MAX_CHUNKS when the byte budget asks for more chunks than that; chunk-local slot numbers
     // must still fit 31 bits (they are stored as unsigned / int in the live list, the light-gradient keys and the band gather)
@@ -1106,33 +1223,14 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     p.bsdf = a->bsdf; p.n = a->n_samples_x; p.S = S; p.seed = a->rnd_seed; p.pix_offset = a->pixel_index_offset;
     p.shadow_scale = a->shadow_scale;
     p.seed_dev = a->rnd_seed_offset;
-    int L = 1, lg = 0;
-    while (L < (int)S && L < 64) { L <<= 1; lg++; }
     p.L = L; p.log2L = lg;
     p.vis_cache = a->vis_cache;
     p.vis_words = (int)((S + 31) / 32);
     p.debug = c->debug;
     p.pix_cap = (unsigned)cap;
 
-    // light gradient: band gather when the probe's accumulators fit <= 16 LDS bands, memory-side atomics otherwise
-    const int n_texels = (int)(a->light.size[0] * a->light.size[1]);
-    int n_bands = 0, band_texels = 0, lg_rows = 8;
-    size_t lg_lds = 0;
-    if (backward) {
-        const size_t lds_budget = lg_lds_budget();
-        // a band = the largest power-of-two number of texels whose fp32 accumulators fit the LDS budget (band = texel >> shift)
-        int shift = 0;
-        while ((size_t)(2 << shift) * 12 <= lds_budget) ++shift;
-        band_texels = 1 << shift;
-        n_bands = (n_texels + band_texels - 1) / band_texels;
-        p.lg_records = (n_bands <= 16 && !(c->debug & 16u)) ? 1 : 0;
-        p.lg_shift = shift;
-        if (p.lg_records) {
-            if (band_texels > n_texels) band_texels = n_texels;
-            lg_lds = (size_t)band_texels * 12;
-            lg_rows = c->n_cus / n_bands < 1 ? 1 : c->n_cus / n_bands;
-        }
-    }
+    p.lg_records = backward ? lg_records : 0;
+    p.lg_shift = lg_shift;
 
     if (!backward) {
         NVDR_REQUIRE(a->diff && a->spec, "env_shade_fwd: NULL output");
@@ -1174,7 +1272,24 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             if (c->debug & 2u) NVDR_HIP_TRY(hipMemsetAsync(p.g_light, 0, sizeof(float) * p.light_elems, stream));
         }
     }
-    if ((r = reserve_stream(c, npix, cap, S, stream))) return r;
+    // persistent grids (the covered-pixel count lives on the device)
+    const int64_t max_groups = (cap + G - 1) / G;
+    int64_t pb[3];
+    for (int k = 0; k < 3; ++k) {
+        pb[k] = (int64_t)c->n_cus * (per_cu[k] < 1 ? 1 : per_cu[k]);
+        if (pb[k] * waves_per_block > max_groups) pb[k] = (max_groups + waves_per_block - 1) / waves_per_block;
+        if (pb[k] < 1) pb[k] = 1;
+    }
+    const size_t own_slots = ((size_t)max_groups * group_slots + 127) & ~(size_t)127;
+    const size_t spare_blocks = (size_t)pb[2] * waves_per_block * lg_spw;
+    if ((r = reserve_stream(c, npix, cap, own_slots, spare_blocks * 128, stream))) return r;
+    p.lg_tags = c->lg_tags;
+    p.lg_spare_base = (unsigned)(own_slots >> 7);
+    p.lg_spw = lg_spw;
+    if (backward && lg_records) {
+        if (c->lg_tags_dirty) NVDR_HIP_TRY(hipMemsetAsync(c->lg_tags, 0xFF, sizeof(uint16_t) * c->lg_tags_cap, stream));
+        c->lg_tags_dirty = true;        // until the gather of the last chunk has been enqueued
+    }
     p.pix_list = c->pix_list;
     p.pix_count = &c->dinfo->pix_count;
     p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.vis = c->vis;
@@ -1184,18 +1299,6 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     // backward pass of a forward launch whose work list (and, if it fitted one chunk, ray stream) is still in the context
     const bool reuse = backward && a->reuse_stream_id != 0 && a->reuse_stream_id == c->stream_id;
     p.reuse = reuse ? 1 : 0;
-    // persistent grids (the covered-pixel count lives on the device)
-    const int waves_per_block = 4;
-    const int64_t max_groups = (cap + (64 / L) - 1) / (64 / L);
-    // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading); NVDR_PBLOCKS="g,f,b"
-    // overrides them for tuning
-    const int *per_cu = c->per_cu;   // {8, 6, 6}: measured within 3 % of the best for each kernel; NVDR_PBLOCKS is read once per context
-    int64_t pb[3];
-    for (int k = 0; k < 3; ++k) {
-        pb[k] = (int64_t)c->n_cus * (per_cu[k] < 1 ? 1 : per_cu[k]);
-        if (pb[k] * waves_per_block > max_groups) pb[k] = (max_groups + waves_per_block - 1) / waves_per_block;
-        if (pb[k] < 1) pb[k] = 1;
-    }
 #ifndef NVDR_TRACE_BLOCKS_PER_CU
 #define NVDR_TRACE_BLOCKS_PER_CU 8
 #endif
@@ -1212,7 +1315,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     c->stream_id = 0; // invalid while being rewritten
     begin_launch_kernel<<<1, 256, 0, stream>>>(&c->dinfo->pix_count, c->chunk_counts, n_chunks, p.reuse, p.pix_cap);
     if (!reuse)
-        compact_pixels_kernel<<<div_up(npix, 256), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
+        compact_pixels_kernel<<<div_up(npix, 256 * NVDR_COMPACT_ROUNDS), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
                                                                       &c->dinfo->pix_count);
     for (int k = 0; k < n_chunks; ++k) {
         p.pix_begin = (unsigned)((int64_t)k * cap);
@@ -1246,8 +1349,9 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (backward) {
             env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
             if (p.lg_records && !(c->debug & 2u)) {
-                light_grad_band_kernel<<<dim3((unsigned)lg_rows, (unsigned)n_bands), NVDR_LG_THREADS, lg_lds, stream>>>(
-                    c->vis, c->rays, p.pix_count, p.pix_begin, p.pix_cap, 2 * S, 1 << p.lg_shift, n_texels, c->lg_part);
+                light_grad_block_kernel<<<(unsigned)lg_rows, NVDR_LG_THREADS, lg_lds, stream>>>(
+                    c->lg_tags, c->rays, p.pix_count, p.pix_begin, p.pix_cap, (unsigned)G, (unsigned)group_slots, p.lg_spare_base,
+                    (unsigned)spare_blocks, 1 << p.lg_shift, n_bands, n_texels, c->lg_part);
                 light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, lg_rows, p.g_light,
                                                                                          k > 0 ? 1 : 0, p.pix_count, p.pix_begin);
             }
@@ -1256,6 +1360,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));
     }
+    if (backward && p.lg_records) c->lg_tags_dirty = false;    // every chunk's gather consumed (and reset) the tags its shading kernel wrote
     if (backward && !p.lg_records && !(c->debug & 2u))
         light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, 8, p.g_light, 0, nullptr, 0);
     NVDR_LAUNCH_CHECK();
@@ -1288,7 +1393,7 @@ static int trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, 
     if (int r0 = ctx_check_overflow(c, who)) return r0;
     if (n_rays <= 0) return 0;
     NVDR_HIP_TRY(hipSetDevice(c->device));
-    int r = reserve_stream(c, n_rays, n_rays, 1, stream);
+    int r = reserve_stream(c, n_rays, n_rays, ((size_t)n_rays * 2 + 127) & ~(size_t)127, 0, stream);
     if (r) return r;
     c->stream_id = 0;
     if (int rw = ctx_wait_built(c, stream)) return rw;

@@ -1,0 +1,106 @@
+// optim.hip -- the parameter update of one training iteration as ONE launch.
+//
+// Replaces, for the three tensors the direct-lighting iteration trains (kd texture, ks, light probe), the sequence
+//     lgt.base.grad *= 64                      train.py:439-440
+//     optimizer.step()                         train.py:452-461  (torch.optim.Adam, no weight decay, no amsgrad)
+//     clamps of the parameters                 train.py:470-476 / material clamps
+// which on ROCm is a multi-tensor Adam launch that puts ~1 M elements on 16 workgroups (45 us on a 256-CU part) plus five
+// small elementwise kernels.  One thread per element over all tensors, the step counter in device memory (the launch can be
+// captured in a HIP graph and replayed), same arithmetic and the same order of operations as torch's single-tensor Adam:
+//     m = m + (g - m) * (1 - b1);  v = v * b2 + (1 - b2) * g * g
+//     p = p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps);  p = max(min(p, hi), lo)
+#include "common.h"
+#include "nvdr_hip.h"
+
+struct AdamTable {
+    nvdr_adam_tensor t[NVDR_ADAM_MAX_TENSORS];
+    int first_block[NVDR_ADAM_MAX_TENSORS + 1];     // workgroups [first_block[k], first_block[k + 1]) work on tensor k
+    int per_thread;                                 // elements per thread (a workgroup covers 256 * per_thread of them)
+    int n;
+};
+
+__global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, float lr, float beta1, float beta2, float eps, int *state)
+{
+    // state[0] = steps taken so far, state[1] = workgroups done with this launch, then two doubles: beta1^step, beta2^step (kept
+    // as running products: pow() in double costs a workgroup ~10 us of latency).  Every workgroup reads the state before it takes
+    // its ticket; the one that draws the last ticket publishes the next state -- nobody can still be reading by then.
+    __shared__ float corr[2];
+    __shared__ double pows[2];
+    const int step = state[0] + 1;
+    if (threadIdx.x == 0) {
+        const double *pw = (const double *)(state + 2);
+        const double b1p = (step == 1 ? 1.0 : pw[0]) * (double)beta1, b2p = (step == 1 ? 1.0 : pw[1]) * (double)beta2;
+        pows[0] = b1p;
+        pows[1] = b2p;
+        corr[0] = (float)((double)lr / (1.0 - b1p));        // step_size = lr / bias_correction1
+        corr[1] = (float)sqrt(1.0 - b2p);                   // sqrt(bias_correction2)
+    }
+    __syncthreads();
+    const float step_size = corr[0], bc2_sqrt = corr[1];
+    // the tensor of this workgroup (uniform: the table entry is read with scalar loads)
+    int k = 0;
+    for (int q = 1; q < tab.n; ++q)
+        if ((int)blockIdx.x >= tab.first_block[q]) k = q;
+    const nvdr_adam_tensor &T = tab.t[k];
+    const int64_t e0 = (int64_t)((int)blockIdx.x - tab.first_block[k]) * 256 * tab.per_thread;
+    for (int j = 0; j < tab.per_thread; ++j) {
+        const int64_t e = e0 + (int64_t)j * 256 + threadIdx.x;
+        if (e >= T.n) break;
+        const float g = T.grad[e] * T.grad_scale;
+        float m = T.exp_avg[e], v = T.exp_avg_sq[e];
+        m = m + (g - m) * (1.0f - beta1);                   // lerp_(grad, 1 - beta1)
+        v = v * beta2 + ((1.0f - beta2) * g) * g;           // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        float p = T.param[e] - step_size * (m / denom);     // addcdiv_(exp_avg, denom, value = -step_size)
+        float lo = T.lo, hi = T.hi;
+        if (T.lo_vec) lo = fmaxf(lo, T.lo_vec[e % T.lo_vec_n]);
+        p = fmaxf(fminf(p, hi), lo);
+        T.exp_avg[e] = m;
+        T.exp_avg_sq[e] = v;
+        T.param[e] = p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(&state[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+            state[1] = 0;
+            ((double *)(state + 2))[0] = pows[0];
+            ((double *)(state + 2))[1] = pows[1];
+            __hip_atomic_store(&state[0], step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
+                              int *state, void *stream_)
+{
+    NVDR_REQUIRE(tensors && state, "adam_step: NULL argument");
+    NVDR_REQUIRE(n_tensors >= 1 && n_tensors <= NVDR_ADAM_MAX_TENSORS, "adam_step: %d tensors (1..%d supported)", n_tensors, NVDR_ADAM_MAX_TENSORS);
+    NVDR_REQUIRE(lr > 0.0f && beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, "adam_step: bad hyper-parameters");
+    AdamTable tab;
+    memset(&tab, 0, sizeof(tab));
+    tab.n = n_tensors;
+    int64_t total = 0;
+    for (int k = 0; k < n_tensors; ++k) {
+        const nvdr_adam_tensor &t = tensors[k];
+        NVDR_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq && t.n >= 0, "adam_step: tensor %d has a NULL buffer", k);
+        NVDR_REQUIRE(!t.lo_vec || t.lo_vec_n > 0, "adam_step: tensor %d: lo_vec without length", k);
+        tab.t[k] = t;
+        total += t.n;
+    }
+    NVDR_REQUIRE(total < (1ll << 40), "adam_step: too many elements");
+    // four elements per thread, more when that would take over 2048 workgroups (each draws one ticket at the end)
+    int64_t per_thread = 4;
+    while (total / (256 * per_thread) > 2048) per_thread *= 2;
+    tab.per_thread = (int)per_thread;
+    int64_t blocks = 0;
+    for (int k = 0; k < n_tensors; ++k) {
+        tab.first_block[k] = (int)blocks;
+        blocks += div_up(tensors[k].n, 256 * per_thread);
+    }
+    for (int k = n_tensors; k <= NVDR_ADAM_MAX_TENSORS; ++k) tab.first_block[k] = (int)blocks;
+    if (blocks < 1) blocks = 1;
+    adam_step_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(tab, lr, beta1, beta2, eps, state);
+    NVDR_LAUNCH_CHECK();
+    return 0;
+}

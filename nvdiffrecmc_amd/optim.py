@@ -1,0 +1,68 @@
+"""Adam + gradient scale + parameter clamps of one iteration in ONE kernel launch (csrc/optim.hip).
+
+Same update as torch.optim.Adam(params, lr, betas, eps) without weight decay / amsgrad (the optimizer of the reference,
+train.py:452-461), followed by the clamps the reference applies to its parameters after the step (train.py:470-476); the
+multiplication of the light gradient by 64 (train.py:439-440) enters as a per-tensor gradient scale.  The step counter lives in
+device memory, so the launch can be captured in a HIP graph.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam:
+    """params: list of tensors (requires_grad, contiguous fp32, on one GPU).
+    clamps[i]: None or (lo, hi, lo_vec) with lo / hi floats or None and lo_vec an optional per-channel lower bound (device
+    tensor whose length divides the parameter's innermost extent pattern: element e is bounded by lo_vec[e % len(lo_vec)]).
+    grad_scales[i]: factor applied to the gradient of parameter i inside the update (p.grad itself is left alone)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clamps=None, grad_scales=None):
+        self.params = list(params)
+        if not 1 <= len(self.params) <= 8:
+            raise ValueError('FusedAdam: 1..8 parameter tensors')
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+                raise ValueError('FusedAdam: parameters must be contiguous fp32 tensors on the GPU')
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.clamps = list(clamps) if clamps is not None else [None] * len(self.params)
+        self.grad_scales = list(grad_scales) if grad_scales is not None else [1.0] * len(self.params)
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        self.state = torch.zeros(8, dtype=torch.int32, device=self.params[0].device)     # steps taken, scratch, beta1^t, beta2^t (doubles)
+
+    @property
+    def step_count(self):
+        return int(self.state[0].item())
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self):
+        tab = (_lib.NvdrAdamTensor * len(self.params))()
+        keep = []
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                raise RuntimeError('FusedAdam.step: parameter %d has no gradient' % i)
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            keep.append(g)
+            lo, hi, lo_vec = -math.inf, math.inf, None
+            if self.clamps[i] is not None:
+                c = self.clamps[i]
+                lo = -math.inf if c[0] is None else float(c[0])
+                hi = math.inf if c[1] is None else float(c[1])
+                lo_vec = c[2] if len(c) > 2 else None
+            t = tab[i]
+            t.param, t.grad, t.exp_avg, t.exp_avg_sq = p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
+            t.n = p.numel()
+            t.grad_scale, t.lo, t.hi = float(self.grad_scales[i]), lo, hi
+            t.lo_vec = lo_vec.data_ptr() if lo_vec is not None else None
+            t.lo_vec_n = lo_vec.numel() if lo_vec is not None else 0
+        with torch.no_grad():
+            _lib.check(_lib.load().nvdr_adam_step(tab, len(self.params), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                  _lib.ptr(self.state), _lib.stream_ptr()), 'adam_step')

@@ -28,6 +28,7 @@ from . import renderutils as ru
 from . import scene as sc
 from .denoiser import BilateralDenoiser, _safe_normalize
 from .light import EnvironmentLight
+from .optim import FusedAdam
 from .parallel import allreduce_gradients
 
 
@@ -136,12 +137,18 @@ class DirectLightingStep:
         self.light = EnvironmentLight(torch.full((probe_res, probe_res, 3), 0.5, device=self.dev).requires_grad_(True))
         self._ks_min = torch.tensor([0.0, 0.08, 0.0], device=self.dev)
         self.params = [self.kd_tex, self.ks, self.light.base]
-        # the same Adam as the reference (train.py:452-461); `fused` only selects torch's single-kernel implementation
-        # (8 multi_tensor_apply launches -> 1) where this build of torch has it for the device
-        try:
-            self.opt = torch.optim.Adam(self.params, lr=lr, fused=self.dev.type == 'cuda', capturable=use_graph)
-        except (RuntimeError, TypeError):
-            self.opt = torch.optim.Adam(self.params, lr=lr, capturable=use_graph)
+        # The same Adam as the reference (train.py:452-461).  fused: ONE launch for the light-gradient scale, the Adam update
+        # of the three tensors and their clamps (csrc/optim.hip; torch's multi-tensor Adam puts the ~1 M elements on 16
+        # workgroups: 45 us + five small kernels); otherwise torch.optim.Adam and the reference's sequence of calls.
+        self._fused_update = bool(fused) and self.dev.type == 'cuda'
+        if self._fused_update:
+            self.opt = FusedAdam(self.params, lr=lr, grad_scales=[1.0, 1.0, light_grad_scale],
+                                 clamps=[(0.0, 1.0), (None, 1.0, self._ks_min), (0.0, None)])
+        else:
+            try:
+                self.opt = torch.optim.Adam(self.params, lr=lr, fused=self.dev.type == 'cuda', capturable=use_graph)
+            except (RuntimeError, TypeError):
+                self.opt = torch.optim.Adam(self.params, lr=lr, capturable=use_graph)
         self.covered = int(self.mask.sum().item())
 
     @property
@@ -204,6 +211,9 @@ class DirectLightingStep:
 
     def _update(self):
         """Everything after the gradient exchange: light-gradient scale, Adam, clamps (train.py:439-476)."""
+        if self._fused_update:
+            self.opt.step()
+            return
         if self.light.base.grad is not None and self.light_grad_scale != 1.0:
             self.light.base.grad *= self.light_grad_scale       # train.py:439-440
         self.opt.step()

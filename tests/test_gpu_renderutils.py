@@ -170,3 +170,34 @@ def test_shade_composite_vs_torch(cd, cs, bsdf, dev):
         assert_close(a.grad, b.grad, 2e-5, floor=1e-5 * max(1.0, b.grad.abs().max().item()), what=name)
     with pytest.raises(RuntimeError):
         ru.shade_composite(torch.rand(1, 4, 4, 2, device=dev), gpu[1].detach(), gpu[2][..., 1:4].detach(), gpu[3].detach())
+
+
+def test_fused_adam_matches_torch_adam_and_clamps(dev):
+    """csrc/optim.hip (gradient scale + Adam + clamps in one launch, device-resident step counter) against torch.optim.Adam on
+    the CPU followed by the reference's own sequence (train.py:439-476): lgt.base.grad *= 64, optimizer.step(), clamps."""
+    from nvdiffrecmc_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    shapes = [(300, 3), (3,), (17, 33, 3)]
+    ks_min = torch.tensor([0.0, 0.08, 0.0])
+    p_ref = [torch.nn.Parameter(torch.rand(*s) * 0.9 + 0.05) for s in shapes]
+    p_gpu = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in p_ref]
+    opt_ref = torch.optim.Adam(p_ref, lr=0.03)
+    opt_gpu = FusedAdam(p_gpu, lr=0.03, grad_scales=[1.0, 1.0, 64.0],
+                        clamps=[(0.0, 1.0), (None, 1.0, ks_min.to(dev)), (0.0, None)])
+    for it in range(12):
+        grads = [torch.randn(*s) * (0.3 if k < 2 else 0.3 / 64.0) for k, s in enumerate(shapes)]
+        for p, q, g in zip(p_ref, p_gpu, grads):
+            p.grad = g.clone()
+            q.grad = g.clone().to(dev)
+        p_ref[2].grad *= 64.0
+        opt_ref.step()
+        with torch.no_grad():
+            p_ref[0].clamp_(0.0, 1.0)
+            p_ref[1].copy_(torch.maximum(p_ref[1].clamp(max=1.0), ks_min))
+            p_ref[2].clamp_(min=0.0)
+        opt_gpu.step()
+        for p, q in zip(p_ref, p_gpu):
+            assert_close(q.detach().cpu(), p.detach(), 2e-6, floor=2e-6)
+    assert opt_gpu.step_count == 12
+    assert (p_gpu[0].min() >= 0) and (p_gpu[0].max() <= 1) and p_gpu[1][1] >= 0.08
+    assert torch.equal(p_gpu[2].grad.cpu(), grads[2])           # the gradient itself is left alone (the scale is applied inside)

@@ -333,7 +333,7 @@ typedef struct nvdr_adam_tensor {
     const float *lo_vec;    /* optional per-channel lower bounds (device), NULL for none */
     int64_t lo_vec_n;
 } nvdr_adam_tensor;
-int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps, int *state,
+int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps, int *state,
                    void *stream);
 
 /* ---- test hook: evaluate include/nvdr_detmath.h on device.  op: 0 sin, 1 cos, 2 acos, 3 atan2(x,y). */

@@ -129,7 +129,7 @@ _SIGNATURES = {
     'nvdr_shade_composite_fwd': [_T] * 4 + [c_int, c_void_p, c_void_p],
     'nvdr_shade_composite_bwd': [_T] * 4 + [c_int, _T] + [c_void_p] * 4 + [c_void_p],
     'nvdr_light_update_pdf': [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
-    'nvdr_adam_step': [ctypes.POINTER(NvdrAdamTensor), c_int, c_float, c_float, c_float, c_float, c_void_p, c_void_p],
+    'nvdr_adam_step': [ctypes.POINTER(NvdrAdamTensor), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p],
     'nvdr_test_detmath': [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
 }
 _RESTYPES = {'nvdr_last_error': ctypes.c_char_p, 'nvdr_image_loss_num_partials': c_int64}

@@ -47,7 +47,7 @@ __device__ __forceinline__ void bwd_safe_normalize(F3 v, F3 &d_v, F3 d_out)
     const float l2 = v.x * v.x + v.y * v.y + v.z * v.z;
     const float l = sqrtf(l2);
     if (l > 0.0f) {
-        const float fac = (float)(1.0 / (double)(l2 * sqrtf(l2)));
+        const float fac = 1.0f / (l2 * sqrtf(l2));      // == (float)(1.0 / (double)(.)) of the reference: a double quotient of floats rounds to the float quotient
         d_v.x += (d_out.x * (v.y * v.y + v.z * v.z) - d_out.y * (v.x * v.y) - d_out.z * (v.x * v.z)) * fac;
         d_v.y += (d_out.y * (v.x * v.x + v.z * v.z) - d_out.x * (v.y * v.x) - d_out.z * (v.y * v.z)) * fac;
         d_v.z += (d_out.z * (v.x * v.x + v.y * v.y) - d_out.x * (v.z * v.x) - d_out.y * (v.z * v.y)) * fac;

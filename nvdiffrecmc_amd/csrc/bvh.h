@@ -159,6 +159,7 @@ struct nvdr_ctx {
     size_t stream_cap_total = 0;   // slots of rays: the chunk's own + the spare blocks of the light-gradient records
     uint16_t *lg_tags = nullptr;   // (band, fill) of every block of 128 slots of `rays` (0xFFFF: no records)
     size_t lg_tags_cap = 0;
+    int lg_mode = -1;              // gather work split: -1 by launch size, 0 all bands per workgroup, 1 one set of workgroups per band (NVDR_LG_MODE)
     bool lg_tags_dirty = true;     // the array may hold tags nobody consumed (fresh allocation, a backward pass without gather)
     uint64_t stream_id = 0;        // id of the ray stream currently held in rays/texel/pix_origin/pix_list
     uint64_t stream_seq = 0;

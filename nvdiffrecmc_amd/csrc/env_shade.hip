@@ -32,6 +32,12 @@
 #include "bsdf_device.h"
 
 #define NVDR_PI_DBL 3.14159265358979323846
+// Division of a FLOAT by pi or 2 pi in double precision, rounded back to float (the reference's `x / M_PI` with float x): the double
+// product with the rounded reciprocal gives the same float for EVERY finite float x -- checked exhaustively, all 4 278 190 080 of them,
+// also under the `+ 0.5` of dir_to_tc and the fmax(1e-6f, .) of cosine_sample (tools/div_by_constant_check.c,
+// profiles/r03_div_by_constant_check.txt).  One v_mul_f64 instead of the ~14 fp64 instructions of an IEEE division.
+#define NVDR_INV_PI_DBL (1.0 / NVDR_PI_DBL)
+#define NVDR_INV_2PI_DBL (1.0 / (2.0 * NVDR_PI_DBL))
 
 // minimum waves per SIMD the backward shading kernel is compiled for (register budget = 512 / this).  Measured in one GPU
 // session (8-view launch, backward shading + light-gradient gather): unrolled sample loop, 192 VGPRs, 2 waves/SIMD 4.85 ms;
@@ -219,7 +225,7 @@ __device__ __forceinline__ F3 cosine_sample(F3 N, float u, float v, float &pdf)
     float sp, cp;
     nvdr_sincosf(phi, &sp, &cp);
     const float x = cp * sintheta, y = sp * sintheta, z = costheta;
-    pdf = (float)fmax((double)0.000001f, (double)costheta / NVDR_PI_DBL);
+    pdf = (float)fmax((double)0.000001f, (double)costheta * NVDR_INV_PI_DBL);       // == costheta / pi (see NVDR_INV_PI_DBL)
     const F3 vec = (dx * x + dy * y) + N * z;
     return safe_normalize(vec);
 }
@@ -235,8 +241,8 @@ __device__ __forceinline__ float albedo(F3 baseColor, F3 wo, F3 N)
 }
 __device__ __forceinline__ void dir_to_tc(F3 dir, float &u, float &v)
 {
-    u = (float)((double)nvdr_atan2f(dir.x, -dir.z) / (2.0 * NVDR_PI_DBL) + 0.5);
-    v = (float)((double)nvdr_acosf(clampf(dir.y, -1.0f, 1.0f)) / NVDR_PI_DBL);
+    u = (float)((double)nvdr_atan2f(dir.x, -dir.z) * NVDR_INV_2PI_DBL + 0.5);          // == atan2 / (2 pi) + 0.5 (see NVDR_INV_PI_DBL)
+    v = (float)((double)nvdr_acosf(clampf(dir.y, -1.0f, 1.0f)) * NVDR_INV_PI_DBL);     // == acos / pi
 }
 __device__ __forceinline__ F3 tc_to_dir(float u, float v)
 {
@@ -397,7 +403,7 @@ __device__ __forceinline__ F3 bsdf_sample(float pDiffuse, float pSpecular, F3 N,
     } else {
         wi_o = ggx_sample(N, wo, sx, sy, alpha, pdf);
         pdf *= 1.f - pDiffuse;
-        if (pDiffuse > 0) update_pdf(pdf, (float)(fmax((double)dot3(N, wi_o), 0.0) / NVDR_PI_DBL), pDiffuse);
+        if (pDiffuse > 0) update_pdf(pdf, (float)(fmax((double)dot3(N, wi_o), 0.0) * NVDR_INV_PI_DBL), pDiffuse);
     }
     return wi_o;
 }
@@ -406,7 +412,7 @@ __device__ __forceinline__ float bsdf_pdf(float pDiffuse, float pSpecular, F3 N,
     const float NdotL = dot3(N, wi), NdotV = dot3(N, wo);
     float pdf = 0.0f;
     if (fminf(NdotV, NdotL) < 1e-6f) return 1.0f;
-    if (pDiffuse > 0) update_pdf(pdf, (float)(fmax((double)dot3(N, wi), 0.0) / NVDR_PI_DBL), pDiffuse);
+    if (pDiffuse > 0) update_pdf(pdf, (float)(fmax((double)dot3(N, wi), 0.0) * NVDR_INV_PI_DBL), pDiffuse);
     if (pSpecular > 0) update_pdf(pdf, ggx_pdf(N, wo, wi, alpha), 1.0f - pDiffuse);
     return pdf;
 }
@@ -676,6 +682,8 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             const int64_t rbase = (int64_t)(valid ? pi : 0) * 2 * S;
             const int64_t rA = rbase + ii, rB = rbase + S + ii;
             // the two rays of this stratum; a set sign bit on the pdf sum marks a dead sample (stage 1)
+            // (Streaming / non-temporal loads here -- to keep the half-written record lines of the backward pass in L2 until the next
+            // round completes them -- change nothing: 3.219 vs 3.229 ms backward shading + gather per 8-view launch, session 15.)
             const float4 rdA = p.rays[rA], rdB = p.rays[rB];
             const unsigned dead = active ? ((__float_as_uint(rdA.w) >> 31) | ((__float_as_uint(rdB.w) >> 31) << 1)) : 3u;
             unsigned occ = 0;
@@ -731,7 +739,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 const F3 dir = f3(rd.x, rd.y, rd.z);
                 const float pdfSum = rd.w;
                 const F3 light_col = fetch_light_texel(p.light, texel);
-                const float mis_weight = (float)(1.0 / (double)fmaxf(pdfSum, 0.0001f));
+                // (float)(1.0 / (double)f) of the reference == the IEEE float quotient 1.0f / f: rounding a double quotient of two floats
+                // to float is innocuous double rounding (53 >= 2 * 24 + 2 bits)
+                const float mis_weight = 1.0f / fmaxf(pdfSum, 0.0001f);
                 F3 _diff = f3(0.0f), _spec = f3(0.0f);
                 if (p.bsdf == 1 || p.bsdf == 2)
                     _diff = f3(fwd_lambert(nrm, dir));
@@ -834,6 +844,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 // Sorting at the source removes both: 0.34 GB of block reads, all lanes busy.
 
 #define NVDR_LG_THREADS 1024
+#define NVDR_LG_PER_BAND_MAX_SLOTS (192ll << 20)    // launches of up to this many stream slots (6 views of 512^2 x 64 spp) deal the CUs to the bands (measured: -13 % / -6 % / -2 % / +-0 of the backward shading + gather time at 1 / 2 / 4 / 8 views)
 #ifndef NVDR_LG_NATIVE_ATOMICS
 #define NVDR_LG_NATIVE_ATOMICS 0        // 1: ds_add_f32 (A/B only)
 #endif
@@ -852,7 +863,11 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
     // Every band costs every workgroup the same, however unevenly the records are spread over the bands -- with one set of
     // workgroups per band (the first version) the equatorial bands of a lat-long probe kept their 32 CUs busy four times longer than
     // the polar ones kept theirs.
+    // (Small launches -- gridDim.y = number of bands: workgroup (g, band) walks the g-th of gridDim.x slices for ITS band only; the
+    // eight passes of a workgroup, each with its own zeroing, tag scan, record fetch and 96 KB row, are ~10 us apiece whatever the
+    // number of records: 90 us of a one-view iteration.)
     const int g = blockIdx.x, G = gridDim.x;
+    const int band_first = gridDim.y > 1 ? (int)blockIdx.y : 0, band_last = gridDim.y > 1 ? (int)blockIdx.y + 1 : n_bands;
     // blocks that may hold records: the chunk's own slots (whole groups of pixels) and the wavefronts' spare blocks behind them
     const unsigned n_groups = (P + pixels_per_group - 1u) / pixels_per_group;
     const unsigned n_own = (n_groups * group_slots + 127u) >> 7;
@@ -861,7 +876,7 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
     const unsigned v_lo = min((unsigned)g * per, n_all), v_hi = min(v_lo + per, n_all);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const float4 none = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-    for (int band = 0; band < n_bands; ++band) {
+    for (int band = band_first; band < band_last; ++band) {
         const int t_lo = band * band_texels, t_hi = min(t_lo + band_texels, n_texels);
         const int n_acc = (t_hi - t_lo) * 3;
         for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) lg_acc[i] = 0.0f;
@@ -1179,7 +1194,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     // forward already reserves the spare blocks the backward shading kernel's wavefronts will need (a reallocation in between
     // would lose the forward's stream).
     const int n_texels = (int)(a->light.size[0] * a->light.size[1]);
-    int n_bands = 0, band_texels = 0, lg_rows = 8, lg_shift = 0, lg_records = 0;
+    int n_bands = 0, band_texels = 0, lg_rows = 8, lg_shift = 0, lg_records = 0, lg_grid_y = 1;
     size_t lg_lds = 0;
     {
         const size_t lds_budget = lg_lds_budget();
@@ -1191,7 +1206,11 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (lg_records) {
             if (band_texels > n_texels) band_texels = n_texels;
             lg_lds = (size_t)band_texels * 12;
-            lg_rows = c->n_cus;             // one gather workgroup per CU (its accumulators take most of the CU's LDS)
+            // one gather workgroup per CU (its accumulators take most of the CU's LDS): each walks all bands (large launches), or
+            // the CUs are dealt to the bands (small launches: fewer passes and partial rows, at the price of uneven bands)
+            const bool per_band = c->lg_mode >= 0 ? c->lg_mode == 1 : npix * 2 * (int64_t)S <= NVDR_LG_PER_BAND_MAX_SLOTS;
+            lg_rows = per_band ? (c->n_cus / n_bands < 1 ? 1 : c->n_cus / n_bands) : c->n_cus;
+            lg_grid_y = per_band ? n_bands : 1;
         }
     }
     // spare blocks per wavefront of the backward shading kernel: one open block per band + the records of the first group (nothing
@@ -1349,7 +1368,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (backward) {
             env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
             if (p.lg_records && !(c->debug & 2u)) {
-                light_grad_block_kernel<<<(unsigned)lg_rows, NVDR_LG_THREADS, lg_lds, stream>>>(
+                light_grad_block_kernel<<<dim3((unsigned)lg_rows, (unsigned)lg_grid_y), NVDR_LG_THREADS, lg_lds, stream>>>(
                     c->lg_tags, c->rays, p.pix_count, p.pix_begin, p.pix_cap, (unsigned)G, (unsigned)group_slots, p.lg_spare_base,
                     (unsigned)spare_blocks, 1 << p.lg_shift, n_bands, n_texels, c->lg_part);
                 light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, lg_rows, p.g_light,

@@ -19,20 +19,23 @@ struct AdamTable {
     int n;
 };
 
-__global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, float lr, float beta1, float beta2, float eps, int *state)
+__global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr, double beta1d, double beta2d, float eps, int *state)
 {
     // state[0] = steps taken so far, state[1] = workgroups done with this launch, then two doubles: beta1^step, beta2^step (kept
     // as running products: pow() in double costs a workgroup ~10 us of latency).  Every workgroup reads the state before it takes
     // its ticket; the one that draws the last ticket publishes the next state -- nobody can still be reading by then.
     __shared__ float corr[2];
     __shared__ double pows[2];
+    // the hyper-parameters arrive as doubles, like the Python floats torch's Adam computes 1 - beta from: (float)(1 - 0.999) is
+    // 0.001f, 1 - 0.999f is 1.3e-5 off (visible in the parameters after ten steps)
+    const float beta1 = (float)beta1d, beta2 = (float)beta2d, omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
     const int step = state[0] + 1;
     if (threadIdx.x == 0) {
         const double *pw = (const double *)(state + 2);
-        const double b1p = (step == 1 ? 1.0 : pw[0]) * (double)beta1, b2p = (step == 1 ? 1.0 : pw[1]) * (double)beta2;
+        const double b1p = (step == 1 ? 1.0 : pw[0]) * beta1d, b2p = (step == 1 ? 1.0 : pw[1]) * beta2d;
         pows[0] = b1p;
         pows[1] = b2p;
-        corr[0] = (float)((double)lr / (1.0 - b1p));        // step_size = lr / bias_correction1
+        corr[0] = (float)(lr / (1.0 - b1p));        // step_size = lr / bias_correction1
         corr[1] = (float)sqrt(1.0 - b2p);                   // sqrt(bias_correction2)
     }
     __syncthreads();
@@ -48,8 +51,8 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, float lr,
         if (e >= T.n) break;
         const float g = T.grad[e] * T.grad_scale;
         float m = T.exp_avg[e], v = T.exp_avg_sq[e];
-        m = m + (g - m) * (1.0f - beta1);                   // lerp_(grad, 1 - beta1)
-        v = v * beta2 + ((1.0f - beta2) * g) * g;           // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        m = m + (g - m) * omb1;                             // lerp_(grad, 1 - beta1)
+        v = v * beta2 + (omb2 * g) * g;                     // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
         const float denom = sqrtf(v) / bc2_sqrt + eps;
         float p = T.param[e] - step_size * (m / denom);     // addcdiv_(exp_avg, denom, value = -step_size)
         float lo = T.lo, hi = T.hi;
@@ -71,12 +74,12 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, float lr,
     }
 }
 
-extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, float lr, float beta1, float beta2, float eps,
+extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps,
                               int *state, void *stream_)
 {
     NVDR_REQUIRE(tensors && state, "adam_step: NULL argument");
     NVDR_REQUIRE(n_tensors >= 1 && n_tensors <= NVDR_ADAM_MAX_TENSORS, "adam_step: %d tensors (1..%d supported)", n_tensors, NVDR_ADAM_MAX_TENSORS);
-    NVDR_REQUIRE(lr > 0.0f && beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f && eps >= 0.0f, "adam_step: bad hyper-parameters");
+    NVDR_REQUIRE(lr > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "adam_step: bad hyper-parameters");
     AdamTable tab;
     memset(&tab, 0, sizeof(tab));
     tab.n = n_tensors;
@@ -100,7 +103,7 @@ extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, fl
     }
     for (int k = n_tensors; k <= NVDR_ADAM_MAX_TENSORS; ++k) tab.first_block[k] = (int)blocks;
     if (blocks < 1) blocks = 1;
-    adam_step_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(tab, lr, beta1, beta2, eps, state);
+    adam_step_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(tab, lr, beta1, beta2, (float)eps, state);
     NVDR_LAUNCH_CHECK();
     return 0;
 }

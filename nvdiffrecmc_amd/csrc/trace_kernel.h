@@ -27,9 +27,7 @@
 // Measured (round 2, same GPU session, 8-view launch, 43 M live rays): static round-robin chunks 4.30 ms, 64 queues x 256
 // rays 3.75 ms (-13 %), 128 x 256 4.06 ms, 64 x 128 4.07 ms.
 #define NVDR_TRACE_QUEUES 64
-#ifndef NVDR_TRACE_QCHUNK
-#define NVDR_TRACE_QCHUNK 256
-#endif
+#define NVDR_TRACE_QCHUNK 256    // (ChunkDealer::init holds its log2)
 #ifndef NVDR_TRACE_OCC
 #define NVDR_TRACE_OCC 8       // waves per SIMD the kernel is compiled for (= resident workgroups per CU of the persistent grid)
 #endif
@@ -61,12 +59,18 @@ struct TraceLaunch {
 // dealing without atomics (wave w walks the chunks w, w + waves, ...) is within 1 % of the claiming on 684 k triangles.)
 struct ChunkDealer {
     unsigned *queue;               // this wave's counter
-    unsigned n_chunks, total, sub;
+    unsigned n_chunks, total, sub, shift;
 
-    __device__ __forceinline__ void init(unsigned *queues, unsigned total_, unsigned wid)
+    // Chunk size: NVDR_TRACE_QCHUNK rays, but a small launch (one view: 5 M rays over 8192 wavefronts = 2.6 chunks of 256 each) is
+    // cut finer -- at least ~8 claims per wavefront, 64 rays at the least -- so that the wavefronts run out of work together.
+    __device__ __forceinline__ void init(unsigned *queues, unsigned total_, unsigned wid, unsigned n_waves)
     {
         total = total_;
-        n_chunks = (total_ + NVDR_TRACE_QCHUNK - 1u) / NVDR_TRACE_QCHUNK;
+        shift = 8u;                                                     // log2(NVDR_TRACE_QCHUNK)
+#ifndef NVDR_TRACE_COARSE_CHUNKS              // (A/B variants only)
+        while (shift > 6u && (total_ >> shift) < 8u * n_waves) --shift;
+#endif
+        n_chunks = (total_ + (1u << shift) - 1u) >> shift;
         sub = wid % NVDR_TRACE_QUEUES;
         queue = queues + sub * 32u;
     }
@@ -78,8 +82,8 @@ struct ChunkDealer {
         j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
         const unsigned c = j * NVDR_TRACE_QUEUES + sub;
         if (c >= n_chunks) return false;
-        next = c * NVDR_TRACE_QCHUNK;
-        end = min(next + NVDR_TRACE_QCHUNK, total);
+        next = c << shift;
+        end = min(next + (1u << shift), total);
         return true;
     }
 };
@@ -151,7 +155,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     const unsigned total = *a.ray_count;
     const unsigned wid = blockIdx.x * (blockDim.x >> 6) + wave;
     ChunkDealer dealer;
-    dealer.init(a.queues, total, wid);
+    dealer.init(a.queues, total, wid, gridDim.x * (blockDim.x >> 6));
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
     bool more = total > 0;
     unsigned n_box = 0, n_tri = 0, n_ray = 0, n_step = 0, n_batch = 0;

@@ -48,7 +48,7 @@ __device__ __forceinline__ void env_trace_body_r2(const TraceLaunch &a, int *sme
     const unsigned total = *a.ray_count;
     const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     ChunkDealer dealer;
-    dealer.init(a.queues, total, wid);
+    dealer.init(a.queues, total, wid, gridDim.x * (blockDim.x >> 6));
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
     bool more = total > 0;
     unsigned n_box = 0, n_tri = 0, n_ray = 0;

@@ -197,7 +197,7 @@ def test_fused_adam_matches_torch_adam_and_clamps(dev):
             p_ref[2].clamp_(min=0.0)
         opt_gpu.step()
         for p, q in zip(p_ref, p_gpu):
-            assert_close(q.detach().cpu(), p.detach(), 2e-6, floor=2e-6)
+            assert_close(q.detach().cpu(), p.detach(), 1e-6, floor=1.0)        # parameters are O(1): 1-3 ulp; one side of a clamp may sit at 0, the other at 1e-8
     assert opt_gpu.step_count == 12
     assert (p_gpu[0].min() >= 0) and (p_gpu[0].max() <= 1) and p_gpu[1][1] >= 0.08
     assert torch.equal(p_gpu[2].grad.cpu(), grads[2])           # the gradient itself is left alone (the scale is applied inside)

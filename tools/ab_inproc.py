@@ -16,6 +16,9 @@ nviews = int(os.environ.get('PROBE_VIEWS', '8'))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 base = _build.LIB
 paths = [('current', base)] + [(p.split('.so.')[-1], p) for p in sorted(glob.glob(os.path.join(_build.BUILD, 'variants', 'libnvdr_hip.so.*')))]
+if os.environ.get('AB_LG', '0') != '0':
+    paths.append(('lg_all', base))         # light-gradient gather: every workgroup walks all bands (NVDR_LG_MODE=0)
+    paths.append(('lg_perband', base))     # one set of workgroups per band (NVDR_LG_MODE=1)
 if os.environ.get('AB_R2', '1') != '0':
     paths.append(('r2kernel', base))       # the same library with the round-2 shadow-ray kernel selected (NVDR_TRACE_VARIANT=0)
 only = os.environ.get('AB_ONLY')
@@ -31,8 +34,11 @@ for tag, path in paths:
         os.environ['NVDR_TRACE_VARIANT'] = '0'
     else:
         os.environ.pop('NVDR_TRACE_VARIANT', None)
+    if tag.startswith('lg_'):
+        os.environ['NVDR_LG_MODE'] = '1' if tag == 'lg_perband' else '0'
     st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
     os.environ.pop('NVDR_TRACE_VARIANT', None)
+    os.environ.pop('NVDR_LG_MODE', None)
     assert st.ctx.cpp_wrapper.lib is lib
     with torch.no_grad():
         m = st.mask[..., None]

@@ -128,6 +128,7 @@ struct nvdr_ctx {
     int *ovf_host = nullptr;       // host-mapped overflow flag (a push beyond stack_max sets it)
     int *ovf_dev = nullptr;        // its device address
     unsigned debug = 0;            // NVDR_DEBUG, read ONCE when the context is created
+    bool per_cu_user = false;      // NVDR_PBLOCKS was given: no launch-size rule on top of it
     int per_cu[3] = {8, 6, 6};     // workgroups per CU of the sample-generation, forward- and backward-shading kernels (NVDR_PBLOCKS="g,f,b")
     // BVH builds run on the context's own side stream, overlapped with whatever the caller enqueues next that does not need the
     // tree (pixel compaction and sample generation of env-shade: ~0.35-2.3 ms against a 0.25 ms build); consumers wait on `ev_built`
@@ -159,6 +160,10 @@ struct nvdr_ctx {
     size_t stream_cap_total = 0;   // slots of rays: the chunk's own + the spare blocks of the light-gradient records
     uint16_t *lg_tags = nullptr;   // (band, fill) of every block of 128 slots of `rays` (0xFFFF: no records)
     size_t lg_tags_cap = 0;
+    float *dp_cost = nullptr;      // [2 * cap][7] collapse-DP tables of the two children of every binary node (bvh_fit_kernel)
+    unsigned *dp_split = nullptr;  // [cap] the slot splits the DP chose
+    bool oct_dp = true;            // SAH-optimal collapse (false: greedy largest-area, NVDR_OCT_DP=0)
+    float oct_c_leaf = 0.45f;      // cost of a triangle test relative to a node step in the collapse DP
     int lg_mode = -1;              // gather work split: -1 by launch size, 0 all bands per workgroup, 1 one set of workgroups per band (NVDR_LG_MODE)
     bool lg_tags_dirty = true;     // the array may hold tags nobody consumed (fresh allocation, a backward pass without gather)
     uint64_t stream_id = 0;        // id of the ray stream currently held in rays/texel/pix_origin/pix_list

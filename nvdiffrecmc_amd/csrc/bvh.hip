@@ -170,7 +170,8 @@ __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, u
 // one acquire fence and then plain loads.
 __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *__restrict__ tris,
                                const uint32_t *__restrict__ order, int n, float4 *__restrict__ tri_rec, uint4 *nodes,
-                               const int *__restrict__ parent, int *flags, int *heights, BvhDeviceInfo *info)
+                               const int *__restrict__ parent, int *flags, int *heights, BvhDeviceInfo *info,
+                               float *dp_cost, unsigned *dp_split, float c_leaf)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -202,6 +203,19 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
     int height = 0;
     int me = ~k;
     int node = parent[n + k];
+    // The collapse into eight-wide nodes is chosen by dynamic programming over this same bottom-up pass (Ylitie, Karras, Laine 2017,
+    // section 4.1): cost[i - 1] = cheapest representation of the subtree carried by this thread in AT MOST i slots of an ancestor's
+    // wide node (i = 1..7), in units of (surface area x cost of one node step); a triangle costs c_leaf of a node step.
+    //   c(v, 1) = A_v + min_k c(l, k) + c(r, 8 - k)            v becomes the root of a wide node; the argmin is kept as its root split
+    //   c(v, i) = min(c(v, 1), min_k c(l, k) + c(r, i - k))    or its slots go to the children; the argmin (0 = stay one slot) is kept
+    const float wxs = 1.0f / info->g_scale[0], wys = 1.0f / info->g_scale[1], wzs = 1.0f / info->g_scale[2];
+    float cost[7];
+    {
+        const float ex = (float)(qmx[0] - qmn[0]) * wxs, ey = (float)(qmx[1] - qmn[1]) * wys, ez = (float)(qmx[2] - qmn[2]) * wzs;
+        const float leaf = (ex * ey + ey * ez + ez * ex) * c_leaf;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) cost[i] = leaf;
+    }
     while (true) {
         unsigned *rec = (unsigned *)(nodes + 2 * (int64_t)node);
         const int cl = (int)rec[6];
@@ -211,6 +225,11 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
         dst[1] = (unsigned)qmn[2] | ((unsigned)qmx[0] << 16);
         dst[2] = (unsigned)qmx[1] | ((unsigned)qmx[2] << 16);
         heights[2 * node + slot] = height;
+        if (dp_cost) {
+            float *dc = dp_cost + 7 * (2 * (int64_t)node + slot);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) dc[i] = cost[i];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int old = atomicAdd(&flags[node], 1);
@@ -221,6 +240,41 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
         qmn[0] = min(qmn[0], (int)(s0 & 0xffffu)); qmn[1] = min(qmn[1], (int)(s0 >> 16)); qmn[2] = min(qmn[2], (int)(s1 & 0xffffu));
         qmx[0] = max(qmx[0], (int)(s1 >> 16)); qmx[1] = max(qmx[1], (int)(s2 & 0xffffu)); qmx[2] = max(qmx[2], (int)(s2 >> 16));
         height = 1 + max(height, heights[2 * node + (1 - slot)]);
+        if (dp_cost) {
+            // (left, right) tables in tree order, whichever of the two this thread carried
+            float sib[7];
+            const float *sc = dp_cost + 7 * (2 * (int64_t)node + (1 - slot));
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sib[i] = sc[i];
+            float Lc[7], Rc[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { Lc[i] = slot == 0 ? cost[i] : sib[i]; Rc[i] = slot == 0 ? sib[i] : cost[i]; }
+            const float ex = (float)(qmx[0] - qmn[0]) * wxs, ey = (float)(qmx[1] - qmn[1]) * wys, ez = (float)(qmx[2] - qmn[2]) * wzs;
+            const float area = ex * ey + ey * ez + ez * ex;
+            float best = 3.0e38f;
+            unsigned packed = 0u, bk = 1u;
+#pragma unroll
+            for (int kk = 1; kk <= 7; ++kk) {               // root of a wide node: kk slots to the left child, 8 - kk to the right
+                const float cc = Lc[kk - 1] + Rc[7 - kk];
+                if (cc < best) { best = cc; bk = (unsigned)kk; }
+            }
+            packed |= bk << 24;
+            const float c1 = area + best;
+            cost[0] = c1;
+#pragma unroll
+            for (int i = 2; i <= 7; ++i) {
+                float bi = c1;
+                unsigned ki = 0u;
+#pragma unroll
+                for (int kk = 1; kk < i; ++kk) {
+                    const float cc = Lc[kk - 1] + Rc[i - kk - 1];
+                    if (cc < bi) { bi = cc; ki = (unsigned)kk; }
+                }
+                cost[i - 1] = bi;
+                packed |= ki << (3 * i);
+            }
+            dp_split[node] = packed;                        // bits 3i..3i+2: slots for the left child at budget i (0: stay one slot); 24..26: the root split
+        }
         if (node == 0) {
             info->height = height;
             return;
@@ -336,6 +390,7 @@ struct OctBuildArgs {
     unsigned *ctl;          // four counters, one 128-byte line each (OCT_CTL_*): next ticket, oct nodes allocated, oct nodes finished, triangles placed
     const BvhDeviceInfo *info;
     int cap;                // entries of task[] / oct nodes that fit (>= n_tris)
+    const unsigned *dp_split;   // per binary node: the slot split chosen by the collapse DP of bvh_fit_kernel (NULL: greedy largest-area collapse)
 };
 
 __global__ void bvh_oct_init_kernel(OctBuildArgs a, int n_tris)
@@ -379,6 +434,34 @@ __device__ void oct_build_node(const OctBuildArgs &a, int b, int m, int *sl)
     int n = 2;
     oct_load_children(a.nodes, b, sl, 0, 1);
     const float wx = 1.0f / a.info->g_scale[0], wy = 1.0f / a.info->g_scale[1], wz = 1.0f / a.info->g_scale[2];
+    if (a.dp_split) {
+        // the split the DP chose: slot k carries a budget; an internal child with budget i > 1 whose table says "give s of them to my
+        // left child" is replaced by its two children with budgets (s, i - s)
+        int budget[8];
+        {
+            const unsigned root = a.dp_split[b] >> 24;
+            budget[0] = (int)root;
+            budget[1] = 8 - (int)root;
+        }
+        bool again = true;
+        while (again) {
+            again = false;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k >= n) continue;
+                const int c = OCT_SL(k, 0);
+                if (c < 0 || budget[k] < 2) continue;
+                const unsigned sp = (a.dp_split[c] >> (3 * budget[k])) & 7u;
+                if (sp == 0u) { budget[k] = 1; continue; }         // stays one slot (decided once)
+                const int bl = (int)sp, br = budget[k] - (int)sp;
+                oct_load_children(a.nodes, c, sl, k, n);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { if (j == k) budget[j] = bl; if (j == n) budget[j] = br; }
+                n++;
+                again = true;
+            }
+        }
+    } else
     while (n < 8) {
         int best = -1;
         float best_area = -1.0f;
@@ -526,7 +609,7 @@ static int ctx_free_bvh(nvdr_ctx *c)
 {
     ctx_free(c, c->nodes); ctx_free(c, c->wide); ctx_free(c, c->oct); ctx_free(c, c->tris8); ctx_free(c, c->oct_task); ctx_free(c, c->tris);
     ctx_free(c, c->keys[0]); ctx_free(c, c->keys[1]); ctx_free(c, c->vals[0]); ctx_free(c, c->vals[1]);
-    ctx_free(c, c->parent); ctx_free(c, c->flags); ctx_free(c, c->heights); ctx_free(c, c->sort_tmp);
+    ctx_free(c, c->parent); ctx_free(c, c->flags); ctx_free(c, c->heights); ctx_free(c, c->dp_cost); ctx_free(c, c->dp_split); ctx_free(c, c->sort_tmp);
     c->sort_tmp_bytes = 0;
     c->cap_tris = 0;
     return 0;
@@ -576,9 +659,14 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     }
     if (const char *pb = getenv("NVDR_PBLOCKS")) {
         sscanf(pb, "%d,%d,%d", &c->per_cu[0], &c->per_cu[1], &c->per_cu[2]);
+        c->per_cu_user = true;
         for (int k = 0; k < 3; ++k) c->per_cu[k] = c->per_cu[k] < 1 ? 1 : (c->per_cu[k] > 16 ? 16 : c->per_cu[k]);
     }
     if (const char *ab = getenv("NVDR_ASYNC_BUILD")) c->async_build = atoi(ab) != 0;
+    // NVDR_OCT_DP=0: greedy largest-area collapse into eight-wide nodes instead of the SAH-optimal one; NVDR_OCT_CLEAF: cost of a
+    // triangle test in units of a node step (experiments)
+    if (const char *od = getenv("NVDR_OCT_DP")) c->oct_dp = atoi(od) != 0;
+    if (const char *cl = getenv("NVDR_OCT_CLEAF")) { const float v = (float)atof(cl); if (v > 0.0f) c->oct_c_leaf = v; }
     // NVDR_LG_MODE: work split of the light-gradient gather (env_shade.hip): 0 every workgroup walks all bands, 1 one set of
     // workgroups per band, unset = by launch size
     if (const char *lm = getenv("NVDR_LG_MODE")) c->lg_mode = atoi(lm) ? 1 : 0;
@@ -643,6 +731,8 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     NVDR_HIP_TRY(ctx_malloc(c, &c->parent, sizeof(int) * 2 * cap));
     NVDR_HIP_TRY(ctx_malloc(c, &c->flags, sizeof(int) * cap));
     NVDR_HIP_TRY(ctx_malloc(c, &c->heights, sizeof(int) * 2 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->dp_cost, sizeof(float) * 14 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->dp_split, sizeof(unsigned) * cap));
     size_t bytes = 0;
     NVDR_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1], (size_t)cap, 0, 30));
     NVDR_HIP_TRY(ctx_malloc(c, &c->sort_tmp, bytes + 256));
@@ -738,7 +828,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     }
     NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
     bvh_fit_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->parent,
-                                                        c->flags, c->heights, c->dinfo);
+                                                        c->flags, c->heights, c->dinfo, c->oct_dp ? c->dp_cost : nullptr, c->dp_split, c->oct_c_leaf);
     if (c->trace_variant == 0 && n > 1) {
         if (!c->wide) NVDR_HIP_TRY(ctx_malloc(c, &c->wide, sizeof(uint4) * 4 * c->cap_tris, stream));
         bvh_widen_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->nodes, n - 1, c->wide);
@@ -747,7 +837,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         // eight-wide nodes for the shadow-ray walk: one launch, ticket-driven (see bvh_oct_build_kernel)
         OctBuildArgs oa;
         oa.nodes = c->nodes; oa.tris = c->tris; oa.oct = c->oct; oa.tris8 = c->tris8; oa.task = c->oct_task; oa.ctl = c->oct_ctl;
-        oa.info = c->dinfo; oa.cap = n; oa.fault = c->ovf_dev;
+        oa.info = c->dinfo; oa.cap = n; oa.fault = c->ovf_dev; oa.dp_split = c->oct_dp ? c->dp_split : nullptr;
         bvh_oct_init_kernel<<<min(div_up(n, 256), 1024u), 256, 0, stream>>>(oa, n);
         if (n > 1) {
             const unsigned blocks = min(div_up((n + 3) / 4, 256), (unsigned)c->n_cus * 4u);

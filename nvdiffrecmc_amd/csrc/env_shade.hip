@@ -435,7 +435,9 @@ __device__ __forceinline__ F3 fetch_light_texel(const Tab &t, int texel)
 // ---------------------------------------------------------------------------------------------
 // stage 1: sample generation (kernel.cu:463-526 minus process_sample)
 
-#define NVDR_GEN_STAGE 1024u
+#define NVDR_GEN_STAGE 512u
+#define NVDR_GEN_RING 64u          // pixels whose set-up the deferred BSDF samples of a wavefront may still refer to
+#define NVDR_GEN_QCAP 128u         // entries of one lobe queue (< 64 waiting + <= 64 pushed per round)
 
 // one list-space claim for `staged` slots of a wavefront, then a coalesced copy out of LDS; returns the new fill (0)
 __device__ __forceinline__ unsigned flush_live(const unsigned *stage, unsigned staged, int lane, const ShadeParams &p)
@@ -467,10 +469,68 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     __shared__ unsigned stage_all[4][NVDR_GEN_STAGE];
     unsigned *stage = stage_all[wave];
     unsigned staged = 0;
+    // BSDF samples by lobe.  bsdf_sample (kernel.cu:330-352) picks the diffuse or the specular lobe per SAMPLE (sz < pDiffuse), so
+    // the 64 strata of a pixel split between two long branches and a wavefront that samples in place executes both, each with part
+    // of its lanes.  Here a lane only draws its numbers and queues a task (sx, sy, stratum, pixel) for the lobe it picked; a lobe is
+    // evaluated when 64 of its tasks wait -- every lane busy, one branch -- together with everything that follows from the direction
+    // (light pdf, culling, stream slot).  The same arithmetic per sample, in another order.  The pixel's set-up a task needs
+    // (normal, wo, alpha, pDiffuse) waits in a small ring; before a ring entry is reused the queues are drained, full or not.
+    __shared__ float4 ring_all[4][NVDR_GEN_RING * 2];
+    __shared__ float4 queue_all[4][2][NVDR_GEN_QCAP];
+    float4 *ring = ring_all[wave];
+    float4 *queue[2] = {queue_all[wave][0], queue_all[wave][1]};       // [0] diffuse lobe, [1] specular lobe
+    unsigned q_head[2] = {0u, 0u}, q_count[2] = {0u, 0u};               // wave-uniform
+    const unsigned ring_groups = NVDR_GEN_RING / (unsigned)G;           // groups of pixels the ring holds (G <= 64)
+    unsigned groups_done = 0;
     // the lane's jump (5 draws per stratum, kernel.cu:513-524) is the same for every pixel: computed once when one round
     // of L lanes covers all S strata, per round otherwise
     unsigned jump_m, jump_a;
     lcg_skip_coeff(5u * (unsigned)sub, jump_m, jump_a);
+
+    // live slots of this round / batch -> the wavefront's staging buffer (ballot ranks; `staged` is wave-uniform)
+    auto stage_live = [&](bool live, unsigned r) {
+        const unsigned long long m = __ballot(live);
+        if (live) stage[staged + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = r;
+        staged += (unsigned)__popcll(m);
+        if (staged > NVDR_GEN_STAGE - 64u) staged = flush_live(stage, staged, lane, p);      // (room for the next append of <= 64)
+    };
+    // one batch of `cnt` (<= 64) tasks of one lobe (wave-uniform arguments)
+    auto run_batch = [&](int lobe, unsigned cnt) {
+        __builtin_amdgcn_wave_barrier();                    // tasks and ring entries were written by other lanes of this wavefront
+        const bool has = (unsigned)lane < cnt;
+        const float4 t = queue[lobe][(q_head[lobe] + (unsigned)lane) & (NVDR_GEN_QCAP - 1u)];
+        q_head[lobe] += cnt;
+        q_count[lobe] -= cnt;
+        if (has) {
+            const unsigned key = __float_as_uint(t.z), pix = __float_as_uint(t.w);
+            const unsigned pb = key & 0xffffu, ri = key >> 16;
+            const float4 s0 = ring[2u * ri], s1 = ring[2u * ri + 1u];
+            const F3 N = f3(s0.x, s0.y, s0.z), wo = f3(s1.x, s1.y, s1.z);
+            const float alpha = s0.w, pDiffuse = s1.w, sx = t.x, sy = t.y;
+            float pdfB_bsdf = 0.0f;
+            F3 dirB;
+            if (lobe == 0) {                                // bsdf_sample, the branch sz < pDiffuse
+                if (pDiffuse < 0.0001f) {
+                    pdfB_bsdf = 1.0f;
+                    dirB = N;
+                } else {
+                    dirB = cosine_sample(N, sx, sy, pdfB_bsdf);
+                    pdfB_bsdf *= pDiffuse;
+                    if (1.0f - pDiffuse > 0) update_pdf(pdfB_bsdf, ggx_pdf(N, wo, dirB, alpha), 1.0f - pDiffuse);
+                }
+            } else {                                        // ... and the other one
+                dirB = ggx_sample(N, wo, sx, sy, alpha, pdfB_bsdf);
+                pdfB_bsdf *= 1.f - pDiffuse;
+                if (pDiffuse > 0) update_pdf(pdfB_bsdf, (float)(fmax((double)dot3(N, dirB), 0.0) * NVDR_INV_PI_DBL), pDiffuse);
+            }
+            int txB, tyB;
+            const float pdfB_light = light_pdf(p, dirB, txB, tyB);
+            const unsigned rB = pix * 2u * S + S + pb;
+            const unsigned deadB = (!(p.debug & 8u) && !(dot3(N, dirB) > 0.0f)) ? 0x80000000u : 0u;
+            p.rays[rB] = make_float4(dirB.x, dirB.y, dirB.z, __uint_as_float(__float_as_uint(pdfB_light + pdfB_bsdf) | deadB));
+            p.texel[rB] = tyB * p.light.n1 + txB;
+        }
+    };
 
     for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
         const unsigned pi = grp * G + slot;                 // index inside the chunk
@@ -479,10 +539,6 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
         const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
         const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
-        if (sub == 0 && valid) {
-            const F3 ro = fetch3(p.ro, z, y, x);
-            p.pix_origin[pi] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-        }
         // per-pixel set-up (kernel.cu:490-505)
         const float alpha = ks.y * ks.y;
         const F3 wo = safe_normalize(view_pos - pos);
@@ -492,6 +548,13 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         const float specularWeight = albedo(specColor, wo, nrm);
         const float pDiffuse = (diffuseWeight + specularWeight) > 0.f ? diffuseWeight / (diffuseWeight + specularWeight) : 1.f;
         const float pSpecular = 1.0f - pDiffuse;
+        const unsigned ring_at = (groups_done % ring_groups) * (unsigned)G + (unsigned)slot;
+        if (sub == 0 && valid) {
+            const F3 ro = fetch3(p.ro, z, y, x);
+            p.pix_origin[pi] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+            ring[2u * ring_at] = make_float4(nrm.x, nrm.y, nrm.z, alpha);
+            ring[2u * ring_at + 1u] = make_float4(wo.x, wo.y, wo.z, pDiffuse);
+        }
         unsigned a_seed = launch_seed(p), b_seed = (unsigned)lin + p.pix_offset;
         unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
         const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
@@ -499,9 +562,11 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
 
         for (unsigned base = 0; base < S; base += L) {
             const unsigned i = base + sub;
-            unsigned deadA = 0x80000000u, deadB = 0x80000000u;   // lanes without a sample stage nothing
-            int64_t rA = 0, rB = 0;
-            if (valid && i < S) {
+            const bool has = valid && i < S;
+            bool liveA = false, cosine = false;
+            unsigned rA = 0;
+            float4 task = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (has) {
                 unsigned jm = jump_m, ja = jump_a;
                 if (base != 0u) lcg_skip_coeff(5u * i, jm, ja);
                 unsigned rng = jm * rng0 + ja;
@@ -509,50 +574,64 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
                 float sx = ((float)(pl % n) + uniform_pcg(rng)) * strata_frac;
                 float sy = ((float)(pl / n) + uniform_pcg(rng)) * strata_frac;
-                float pdfA_light, pdfB_bsdf;
-                int txA, tyA, txB, tyB;
+                float pdfA_light;
+                int txA, tyA;
                 const F3 dirA = light_sample(p, sx, sy, pdfA_light, txA, tyA);
                 const float pdfA_bsdf = bsdf_pdf(pDiffuse, pSpecular, nrm, wo, dirA, alpha);
-                // BSDF importance sample (kernel.cu:522-526)
+                // BSDF importance sample (kernel.cu:522-526): the numbers are drawn here, the lobe is sampled in run_batch
                 const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
                 sx = ((float)(pb % n) + uniform_pcg(rng)) * strata_frac;
                 sy = ((float)(pb / n) + uniform_pcg(rng)) * strata_frac;
                 const float sz = uniform_pcg(rng);
-                const F3 dirB = bsdf_sample(pDiffuse, pSpecular, nrm, wo, sx, sy, sz, alpha, pdfB_bsdf);
-                const float pdfB_light = light_pdf(p, dirB, txB, tyB);
+                cosine = sz < pDiffuse;
+                task = make_float4(sx, sy, __uint_as_float(pb | (ring_at << 16)), __uint_as_float(pi));
                 // Stream order inside a pixel: the S light-sampled rays by THEIR STRATUM (pl), then the S BSDF-sampled rays by
                 // theirs (pb).  The permutation tables scramble which sample draws which stratum; ordering by stratum puts
                 // neighbouring cells of the CDF / hemisphere grid -- i.e. nearby directions -- into neighbouring lanes of the
                 // traversal kernel, which keeps its wavefronts coherent (both rows are permutations of 0..S-1: a bijection).
-            // (The other grouping -- one stratum of 64 neighbouring pixels per wave, i.e. near-parallel rays from spread-out
-            // origins -- was measured 3-12 % slower than this one: shared origins matter more than shared directions.)
-                rA = (int64_t)pi * 2 * S + pl;
-                rB = (int64_t)pi * 2 * S + S + pb;
+                // (The other grouping -- one stratum of 64 neighbouring pixels per wave, i.e. near-parallel rays from spread-out
+                // origins -- was measured 3-12 % slower than this one: shared origins matter more than shared directions.)
+                rA = pi * 2u * S + pl;
                 // Dead samples: with dot(n, wi) <= 0 the Lambert term is max(.,0) = 0 and the GGX lobe fails its front-facing
                 // gate (bsdf.h:121,165 -- the same dot product), forward AND backward, so the sample contributes exactly
                 // zero whatever its visibility.  Such rays (about half of the light-sampled ones: the probe covers the whole
                 // sphere) are flagged in the sign bit of the pdf sum (never negative) for stage 3, which skips them, and are
-                // left out of the list of stream slots stage 2 traverses (appended per wavefront: one atomic per wave and
-                // round; the list order varies from run to run, the visibility of a slot does not).
+                // left out of the list of stream slots stage 2 traverses (appended per wavefront; the list order varies from
+                // run to run, the visibility of a slot does not).
                 // NVDR_DEBUG bit 8 switches the culling off (traces every ray like the reference).
-                const bool cull = !(p.debug & 8u);
-                deadA = (cull && !(dot3(nrm, dirA) > 0.0f)) ? 0x80000000u : 0u;
-                deadB = (cull && !(dot3(nrm, dirB) > 0.0f)) ? 0x80000000u : 0u;
+                const unsigned deadA = (!(p.debug & 8u) && !(dot3(nrm, dirA) > 0.0f)) ? 0x80000000u : 0u;
                 p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(__float_as_uint(pdfA_light + pdfA_bsdf) | deadA));
-                p.rays[rB] = make_float4(dirB.x, dirB.y, dirB.z, __uint_as_float(__float_as_uint(pdfB_light + pdfB_bsdf) | deadB));
                 p.texel[rA] = tyA * p.light.n1 + txA;
-                p.texel[rB] = tyB * p.light.n1 + txB;
+                liveA = deadA == 0u;
             }
-            // append the live slots to this wavefront's LDS staging buffer (ballot ranks; `staged` is wave-uniform)
-            const unsigned long long mA = __ballot(deadA == 0u), mB = __ballot(deadB == 0u);
-            const unsigned nA = (unsigned)__popcll(mA), nB = (unsigned)__popcll(mB);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (!deadA) stage[staged + (unsigned)__popcll(mA & below)] = (unsigned)rA;
-            if (!deadB) stage[staged + nA + (unsigned)__popcll(mB & below)] = (unsigned)rB;
-            staged += nA + nB;
-            if (staged > NVDR_GEN_STAGE - 128u) staged = flush_live(stage, staged, lane, p);
+            stage_live(liveA, rA);
+            // The BSDF-sampled ray goes on the list of rays to traverse NOW, in the order of the round, whether it turns out dead or
+            // not: its direction is not known yet, dead BSDF samples are 0.3 % of the rays (the lobes point away from the surface), and
+            // listing them by batch instead -- a pixel's rays in three places of the list -- costs the traversal kernel 1.8 %.
+            stage_live(has, pi * 2u * S + S + (__float_as_uint(task.z) & 0xffffu));
+            // queue the BSDF tasks by lobe, run the lobes that have a full wavefront of them
+            {
+                const unsigned long long m0 = __ballot(has && cosine), m1 = __ballot(has && !cosine);
+                const unsigned long long mine = cosine ? m0 : m1;
+                if (has) {
+                    const unsigned at = (cosine ? q_head[0] + q_count[0] : q_head[1] + q_count[1]) +
+                                        __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+                    (cosine ? queue[0] : queue[1])[at & (NVDR_GEN_QCAP - 1u)] = task;
+                }
+                q_count[0] += (unsigned)__popcll(m0);
+                q_count[1] += (unsigned)__popcll(m1);
+                if (q_count[0] >= 64u) run_batch(0, 64u);
+                if (q_count[1] >= 64u) run_batch(1, 64u);
+            }
+        }
+        // the ring is about to wrap: nothing may wait on the entries the next groups overwrite
+        if (++groups_done % ring_groups == 0u) {
+            if (q_count[0]) run_batch(0, q_count[0]);
+            if (q_count[1]) run_batch(1, q_count[1]);
         }
     }
+    if (q_count[0]) run_batch(0, q_count[0]);
+    if (q_count[1]) run_batch(1, q_count[1]);
     flush_live(stage, staged, lane, p);
 }
 
@@ -1185,7 +1264,12 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     while (L < (int)S && L < 64) { L <<= 1; lg++; }
     const int G = 64 / L;                                       // pixels per wavefront round (a "group")
     const int64_t group_slots = (int64_t)G * 2 * S;
-    const int *per_cu = c->per_cu;   // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading): {8, 6, 6},
+    // (small launches -- up to four views of 512^2 -- start the generation kernel with 4 workgroups per CU, exactly what is resident:
+    // its wavefronts hold BSDF tasks back until 64 of one lobe wait and drain the rest when they run out of pixels, so few pixels per
+    // wavefront mean many half-empty batches: 0.301 vs 0.315 ms for one view; 8 per CU is 3 % better for eight views)
+    int per_cu_launch[3] = {c->per_cu[0], c->per_cu[1], c->per_cu[2]};
+    if (!c->per_cu_user && npix <= (1ll << 20)) per_cu_launch[0] = 4;
+    const int *per_cu = per_cu_launch;   // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading): {8, 6, 6},
                                      // measured within 3 % of the best for each kernel; NVDR_PBLOCKS="g,f,b" is read once per context
     const int waves_per_block = 4;
 

@@ -16,6 +16,12 @@ nviews = int(os.environ.get('PROBE_VIEWS', '8'))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 base = _build.LIB
 paths = [('current', base)] + [(p.split('.so.')[-1], p) for p in sorted(glob.glob(os.path.join(_build.BUILD, 'variants', 'libnvdr_hip.so.*')))]
+# AB_ENV="tag:VAR=value;VAR2=value|tag2:VAR=value": the current library with environment switches set while the context is created
+env_variants = {}
+for spec in filter(None, os.environ.get('AB_ENV', '').split('|')):
+    tag, kv = spec.split(':', 1)
+    env_variants[tag] = dict(x.split('=', 1) for x in kv.split(';'))
+    paths.append((tag, base))
 if os.environ.get('AB_LG', '0') != '0':
     paths.append(('lg_all', base))         # light-gradient gather: every workgroup walks all bands (NVDR_LG_MODE=0)
     paths.append(('lg_perband', base))     # one set of workgroups per band (NVDR_LG_MODE=1)
@@ -34,11 +40,15 @@ for tag, path in paths:
         os.environ['NVDR_TRACE_VARIANT'] = '0'
     else:
         os.environ.pop('NVDR_TRACE_VARIANT', None)
+    for k_, v_ in env_variants.get(tag, {}).items():
+        os.environ[k_] = v_
     if tag.startswith('lg_'):
         os.environ['NVDR_LG_MODE'] = '1' if tag == 'lg_perband' else '0'
     st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
     os.environ.pop('NVDR_TRACE_VARIANT', None)
     os.environ.pop('NVDR_LG_MODE', None)
+    for k_ in env_variants.get(tag, {}):
+        os.environ.pop(k_, None)
     assert st.ctx.cpp_wrapper.lib is lib
     with torch.no_grad():
         m = st.mask[..., None]

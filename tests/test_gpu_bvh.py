@@ -447,11 +447,15 @@ def _check_oct_tree(ctx, v, t):
     return cnt['nodes'], float((n_int + n_leaf).mean())
 
 
+@pytest.mark.parametrize('rule', ['dp', 'greedy'])
 @pytest.mark.parametrize('kind', ['bob', 'spot', 'single', 'pair', 'fan', 'subdiv1'])
-def test_oct_tree_invariants(kind, dev):
+def test_oct_tree_invariants(kind, rule, dev, monkeypatch):
     """The eight-wide tree built by the ticket-driven collapse (bvh_oct_build_kernel): every triangle placed once, children and
-    leaves stored contiguously, every 8-bit box contains what it stands for -- on regular meshes, degenerate ones, and after a refit."""
+    leaves stored contiguously, every 8-bit box contains what it stands for -- on regular meshes, degenerate ones, and after a refit;
+    with the SAH-optimal slot choice of the fit kernel's dynamic programme (default) and with the greedy largest-area rule."""
     from nvdiffrecmc_amd import optixutils as ou
+    if rule == 'greedy':
+        monkeypatch.setenv('NVDR_OCT_DP', '0')          # read when a context is created
     if kind in ('bob', 'spot'):
         m = sc.load_mesh(kind)
         v, t = m['v_pos'], m['t_pos_idx']
@@ -469,6 +473,19 @@ def test_oct_tree_invariants(kind, dev):
     print('\n[%s] %d triangles -> %d oct nodes, %.2f slots used per node' % (kind, t.shape[0], nodes, fill))
     if t.shape[0] > 8:
         assert nodes < t.shape[0] / 3 and fill > 4.0
+    if rule == 'dp' and kind in ('bob', 'spot'):
+        # the optimal collapse needs fewer, fuller nodes than the greedy one (bob: 2 2xx against 3 283)
+        monkeypatch.setenv('NVDR_OCT_DP', '0')
+        ctx_g = ou.OptiXContext()
+        monkeypatch.delenv('NVDR_OCT_DP')
+        ou.optix_build_bvh(ctx_g, v.to(dev), t.to(dev), rebuild=1)
+        nodes_g, _ = _check_oct_tree(ctx_g, v, t)
+        assert nodes < nodes_g
+        # and both trees answer alike
+        g0 = torch.Generator().manual_seed(3)
+        ro = (torch.rand(20000, 3, generator=g0) * 2 - 1).to(dev) * float(v.abs().max())
+        rd = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g0), dim=-1).to(dev)
+        assert torch.equal(ou.ops.trace_visibility_wide(ctx, ro, rd), ou.ops.trace_visibility_wide(ctx_g, ro, rd))
     g = torch.Generator().manual_seed(1)
     v2 = (v * 1.05 + 0.01 * torch.randn(v.shape, generator=g)).contiguous()
     ou.optix_build_bvh(ctx, v2.to(dev), t.to(dev), rebuild=0)                   # refit: the oct tree is rebuilt over the new boxes

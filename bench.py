@@ -599,13 +599,14 @@ def run(args):
                 roof['traffic_source'] = 'rocprofv3 --kernel-trace --pmc passes of this run (bench.py --pmc-child, %d dispatches)' % int(c.get('dispatches_pass1', 0))
                 # the other env-shade kernels from the same passes (durations: HIP-event stage times, backward stage 3 includes the gather)
                 others = {}
-                for needle, ms in (('env_shade_kernel<true>', None), ('env_gen_kernel', gen_ms), ('env_shade_kernel<false>', shade_ms),
-                                   ('light_grad_band_kernel', None)):
+                for label, needle, ms in (('env_shade_kernel<backward>', 'env_shade_kernel<true', None), ('env_gen_kernel', 'env_gen_kernel', gen_ms),
+                                          ('env_shade_kernel<forward>', 'env_shade_kernel<false', shade_ms),
+                                          ('light_grad_block_kernel', 'light_grad_block_kernel', None)):
                     oc = find_kernel(counters, needle)
                     if oc:
                         mm = mem_figures(oc, ms)
                         vv = valu_figures(oc, ms) if ms else None
-                        others[needle] = {'hbm_bytes': mm.get('hbm_bytes'), 'hbm_GBs': mm.get('hbm_GBs'), 'l2_hit': mm.get('l2_hit'),
+                        others[label] = {'hbm_bytes': mm.get('hbm_bytes'), 'hbm_GBs': mm.get('hbm_GBs'), 'l2_hit': mm.get('l2_hit'),
                                           'valu_wave_instructions': oc.get('SQ_INSTS_VALU'),
                                           'active_lane_fraction': (oc['SQ_THREAD_CYCLES_VALU'] / (64.0 * oc['SQ_ACTIVE_INST_VALU'])
                                                                    if oc.get('SQ_ACTIVE_INST_VALU') else None),

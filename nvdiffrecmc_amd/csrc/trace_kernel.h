@@ -291,6 +291,10 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 const float tf = fminf(fminf(tfx, tfy), tfz);
                 miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);     // (miss << 1) | sign(tf - tn)
             }
+            // (Measured and dropped, round 3, session 19: the (near, far) distances of an axis as ONE v_pk_fma_f32 -- 24 instead of 48 fma
+            // instructions per node step, bit-identical -- is 5 % SLOWER (2.577 vs 2.455 ms per 8-view launch, 8.68 vs 8.35 ms on 684 k
+            // triangles): packed fp32 issues at 2.8 cycles against 1.85 for v_fma_f32 at this occupancy and needs its operands in aligned
+            // register pairs, which cost copies and three more spilled dwords.)
             // (Measured and dropped, round 3: bytes -> distances through v_perm_b32 + v_fma_mix_f32 -- two bytes and the constant
             // 0x64 make two f16 values 1024 + q, which an f32 fma consumes directly: 3 VALU per byte pair instead of 4, exact to 8e-5
             // quantisation steps -- is NOT faster: v_fma_mix_f32 and v_perm_b32 issue at 2.6-2.7 cycles against 2.1 / 1.9 for the

@@ -299,6 +299,14 @@ __device__ __forceinline__ float light_pdf(const ShadeParams &p, F3 dir, int &tx
     const float pdf_weight = (float)((double)(Hl * Wl) / (2.0 * NVDR_PI_DBL * NVDR_PI_DBL * (double)fmaxf(s, 0.0001f)));
     return p.pdf.p[y * p.pdf.s0 + x * p.pdf.s1] * pdf_weight;
 }
+// the direction of a light sample alone (light_sample without its pdf: the generation kernel asks for the pdf of live samples only)
+__device__ __forceinline__ F3 light_sample_dir(const ShadeParams &p, float u, float v)
+{
+    unsigned x, y;
+    const float ry = sample_cdf(p.rows.p, p.rows.s0, p.rows.n0, v, y);
+    const float rx = sample_cdf(p.cols.p + (int64_t)y * p.cols.s0, p.cols.s1, p.cols.n1, u, x);
+    return tc_to_dir(((float)x + rx) / (float)p.pdf.n1, ((float)y + ry) / (float)p.pdf.n0);
+}
 __device__ __forceinline__ F3 light_sample(const ShadeParams &p, float u, float v, float &pdf, int &tx, int &ty)
 {
     unsigned x, y;
@@ -436,7 +444,7 @@ __device__ __forceinline__ F3 fetch_light_texel(const Tab &t, int texel)
 // stage 1: sample generation (kernel.cu:463-526 minus process_sample)
 
 #define NVDR_GEN_STAGE 512u
-#define NVDR_GEN_RING 64u          // pixels whose set-up the deferred BSDF samples of a wavefront may still refer to
+#define NVDR_GEN_RING 64u          // pixels whose set-up the queued samples of a wavefront may still refer to
 #define NVDR_GEN_QCAP 128u         // entries of one lobe queue (< 64 waiting + <= 64 pushed per round)
 
 // one list-space claim for `staged` slots of a wavefront, then a coalesced copy out of LDS; returns the new fill (0)
@@ -475,11 +483,21 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     // evaluated when 64 of its tasks wait -- every lane busy, one branch -- together with everything that follows from the direction
     // (light pdf, culling, stream slot).  The same arithmetic per sample, in another order.  The pixel's set-up a task needs
     // (normal, wo, alpha, pDiffuse) waits in a small ring; before a ring entry is reused the queues are drained, full or not.
-    __shared__ float4 ring_all[4][NVDR_GEN_RING * 2];
-    __shared__ float4 queue_all[4][2][NVDR_GEN_QCAP];
-    float4 *ring = ring_all[wave];
-    float4 *queue[2] = {queue_all[wave][0], queue_all[wave][1]};       // [0] diffuse lobe, [1] specular lobe
-    unsigned q_head[2] = {0u, 0u}, q_count[2] = {0u, 0u};               // wave-uniform
+    // A third queue does the same for the LIGHT samples: half of them point under the horizon -- known as soon as the direction is --
+    // and need neither the light pdf (atan2, acos, sincos, pdf lookup) nor the BSDF pdf; the live ones are queued (direction, stratum,
+    // pixel) and get both 64 at a time.
+    // (LDS of a workgroup: 38 KB, four workgroups per CU.)
+    __shared__ float4 ring_a_all[4][NVDR_GEN_RING], ring_b_all[4][NVDR_GEN_RING];      // (normal, alpha), (wo, pDiffuse)
+    __shared__ unsigned ring_pi_all[4][NVDR_GEN_RING];                                  // the pixel's index in the chunk
+    __shared__ float2 lobe_xy_all[4][2][NVDR_GEN_QCAP];                                 // BSDF tasks: (sx, sy) ...
+    __shared__ unsigned lobe_key_all[4][2][NVDR_GEN_QCAP];                              // ... and stratum | ring entry << 16; [0] diffuse, [1] specular lobe
+    __shared__ float4 lightq_all[4][NVDR_GEN_QCAP];                                     // live light samples: (direction, stratum | ring entry << 16)
+    float4 *ring_a = ring_a_all[wave], *ring_b = ring_b_all[wave];
+    unsigned *ring_pi = ring_pi_all[wave];
+    float2 *lobe_xy[2] = {lobe_xy_all[wave][0], lobe_xy_all[wave][1]};
+    unsigned *lobe_key[2] = {lobe_key_all[wave][0], lobe_key_all[wave][1]};
+    float4 *lightq = lightq_all[wave];
+    unsigned q_head[3] = {0u, 0u, 0u}, q_count[3] = {0u, 0u, 0u};       // wave-uniform; [2]: the light-sample queue
     const unsigned ring_groups = NVDR_GEN_RING / (unsigned)G;           // groups of pixels the ring holds (G <= 64)
     unsigned groups_done = 0;
     // the lane's jump (5 draws per stratum, kernel.cu:513-524) is the same for every pixel: computed once when one round
@@ -498,15 +516,35 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     auto run_batch = [&](int lobe, unsigned cnt) {
         __builtin_amdgcn_wave_barrier();                    // tasks and ring entries were written by other lanes of this wavefront
         const bool has = (unsigned)lane < cnt;
-        const float4 t = queue[lobe][(q_head[lobe] + (unsigned)lane) & (NVDR_GEN_QCAP - 1u)];
+        const unsigned qi = (q_head[lobe] + (unsigned)lane) & (NVDR_GEN_QCAP - 1u);
+        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        unsigned key;
+        if (lobe == 2) {
+            t = lightq[qi];
+            key = __float_as_uint(t.w);
+        } else {
+            const float2 xy = lobe_xy[lobe][qi];
+            t.x = xy.x; t.y = xy.y;
+            key = lobe_key[lobe][qi];
+        }
         q_head[lobe] += cnt;
         q_count[lobe] -= cnt;
         if (has) {
-            const unsigned key = __float_as_uint(t.z), pix = __float_as_uint(t.w);
             const unsigned pb = key & 0xffffu, ri = key >> 16;
-            const float4 s0 = ring[2u * ri], s1 = ring[2u * ri + 1u];
+            const float4 s0 = ring_a[ri], s1 = ring_b[ri];
+            const unsigned pix = ring_pi[ri];
             const F3 N = f3(s0.x, s0.y, s0.z), wo = f3(s1.x, s1.y, s1.z);
             const float alpha = s0.w, pDiffuse = s1.w, sx = t.x, sy = t.y;
+            if (lobe == 2) {                                // a live light sample: both pdfs, the ray, the texel (kernel.cu:513-520)
+                const F3 dirA = f3(t.x, t.y, t.z);
+                int txA, tyA;
+                const float pdfA_light = light_pdf(p, dirA, txA, tyA);
+                const float pdfA_bsdf = bsdf_pdf(pDiffuse, 1.0f - pDiffuse, N, wo, dirA, alpha);
+                const unsigned rA = pix * 2u * S + pb;      // (pb holds the light stratum here)
+                p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, pdfA_light + pdfA_bsdf);
+                p.texel[rA] = tyA * p.light.n1 + txA;
+                return;
+            }
             float pdfB_bsdf = 0.0f;
             F3 dirB;
             if (lobe == 0) {                                // bsdf_sample, the branch sz < pDiffuse
@@ -552,8 +590,9 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         if (sub == 0 && valid) {
             const F3 ro = fetch3(p.ro, z, y, x);
             p.pix_origin[pi] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-            ring[2u * ring_at] = make_float4(nrm.x, nrm.y, nrm.z, alpha);
-            ring[2u * ring_at + 1u] = make_float4(wo.x, wo.y, wo.z, pDiffuse);
+            ring_a[ring_at] = make_float4(nrm.x, nrm.y, nrm.z, alpha);
+            ring_b[ring_at] = make_float4(wo.x, wo.y, wo.z, pDiffuse);
+            ring_pi[ring_at] = pi;
         }
         unsigned a_seed = launch_seed(p), b_seed = (unsigned)lin + p.pix_offset;
         unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
@@ -565,7 +604,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
             const bool has = valid && i < S;
             bool liveA = false, cosine = false;
             unsigned rA = 0;
-            float4 task = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float4 task = make_float4(0.0f, 0.0f, 0.0f, 0.0f), taskA = task;
             if (has) {
                 unsigned jm = jump_m, ja = jump_a;
                 if (base != 0u) lcg_skip_coeff(5u * i, jm, ja);
@@ -574,17 +613,14 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
                 float sx = ((float)(pl % n) + uniform_pcg(rng)) * strata_frac;
                 float sy = ((float)(pl / n) + uniform_pcg(rng)) * strata_frac;
-                float pdfA_light;
-                int txA, tyA;
-                const F3 dirA = light_sample(p, sx, sy, pdfA_light, txA, tyA);
-                const float pdfA_bsdf = bsdf_pdf(pDiffuse, pSpecular, nrm, wo, dirA, alpha);
+                const F3 dirA = light_sample_dir(p, sx, sy);
                 // BSDF importance sample (kernel.cu:522-526): the numbers are drawn here, the lobe is sampled in run_batch
                 const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
                 sx = ((float)(pb % n) + uniform_pcg(rng)) * strata_frac;
                 sy = ((float)(pb / n) + uniform_pcg(rng)) * strata_frac;
                 const float sz = uniform_pcg(rng);
                 cosine = sz < pDiffuse;
-                task = make_float4(sx, sy, __uint_as_float(pb | (ring_at << 16)), __uint_as_float(pi));
+                task = make_float4(sx, sy, __uint_as_float(pb | (ring_at << 16)), 0.0f);
                 // Stream order inside a pixel: the S light-sampled rays by THEIR STRATUM (pl), then the S BSDF-sampled rays by
                 // theirs (pb).  The permutation tables scramble which sample draws which stratum; ordering by stratum puts
                 // neighbouring cells of the CDF / hemisphere grid -- i.e. nearby directions -- into neighbouring lanes of the
@@ -599,12 +635,18 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 // left out of the list of stream slots stage 2 traverses (appended per wavefront; the list order varies from
                 // run to run, the visibility of a slot does not).
                 // NVDR_DEBUG bit 8 switches the culling off (traces every ray like the reference).
-                const unsigned deadA = (!(p.debug & 8u) && !(dot3(nrm, dirA) > 0.0f)) ? 0x80000000u : 0u;
-                p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(__float_as_uint(pdfA_light + pdfA_bsdf) | deadA));
-                p.texel[rA] = tyA * p.light.n1 + txA;
-                liveA = deadA == 0u;
+                liveA = (p.debug & 8u) || dot3(nrm, dirA) > 0.0f;
+                // a dead sample's slot only says so (nobody reads its pdfs or its texel); a live one gets them in run_batch
+                if (!liveA) p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(0x80000000u));
+                taskA = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(pl | (ring_at << 16)));
             }
             stage_live(liveA, rA);
+            {
+                const unsigned long long m2 = __ballot(liveA);
+                if (liveA) lightq[(q_head[2] + q_count[2] + __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u))) & (NVDR_GEN_QCAP - 1u)] = taskA;
+                q_count[2] += (unsigned)__popcll(m2);
+                if (q_count[2] >= 64u) run_batch(2, 64u);
+            }
             // The BSDF-sampled ray goes on the list of rays to traverse NOW, in the order of the round, whether it turns out dead or
             // not: its direction is not known yet, dead BSDF samples are 0.3 % of the rays (the lobes point away from the surface), and
             // listing them by batch instead -- a pixel's rays in three places of the list -- costs the traversal kernel 1.8 %.
@@ -616,7 +658,8 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 if (has) {
                     const unsigned at = (cosine ? q_head[0] + q_count[0] : q_head[1] + q_count[1]) +
                                         __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
-                    (cosine ? queue[0] : queue[1])[at & (NVDR_GEN_QCAP - 1u)] = task;
+                    (cosine ? lobe_xy[0] : lobe_xy[1])[at & (NVDR_GEN_QCAP - 1u)] = make_float2(task.x, task.y);
+                    (cosine ? lobe_key[0] : lobe_key[1])[at & (NVDR_GEN_QCAP - 1u)] = __float_as_uint(task.z);
                 }
                 q_count[0] += (unsigned)__popcll(m0);
                 q_count[1] += (unsigned)__popcll(m1);
@@ -628,10 +671,12 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         if (++groups_done % ring_groups == 0u) {
             if (q_count[0]) run_batch(0, q_count[0]);
             if (q_count[1]) run_batch(1, q_count[1]);
+            if (q_count[2]) run_batch(2, q_count[2]);
         }
     }
     if (q_count[0]) run_batch(0, q_count[0]);
     if (q_count[1]) run_batch(1, q_count[1]);
+    if (q_count[2]) run_batch(2, q_count[2]);
     flush_live(stage, staged, lane, p);
 }
 

@@ -226,6 +226,13 @@ int nvdr_bilateral_denoiser_fwd(const nvdr_tensor *col, const nvdr_tensor *nrm, 
                                 float *out, void *stream);
 int nvdr_bilateral_denoiser_bwd(const nvdr_tensor *col, const nvdr_tensor *nrm, const nvdr_tensor *zdz, float sigma,
                                 const nvdr_tensor *out_grad, float *col_grad, void *stream);
+/* two images filtered with the same guides in one pass (additive): the weights are evaluated once per tap; bit-identical to two
+ * single calls.  render.py:120-121 filters the diffuse and the specular light of shade() with the same normal / depth. */
+int nvdr_bilateral_denoiser_pair_fwd(const nvdr_tensor *col_a, const nvdr_tensor *col_b, const nvdr_tensor *nrm, const nvdr_tensor *zdz,
+                                     float sigma, float *out_a, float *out_b, void *stream);
+int nvdr_bilateral_denoiser_pair_bwd(const nvdr_tensor *col, const nvdr_tensor *nrm, const nvdr_tensor *zdz, float sigma,
+                                     const nvdr_tensor *out_grad_a, const nvdr_tensor *out_grad_b, float *col_grad_a, float *col_grad_b,
+                                     void *stream);
 
 /* ---- renderutils_plugin (render/renderutils/c_src/torch_bindings.cpp).  All tensors are NHWC
  * 4-d views with size-1 broadcasting; the launch extent is the per-dim max over the inputs

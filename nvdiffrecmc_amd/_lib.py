@@ -103,6 +103,8 @@ _SIGNATURES = {
     'nvdr_env_shade_stage_times': [c_void_p, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int64)],
     'nvdr_bilateral_denoiser_fwd': [_T, _T, _T, c_float, c_void_p, c_void_p],
     'nvdr_bilateral_denoiser_bwd': [_T, _T, _T, c_float, _T, c_void_p, c_void_p],
+    'nvdr_bilateral_denoiser_pair_fwd': [_T, _T, _T, _T, c_float, c_void_p, c_void_p, c_void_p],
+    'nvdr_bilateral_denoiser_pair_bwd': [_T, _T, _T, c_float, _T, _T, c_void_p, c_void_p, c_void_p],
     'nvdr_image_loss_num_partials': [c_int64, c_int64, c_int64],
     'nvdr_image_loss_fwd': [_T, _T, c_int, c_int, c_void_p, c_void_p],
     'nvdr_image_loss_bwd': [_T, _T, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -325,6 +325,36 @@ class _bilateral_denoiser_func(torch.autograd.Function):
         return col_grad, None, None, None
 
 
+class _bilateral_denoiser_pair_func(torch.autograd.Function):
+    """Two images with the same guides in one pass (the diffuse and the specular light of shade(), render.py:120-121): the weights
+    are evaluated once per tap.  Outputs bit-identical to two _bilateral_denoiser_func calls."""
+
+    @staticmethod
+    def forward(ctx, col_a, col_b, nrm, zdz, sigma):
+        for name, t in (('col_a', col_a), ('col_b', col_b), ('nrm', nrm), ('zdz', zdz)):
+            _lib.require_cuda_f32(t, name)
+        ctx.save_for_backward(col_a, nrm, zdz)
+        ctx.sigma = sigma
+        N, H, W = col_a.shape[0], col_a.shape[1], col_a.shape[2]
+        out = torch.empty(2, N, H, W, 4, dtype=torch.float32, device=col_a.device)
+        va, vb, vn, vz = _lib.tensor_view(col_a), _lib.tensor_view(col_b), _lib.tensor_view(nrm), _lib.tensor_view(zdz)
+        _lib.check(_lib.load().nvdr_bilateral_denoiser_pair_fwd(ctypes.byref(va), ctypes.byref(vb), ctypes.byref(vn), ctypes.byref(vz), float(sigma),
+                                                                _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.stream_ptr()), 'bilateral_denoiser_pair_fwd')
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, grad_a, grad_b):
+        col, nrm, zdz = ctx.saved_tensors
+        N, H, W = col.shape[0], col.shape[1], col.shape[2]
+        g = torch.empty(2, N, H, W, 3, dtype=torch.float32, device=col.device)
+        vc, vn, vz = _lib.tensor_view(col), _lib.tensor_view(nrm), _lib.tensor_view(zdz)
+        ga, gb = _lib.tensor_view(grad_a), _lib.tensor_view(grad_b)
+        _lib.check(_lib.load().nvdr_bilateral_denoiser_pair_bwd(ctypes.byref(vc), ctypes.byref(vn), ctypes.byref(vz), float(ctx.sigma), ctypes.byref(ga),
+                                                                ctypes.byref(gb), _lib.ptr(g[0]), _lib.ptr(g[1]), _lib.stream_ptr()),
+                   'bilateral_denoiser_pair_bwd')
+        return g[0], g[1], None, None, None
+
+
 def bilateral_denoiser(col, nrm, zdz, sigma):
     col_w = _bilateral_denoiser_func.apply(col, nrm, zdz, sigma)
     return col_w[..., 0:3] / col_w[..., 3:4]

@@ -20,6 +20,7 @@ render.py:208-234) instead of nvdiffrast, so it is NOT differentiable w.r.t. geo
 lookup into a trainable texture instead of dr.texture.
 """
 import math
+import os
 
 import torch
 
@@ -75,6 +76,7 @@ class DirectLightingStep:
         self.pixel_index_offset = pixel_index_offset
         self.retrace_backward = retrace_backward
         self.fused = fused
+        self.pair_filter = os.environ.get('NVDR_PAIR_FILTER', '1') != '0'      # (A/B switch of the harness)
         self.denoiser_demodulate = denoiser_demodulate    # FLAGS.denoiser_demodulate (train.py:525, default True)
         self.light_grad_scale = light_grad_scale          # lgt.base.grad *= 64 (train.py:439-440)
         self.total_views = n_views if isinstance(n_views, int) else len(n_views)
@@ -191,8 +193,11 @@ class DirectLightingStep:
             # fused composite: ~45 small torch kernels per iteration less
             if self.denoiser is not None:
                 nn = _safe_normalize(nrm)
-                diff = ou.ops._bilateral_denoiser_func.apply(diff, nn, self.gb_depth, self.denoiser.sigma)
-                spec = ou.ops._bilateral_denoiser_func.apply(spec, nn, self.gb_depth, self.denoiser.sigma)
+                if self.pair_filter:     # both images in one pass: same guides, same weights (bit-identical to the two calls below)
+                    diff, spec = ou.ops._bilateral_denoiser_pair_func.apply(diff, spec, nn, self.gb_depth, self.denoiser.sigma)
+                else:
+                    diff = ou.ops._bilateral_denoiser_func.apply(diff, nn, self.gb_depth, self.denoiser.sigma)
+                    spec = ou.ops._bilateral_denoiser_func.apply(spec, nn, self.gb_depth, self.denoiser.sigma)
             return ru.shade_composite(diff, spec, kd, ks)
         if self.denoiser is not None:   # the reference's own sequence of calls (render.py:119-127)
             diff = self.denoiser.forward(torch.cat((diff, nrm, self.gb_depth), dim=-1))

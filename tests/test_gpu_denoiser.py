@@ -107,3 +107,27 @@ def test_denoiser_background_early_out(sigma, dev):
     assert torch.equal(out.detach().cpu()[empty][:, :3], torch.zeros(int(empty.sum()), 3))
     assert torch.equal(out.detach().cpu()[empty][:, 3], torch.full((int(empty.sum()),), 1e-4))
     assert torch.equal(cd.grad.cpu()[empty], torch.zeros(int(empty.sum()), 3))
+
+
+@pytest.mark.parametrize('N,H,W,sigma', [(1, 70, 45, 1.0), (2, 96, 130, 2.0), (1, 40, 40, 4.0)])
+def test_pair_filter_equals_two_single_calls(N, H, W, sigma, dev):
+    """Two images with the same guides filtered in one pass (weights evaluated once per tap; the diffuse and the specular light of
+    shade(), render.py:120-121) are bit-identical to two single calls, forward and backward -- ragged extents, a background region
+    (zero normals), the tiled and (sigma = 4: the three-plane tile no longer fits) the untiled path."""
+    from nvdiffrecmc_amd import optixutils as ou
+    g = torch.Generator().manual_seed(7)
+    ca, cb = torch.rand(N, H, W, 3, generator=g), torch.rand(N, H, W, 3, generator=g) * 3.0
+    nrm = torch.nn.functional.normalize(torch.randn(N, H, W, 3, generator=g), dim=-1)
+    nrm[:, : H // 3, : W // 2] = 0.0                                   # background
+    zdz = torch.rand(N, H, W, 2, generator=g) + 0.1
+    ga, gb = torch.rand(N, H, W, 4, generator=g), torch.rand(N, H, W, 4, generator=g)
+    ca, cb, nrm, zdz, ga, gb = (t.to(dev) for t in (ca, cb, nrm, zdz, ga, gb))
+    xa, xb = ca.clone().requires_grad_(True), cb.clone().requires_grad_(True)
+    oa = ou.ops._bilateral_denoiser_func.apply(xa, nrm, zdz, sigma)
+    ob = ou.ops._bilateral_denoiser_func.apply(xb, nrm, zdz, sigma)
+    torch.autograd.backward([oa, ob], [ga, gb])
+    ya, yb = ca.clone().requires_grad_(True), cb.clone().requires_grad_(True)
+    pa, pb = ou.ops._bilateral_denoiser_pair_func.apply(ya, yb, nrm, zdz, sigma)
+    torch.autograd.backward([pa, pb], [ga, gb])
+    assert torch.equal(pa, oa) and torch.equal(pb, ob)
+    assert torch.equal(ya.grad, xa.grad) and torch.equal(yb.grad, xb.grad)

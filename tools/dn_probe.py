@@ -59,6 +59,29 @@ for r in range(rounds):
         f, b, o, g = run(tag)
         acc[tag].append((f, b))
         assert torch.equal(o, ref[2]) and torch.equal(g, ref[3]), 'variant %s changes the filter output' % tag
+
+
+def run_pair(iters=10):
+    _lib._lib = libs['current']
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    c1, c2 = col.clone().requires_grad_(True), (col * 0.5).clone().requires_grad_(True)
+    tf = tb = 0.0
+    for it in range(iters):
+        c1.grad = c2.grad = None
+        ev[0].record()
+        o1, o2 = ou.ops._bilateral_denoiser_pair_func.apply(c1, c2, nn, st.gb_depth, sigma)
+        ev[1].record()
+        torch.autograd.backward([o1, o2], [og, og])
+        ev[2].record()
+        torch.cuda.synchronize()
+        if it:
+            tf += ev[0].elapsed_time(ev[1]); tb += ev[1].elapsed_time(ev[2])
+    return tf / (iters - 1), tb / (iters - 1)
+
+
+if hasattr(ou.ops, '_bilateral_denoiser_pair_func'):
+    pr = [run_pair() for _ in range(rounds)]
+    print('pair kernel (two images in one pass): fwd %.3f  bwd %.3f   (two single calls = twice the figures below)' % (statistics.median(x[0] for x in pr), statistics.median(x[1] for x in pr)))
 print('bilateral filter, %d views %dx%d, sigma %g: median ms over %d interleaved rounds (outputs bit-identical)' % (nviews, res, res, sigma, rounds))
 for tag, _ in paths:
     print('  %-10s fwd %.3f  bwd %.3f' % (tag, statistics.median(x[0] for x in acc[tag]), statistics.median(x[1] for x in acc[tag])))

@@ -42,7 +42,11 @@ typedef struct nvdr_ctx nvdr_ctx; /* replaces OptiXStateWrapper, optix_wrapper.h
 const char *nvdr_last_error(void);
 int nvdr_version(void);
 
-/* ---- context: owns the BVH buffers, replaces OptiXStateWrapper ctor/dtor (optix_wrapper.cpp:306-348) */
+/* ---- context: owns the BVH buffers, replaces OptiXStateWrapper ctor/dtor (optix_wrapper.cpp:306-348).
+ * ONE STREAM PER CONTEXT AT A TIME: the scratch of a context (tree, ray stream, traversal stacks, chunk counters, light-gradient
+ * partials) is shared by all its launches and is grown / freed after synchronising only the stream of the call that needs more.
+ * Launches of one context must therefore be ordered on one stream (or by events); use one context per concurrent stream.  A
+ * buffer that has to grow inside a HIP-graph capture fails the capture: run a few iterations eagerly first (trainer.py does). */
 int nvdr_ctx_create(nvdr_ctx **out, int device);
 int nvdr_ctx_destroy(nvdr_ctx *ctx);
 /* Synchronises `stream` and reports (non-zero + nvdr_last_error) if any traversal launch on this context ever pushed
@@ -215,7 +219,8 @@ int nvdr_env_shade_stream_id(nvdr_ctx *ctx, uint64_t *out_host);
  * gather), recorded on the launch stream itself into a ring of 512 records, one per (launch, chunk of the ray stream);
  * used by bench.py for the roofline figure of the traversal kernel.  nvdr_env_shade_stage_times sums the recorded
  * launches of one kind (backward = 0 | 1) into ms[3] and returns their number in *count (launches, not chunks); it
- * synchronises on the last recorded event. */
+ * synchronises on the last recorded event.  Reading does not clear the ring (nvdr_ctx_set_profiling(ctx, 1) does); a launch
+ * of more chunks than the ring has records is not recorded at all rather than partially. */
 int nvdr_ctx_set_profiling(nvdr_ctx *ctx, int enable);
 int nvdr_env_shade_stage_times(nvdr_ctx *ctx, int backward, double *ms, int64_t *count);
 

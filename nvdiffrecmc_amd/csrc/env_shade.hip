@@ -1469,7 +1469,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         p.pix_begin = (unsigned)((int64_t)k * cap);
         p.ray_count = c->chunk_counts + k;
         hipEvent_t *pe = nullptr;
-        if (c->profiling) {
+        if (c->profiling && n_chunks <= NVDR_PROF_RING) {      // (a launch of more chunks than records would overwrite its own first chunks)
             const int slot = (int)(c->prof_n % NVDR_PROF_RING);
             pe = c->prof_ev[slot];
             c->prof_kind[slot] = (backward ? 1 : 0) | (k == 0 ? 2 : 0);

@@ -46,21 +46,32 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
         if ((int)blockIdx.x >= tab.first_block[q]) k = q;
     const nvdr_adam_tensor &T = tab.t[k];
     const int64_t e0 = (int64_t)((int)blockIdx.x - tab.first_block[k]) * 256 * tab.per_thread;
-    for (int j = 0; j < tab.per_thread; ++j) {
-        const int64_t e = e0 + (int64_t)j * 256 + threadIdx.x;
-        if (e >= T.n) break;
-        const float g = T.grad[e] * T.grad_scale;
-        float m = T.exp_avg[e], v = T.exp_avg_sq[e];
-        m = m + (g - m) * omb1;                             // lerp_(grad, 1 - beta1)
-        v = v * beta2 + (omb2 * g) * g;                     // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        float p = T.param[e] - step_size * (m / denom);     // addcdiv_(exp_avg, denom, value = -step_size)
-        float lo = T.lo, hi = T.hi;
-        if (T.lo_vec) lo = fmaxf(lo, T.lo_vec[e % T.lo_vec_n]);
-        p = fmaxf(fminf(p, hi), lo);
-        T.exp_avg[e] = m;
-        T.exp_avg_sq[e] = v;
-        T.param[e] = p;
+    for (int j0 = 0; j0 < tab.per_thread; j0 += 4) {        // four elements per round: their twelve loads are in flight together
+        float g[4], m[4], v[4], pp[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t e = e0 + (int64_t)(j0 + u) * 256 + threadIdx.x;
+            ok[u] = j0 + u < tab.per_thread && e < T.n;
+            const int64_t ee = ok[u] ? e : 0;
+            g[u] = T.grad[ee]; m[u] = T.exp_avg[ee]; v[u] = T.exp_avg_sq[ee]; pp[u] = T.param[ee];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const int64_t e = e0 + (int64_t)(j0 + u) * 256 + threadIdx.x;
+            const float gg = g[u] * T.grad_scale;
+            const float mm = m[u] + (gg - m[u]) * omb1;                 // lerp_(grad, 1 - beta1)
+            const float vv = v[u] * beta2 + (omb2 * gg) * gg;           // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+            const float denom = sqrtf(vv) / bc2_sqrt + eps;
+            float p = pp[u] - step_size * (mm / denom);                 // addcdiv_(exp_avg, denom, value = -step_size)
+            float lo = T.lo, hi = T.hi;
+            if (T.lo_vec) lo = fmaxf(lo, T.lo_vec[e % T.lo_vec_n]);
+            p = fmaxf(fminf(p, hi), lo);
+            T.exp_avg[e] = mm;
+            T.exp_avg_sq[e] = vv;
+            T.param[e] = p;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {

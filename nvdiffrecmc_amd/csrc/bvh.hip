@@ -380,6 +380,9 @@ __global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal
 #define OCT_CTL_TRIS 96
 #define OCT_CTL_WORDS 128
 
+#ifndef NVDR_OCT_ORDER
+#define NVDR_OCT_ORDER 1        // internal children of a wide node: smaller surface area first (0: slot order; A/B)
+#endif
 struct OctBuildArgs {
     const uint4 *nodes;     // fitted binary nodes
     const float4 *tris;     // triangle records in Morton order
@@ -477,12 +480,35 @@ __device__ void oct_build_node(const OctBuildArgs &a, int b, int m, int *sl)
         oct_load_children(a.nodes, OCT_SL(best, 0), sl, best, n);
         n++;
     }
-    // order: internal children first (stable), then leaves -- as a 4-bit-per-position permutation of the slots
+    // order: internal children first, then leaves -- as a 4-bit-per-position permutation of the slots.  The walk takes the children of
+    // a group lowest index first, and an any-hit ray is done at its first hit: the internal children with the smaller surface area go
+    // first (insertion sort on the packed permutation; -0.8 ... -1.4 % traversal time, session 23).
     unsigned perm = 0u;
     int n_int = 0, n_leaf = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (k < n && OCT_SL(k, 0) >= 0) perm |= (unsigned)k << (4 * n_int++);
+#if NVDR_OCT_ORDER
+    {
+        float ar[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float ex = (float)(OCT_SL(k, 4) - OCT_SL(k, 1)) * wx, ey = (float)(OCT_SL(k, 5) - OCT_SL(k, 2)) * wy,
+                        ez = (float)(OCT_SL(k, 6) - OCT_SL(k, 3)) * wz;
+            ar[k] = ex * ey + ey * ez + ez * ex;
+        }
+        auto area_of = [&](unsigned slot) { float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if ((unsigned)k == slot) a = ar[k];
+            return a; };
+        for (int i = 1; i < n_int; ++i)
+            for (int j = i; j > 0; --j) {
+                const unsigned a = (perm >> (4 * j)) & 15u, b = (perm >> (4 * (j - 1))) & 15u;
+                if (!(area_of(a) < area_of(b))) break;
+                perm = (perm & ~(0xffu << (4 * (j - 1)))) | (a << (4 * (j - 1))) | (b << (4 * j));
+            }
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (k < n && OCT_SL(k, 0) < 0) perm |= (unsigned)k << (4 * (n_int + n_leaf++));

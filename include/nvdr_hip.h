@@ -260,6 +260,11 @@ int nvdr_prepare_shading_normal_fwd(const nvdr_tensor *pos, const nvdr_tensor *v
                                     const nvdr_tensor *smooth_nrm, const nvdr_tensor *smooth_tng,
                                     const nvdr_tensor *geom_nrm, int two_sided_shading, int opengl, float *out,
                                     void *stream);
+/* additive, forward only: shading normal + its unit copy (the denoiser's guide, render/util.py safe_normalize) + the shadow-ray origin
+ * gb_pos + normal * ro_eps (render.py:107) in one launch */
+int nvdr_shading_frame_fwd(const nvdr_tensor *pos, const nvdr_tensor *view_pos, const nvdr_tensor *perturbed_nrm,
+                           const nvdr_tensor *smooth_nrm, const nvdr_tensor *smooth_tng, const nvdr_tensor *geom_nrm,
+                           int two_sided_shading, int opengl, float ro_eps, float *out_nrm, float *out_unit, float *out_ro, void *stream);
 int nvdr_prepare_shading_normal_bwd(const nvdr_tensor *pos, const nvdr_tensor *view_pos, const nvdr_tensor *perturbed_nrm,
                                     const nvdr_tensor *smooth_nrm, const nvdr_tensor *smooth_tng,
                                     const nvdr_tensor *geom_nrm, const nvdr_tensor *d_out, int two_sided_shading,

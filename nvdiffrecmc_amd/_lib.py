@@ -109,6 +109,7 @@ _SIGNATURES = {
     'nvdr_image_loss_fwd': [_T, _T, c_int, c_int, c_void_p, c_void_p],
     'nvdr_image_loss_bwd': [_T, _T, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_prepare_shading_normal_fwd': [_T] * 6 + [c_int, c_int, c_void_p, c_void_p],
+    'nvdr_shading_frame_fwd': [_T] * 6 + [c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_prepare_shading_normal_bwd': [_T] * 7 + [c_int, c_int] + [c_void_p] * 6 + [c_void_p],
     'nvdr_xfm_fwd': [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p],
     'nvdr_xfm_bwd': [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p],

@@ -310,6 +310,42 @@ extern "C" int nvdr_prepare_shading_normal_fwd(const nvdr_tensor *pos, const nvd
     });
 }
 
+// The shading frame of shade() in one launch (additive, forward only: the harness keeps the geometry fixed): the shading normal as
+// above, its normalised copy for the denoiser's guides (render/util.py safe_normalize: x / sqrt(max(dot(x, x), 1e-20))) and the
+// shadow-ray origin gb_pos + normal * ro_eps (render.py:107) -- eight small torch kernels otherwise.
+extern "C" int nvdr_shading_frame_fwd(const nvdr_tensor *pos, const nvdr_tensor *view_pos, const nvdr_tensor *perturbed_nrm,
+                                      const nvdr_tensor *smooth_nrm, const nvdr_tensor *smooth_tng, const nvdr_tensor *geom_nrm,
+                                      int two_sided_shading, int opengl, float ro_eps, float *out_nrm, float *out_unit, float *out_ro,
+                                      void *stream)
+{
+    static const char *OP = "shading_frame_fwd";
+    NVDR_REQUIRE(pos && view_pos && perturbed_nrm && smooth_nrm && smooth_tng && geom_nrm && out_nrm && out_unit && out_ro, "%s: NULL argument", OP);
+    const Extent e = make_extent(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm);
+    CHECK_VIEW(pos, 3); CHECK_VIEW(view_pos, 3); CHECK_VIEW(perturbed_nrm, 3);
+    CHECK_VIEW(smooth_nrm, 3); CHECK_VIEW(smooth_tng, 3); CHECK_VIEW(geom_nrm, 3);
+    const View4 vp = make_view4(*pos), vv = make_view4(*view_pos), vpn = make_view4(*perturbed_nrm),
+                vsn = make_view4(*smooth_nrm), vst = make_view4(*smooth_tng), vgn = make_view4(*geom_nrm);
+    const bool two = two_sided_shading != 0, ogl = opengl != 0;
+    return launch_ew(e, (hipStream_t)stream, [=] __device__(int n, int h, int w, int64_t i) {
+        const F3 p = fetch3(vp, n, h, w), vw = fetch3(vv, n, h, w), pn = fetch3(vpn, n, h, w);
+        const F3 sn = safe_normalize(fetch3(vsn, n, h, w)), st = safe_normalize(fetch3(vst, n, h, w));
+        const F3 gn = fetch3(vgn, n, h, w);
+        const F3 view = safe_normalize(vw - p);
+        const F3 sh = fwd_perturb_normal(pn, sn, st, ogl);
+        F3 res;
+        if (two && dot3(view, gn) < 0.0f)
+            res = fwd_bend_normal(view, -sh, -gn);
+        else
+            res = fwd_bend_normal(view, sh, gn);
+        store3(out_nrm, i, res);
+        // (x^2 + z^2) + y^2: the order torch.sum takes over three elements (one per lane, shuffle-down by 2 then by 1), so that the unit
+        // normal is bit-identical to the composed torch expression -- the filter raises dot products of it to the 128th power
+        const float len = sqrtf(fmaxf((res.x * res.x + res.z * res.z) + res.y * res.y, 1e-20f));
+        store3(out_unit, i, f3(res.x / len, res.y / len, res.z / len));
+        store3(out_ro, i, f3(p.x + res.x * ro_eps, p.y + res.y * ro_eps, p.z + res.z * ro_eps));
+    });
+}
+
 extern "C" int nvdr_prepare_shading_normal_bwd(const nvdr_tensor *pos, const nvdr_tensor *view_pos,
                                                const nvdr_tensor *perturbed_nrm, const nvdr_tensor *smooth_nrm,
                                                const nvdr_tensor *smooth_tng, const nvdr_tensor *geom_nrm,

@@ -174,6 +174,30 @@ def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng,
     return _finite(out, 'prepare_shading_normal')
 
 
+def shading_frame(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True, ro_eps=0.001):
+    """(shading normal, its unit copy, shadow-ray origin pos + normal * ro_eps) in one launch -- prepare_shading_normal, the
+    safe_normalize of the denoiser's guide and the offset of render.py:107.  Additive and forward only: with an input that requires a
+    gradient it composes the differentiable ops instead."""
+    if perturbed_nrm is None:
+        perturbed_nrm = _UNIT_Z.get(pos.device)
+        if perturbed_nrm is None:
+            perturbed_nrm = _UNIT_Z[pos.device] = torch.tensor([0, 0, 1], dtype=torch.float32, device=pos.device,
+                                                               requires_grad=False)[None, None, None, ...]
+    ins = (pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in ins):
+        nrm = prepare_shading_normal(*ins, two_sided_shading=two_sided_shading, opengl=opengl)
+        unit = nrm / torch.sqrt(torch.clamp(torch.sum(nrm * nrm, -1, keepdim=True), min=1e-20))
+        return nrm, unit, pos + nrm * ro_eps
+    for name, t in zip(('pos', 'view_pos', 'perturbed_nrm', 'smooth_nrm', 'smooth_tng', 'geom_nrm'), ins):
+        _lib.require_cuda_f32(t, name)
+    N, H, W = (max(t.shape[k] for t in ins) for k in range(3))
+    out = torch.empty(3, N, H, W, 3, dtype=torch.float32, device=pos.device)
+    refs = [ctypes.byref(_lib.tensor_view(t)) for t in ins]
+    _lib.check(_lib.load().nvdr_shading_frame_fwd(*refs, int(two_sided_shading), int(opengl), float(ro_eps), _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                                  _lib.ptr(out[2]), _lib.stream_ptr()), 'shading_frame_fwd')
+    return out[0], out[1], out[2]
+
+
 # ----------------------------------------------------------------------------------------------
 # BSDF functions (ops.py:232-386)
 

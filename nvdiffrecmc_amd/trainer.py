@@ -171,9 +171,15 @@ class DirectLightingStep:
         kd = kd.view(self.nv, self.res, self.res, 3)
         # uncovered pixels are skipped by the mask in env-shade and have zero light in the composite: no ks * mask needed
         ks = _broadcast_pixels.apply(ks_vec, self.nv, self.res, self.res) if self.fused else (ks_vec.view(1, 1, 1, 3) * m)
-        nrm = ru.prepare_shading_normal(self.gb_pos, self.view_pos, None, self.gb_smooth_nrm, self.gb_tangent,
-                                        self.gb_geom_nrm, two_sided_shading=True, opengl=True)
-        ro = self.gb_pos + nrm * 0.001
+        nn = None
+        if self.fused:
+            # shading normal, its unit copy (the filter's guide) and the shadow-ray origin in one launch (eight otherwise)
+            nrm, nn, ro = ru.shading_frame(self.gb_pos, self.view_pos, None, self.gb_smooth_nrm, self.gb_tangent, self.gb_geom_nrm,
+                                           two_sided_shading=True, opengl=True, ro_eps=0.001)
+        else:
+            nrm = ru.prepare_shading_normal(self.gb_pos, self.view_pos, None, self.gb_smooth_nrm, self.gb_tangent,
+                                            self.gb_geom_nrm, two_sided_shading=True, opengl=True)
+            ro = self.gb_pos + nrm * 0.001
         self.ctx.pixel_index_offset = self.pixel_index_offset          # per-context switches (ops.OptiXContext)
         self.ctx.cache_visibility = not self.retrace_backward
         diff, spec = ou.optix_env_shade(self.ctx, self.mask, ro, self.gb_pos, nrm, self.view_pos, kd, ks, light.base,
@@ -184,7 +190,7 @@ class DirectLightingStep:
             # the non-demodulated branch of shade() (render.py:124-131): ONE filter pass over the combined colour
             shaded = ru.shade_composite(diff, spec, kd, ks) if self.fused else diff * (kd * (1.0 - ks[..., 2:3])) + spec
             if self.fused:
-                cw = ou.ops._bilateral_denoiser_func.apply(shaded, _safe_normalize(nrm), self.gb_depth, self.denoiser.sigma)
+                cw = ou.ops._bilateral_denoiser_func.apply(shaded, nn if nn is not None else _safe_normalize(nrm), self.gb_depth, self.denoiser.sigma)
                 return cw[..., 0:3] / cw[..., 3:4]
             return self.denoiser.forward(torch.cat((shaded, nrm, self.gb_depth), dim=-1))
         if self.fused:
@@ -192,7 +198,8 @@ class DirectLightingStep:
             # kernel is called without the 8-channel cat, and its (colour sum, weight) output goes straight into the
             # fused composite: ~45 small torch kernels per iteration less
             if self.denoiser is not None:
-                nn = _safe_normalize(nrm)
+                if nn is None:
+                    nn = _safe_normalize(nrm)
                 if self.pair_filter:     # both images in one pass: same guides, same weights (bit-identical to the two calls below)
                     diff, spec = ou.ops._bilateral_denoiser_pair_func.apply(diff, spec, nn, self.gb_depth, self.denoiser.sigma)
                 else:

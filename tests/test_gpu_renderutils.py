@@ -201,3 +201,26 @@ def test_fused_adam_matches_torch_adam_and_clamps(dev):
     assert opt_gpu.step_count == 12
     assert (p_gpu[0].min() >= 0) and (p_gpu[0].max() <= 1) and p_gpu[1][1] >= 0.08
     assert torch.equal(p_gpu[2].grad.cpu(), grads[2])           # the gradient itself is left alone (the scale is applied inside)
+
+
+def test_shading_frame_equals_the_composed_ops(dev):
+    """The fused shading frame (shading normal, unit copy, shadow-ray origin in one launch) against prepare_shading_normal + the
+    safe_normalize of the filter's guide + the offset of render.py:107; with an input that requires a gradient it composes them."""
+    from nvdiffrecmc_amd import renderutils as ru
+    g = torch.Generator().manual_seed(3)
+    N, H, W = 2, 37, 53
+    pos = torch.randn(N, H, W, 3, generator=g).to(dev)
+    view = (torch.randn(N, 1, 1, 3, generator=g) * 3).to(dev)
+    sn = torch.nn.functional.normalize(torch.randn(N, H, W, 3, generator=g), dim=-1).to(dev)
+    st = torch.nn.functional.normalize(torch.randn(N, H, W, 3, generator=g), dim=-1).to(dev)
+    gn = torch.nn.functional.normalize(sn.cpu() + 0.3 * torch.randn(N, H, W, 3, generator=g), dim=-1).to(dev)
+    sn[0, :5] = 0.0                                                     # degenerate pixels (background)
+    nrm, unit, ro = ru.shading_frame(pos, view, None, sn, st, gn, ro_eps=0.001)
+    ref = ru.prepare_shading_normal(pos, view, None, sn, st, gn, two_sided_shading=True, opengl=True)
+    assert torch.equal(nrm, ref)
+    ref_unit = ref / torch.sqrt(torch.clamp(torch.sum(ref * ref, -1, keepdim=True), min=1e-20))
+    assert torch.equal(unit, ref_unit)          # same association as torch.sum: the filter raises dot products of it to the 128th power
+    assert torch.equal(ro, pos + ref * 0.001)
+    p2 = pos.clone().requires_grad_(True)
+    n2, u2, r2 = ru.shading_frame(p2, view, None, sn, st, gn)
+    assert r2.requires_grad and torch.equal(n2.detach(), ref)

@@ -327,6 +327,11 @@ int nvdr_shade_composite_bwd(const nvdr_tensor *diff, const nvdr_tensor *spec, c
                              int bsdf, const nvdr_tensor *d_out, float *diff_grad, float *spec_grad, float *kd_grad,
                              float *ks_grad, void *stream);
 
+/* ---- rows of a table by index (additive; the nearest-texel lookup of a trained texture in the iteration harness):
+ * out[i,:] = index[i] >= 0 ? table[index[i],:] : 0; the backward zeroes dtable [table_rows, channels] and accumulates. */
+int nvdr_gather_rows_fwd(const float *table, const int *index, int64_t n, int channels, float *out, void *stream);
+int nvdr_gather_rows_bwd(const float *dout, const int *index, int64_t n, int channels, int64_t table_rows, float *dtable, void *stream);
+
 /* ---- EnvironmentLight.update_pdf (render/light.py:46-59) fused on device: base f32 [Hl,Wl,3] contiguous ->
  * pdf [Hl,Wl], cols [Hl,Wl], rows [Hl] (the reference materialises rows as [Hl,Wl] with identical
  * columns and passes rows[:,0], render.py:114). */

@@ -774,3 +774,47 @@ extern "C" int nvdr_shade_composite_bwd(const nvdr_tensor *diff, const nvdr_tens
         store3(ks_grad, i, f3(0.0f, 0.0f, bsdf == 0 ? -sum3(go * dn * k) : 0.0f));
     });
 }
+
+// ---------------------------------------------------------------------------------------------
+// Rows of a table by index (additive): out[i] = index[i] >= 0 ? table[index[i]] : 0 -- the nearest-texel lookup of the trained kd
+// texture in the iteration harness (trainer.py), which torch composes from zeros + index_select + index_copy (forward) and
+// zeros + index_select + index_add (backward).
+
+__global__ void __launch_bounds__(256) gather_rows_fwd_kernel(const float *__restrict__ table, const int *__restrict__ index, int64_t n, int c,
+                                                              float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const int64_t r = i / c;
+    const int k = (int)(i - r * c), j = index[r];
+    out[i] = j >= 0 ? table[(int64_t)j * c + k] : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) gather_rows_bwd_kernel(const float *__restrict__ dout, const int *__restrict__ index, int64_t n, int c,
+                                                              float *__restrict__ dtable)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const int64_t r = i / c;
+    const int k = (int)(i - r * c), j = index[r];
+    if (j >= 0) atomicAdd(dtable + (int64_t)j * c + k, dout[i]);
+}
+
+extern "C" int nvdr_gather_rows_fwd(const float *table, const int *index, int64_t n, int channels, float *out, void *stream)
+{
+    NVDR_REQUIRE(table && index && out && n >= 0 && channels >= 1 && channels <= 16, "gather_rows_fwd: bad argument");
+    if (n == 0) return 0;
+    gather_rows_fwd_kernel<<<div_up(n * channels, 256), 256, 0, (hipStream_t)stream>>>(table, index, n, channels, out);
+    NVDR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nvdr_gather_rows_bwd(const float *dout, const int *index, int64_t n, int channels, int64_t table_rows, float *dtable, void *stream)
+{
+    NVDR_REQUIRE(dout && index && dtable && n >= 0 && channels >= 1 && channels <= 16 && table_rows >= 0, "gather_rows_bwd: bad argument");
+    NVDR_HIP_TRY(hipMemsetAsync(dtable, 0, sizeof(float) * (size_t)table_rows * channels, (hipStream_t)stream));
+    if (n == 0) return 0;
+    gather_rows_bwd_kernel<<<div_up(n * channels, 256), 256, 0, (hipStream_t)stream>>>(dout, index, n, channels, dtable);
+    NVDR_LAUNCH_CHECK();
+    return 0;
+}

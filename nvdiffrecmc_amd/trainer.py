@@ -51,6 +51,30 @@ class _gather_rows(torch.autograd.Function):
         return out, None
 
 
+class _lookup_rows(torch.autograd.Function):
+    """out[i] = idx[i] >= 0 ? tex[idx[i]] : 0 in one launch (csrc/renderutils.hip gather_rows), backward = memset + one atomic pass:
+    three launches instead of the six of zeros / index_select / index_copy and their adjoints."""
+
+    @staticmethod
+    def forward(ctx, tex, idx):
+        from . import _lib
+        ctx.save_for_backward(idx)
+        ctx.rows = tex.shape[0]
+        tex = tex.contiguous()
+        out = torch.empty(idx.numel(), tex.shape[1], dtype=torch.float32, device=tex.device)
+        _lib.check(_lib.load().nvdr_gather_rows_fwd(_lib.ptr(tex), _lib.ptr(idx), idx.numel(), tex.shape[1], _lib.ptr(out), _lib.stream_ptr()), 'gather_rows_fwd')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        idx, = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty(ctx.rows, g.shape[1], dtype=torch.float32, device=g.device)
+        _lib.check(_lib.load().nvdr_gather_rows_bwd(_lib.ptr(g), _lib.ptr(idx), idx.numel(), g.shape[1], ctx.rows, _lib.ptr(out), _lib.stream_ptr()), 'gather_rows_bwd')
+        return out, None
+
+
 class _broadcast_pixels(torch.autograd.Function):
     """x[C] -> [N,H,W,C] stride-0 view, with a column sum as backward that does not go through torch's generic
     reduction (summing [262144, 3] over its long dimension took 91 us: one wavefront per output column)."""
@@ -124,6 +148,7 @@ class DirectLightingStep:
         # only covered pixels look the texture up (the background would pile ~200k duplicates on one texel)
         self.cov = self.mask.view(-1).nonzero().view(-1)
         self.texel_cov = self.texel[self.cov].contiguous()
+        self.texel_or_none = torch.where(self.mask.view(-1) > 0, self.texel, torch.full_like(self.texel, -1)).to(torch.int32).contiguous()
 
         # ---- reference ("true") parameters -> target image; trainable parameters start elsewhere
         self.denoiser = BilateralDenoiser(influence=1.0) if denoise else None
@@ -167,7 +192,10 @@ class DirectLightingStep:
 
     def _render(self, kd_tex, ks_vec, light):
         m = self.mask[..., None]
-        kd = torch.zeros(self.nv * self.res * self.res, 3, device=self.dev).index_copy(0, self.cov, _gather_rows.apply(kd_tex, self.texel_cov))
+        if self.fused and self.dev.type == 'cuda':
+            kd = _lookup_rows.apply(kd_tex, self.texel_or_none)
+        else:
+            kd = torch.zeros(self.nv * self.res * self.res, 3, device=self.dev).index_copy(0, self.cov, _gather_rows.apply(kd_tex, self.texel_cov))
         kd = kd.view(self.nv, self.res, self.res, 3)
         # uncovered pixels are skipped by the mask in env-shade and have zero light in the composite: no ks * mask needed
         ks = _broadcast_pixels.apply(ks_vec, self.nv, self.res, self.res) if self.fused else (ks_vec.view(1, 1, 1, 3) * m)

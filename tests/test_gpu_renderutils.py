@@ -224,3 +224,19 @@ def test_shading_frame_equals_the_composed_ops(dev):
     p2 = pos.clone().requires_grad_(True)
     n2, u2, r2 = ru.shading_frame(p2, view, None, sn, st, gn)
     assert r2.requires_grad and torch.equal(n2.detach(), ref)
+
+
+def test_lookup_rows_matches_torch_indexing(dev):
+    """csrc/renderutils.hip gather_rows (the texture lookup of the iteration harness in one launch) against torch indexing: rows by
+    index with -1 = zero row, and its adjoint (an index_add)."""
+    from nvdiffrecmc_amd.trainer import _lookup_rows
+    g = torch.Generator().manual_seed(4)
+    tex = torch.rand(500, 3, generator=g).to(dev).requires_grad_(True)
+    idx = torch.randint(-1, 500, (4000,), generator=g).to(torch.int32).to(dev)
+    out = _lookup_rows.apply(tex, idx)
+    ref = torch.where((idx >= 0)[:, None], tex.detach()[idx.clamp(min=0).long()], torch.zeros(1, 3, device=dev))
+    assert torch.equal(out.detach(), ref)
+    w = torch.rand(4000, 3, generator=g).to(dev)
+    out.backward(w)
+    gref = torch.zeros(500, 3, device=dev).index_add_(0, idx.clamp(min=0).long(), w * (idx >= 0)[:, None])
+    assert_close(tex.grad, gref, 1e-6, floor=1e-3)

@@ -349,3 +349,49 @@ def test_hip_graph_iteration_matches_eager(dev):
         assert abs(a - b) < 2e-3 * abs(a), (le, lg)
     assert lg[-1] < lg[0]
     graph.ctx.check()
+
+
+@pytest.mark.parametrize('probe,n,res,mode', [
+    ((256, 512), 4, 96, None),      # 16 bands (the most the records path takes), 4 pixels per wavefront round
+    ((64, 64), 2, 64, None),        # one band, 16 pixels per round
+    ((256, 256), 16, 48, None),     # S = 256: four rounds per pixel, a group of 512 slots = four blocks
+    ((256, 256), 8, 128, '0'),      # the work split of large launches (every workgroup walks all bands) on a small one
+    ((256, 256), 8, 128, '1'),      # ... and the per-band split
+    ((512, 512), 4, 64, None),      # 32 bands: too many for the records path, falls back to the atomics
+])
+def test_light_gradient_records_vs_atomics_over_shapes(probe, n, res, mode, dev, monkeypatch):
+    """The band-sorted record blocks + LDS gather against the reference's atomics formulation (NVDR_DEBUG bit 16) over probe shapes
+    (1, 8, 16, 32 bands), sample counts (several pixels per wavefront round, several rounds per pixel) and both work splits of the
+    gather; the per-pixel gradients, which the same kernel writes, must not care at all."""
+    from nvdiffrecmc_amd import optixutils as ou
+    mesh, ctx0, kw, perms = _gpu_scene('bob', res, n, dev, view=2)
+    g = torch.Generator().manual_seed(9)
+    base = (torch.rand(probe[0], probe[1], 3, generator=g) + 0.05).to(dev)
+    pdf, rows, cols = sc.light_tables(base)
+    kw = dict(kw, light=base, pdf=pdf, rows=rows[:, 0], cols=cols)
+    dg, sg = torch.rand(1, res, res, 3, generator=g).to(dev), torch.rand(1, res, res, 3, generator=g).to(dev)
+
+    def grads(c):
+        light = kw['light'].clone().requires_grad_(True)
+        kd = kw['gb_kd'].clone().requires_grad_(True)
+        d, s = _shade(c, dict(kw, light=light, gb_kd=kd), n, 3)
+        ((d * dg).sum() + (s * sg).sum()).backward()
+        c.check()
+        return light.grad, kd.grad
+
+    if mode is not None:
+        monkeypatch.setenv('NVDR_LG_MODE', mode)
+    ctx = ou.OptiXContext()
+    monkeypatch.delenv('NVDR_LG_MODE', raising=False)
+    ou.optix_build_bvh(ctx, mesh['v_pos'].to(dev), mesh['t_pos_idx'].to(dev), 1)
+    lg, kg = grads(ctx)
+    monkeypatch.setenv('NVDR_DEBUG', '16')
+    ctx2 = ou.OptiXContext()
+    monkeypatch.delenv('NVDR_DEBUG')
+    ou.optix_build_bvh(ctx2, mesh['v_pos'].to(dev), mesh['t_pos_idx'].to(dev), 1)
+    la, ka = grads(ctx2)
+    assert la.abs().max().item() > 0
+    assert_close(lg, la, 1e-4, floor=1e-3 * la.abs().max().item())
+    assert torch.equal(kg, ka)
+    lg2, _ = grads(ctx)                                       # the tag array is clean again after a launch
+    assert_close(lg2, lg, 1e-4, floor=1e-3 * la.abs().max().item())

@@ -587,6 +587,13 @@ def run(args):
                 roof['pmc_note'] = note
             c = find_kernel(counters, DOMINANT) if counters else None
             if c:
+                # The child ran 3 iterations + the target render = 7 env-shade passes.  A launch whose ray stream is cut into chunks
+                # (spot512x256: 3 GB of stream against the 2 GiB budget) dispatches the kernel once per non-empty chunk and pass;
+                # the counter sums are per DISPATCH, the HIP-event time is per pass: bring the counters to the pass.
+                chunks = max(1, int(round(c.get('dispatches_pass0', 7) / 7.0)))
+                if chunks > 1:
+                    c = {k: (v_ * chunks if not k.startswith('dispatches_pass') else v_) for k, v_ in c.items()}
+                    roof['dispatches_per_launch'] = chunks
                 v = valu_figures(c, trace_ms)
                 mem = mem_figures(c, trace_ms)
                 if v:
@@ -603,6 +610,8 @@ def run(args):
                                           ('env_shade_kernel<forward>', 'env_shade_kernel<false', shade_ms),
                                           ('light_grad_block_kernel', 'light_grad_block_kernel', None)):
                     oc = find_kernel(counters, needle)
+                    if oc and chunks > 1:
+                        oc = {k: (v_ * chunks if not k.startswith('dispatches_pass') else v_) for k, v_ in oc.items()}
                     if oc:
                         mm = mem_figures(oc, ms)
                         vv = valu_figures(oc, ms) if ms else None

@@ -360,7 +360,7 @@ def parse_args():
     ap.add_argument('--no-large-mesh', action='store_true', help='skip the `large_mesh` object (dmtet800: 684 k triangles) of the default N = 1 line')
     ap.add_argument('--no-extended', action='store_true', help='skip the extended median phase and the cached-visibility loop')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
-                    help='capture the iteration in HIP graphs (auto: when a rank renders <= 2 views, the launch-bound regime)')
+                    help='capture the iteration in HIP graphs (auto: when a rank renders <= 2 views -- the launch-bound regime -- or there are several ranks)')
     return ap.parse_args()
 
 
@@ -437,7 +437,9 @@ def run(args):
     my_views = shard_views(n_views, rank, world)
     if not my_views:
         raise SystemExit('bench.py: rank %d of %d has no view of the batch of %d' % (rank, world, n_views))
-    use_graph = args.graph == 'on' or (args.graph == 'auto' and len(my_views) <= 2)
+    # auto: graphs when a rank renders <= 2 views (launch-bound) and whenever there are several ranks (-1.6 % at 8 views per rank); the
+    # one-GPU default stays eager so that the per-stage HIP events behind `roofline` are recorded inside the timed steps themselves
+    use_graph = args.graph == 'on' or (args.graph == 'auto' and (len(my_views) <= 2 or world > 1))
     if args.pmc_child:
         use_graph = False
     step = DirectLightingStep(preset['mesh'], H, n, view=my_views, n_views=n_views, device=dev,

@@ -329,6 +329,12 @@ def large_mesh_object(args, dev):
         counters, note = collect_pmc(args, keep_dir=args.pmc_keep, config='dmtet800', passes=[['FETCH_SIZE'], ['TCC_REQ_sum', 'WRITE_SIZE', 'TCC_MISS_sum']])
         c = find_kernel(counters, DOMINANT) if counters else None
         if c:
+            # per DISPATCH -> per pass: this workload's ray stream (3.5 GB) is cut into two chunks by the 2 GiB budget, and the child runs
+            # 7 env-shade passes (see the roofline object below)
+            chunks = max(1, int(round(c.get('dispatches_pass0', 7) / 7.0)))
+            if chunks > 1:
+                c = {k: (v_ * chunks if not k.startswith('dispatches_pass') else v_) for k, v_ in c.items()}
+                out['dispatches_per_launch'] = chunks
             mem = mem_figures(c, trace_ms)
             out['hbm'] = {k: mem[k] for k in ('hbm_bytes', 'fetch_bytes_corrected', 'write_bytes', 'hbm_GBs', 'hbm_frac') if k in mem}
             out['l2'] = {k: mem[k] for k in ('l2_requests', 'l2_hit', 'l2_GBs_at_64B_per_request', 'l2_frac') if k in mem}

@@ -160,6 +160,8 @@ struct nvdr_ctx {
     size_t stream_cap_total = 0;   // slots of rays: the chunk's own + the spare blocks of the light-gradient records
     uint16_t *lg_tags = nullptr;   // (band, fill) of every block of 128 slots of `rays` (0xFFFF: no records)
     size_t lg_tags_cap = 0;
+    uint16_t *cdf_guide = nullptr; // guide tables of the light's CDF inversion (env_shade.hip), rebuilt per launch
+    size_t guide_cap = 0;
     float *dp_cost = nullptr;      // [2 * cap][7] collapse-DP tables of the two children of every binary node (bvh_fit_kernel)
     unsigned *dp_split = nullptr;  // [cap] the slot splits the DP chose
     bool oct_dp = true;            // SAH-optimal collapse (false: greedy largest-area, NVDR_OCT_DP=0)

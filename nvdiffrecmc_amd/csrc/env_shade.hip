@@ -51,6 +51,9 @@
 #define NVDR_BWD_ROLL 1
 #endif
 // measurements only (variants): 1 = no light-gradient records at all, 2 = none + round-robin groups, 3 = unsorted in-place records + round-robin
+#ifndef NVDR_CDF_GUIDE
+#define NVDR_CDF_GUIDE 1          // CDF inversion through guide tables (0: the reference's bisection; A/B)
+#endif
 #ifndef NVDR_LG_EXPERIMENT
 #define NVDR_LG_EXPERIMENT 0
 #endif
@@ -95,6 +98,8 @@ struct ShadeParams {
     int reuse;                // backward: the forward's stream is still in the context IF the whole launch fitted one chunk
     int lg_records;           // backward: 1 = write (texel, rgb) records for the band gather, 0 = global atomics
     int lg_shift;             // band of a texel = texel >> lg_shift (bands hold a power-of-two number of texels)
+    const uint16_t *cdf_guide; // [Hl + 1][1 << guide_log] first CDF entry above k / 2^guide_log: row y of the column CDFs, last row = the row CDF
+    int guide_log_rows, guide_log_cols;
     uint16_t *lg_tags;        // per block of 128 stream slots: band | fill << 8 of the light-gradient records it holds (0xFFFF: none)
     unsigned lg_spare_base;   // first spare block (behind the chunk's own slots); wavefront w owns lg_spw of them from lg_spare_base + w * lg_spw
     unsigned lg_spw;
@@ -282,6 +287,52 @@ __device__ __forceinline__ float sample_cdf(const float *__restrict__ cdf, int s
     }
     return fminf(sample / pdf, 0.99999994f);
 }
+// The same inversion through a GUIDE TABLE (cdf_guide_kernel): the bisection above returns the first entry above x (or the last
+// entry); guide[k] is the first entry above k / K for the cell k = floor(x * K) of x (K a power of two: the product is exact), which
+// cannot lie behind it, so a short linear walk from there ends on the same entry -- two or three dependent loads instead of nine.
+__device__ __forceinline__ float sample_cdf_guided(const float *__restrict__ cdf, int stride, int size, float x, const uint16_t *__restrict__ guide,
+                                                   int guide_log, unsigned &idx)
+{
+    x = fminf(x, 0.99999994f);
+    unsigned hi = guide[(unsigned)(x * (float)(1u << guide_log))];
+    float d0 = cdf[hi * stride];
+    while (hi + 1u < (unsigned)size && !(x < d0)) {
+        ++hi;
+        d0 = cdf[hi * stride];
+    }
+    idx = hi;
+    float pdf, sample;
+    if (hi == 0) {
+        pdf = cdf[0];
+        sample = x;
+    } else {
+        const float d1 = cdf[(hi - 1) * stride];
+        pdf = d0 - d1;
+        sample = x - d1;
+    }
+    return fminf(sample / pdf, 0.99999994f);
+}
+// one thread per (table row, cell): lower bound of cell / K in the row's CDF (rows < n_rows: the column CDF of that row; row n_rows:
+// the row CDF), cells K_cols resp. K_rows wide rows of `guide` (row pitch = max of the two)
+__global__ void __launch_bounds__(256) cdf_guide_kernel(Tab rows, Tab cols, int log_rows, int log_cols, uint16_t *__restrict__ guide)
+{
+    const int pitch = 1 << max(log_rows, log_cols);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = i / pitch, k = i - y * pitch;
+    if (y > cols.n0) return;
+    const bool is_rows = y == cols.n0;
+    const int lg = is_rows ? log_rows : log_cols, size = is_rows ? rows.n0 : cols.n1;
+    if (k >= (1 << lg)) return;
+    const float *cdf = is_rows ? rows.p : cols.p + (int64_t)y * cols.s0;
+    const int stride = is_rows ? rows.s0 : cols.s1;
+    const float t = (float)k / (float)(1 << lg);
+    int lo = 0, hi = size;                      // first entry with cdf > t
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid * stride] > t) hi = mid; else lo = mid + 1;
+    }
+    guide[(int64_t)y * pitch + k] = (uint16_t)min(lo, size - 1);
+}
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
 
 __device__ __forceinline__ float light_pdf(const ShadeParams &p, F3 dir, int &tx, int &ty)
@@ -303,8 +354,11 @@ __device__ __forceinline__ float light_pdf(const ShadeParams &p, F3 dir, int &tx
 __device__ __forceinline__ F3 light_sample_dir(const ShadeParams &p, float u, float v)
 {
     unsigned x, y;
-    const float ry = sample_cdf(p.rows.p, p.rows.s0, p.rows.n0, v, y);
-    const float rx = sample_cdf(p.cols.p + (int64_t)y * p.cols.s0, p.cols.s1, p.cols.n1, u, x);
+    const int pitch = 1 << max(p.guide_log_rows, p.guide_log_cols);
+    const float ry = p.cdf_guide ? sample_cdf_guided(p.rows.p, p.rows.s0, p.rows.n0, v, p.cdf_guide + (int64_t)p.cols.n0 * pitch, p.guide_log_rows, y)
+                                 : sample_cdf(p.rows.p, p.rows.s0, p.rows.n0, v, y);
+    const float rx = p.cdf_guide ? sample_cdf_guided(p.cols.p + (int64_t)y * p.cols.s0, p.cols.s1, p.cols.n1, u, p.cdf_guide + (int64_t)y * pitch, p.guide_log_cols, x)
+                                 : sample_cdf(p.cols.p + (int64_t)y * p.cols.s0, p.cols.s1, p.cols.n1, u, x);
     return tc_to_dir(((float)x + rx) / (float)p.pdf.n1, ((float)y + ry) / (float)p.pdf.n0);
 }
 __device__ __forceinline__ F3 light_sample(const ShadeParams &p, float u, float v, float &pdf, int &tx, int &ty)
@@ -1463,6 +1517,25 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     const size_t count_lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
     const bool replay = backward && p.vis_cache != nullptr;   // forward bits handed back by the caller: no traversal
 
+    // guide tables of the CDF inversion (rebuilt per launch: the light is a trained parameter); tables up to 2^15 entries per row
+    p.cdf_guide = nullptr;
+    if (!(reuse && n_chunks == 1) && a->rows.size[0] <= 32768 && a->cols.size[1] <= 32768 && NVDR_CDF_GUIDE) {
+        int lr = 0, lc = 0;
+        while ((1 << lr) < (int)a->rows.size[0]) ++lr;
+        while ((1 << lc) < (int)a->cols.size[1]) ++lc;
+        const size_t pitch = (size_t)1 << (lr > lc ? lr : lc), need = pitch * ((size_t)a->cols.size[0] + 1);
+        if (c->guide_cap < need) {
+            NVDR_HIP_TRY(hipStreamSynchronize(stream));
+            ctx_free(c, c->cdf_guide);
+            c->guide_cap = 0;
+            NVDR_HIP_TRY(ctx_malloc(c, &c->cdf_guide, sizeof(uint16_t) * need, stream));
+            c->guide_cap = need;
+        }
+        cdf_guide_kernel<<<div_up((int64_t)need, 256), 256, 0, stream>>>(p.rows, p.cols, lr, lc, c->cdf_guide);
+        p.cdf_guide = c->cdf_guide;
+        p.guide_log_rows = lr;
+        p.guide_log_cols = lc;
+    }
     c->stream_id = 0; // invalid while being rewritten
     begin_launch_kernel<<<1, 256, 0, stream>>>(&c->dinfo->pix_count, c->chunk_counts, n_chunks, p.reuse, p.pix_cap);
     if (!reuse)

@@ -754,6 +754,9 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
 // ---------------------------------------------------------------------------------------------
 // stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
 
+// Tried in round 3 and dropped (session 29): fetching the next pixel's list entry one iteration ahead, and starting both samples'
+// texel -> radiance load chains before the arithmetic: forward +1 ... +2.6 %, backward +5 ... +8 % (the registers they hold cost more than
+// the latency they hide at 3 waves per SIMD).
 // Tried on the backward instantiation and dropped (no gain, same GPU session): issuing the light-gradient atomics after both
 // samples / 3-4 waves per SIMD with spills (launch bounds) / fast division + contraction + fp32 islands (-23 % VALU
 // instructions, but gradient errors of 1e-2) -- all 0.87-0.93 ms.  0.37 ms of it is the 8 M float atomics: every one leaves

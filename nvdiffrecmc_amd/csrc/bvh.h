@@ -129,7 +129,7 @@ struct nvdr_ctx {
     int *ovf_dev = nullptr;        // its device address
     unsigned debug = 0;            // NVDR_DEBUG, read ONCE when the context is created
     bool per_cu_user = false;      // NVDR_PBLOCKS was given: no launch-size rule on top of it
-    int per_cu[3] = {8, 6, 6};     // workgroups per CU of the sample-generation, forward- and backward-shading kernels (NVDR_PBLOCKS="g,f,b")
+    int per_cu[3] = {10, 6, 6};     // workgroups per CU of the sample-generation, forward- and backward-shading kernels (NVDR_PBLOCKS="g,f,b")
     // BVH builds run on the context's own side stream, overlapped with whatever the caller enqueues next that does not need the
     // tree (pixel compaction and sample generation of env-shade: ~0.35-2.3 ms against a 0.25 ms build); consumers wait on `ev_built`
     // (ctx_wait_built).  The reference builds on stream 0 while everything else runs on torch's stream (torch_bindings.cpp:99).

@@ -42,7 +42,9 @@ struct DnView {
 };
 
 // tile height of the PAIR kernels: 32 x 32 pixels, one workgroup of 16 wavefronts per CU (three float4 planes: 144 KB of LDS at sigma = 2)
+#ifndef DN_BY_PAIR
 #define DN_BY_PAIR 32
+#endif
 #define DN_LDS_KB_PAIR 156
 
 __device__ __forceinline__ float pow128(float x)

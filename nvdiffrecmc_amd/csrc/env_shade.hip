@@ -1374,7 +1374,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         per_cu_launch[0] = 4;
         per_cu_launch[2] = 8;        // (backward shading of one view: 0.465 vs 0.483 ms with 8 instead of 6 workgroups per CU; 8 views: +1.5 %)
     }
-    const int *per_cu = per_cu_launch;   // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading): {8, 6, 6},
+    const int *per_cu = per_cu_launch;   // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading): {10, 6, 6},
                                      // measured within 3 % of the best for each kernel; NVDR_PBLOCKS="g,f,b" is read once per context
     const int waves_per_block = 4;
 

@@ -61,8 +61,8 @@ for r in range(rounds):
         assert torch.equal(o, ref[2]) and torch.equal(g, ref[3]), 'variant %s changes the filter output' % tag
 
 
-def run_pair(iters=10):
-    _lib._lib = libs['current']
+def run_pair(tag='current', iters=10):
+    _lib._lib = libs[tag]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     c1, c2 = col.clone().requires_grad_(True), (col * 0.5).clone().requires_grad_(True)
     tf = tb = 0.0
@@ -80,8 +80,12 @@ def run_pair(iters=10):
 
 
 if hasattr(ou.ops, '_bilateral_denoiser_pair_func'):
-    pr = [run_pair() for _ in range(rounds)]
-    print('pair kernel (two images in one pass): fwd %.3f  bwd %.3f   (two single calls = twice the figures below)' % (statistics.median(x[0] for x in pr), statistics.median(x[1] for x in pr)))
+    acc_p = {t: [] for t, _ in paths}
+    for r in range(rounds):
+        for t, _ in paths:
+            acc_p[t].append(run_pair(t))
+    for t, _ in paths:
+        print('pair kernel (two images in one pass) %-10s fwd %.3f  bwd %.3f   (two single calls = twice the figures below)' % (t, statistics.median(x[0] for x in acc_p[t]), statistics.median(x[1] for x in acc_p[t])))
 print('bilateral filter, %d views %dx%d, sigma %g: median ms over %d interleaved rounds (outputs bit-identical)' % (nviews, res, res, sigma, rounds))
 for tag, _ in paths:
     print('  %-10s fwd %.3f  bwd %.3f' % (tag, statistics.median(x[0] for x in acc[tag]), statistics.median(x[1] for x in acc[tag])))

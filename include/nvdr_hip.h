@@ -54,7 +54,7 @@ int nvdr_ctx_destroy(nvdr_ctx *ctx);
  * (host-mapped) flag without synchronising, so such a failure surfaces at the latest on the next call.  The reference
  * has no counterpart: OptiX errors are swallowed (render/optixutils/c_src/common.h:37-77). */
 int nvdr_ctx_check(nvdr_ctx *ctx, void *stream);
-/* Bytes of HBM the env-shade ray stream of this context may take (default 2 GiB, or NVDR_STREAM_BUDGET_MB read when the
+/* Bytes of HBM the env-shade ray stream of this context may take (default 8 GiB, or NVDR_STREAM_BUDGET_MB read when the
  * context is created).  The stream holds one chunk of covered pixels (2*S rays x 25 B each); a launch whose covered pixels
  * exceed the chunk is processed chunk by chunk with identical results.  The reference needs no scratch (one thread per
  * pixel keeps its rays in registers); a worst-case allocation would be N*H*W*2S*25 B (16 GB for 8 x 800^2 x 64 spp). */

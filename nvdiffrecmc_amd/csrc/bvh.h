@@ -148,7 +148,7 @@ struct nvdr_ctx {
     int64_t pix_cap = 0;
     unsigned *chunk_counts = nullptr; // [NVDR_MAX_CHUNKS] live-ray count of every chunk of the ray stream
     int64_t stream_cap_pixels = 0; // pixels one chunk of the ray stream holds (x 2S rays)
-    int64_t stream_budget = 2048ll << 20;   // bytes the ray stream may take (nvdr_ctx_set_stream_budget)
+    int64_t stream_budget = 8192ll << 20;   // bytes the ray stream may take (nvdr_ctx_set_stream_budget); 2.8 % of the HBM of an MI355X
     // ray stream of the three-stage env-shade (csrc/env_shade.hip)
     float4 *rays = nullptr;
     int *texel = nullptr;

@@ -1249,7 +1249,7 @@ static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t s
 // Scratch for the ray stream.  Round 1 sized it for the worst case -- every pixel of the launch covered -- which was
 // 6.7 GB for the 8-view benchmark (23 % coverage) and rejected launches beyond 2^31 rays.  Now the stream holds ONE CHUNK
 // of `cap` covered pixels (x 2S rays x 25 B), cap from the context's byte budget (nvdr_ctx_set_stream_budget; default
-// 2 GiB or NVDR_STREAM_BUDGET_MB, read once when the context is created), and a launch
+// 8 GiB or NVDR_STREAM_BUDGET_MB, read once when the context is created), and a launch
 // walks the compacted pixel list chunk by chunk: gen -> trace -> shade per chunk.  The host never learns the covered
 // count (no synchronisation): it issues ceil(N*H*W / cap) chunks and the ones behind the device-side count are empty
 // launches (~4 us each).  Slot numbers are chunk-local, so the 31-bit limit applies to cap * 2S only.

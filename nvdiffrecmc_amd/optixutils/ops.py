@@ -70,7 +70,7 @@ class OptiXContext:
         self.seed_offset = None
 
     def set_stream_budget(self, megabytes):
-        """HBM the ray stream between the three env-shade stages may take (default 2048 MB); larger launches are processed
+        """HBM the ray stream between the three env-shade stages may take (default 8192 MB); larger launches are processed
         in chunks of covered pixels with identical results."""
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')

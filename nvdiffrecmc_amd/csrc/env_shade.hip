@@ -639,7 +639,6 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         const float diffuseWeight = (1.f - metallic) * luminance(kd);
         const float specularWeight = albedo(specColor, wo, nrm);
         const float pDiffuse = (diffuseWeight + specularWeight) > 0.f ? diffuseWeight / (diffuseWeight + specularWeight) : 1.f;
-        const float pSpecular = 1.0f - pDiffuse;
         const unsigned ring_at = (groups_done % ring_groups) * (unsigned)G + (unsigned)slot;
         if (sub == 0 && valid) {
             const F3 ro = fetch3(p.ro, z, y, x);

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
     __shared__ double pows[2];
     // the hyper-parameters arrive as doubles, like the Python floats torch's Adam computes 1 - beta from: (float)(1 - 0.999) is
     // 0.001f, 1 - 0.999f is 1.3e-5 off (visible in the parameters after ten steps)
-    const float beta1 = (float)beta1d, beta2 = (float)beta2d, omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
+    const float beta2 = (float)beta2d, omb1 = (float)(1.0 - beta1d), omb2 = (float)(1.0 - beta2d);
     const int step = state[0] + 1;
     if (threadIdx.x == 0) {
         const double *pw = (const double *)(state + 2);

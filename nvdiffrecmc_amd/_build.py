@@ -79,7 +79,7 @@ def build(force=False, verbose=False):
         res = list(ex.map(lambda s: _compile(s, force, hdr_mtime, verbose), srcs))
     objs = [o for o, _ in res]
     if force or any(c for _, c in res) or not os.path.exists(LIB):
-        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', LIB]
+        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-ldl', '-o', LIB]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

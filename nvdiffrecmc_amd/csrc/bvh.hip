@@ -770,6 +770,7 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
 extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, const int32_t *tris, int64_t n_tris,
                               int rebuild, void *stream_)
 {
+    NvdrRange range(rebuild ? "nvdr_bvh_build" : "nvdr_bvh_build(refit)");
     NVDR_REQUIRE(c != nullptr, "nvdr_bvh_build: ctx is NULL");
     // same message as the Python asserts of the reference (render/optixutils/ops.py:131-132)
     NVDR_REQUIRE(n_tris > 0 && n_verts > 0, "Got empty training triangle mesh (unrecoverable discontinuity)");

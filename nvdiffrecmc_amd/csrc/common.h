@@ -36,6 +36,16 @@ void nvdr_set_error(const char *fmt, ...);
 
 #define NVDR_LAUNCH_CHECK() NVDR_HIP_TRY(hipGetLastError())
 
+// roctx range for the lifetime of a scope (core.hip; a no-op unless NVDR_ROCTX=1)
+void nvdr_range_push(const char *name);
+void nvdr_range_pop(void);
+struct NvdrRange {
+    explicit NvdrRange(const char *name) { nvdr_range_push(name); }
+    ~NvdrRange() { nvdr_range_pop(); }
+    NvdrRange(const NvdrRange &) = delete;
+    NvdrRange &operator=(const NvdrRange &) = delete;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Strided / broadcast views (semantics of fetch3 in optixutils/c_src/common.h:13-27 and
 // Tensor::nhwcIndex in renderutils/c_src/tensor.h:31): a dim of size 1 is read with index 0.

@@ -1,5 +1,7 @@
-// core.hip -- error state, version, and the detmath device test hook.
+// core.hip -- error state, version, roctx ranges, and the detmath device test hook.
+#include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -14,6 +16,37 @@ void nvdr_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *nvdr_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// roctx ranges around the entry points and their stages (bvh build, gen, trace, shade, light gradient, filter, optimiser): the
+// reference has no tracing at all (train.py:416,481-492 time the iteration on the host).  Off unless NVDR_ROCTX=1; the marker
+// library is looked up at the first range so that nothing links against the profiler (`rocprofv3 --marker-trace --kernel-trace`
+// shows the ranges on the host timeline beside the kernels they enqueue -- they time the ENQUEUE, the launches are asynchronous).
+static int (*g_range_push)(const char *) = nullptr;
+static int (*g_range_pop)(void) = nullptr;
+static int g_range_state = 0;           // 0 not looked up yet, 1 on, -1 off
+
+bool nvdr_range_enabled(void)
+{
+    if (g_range_state == 0) {
+        const char *e = getenv("NVDR_ROCTX");
+        int st = -1;
+        if (e && atoi(e) > 0) {
+            void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                g_range_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                g_range_pop = (int (*)(void))dlsym(h, "roctxRangePop");
+                if (g_range_push && g_range_pop) st = 1;
+            }
+            if (st < 0) fprintf(stderr, "nvdr: NVDR_ROCTX=1 but no roctx library could be loaded (%s)\n", dlerror());
+        }
+        g_range_state = st;
+    }
+    return g_range_state > 0;
+}
+void nvdr_range_push(const char *name) { if (nvdr_range_enabled()) g_range_push(name); }
+void nvdr_range_pop(void) { if (nvdr_range_enabled()) g_range_pop(); }
 extern "C" int nvdr_version(void) { return 100; }
 
 __global__ void detmath_kernel(int op, const float *__restrict__ x, const float *__restrict__ y, int64_t n,

@@ -200,6 +200,7 @@ static int launch_bilateral(const nvdr_tensor *col_or_grad, const nvdr_tensor *c
                             const nvdr_tensor *zdz, float sigma, bool backward, float *out, float *out2, hipStream_t stream,
                             const char *op)
 {
+    NvdrRange range(op);
     const bool pair = col2_or_grad2 != nullptr;
     const int64_t N = col_shape->size[0], H = col_shape->size[1], W = col_shape->size[2];
     NVDR_REQUIRE(sigma > 0.0f, "%s: sigma must be positive", op);

@@ -1556,10 +1556,14 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         }
         // stage 1 (skipped on the host when the forward's stream is known to be whole: one chunk covers the launch;
         // otherwise the kernel itself decides from the device-side pixel count)
-        if (!(reuse && n_chunks == 1)) env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
+        if (!(reuse && n_chunks == 1)) {
+            NvdrRange r("nvdr:gen");
+            env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
+        }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
         // stage 2 (the first launch of this call that needs the tree: a build may still be running on the context's side stream)
         if (!replay) {
+            NvdrRange r("nvdr:trace");
             if (int rw = ctx_wait_built(c, stream)) return rw;
             if (c->debug & 1u) {
                 NVDR_HIP_TRY(hipMemsetAsync(c->vis, 1, (size_t)cap * 2 * S, stream));
@@ -1572,6 +1576,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[2], stream));
         // stage 3
+        NvdrRange r3(backward ? "nvdr:shade_bwd+light_grad" : "nvdr:shade_fwd");
         if (backward) {
             env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
             if (p.lg_records && !(c->debug & 2u)) {
@@ -1697,10 +1702,12 @@ extern "C" int nvdr_env_shade_stage_times(nvdr_ctx *c, int backward, double *ms,
 
 extern "C" int nvdr_env_shade_fwd(nvdr_ctx *c, const nvdr_env_shade_args *a, void *stream)
 {
+    NvdrRange r("nvdr_env_shade_fwd");
     return env_shade_launch(c, a, false, (hipStream_t)stream);
 }
 extern "C" int nvdr_env_shade_bwd(nvdr_ctx *c, const nvdr_env_shade_args *a, void *stream)
 {
+    NvdrRange r("nvdr_env_shade_bwd");
     return env_shade_launch(c, a, true, (hipStream_t)stream);
 }
 extern "C" int nvdr_env_shade_stream_id(nvdr_ctx *c, uint64_t *out)

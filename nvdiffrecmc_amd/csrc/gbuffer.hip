@@ -121,6 +121,7 @@ unsigned query_grid(const nvdr_ctx *c, int64_t items);   // bvh.hip
 
 extern "C" int nvdr_render_gbuffer(nvdr_ctx *c, const nvdr_gbuffer_args *a, void *stream_)
 {
+    NvdrRange range("nvdr_render_gbuffer");
     NVDR_REQUIRE(c && a, "nvdr_render_gbuffer: NULL argument");
     NVDR_REQUIRE(c->n_tris > 0, "nvdr_render_gbuffer: no BVH built on this context (call optix_build_bvh first)");
     NVDR_REQUIRE(a->n_tris == c->n_tris, "nvdr_render_gbuffer: the mesh has %lld triangles, the BVH of this context %lld",

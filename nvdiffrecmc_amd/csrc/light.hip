@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(LT_THREADS) light_rows_cdf_kernel(int H, float
 extern "C" int nvdr_light_update_pdf(const float *base, int64_t hl, int64_t wl, float *pdf, float *cols, float *rows,
                                      void *stream_)
 {
+    NvdrRange range("nvdr_light_update_pdf");
     NVDR_REQUIRE(base && pdf && cols && rows, "light_update_pdf: NULL argument");
     NVDR_REQUIRE(hl > 0 && wl > 0 && hl < (1 << 20) && wl < (1 << 20), "light_update_pdf: bad probe size");
     hipStream_t stream = (hipStream_t)stream_;

@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
 extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps,
                               int *state, void *stream_)
 {
+    NvdrRange range("nvdr_adam_step");
     NVDR_REQUIRE(tensors && state, "adam_step: NULL argument");
     NVDR_REQUIRE(n_tensors >= 1 && n_tensors <= NVDR_ADAM_MAX_TENSORS, "adam_step: %d tensors (1..%d supported)", n_tensors, NVDR_ADAM_MAX_TENSORS);
     NVDR_REQUIRE(lr > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "adam_step: bad hyper-parameters");

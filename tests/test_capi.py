@@ -61,3 +61,23 @@ def test_no_cpu_fallback_errors_are_loud(monkeypatch):
     monkeypatch.setattr(_build, 'LIB', '/nonexistent/libnvdr_hip.so')
     with pytest.raises(RuntimeError, match='not built'):
         _lib.load()
+
+
+def test_roctx_ranges_load_the_marker_library_on_demand():
+    """NVDR_ROCTX=1: the first entry point that opens a range loads the roctx library (nothing is linked against the profiler);
+    without the variable the library is not touched.  The call itself fails on its NULL argument -- no GPU work here."""
+    import subprocess
+    import sys
+    prog = ('import ctypes, os\n'
+            'lib = ctypes.CDLL(%r)\n'
+            'lib.nvdr_last_error.restype = ctypes.c_char_p\n'
+            'r = lib.nvdr_adam_step(None, 0, ctypes.c_double(1e-3), ctypes.c_double(.9), ctypes.c_double(.999), ctypes.c_double(1e-8), None, None)\n'
+            'assert r == -1 and b"NULL" in lib.nvdr_last_error(), (r, lib.nvdr_last_error())\n'
+            'print("roctx" in open("/proc/self/maps").read())\n' % _build.LIB)
+    for flag, want in (('1', 'True'), ('0', 'False'), (None, 'False')):
+        env = {k: v for k, v in os.environ.items() if k != 'NVDR_ROCTX'}
+        if flag is not None:
+            env['NVDR_ROCTX'] = flag
+        out = subprocess.run([sys.executable, '-c', prog], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want, (flag, out.stdout, out.stderr)

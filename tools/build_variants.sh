@@ -7,6 +7,6 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I$R/include
 for spec in "$@"; do
   tag=${spec%%:*}; defs=${spec#*:}
   ( /opt/rocm/bin/hipcc $FLAGS $defs -c ${SRC:-$R/nvdiffrecmc_amd/csrc/env_shade.hip} -o $B/variants/env_shade_$tag.o &&
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/core.o $B/bvh.o $B/variants/env_shade_$tag.o $B/denoise.o $B/renderutils.o $B/light.o $B/gbuffer.o $B/optim.o -o $B/variants/libnvdr_hip.so.$tag && rm $B/variants/env_shade_$tag.o && echo built $tag ) &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/core.o $B/bvh.o $B/variants/env_shade_$tag.o $B/denoise.o $B/renderutils.o $B/light.o $B/gbuffer.o $B/optim.o -ldl -o $B/variants/libnvdr_hip.so.$tag && rm $B/variants/env_shade_$tag.o && echo built $tag ) &
 done
 wait

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- MC shadow rays/s and fwd+bwd iterations/s of the direct-lighting hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config bob512|spot512x256|dmtet800] [--scaling strong|weak]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config bob512|spot512x256|dmtet800|hotdog512x256] [--scaling strong|weak]
 
 `--gpus N` with N > 1 spawns N ranks itself (one process per GPU, RCCL = torch.distributed backend "nccl") unless the
 process was already started by a launcher (WORLD_SIZE set), e.g.
@@ -15,6 +15,8 @@ Workloads (BASELINE.json `configs`):
   spot512x256 (configs[2])  spot, 5 856 triangles, metal, 512x512, n_samples_x = 16 (256 spp), batch of 4 views.
   dmtet800    (configs[3] stand-in)  bob subdivided three times = 684 032 triangles (the size of a 128^3 DMTet
               extraction; 43 MB of nodes + triangles: does NOT fit the 4 MB L2s), 800x800, n_samples_x = 8, batch 8.
+  hotdog512x256 (configs[4] stand-in)  bob subdivided twice = 171 008 triangles, 512x512, n_samples_x = 16 (256 spp), batch 8
+              (configs/nerfactor_hotdog.json:7-8); geometry fixed -- DMTet's joint geometry optimisation is outside the path.
 One step = one optimisation iteration of nvdiffrecmc_amd/trainer.py: update_pdf + BVH rebuild + shading normal +
 env-shade fwd + 2x bilateral denoiser + composite + log-sRGB L1 image loss + full backward (the env-shade backward
 RE-TRACES every ray, as the reference does) + gradient all-reduce (N > 1) + Adam.  Inputs are resident in HBM before
@@ -73,6 +75,10 @@ PRESETS = {
     'dmtet800': dict(mesh='bob', res=800, n=8, batch=8, subdiv=3,
                      metric='MC shadow rays/sec (fwd+bwd train iteration, 800x800 64spp, 684k-triangle DMTet-sized mesh)',
                      what='nerf_lego.json stand-in: bob subdivided 3x (684 032 triangles), 800x800, 64 spp (n_samples_x=8)'),
+    'hotdog512x256': dict(mesh='bob', res=512, n=16, batch=8, subdiv=2,
+                          metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 256spp, 171k-triangle DMTet-sized mesh)',
+                          what='nerfactor_hotdog.json stand-in: bob subdivided 2x (171 008 triangles, the size DMTet extracts from a 128^3 '
+                               'grid), 512x512, 256 spp (n_samples_x=16); geometry fixed (the joint geometry optimisation is outside the path)'),
 }
 DOMINANT = 'env_trace_kernel<false>'
 

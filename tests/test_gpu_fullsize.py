@@ -277,6 +277,34 @@ def test_light_gradient_band_gather_equals_atomics(dev, monkeypatch):
     assert_close(light.grad, g1, 1e-4, floor=1e-3 * g1.abs().max().item())
 
 
+def test_config5_dmtet_sized_256spp_sparse_subset_vs_oracle(dev):
+    """BASELINE configs[4] stand-in (`bench.py --config hotdog512x256`): 512x512, n_samples_x = 16 on a mesh of the size DMTet extracts
+    from a 128^3 grid (bob subdivided twice, 171 008 triangles), sparse pixel subset against the oracle's brute force over every
+    triangle, forward and all five gradients."""
+    res, n, seed = 512, 16, 9
+    mesh, ctx, kw, perms = _gpu_scene('bob', res, n, dev, view=3, subdiv=2)
+    assert ctx.bvh_info()['n_tris'] == 171008
+    sub = torch.zeros_like(kw['mask'])
+    sub[:, 7::37, 5::41] = kw['mask'][:, 7::37, 5::41]
+    kws = dict(kw, mask=sub)
+    g = torch.Generator().manual_seed(4)
+    dg, sg = torch.rand(1, res, res, 3, generator=g), torch.rand(1, res, res, 3, generator=g)
+    leaves = {k: kws[k].clone().requires_grad_(True) for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')}
+    d, s = _shade(ctx, dict(kws, **leaves), n, seed)
+    ((d * dg.to(dev)).sum() + (s * sg.to(dev)).sum()).backward()
+    cpu = {k: v.detach().cpu().contiguous() for k, v in kws.items()}
+    f = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT)
+    b = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, diff_grad=dg, spec_grad=sg, n_threads=NT)
+    assert 15 < f['covered'] < 120
+    assert_close(d, f['diff'], 4e-6)
+    assert_close(s, f['spec'], 4e-6)
+    for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks'):
+        ref = b[k + '_grad']
+        assert_close(leaves[k].grad, ref, 2e-4, floor=1e-3 * max(ref.abs().max().item(), 1e-3), what=k)
+    assert_close(leaves['light'].grad, b['light_grad'], 1e-4, floor=1e-3 * b['light_grad'].abs().max().item())
+    ctx.check()
+
+
 def test_dmtet_sized_mesh_800(dev):
     """configs[3] stand-in: 800x800, n_samples_x = 8 on a 171k-triangle mesh (bob subdivided twice): finite, deterministic,
     and identical visibility-driven result after a refit to the same vertices."""

@@ -28,3 +28,20 @@ out = '\n'.join(lines)
 if len(sys.argv) > 2:
     open(sys.argv[2], 'w').write(out + '\n')
 print(out)
+
+# roctx ranges (rocprofv3 --marker-trace with NVDR_ROCTX=1): host-side spans of the entry points and their stages
+try:
+    # the range's message travels in the event's extdata ({"message": "..."}); `name` is the API call (roctxThreadRangeA)
+    regs = db.execute("""select coalesce(json_extract(extdata, '$.message'), name) as label, count(*), sum(duration), avg(duration),
+                          min(duration), max(duration) from regions where category like '%MARKER%'
+                          group by label order by sum(duration) desc""").fetchall()
+except sqlite3.Error:
+    regs = []
+if regs:
+    rl = ['', '| roctx range (host enqueue span) | calls | total us | avg us | min us | max us |', '|---|---|---|---|---|---|']
+    for r in regs:
+        rl.append('| %s | %d | %.1f | %.2f | %.2f | %.2f |' % (r[0], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3))
+    rt = '\n'.join(rl)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], 'a').write(rt + '\n')
+    print(rt)

@@ -4,9 +4,9 @@
 // their launchers (render/optixutils/c_src/torch_bindings.cpp:274-319).
 //
 // The reference reads 8 floats per tap straight from global memory in 8x8 blocks (529 taps at
-// sigma = 2).  Here a 32x8 workgroup first stages its (32+2R) x (8+2R) halo tile in LDS as two
-// float4 planes -- (col.rgb | out_grad.rgb, z) and (nrm.xyz, dz) -- so that a tap costs two
-// conflict-free ds_read_b128 (half-wave = one row of 32 consecutive pixels).  Taps that fall
+// sigma = 2).  Here a 32x16 workgroup (32x8 in the two-image kernels) first stages its (32+2R) x (rows+2R) halo tile in LDS as two
+// float4 planes -- (col.rgb | out_grad.rgb, z) and (nrm.xyz, dz); a third with the second image -- so that a tap costs two (three)
+// conflict-free 16-byte LDS reads (half-wave = one row of 32 consecutive pixels).  Taps that fall
 // outside the image are zero-filled: a zero normal gives clamp(dot,1e-4,1)^128 == 0 exactly, which
 // reproduces the reference's `continue` (denoising.cu:39-40).
 // The same identity gives the background early-out: a centre pixel whose normal is exactly zero (every pixel the
@@ -21,7 +21,8 @@
 // instead of 0.468 / 0.434 ms per 8-view launch.  The filter is bound by its ~28 VALU instructions per tap, not by LDS reads,
 // and the coarser four-row background early-out costs more than the reads saved.)
 // The per-tap constants exp(-d^2/2s^2) and d are wave-uniform; gfx950 has no scalar float unit, so they are tabulated
-// once per workgroup in LDS and fetched as broadcast reads instead of being recomputed (v_sqrt + v_exp per tap).
+// once per workgroup in LDS (one quadrant: they depend on |fx|, |fy|) and fetched as broadcast reads instead of being recomputed
+// (v_sqrt + v_exp per tap).
 //   forward : w = w_xy * w_n * exp(-|z_t - z_c| / max(dz_c * dist, 1e-4)),  out = (sum w*col_t, max(sum w, 1e-4))
 //   backward: the transposed gather with the TAP's dz in the denominator (denoising.cu:118).
 #include "common.h"
@@ -41,11 +42,18 @@ struct DnView {
     int N, H, W;
 };
 
-// tile height of the PAIR kernels: 32 x 32 pixels, one workgroup of 16 wavefronts per CU (three float4 planes: 144 KB of LDS at sigma = 2)
+// tile height of the PAIR kernels: 32 x 8 pixels, three float4 planes = 78 KB of LDS at sigma = 2, two workgroups per CU.  (At eight
+// 512x512 views the height does not matter -- 8 rows 0.605 / 0.525 ms forward / backward, 32 rows 0.610 / 0.538, 16 rows (one
+// workgroup per CU) 0.70 / 0.64 -- but ONE view has only ~80 live 32x32 tiles for 256 CUs: 0.181 / 0.128 ms against 0.133 / 0.099.)
+// (Tried and dropped: issuing the LDS reads of the next 1, 2 or 4 taps ahead of the arithmetic, with whole ds_read_b128 instead of
+// the ds_read_b96 the compiler narrows two of the three reads to: +10 % at every depth, one view or eight.  The tap loop is bound
+// by its ~36 VALU instructions, which the compiler's own two-tap unrolling already overlaps with the reads.)
 #ifndef DN_BY_PAIR
-#define DN_BY_PAIR 32
+#define DN_BY_PAIR 8
 #endif
-#define DN_LDS_KB_PAIR 156
+#ifndef DN_LDS_KB_PAIR
+#define DN_LDS_KB_PAIR 80
+#endif
 
 __device__ __forceinline__ float pow128(float x)
 {
@@ -90,9 +98,9 @@ __global__ void __launch_bounds__(DN_BX * (PAIR ? DN_BY_PAIR : DN_BY)) bilateral
         return;
     }
     const float inv2var = 1.0f / (2.0f * sigma * sigma);
-    const int side = 2 * rad + 1;
+    const int side = rad + 1;                               // the table is symmetric in fx and fy: one quadrant
     for (int t = threadIdx.x; t < side * side; t += DN_BX * BY) {
-        const int fx = t % side - rad, fy = t / side - rad;
+        const int fx = t % side, fy = t / side;
         const float dist_sqr = (float)(fx * fx + fy * fy);
         tap_tab[t] = make_float2(__expf(-dist_sqr * inv2var), sqrtf(dist_sqr));
     }
@@ -136,41 +144,44 @@ __global__ void __launch_bounds__(DN_BX * (PAIR ? DN_BY_PAIR : DN_BY)) bilateral
     }
     float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
     float bx = 0.f, by = 0.f, bz = 0.f;                     // PAIR: the second image's sums (the weight sum is shared)
-    for (int fy = -rad; fy <= rad; ++fy) {
-        for (int fx = -rad; fx <= rad; ++fx) {
-            const float2 tt = tap_tab[(fy + rad) * side + fx + rad];
-            float4 tAv, tBv, tCv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (TILED) {
+    // one tap: its weight from the guides, applied to the colour(s).  The sums run in tap order (rows of the window, left to right).
+    auto tap = [&](const float4 &tAv, const float4 &tBv, const float4 &tCv, const float2 &tt) {
+        const float w_xy = tt.x, dist = tt.y;
+        const float d = tBv.x * cB.x + tBv.y * cB.y + tBv.z * cB.z;
+        const float w_normal = pow128(fminf(fmaxf(d, DN_EPS), 1.0f));
+        const float dz = BACKWARD ? tBv.w : cB.w;
+        const float w_depth = __expf(-(fabsf(tAv.w - cA.w) * __builtin_amdgcn_rcpf(fmaxf(dz * dist, DN_EPS))));
+        const float w = w_xy * w_normal * w_depth;
+        ax += tAv.x * w;
+        ay += tAv.y * w;
+        az += tAv.z * w;
+        aw += w;
+        if (PAIR) {
+            bx += tCv.x * w;
+            by += tCv.y * w;
+            bz += tCv.z * w;
+        }
+    };
+    if (TILED) {
+        for (int fy = -rad; fy <= rad; ++fy)
+            for (int fx = -rad; fx <= rad; ++fx) {
                 const int t = (ly + rad + fy) * TW + lx + rad + fx;
-                tAv = tA[t];
-                tBv = tB[t];
-                if (PAIR) tCv = tC[t];
-            } else {
+                tap(tA[t], tB[t], PAIR ? tC[t] : make_float4(0.f, 0.f, 0.f, 0.f), tap_tab[(fy < 0 ? -fy : fy) * side + (fx < 0 ? -fx : fx)]);
+            }
+    } else {
+        for (int fy = -rad; fy <= rad; ++fy) {
+            for (int fx = -rad; fx <= rad; ++fx) {
                 const int gx = x + fx, gy = y + fy;
                 if (gx < 0 || gy < 0 || gx >= v.W || gy >= v.H) continue;
                 const F3 c = fetch3(v.col, n, gy, gx), nn = fetch3(v.nrm, n, gy, gx);
                 const float *zp = v.zdz.p + n * v.zdz.s0 + gy * v.zdz.s1 + gx * v.zdz.s2;
-                tAv = make_float4(c.x, c.y, c.z, zp[0]);
-                tBv = make_float4(nn.x, nn.y, nn.z, zp[v.zdz.s3]);
+                float4 tCv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (PAIR) {
                     const F3 d = fetch3(v.col2, n, gy, gx);
                     tCv = make_float4(d.x, d.y, d.z, 0.f);
                 }
-            }
-            const float w_xy = tt.x, dist = tt.y;
-            const float d = tBv.x * cB.x + tBv.y * cB.y + tBv.z * cB.z;
-            const float w_normal = pow128(fminf(fmaxf(d, DN_EPS), 1.0f));
-            const float dz = BACKWARD ? tBv.w : cB.w;
-            const float w_depth = __expf(-(fabsf(tAv.w - cA.w) * __builtin_amdgcn_rcpf(fmaxf(dz * dist, DN_EPS))));
-            const float w = w_xy * w_normal * w_depth;
-            ax += tAv.x * w;
-            ay += tAv.y * w;
-            az += tAv.z * w;
-            aw += w;
-            if (PAIR) {
-                bx += tCv.x * w;
-                by += tCv.y * w;
-                bz += tCv.z * w;
+                tap(make_float4(c.x, c.y, c.z, zp[0]), make_float4(nn.x, nn.y, nn.z, zp[v.zdz.s3]), tCv,
+                    tap_tab[(fy < 0 ? -fy : fy) * side + (fx < 0 ? -fx : fx)]);
             }
         }
     }
@@ -218,7 +229,7 @@ static int launch_bilateral(const nvdr_tensor *col_or_grad, const nvdr_tensor *c
     v.N = (int)N; v.H = (int)H; v.W = (int)W;
     const int rad = 2 * (int)ceil((double)sigma * 2.5) + 1; // denoising.cu:27
     const int by = pair ? DN_BY_PAIR : DN_BY;
-    const size_t lds_tab = (size_t)(2 * rad + 1) * (2 * rad + 1) * sizeof(float2);
+    const size_t lds_tab = (size_t)(rad + 1) * (rad + 1) * sizeof(float2);
     const size_t lds_tile = (size_t)(DN_BX + 2 * rad) * (by + 2 * rad) * (pair ? 3 : 2) * sizeof(float4);
     dim3 grid(div_up(W, DN_BX), div_up(H, by), (unsigned)N);
     // beyond 64 KB of dynamic LDS a kernel needs the attribute

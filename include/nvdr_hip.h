@@ -248,7 +248,8 @@ int nvdr_bilateral_denoiser_pair_bwd(const nvdr_tensor *col, const nvdr_tensor *
  * loss: 0 l1, 1 mse, 2 relmse, 3 smape, 4 n2n;  tonemapper: 0 none, 1 log_srgb.
  * fwd writes ONE partial sum per workgroup into `partials` (n_partials from nvdr_image_loss_num_partials);
  * the caller sums and divides by N*H*W (ops.py:494).  bwd: d_partials f32[n_partials] is the gradient
- * w.r.t. each partial (autograd hands back one value per partial; a pixel uses its own partial's). */
+ * w.r.t. each partial (autograd hands back one value per partial; a pixel uses its own partial's).  target_grad may be
+ * NULL: the gradient w.r.t. the target is then not written (a constant reference image). */
 int64_t nvdr_image_loss_num_partials(int64_t n, int64_t h, int64_t w);
 int nvdr_image_loss_fwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper, float *partials,
                         void *stream);

@@ -194,7 +194,8 @@ extern "C" int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *ta
                                    const float *d_partials, float *img_grad, float *target_grad, void *stream)
 {
     static const char *OP = "image_loss_bwd";
-    NVDR_REQUIRE(img && target && d_partials && img_grad && target_grad, "%s: NULL argument", OP);
+    // target_grad may be NULL (a target that does not require a gradient: the reference image of a training iteration)
+    NVDR_REQUIRE(img && target && d_partials && img_grad, "%s: NULL argument", OP);
     const Extent e = make_extent(img, target);
     CHECK_VIEW(img, 3);
     CHECK_VIEW(target, 3);
@@ -225,7 +226,7 @@ extern "C" int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *ta
             gt[c] = dt;
         }
         store3(img_grad, i, f3(gi[0], gi[1], gi[2]));
-        store3(target_grad, i, f3(gt[0], gt[1], gt[2]));
+        if (target_grad) store3(target_grad, i, f3(gt[0], gt[1], gt[2]));
     });
 }
 

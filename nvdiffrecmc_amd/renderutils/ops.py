@@ -258,10 +258,11 @@ class _image_loss_func(torch.autograd.Function):
         N, H, W = _extent(img, target)
         dout = dout.contiguous()
         gi = torch.empty(N, H, W, 3, dtype=torch.float32, device=img.device)
-        gt = torch.empty(N, H, W, 3, dtype=torch.float32, device=img.device)
+        # the target of a training iteration is a constant: its gradient is neither computed nor written then
+        gt = torch.empty(N, H, W, 3, dtype=torch.float32, device=img.device) if ctx.needs_input_grad[1] else None
         keep, refs = _views(img, target)
         _lib.check(lib.nvdr_image_loss_bwd(*refs, _LOSS.get(ctx.loss, 0), int(ctx.tonemapper == 'log_srgb'), _lib.ptr(dout),
-                                           _lib.ptr(gi), _lib.ptr(gt), _lib.stream_ptr()), 'image_loss_bwd')
+                                           _lib.ptr(gi), _lib.ptr(gt) if gt is not None else None, _lib.stream_ptr()), 'image_loss_bwd')
         return gi, gt, None, None
 
 

@@ -53,6 +53,10 @@ def test_image_loss_vs_reference_module_vectors(loss, tm, dev):
     assert_close(out.detach(), c['out'], 1e-5)
     for i in range(2):
         assert_close(ins[i].grad, c['grad%d' % i], 1e-4, floor=1e-6)
+    # a constant target (no gradient requested: the kernel then does not write one) leaves the image gradient unchanged
+    img2 = ins[0].detach().clone().requires_grad_(True)
+    ru.image_loss(img2, ins[1].detach(), loss=loss, tonemapper=tm).backward()
+    assert torch.equal(img2.grad, ins[0].grad)
 
 
 def test_image_loss_full_size_and_hdr_range(dev):

@@ -1003,6 +1003,296 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 }
 
 // ---------------------------------------------------------------------------------------------
+// stage 3 for S == 64 (one pixel per wavefront round, lane = stratum): the LIGHT-sampled rays go through a queue.
+//
+// A light sample under the pixel's horizon is dead (stage 1 marks it; it contributes exactly zero) -- 45 % of them on bob -- while
+// nearly every BSDF sample is live, so the kernel above shades a pixel in one pass with ~35 and one with ~63 busy lanes.  Here the
+// BSDF samples are shaded in place; the live light samples of consecutive pixels are queued in LDS (ray, texel, visibility, stratum,
+// pixel) and shaded 64 at a time, every lane busy: 1.55 instead of 2 passes per pixel.  A queued sample's contribution is ADDED TO ITS
+// OWN STRATUM'S CELL of the pixel's result row in LDS, which already holds the BSDF sample's; when all samples of a pixel are done the
+// row is summed over the lanes exactly as above.  Forward: per lane (0 + A) + B = A + B, the same operands -- bit-identical images.
+// Backward: each sample's gradient terms are accumulated from zero before they are added to the cell (the kernel above adds them
+// term by term to the running sums): last-bit differences, and like above no dependence on which pixels share a wavefront or a chunk.
+// The ring holds NVDR_SQ_RING pixels (set-up + result row); a pixel whose entry is needed again while samples of it still wait
+// drains the queue with a partial batch (3 entries: 0.552 passes per pixel for the light samples against 0.547 with no limit).
+#define NVDR_SQ_RING 3u
+#define NVDR_SQ_QCAP 128u
+
+template <bool BACKWARD>
+__global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_queue_kernel(ShadeParams p)
+{
+    constexpr int NF = BACKWARD ? 12 : 6;       // floats of a result cell: (diff, spec) or (g_kd, g_ks, g_pos, g_nrm)
+    constexpr int NS = BACKWARD ? 21 : 15;      // floats of a pixel's set-up: pos, nrm, view_pos, kd, ks (, dgrad, sgrad)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    reset_trace_queues(p);
+    const unsigned P = chunk_pixels(p);         // S == 64: a group is one pixel
+    const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
+    const unsigned S = 64u;
+    const float sample_frac = 1.0f / (float)(p.n * p.n);
+    const bool use_bits = BACKWARD && p.vis_cache != nullptr;
+    const bool save_bits = !BACKWARD && p.vis_cache != nullptr;
+
+    __shared__ float res_all[4][NVDR_SQ_RING][NF][64];
+    __shared__ float setup_all[4][NVDR_SQ_RING][NS + 3];
+    __shared__ float4 q_rd_all[4][NVDR_SQ_QCAP];
+    __shared__ unsigned q_meta_all[4][NVDR_SQ_QCAP];    // stratum | ring entry << 6 | occluded << 8
+    __shared__ int q_tex_all[4][NVDR_SQ_QCAP];
+    float (*res)[NF][64] = res_all[wave];
+    float (*setup)[NS + 3] = setup_all[wave];
+    float4 *q_rd = q_rd_all[wave];
+    unsigned *q_meta = q_meta_all[wave];
+    int *q_tex = q_tex_all[wave];
+
+    // work split as in env_shade_kernel: forward round-robin, backward one contiguous run per wavefront (its consumed slots take the records)
+    const unsigned wave_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wave));
+    unsigned grp = wave_id, grp_last = P, grp_step = waves_total;
+    if (BACKWARD) {
+        const unsigned per_wave = (P + waves_total - 1) / waves_total;
+        grp = min(wave_id * per_wave, P);
+        grp_last = min(grp + per_wave, P);
+        grp_step = 1;
+    }
+    // light-gradient records: see env_shade_kernel
+    const unsigned gs = 2u * S;
+    unsigned free_ptr = (grp * gs + 127u) & ~127u, free_end = grp * gs;
+    unsigned spare_next = p.lg_spare_base + wave_id * p.lg_spw;
+    unsigned bpos = 0xFFFFFFFFu, bleft = 0u;
+    auto emit_records = [&](bool hasA, const float4 &recA, bool hasB, const float4 &recB) {      // called in converged control flow
+        const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : -1;
+        const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : -1;
+        unsigned long long remA = __ballot(hasA), remB = __ballot(hasB);
+        while (remA | remB) {
+            const int b = remA ? __builtin_amdgcn_readlane(bandA, __builtin_ctzll(remA)) : __builtin_amdgcn_readlane(bandB, __builtin_ctzll(remB));
+            const unsigned long long mA = __ballot(bandA == b), mB = __ballot(bandB == b);
+            remA &= ~mA;
+            remB &= ~mB;
+            const unsigned nA = (unsigned)__popcll(mA), cnt = nA + (unsigned)__popcll(mB);
+            const unsigned at_slot = (unsigned)__builtin_amdgcn_readlane((int)bpos, b), left = (unsigned)__builtin_amdgcn_readlane((int)bleft, b);
+            unsigned fresh = 0u;
+            if (cnt > left) {
+                unsigned blk;
+                if (free_ptr + 128u <= free_end) { blk = free_ptr >> 7; free_ptr += 128u; }
+                else blk = spare_next++;
+                fresh = blk << 7;
+                if (at_slot != 0xFFFFFFFFu && lane == 0) p.lg_tags[(at_slot + left - 1u) >> 7] = (uint16_t)((unsigned)b | (128u << 8));
+            }
+            const unsigned to_fresh = fresh - left;
+            if (bandA == b) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recA;
+            }
+            if (bandB == b) {
+                const unsigned rank = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recB;
+            }
+            const unsigned at2 = cnt > left ? fresh + (cnt - left) : at_slot + cnt;
+            const unsigned left2 = cnt > left ? 128u - (cnt - left) : left - cnt;
+            bpos = lane == b ? at2 : bpos;
+            bleft = lane == b ? left2 : bleft;
+        }
+    };
+
+    // ring state (wave-uniform): pixel ordinal `it` of this wavefront lives in entry it % RING until it is finalised (in order)
+    unsigned it = 0, fin = 0;
+    unsigned pend0 = 0, pend1 = 0, pend2 = 0;       // queued samples of the entry's pixel that are not shaded yet
+    int lin0 = 0, lin1 = 0, lin2 = 0;               // its index in the frame(s)
+    unsigned q_head = 0, q_count = 0;
+    static_assert(NVDR_SQ_RING == 3u, "the ring state is spelled out for three entries");
+
+    while (true) {
+        const bool ring_full = it - fin == NVDR_SQ_RING;
+        const bool do_home = grp < grp_last && !ring_full;
+        if (!do_home && q_count == 0u && fin == it) break;
+        float4 lg_rec0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), lg_rec1 = lg_rec0;    // [0]: the in-place pass (BSDF samples), [1]: the queue pass
+        bool lg_has0 = false, lg_has1 = false;
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {
+            // what this lane shades in this pass
+            bool has = false;
+            unsigned ent = 0, stratum = (unsigned)lane;
+            float4 rd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            int texel = 0;
+            bool occluded = false;
+            F3 pos, nrm, view_pos, kd, ks, dgrad = f3(0.0f), sgrad = f3(0.0f);     // the set-up of the sample's pixel
+            if (k == 0) {
+                if (!do_home) continue;
+                ent = it % NVDR_SQ_RING;
+                const unsigned pi = grp;
+                const int lin = p.pix_list[p.pix_begin + pi];
+                const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
+                // the pixel's set-up: in registers for this pass (every lane reads the same addresses), in LDS for the lanes that will
+                // shade its queued samples
+                pos = fetch3(p.pos, z, y, x); nrm = fetch3(p.nrm, z, y, x);
+                view_pos = fetch3(p.view_pos, z, y, x); kd = fetch3(p.kd, z, y, x); ks = fetch3(p.ks, z, y, x);
+                if (BACKWARD) { dgrad = fetch3(p.dgrad, z, y, x); sgrad = fetch3(p.sgrad, z, y, x); }
+                if (lane == 0) {
+                    float *su = setup[ent];
+                    su[0] = pos.x; su[1] = pos.y; su[2] = pos.z; su[3] = nrm.x; su[4] = nrm.y; su[5] = nrm.z;
+                    su[6] = view_pos.x; su[7] = view_pos.y; su[8] = view_pos.z; su[9] = kd.x; su[10] = kd.y; su[11] = kd.z;
+                    su[12] = ks.x; su[13] = ks.y; su[14] = ks.z;
+                    if (BACKWARD) { su[15] = dgrad.x; su[16] = dgrad.y; su[17] = dgrad.z; su[18] = sgrad.x; su[19] = sgrad.y; su[20] = sgrad.z; }
+                }
+                const int64_t rA = (int64_t)pi * 2 * S + lane, rB = rA + S;
+                const float4 rdA = p.rays[rA], rdB = p.rays[rB];
+                const unsigned dead = (__float_as_uint(rdA.w) >> 31) | ((__float_as_uint(rdB.w) >> 31) << 1);
+                unsigned occ = 0;
+                if (use_bits) {
+                    const uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
+                    occ |= ((vc[lane >> 5] >> (lane & 31)) & 1u);
+                    occ |= ((vc[p.vis_words + (lane >> 5)] >> (lane & 31)) & 1u) << 1;
+                } else {
+                    if (!(dead & 1u)) occ |= p.vis[rA] ? 0u : 1u;
+                    if (!(dead & 2u)) occ |= p.vis[rB] ? 0u : 2u;
+                }
+                if (save_bits) {
+                    const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
+                    if (lane == 0) {
+                        uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
+                        vc[0] = (uint32_t)ba;
+                        vc[p.vis_words] = (uint32_t)bb;
+                        if (1 < p.vis_words) {
+                            vc[1] = (uint32_t)(ba >> 32);
+                            vc[p.vis_words + 1] = (uint32_t)(bb >> 32);
+                        }
+                    }
+                }
+                // the live light samples wait in the queue
+                const bool liveA = !(dead & 1u);
+                const unsigned long long mq = __ballot(liveA);
+                if (liveA) {
+                    const unsigned at = (q_head + q_count + __builtin_amdgcn_mbcnt_hi((unsigned)(mq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mq, 0u))) & (NVDR_SQ_QCAP - 1u);
+                    q_rd[at] = rdA;
+                    q_meta[at] = (unsigned)lane | (ent << 6) | ((occ & 1u) << 8);
+                    q_tex[at] = p.texel[rA];
+                }
+                const unsigned pushed = (unsigned)__popcll(mq);
+                q_count += pushed;
+                if (ent == 0u) { pend0 = pushed; lin0 = lin; } else if (ent == 1u) { pend1 = pushed; lin1 = lin; } else { pend2 = pushed; lin2 = lin; }
+                ++it;
+                if (BACKWARD) free_end = (grp + 1u) * gs;   // the rays of this pixel have all been read: its slots may hold records now
+                grp += grp_step;
+                // ... and the BSDF sample of this lane's stratum is shaded in place
+                has = !(dead & 2u);
+                rd = rdB;
+                occluded = (occ >> 1) & 1u;
+                if (has) texel = p.texel[rB];
+            } else {
+                // a full batch while pixels keep coming; whatever waits when the ring is full or the pixels have run out
+                const unsigned cnt = q_count >= 64u ? 64u : (do_home ? 0u : q_count);
+                if (cnt == 0u) continue;
+                __builtin_amdgcn_wave_barrier();    // (entries pushed by other lanes in the pass before)
+                has = (unsigned)lane < cnt;
+                const unsigned qi = (q_head + (unsigned)lane) & (NVDR_SQ_QCAP - 1u);
+                unsigned meta = 0;
+                if (has) {
+                    rd = q_rd[qi];
+                    meta = q_meta[qi];
+                    texel = q_tex[qi];
+                }
+                stratum = meta & 63u;
+                ent = (meta >> 6) & 3u;
+                occluded = (meta >> 8) & 1u;
+                q_head += cnt;
+                q_count -= cnt;
+                pend0 -= (unsigned)__popcll(__ballot(has && ent == 0u));
+                pend1 -= (unsigned)__popcll(__ballot(has && ent == 1u));
+                pend2 -= (unsigned)__popcll(__ballot(has && ent == 2u));
+                const float *su = setup[ent];
+                pos = f3(su[0], su[1], su[2]); nrm = f3(su[3], su[4], su[5]); view_pos = f3(su[6], su[7], su[8]);
+                kd = f3(su[9], su[10], su[11]); ks = f3(su[12], su[13], su[14]);
+                if (BACKWARD) { dgrad = f3(su[15], su[16], su[17]); sgrad = f3(su[18], su[19], su[20]); }
+            }
+            float out[NF];
+#pragma unroll
+            for (int c = 0; c < NF; ++c) out[c] = 0.0f;
+            float4 lg_rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            bool lg_has = false;
+            if (has) {
+                const F3 dir = f3(rd.x, rd.y, rd.z);
+                const float pdfSum = rd.w;
+                const F3 light_col = fetch_light_texel(p.light, texel);
+                const float mis_weight = 1.0f / fmaxf(pdfSum, 0.0001f);
+                F3 _diff = f3(0.0f), _spec = f3(0.0f);
+                if (p.bsdf == 1 || p.bsdf == 2)
+                    _diff = f3(fwd_lambert(nrm, dir));
+                else
+                    fwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, _diff, _spec);
+                const float vis = occluded ? 0.0f : 1.0f;
+                const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
+                if (BACKWARD) {
+                    const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
+                    lg_has = !(p.debug & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
+                    lg_rec = make_float4(lg.x, lg.y, lg.z, __int_as_float(texel));
+                    const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
+                    const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
+                    F3 g_kd = f3(0.0f), g_ks = f3(0.0f), g_pos = f3(0.0f), g_nrm = f3(0.0f);
+                    if (p.bsdf == 1 || p.bsdf == 2) {
+                        F3 d_wi = f3(0.0f);
+                        bwd_lambert(nrm, dir, g_nrm, d_wi, sum3(_dg));
+                    } else {
+                        bwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
+                    }
+                    out[0] = g_kd.x; out[1] = g_kd.y; out[2] = g_kd.z; out[3] = g_ks.x; out[4] = g_ks.y; out[5] = g_ks.z;
+                    out[6] = g_pos.x; out[7] = g_pos.y; out[8] = g_pos.z; out[9] = g_nrm.x; out[10] = g_nrm.y; out[11] = g_nrm.z;
+                } else {
+                    const F3 d = (((_diff * light_col) * V) * mis_weight) * sample_frac;
+                    const F3 sp = (((_spec * light_col) * V) * mis_weight) * sample_frac;
+                    out[0] = d.x; out[1] = d.y; out[2] = d.z; out[3] = sp.x; out[4] = sp.y; out[5] = sp.z;
+                }
+            }
+            // into the result row: the in-place pass initialises every cell of its pixel, the queue pass adds to the cell of its stratum
+            if (k == 0) {
+#pragma unroll
+                for (int c = 0; c < NF; ++c) res[ent][c][lane] = out[c];
+                lg_rec0 = lg_rec;
+                lg_has0 = lg_has;
+            } else {
+                __builtin_amdgcn_wave_barrier();    // (cells initialised by other lanes in an in-place pass)
+                if (has) {
+#pragma unroll
+                    for (int c = 0; c < NF; ++c) res[ent][c][stratum] = out[c] + res[ent][c][stratum];
+                }
+                lg_rec1 = lg_rec;
+                lg_has1 = lg_has;
+            }
+        }
+        if (BACKWARD && p.lg_records) emit_records(lg_has1, lg_rec1, lg_has0, lg_rec0);     // light-sampled records first, as above
+        // pixels whose samples are all shaded, in order: the row is summed over the lanes and written
+        while (fin < it) {
+            const unsigned e = fin % NVDR_SQ_RING;
+            const unsigned pend = e == 0u ? pend0 : (e == 1u ? pend1 : pend2);
+            if (pend != 0u) break;
+            const int lin = e == 0u ? lin0 : (e == 1u ? lin1 : lin2);
+            __builtin_amdgcn_wave_barrier();
+            float v[NF];
+#pragma unroll
+            for (int c = 0; c < NF; ++c) v[c] = group_sum(res[e][c][lane], 64);
+            if (lane == 0) {
+                if (BACKWARD) {
+                    float *o = p.g_kd + (int64_t)lin * 3;
+                    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+                    o = p.g_ks + (int64_t)lin * 3;
+                    o[0] = v[3]; o[1] = v[4]; o[2] = v[5];
+                    o = p.g_pos + (int64_t)lin * 3;
+                    o[0] = v[6]; o[1] = v[7]; o[2] = v[8];
+                    o = p.g_nrm + (int64_t)lin * 3;
+                    o[0] = v[9]; o[1] = v[10]; o[2] = v[11];
+                } else {
+                    float *o = p.diff + (int64_t)lin * 3;
+                    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+                    o = p.spec + (int64_t)lin * 3;
+                    o[0] = v[3]; o[1] = v[4]; o[2] = v[5];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();        // (the entry is free for the next pixel once its cells have been read)
+            ++fin;
+        }
+    }
+    if (BACKWARD && p.lg_records && bpos != 0xFFFFFFFFu)
+        p.lg_tags[(bpos + bleft - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - bleft) << 8));
+}
+
+// ---------------------------------------------------------------------------------------------
 // light gradient (eval_light_bwd, kernel.cu:203-211) without global atomics: BAND-SORTED RECORD BLOCKS + LDS GATHER.
 //
 // The reference adds every sample's addend to light_grad[texel] with three atomicAdds.  On MI355X fp32 atomics are
@@ -1401,6 +1691,18 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             lg_grid_y = per_band ? n_bands : 1;
         }
     }
+    // S == 64 (one pixel per wavefront round): the shading kernels that queue the live light samples across pixels
+    // (env_shade_queue_kernel; NVDR_SHADE_QUEUE bit 0 backward, bit 1 forward).  The atomics fallback of the light gradient and the
+    // contention experiment (NVDR_DEBUG bit 4) stay with the plain kernels.  Decided the same way by the forward and the backward
+    // launch (the grid of the backward kernel sizes the spare blocks).  Their workgroups hold 31 / 49 KB of LDS -- 5 / 3 resident per
+    // CU -- and a finer split evens out what the pixels cost: forward 15 per CU (0.823 ms per 8-view launch; 5: 0.866, 10: 0.839,
+    // 30: 0.825), backward 12 (2.52 ms; 6: 2.60, 9: 2.58, 18: 2.51); one view: 10 and 3 (0.120 / 0.405 ms; 15 and 12: 0.120 / 0.432).
+    const bool queue_fwd = (c->shade_queue & 2) && S == 64 && L == 64;
+    const bool queue_bwd = (c->shade_queue & 1) && S == 64 && L == 64 && lg_records && !(c->debug & 4u);
+    if (!c->per_cu_user) {
+        if (queue_fwd) per_cu_launch[1] = npix <= (1ll << 20) ? 10 : 15;
+        if (queue_bwd) per_cu_launch[2] = npix <= (1ll << 20) ? 3 : 12;
+    }
     // spare blocks per wavefront of the backward shading kernel: one open block per band + the records of the first group (nothing
     // consumed yet) + the alignment of its range to 128 slots + the round in flight (env_shade_kernel<true>)
     const unsigned lg_spw = lg_records ? (unsigned)(n_bands + (group_slots + 127) / 128 + 2) : 0u;
@@ -1437,6 +1739,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     p.pix_cap = (unsigned)cap;
 
     p.lg_records = backward ? lg_records : 0;
+    const bool shade_queue = backward ? queue_bwd : queue_fwd;
     p.lg_shift = lg_shift;
 
     if (!backward) {
@@ -1578,7 +1881,8 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         // stage 3
         NvdrRange r3(backward ? "nvdr:shade_bwd+light_grad" : "nvdr:shade_fwd");
         if (backward) {
-            env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
+            if (shade_queue) env_shade_queue_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
+            else env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
             if (p.lg_records && !(c->debug & 2u)) {
                 light_grad_block_kernel<<<dim3((unsigned)lg_rows, (unsigned)lg_grid_y), NVDR_LG_THREADS, lg_lds, stream>>>(
                     c->lg_tags, c->rays, p.pix_count, p.pix_begin, p.pix_cap, (unsigned)G, (unsigned)group_slots, p.lg_spare_base,
@@ -1587,7 +1891,8 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
                                                                                          k > 0 ? 1 : 0, p.pix_count, p.pix_begin);
             }
         } else {
-            env_shade_kernel<false><<<(unsigned)pb[1], 256, 0, stream>>>(p);
+            if (shade_queue) env_shade_queue_kernel<false><<<(unsigned)pb[1], 256, 0, stream>>>(p);
+            else env_shade_kernel<false><<<(unsigned)pb[1], 256, 0, stream>>>(p);
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));
     }

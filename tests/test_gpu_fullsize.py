@@ -423,3 +423,42 @@ def test_light_gradient_records_vs_atomics_over_shapes(probe, n, res, mode, dev,
     assert torch.equal(kg, ka)
     lg2, _ = grads(ctx)                                       # the tag array is clean again after a launch
     assert_close(lg2, lg, 1e-4, floor=1e-3 * la.abs().max().item())
+
+
+@pytest.mark.parametrize('cache_vis', [False, True], ids=['retrace', 'cached_visibility'])
+def test_queue_shading_kernels_equal_the_plain_ones(cache_vis, dev, monkeypatch):
+    """n_samples_x = 8 (S = 64): the shading kernels that queue the live light samples across pixels (env_shade_queue_kernel) against
+    the plain ones (NVDR_SHADE_QUEUE=0): images bit for bit (per lane the same two addends), per-pixel gradients up to the order in
+    which a sample's own terms are added, the light gradient up to the order of the records."""
+    from nvdiffrecmc_amd import optixutils as ou
+    res, n, seed, nv = 160, 8, 12, 3
+    views = [_gpu_scene('bob', res, n, dev, view=v) for v in range(nv)]
+    mesh = views[0][0]
+    kw = {k: torch.cat([v[2][k] for v in views], 0).contiguous() for k in ('mask', 'ro', 'gb_pos', 'gb_normal', 'gb_view_pos', 'gb_kd', 'gb_ks')}
+    kw.update({k: views[0][2][k] for k in ('light', 'pdf', 'rows', 'cols')})
+    g = torch.Generator().manual_seed(3)
+    dg, sg = torch.rand(nv, res, res, 3, generator=g).to(dev), torch.rand(nv, res, res, 3, generator=g).to(dev)
+    names = ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')
+
+    def run(flag):
+        monkeypatch.setenv('NVDR_SHADE_QUEUE', flag)
+        ctx = ou.OptiXContext()
+        monkeypatch.delenv('NVDR_SHADE_QUEUE')
+        ou.optix_build_bvh(ctx, mesh['v_pos'].to(dev), mesh['t_pos_idx'].to(dev), 1)
+        ctx.cache_visibility = cache_vis
+        leaves = {k: kw[k].clone().requires_grad_(True) for k in names}
+        d, s = _shade(ctx, dict(kw, **leaves), n, seed)
+        ((d * dg).sum() + (s * sg).sum()).backward()
+        ctx.check()
+        return d.detach(), s.detach(), {k: leaves[k].grad for k in names}
+
+    d0, s0, g0 = run('0')
+    d1, s1, g1 = run('3')
+    assert d0.abs().sum().item() > 0
+    assert torch.equal(d0, d1) and torch.equal(s0, s1)
+    for k in names[:4]:
+        assert_close(g1[k], g0[k], 2e-5, floor=1e-5 * g0[k].abs().max().item(), what=k)
+    assert_close(g1['light'], g0['light'], 1e-4, floor=1e-3 * g0['light'].abs().max().item())
+    # the same launch twice: deterministic
+    d2, s2, g2 = run('3')
+    assert torch.equal(d1, d2) and all(torch.equal(g1[k], g2[k]) for k in names[:4])

@@ -221,9 +221,11 @@ def collect_pmc(args, keep_dir=None, config=None, passes=None):
 
 
 def find_kernel(counters, needle):
-    for name, c in counters.items():
-        if needle in name:
-            return c
+    """Counters of the first kernel whose name contains `needle` (or the first of several alternatives that occurs)."""
+    for nd in ((needle,) if isinstance(needle, str) else needle):
+        for name, c in counters.items():
+            if nd in name:
+                return c
     return None
 
 
@@ -620,8 +622,9 @@ def run(args):
                 roof['traffic_source'] = 'rocprofv3 --kernel-trace --pmc passes of this run (bench.py --pmc-child, %d dispatches)' % int(c.get('dispatches_pass1', 0))
                 # the other env-shade kernels from the same passes (durations: HIP-event stage times, backward stage 3 includes the gather)
                 others = {}
-                for label, needle, ms in (('env_shade_kernel<backward>', 'env_shade_kernel<true', None), ('env_gen_kernel', 'env_gen_kernel', gen_ms),
-                                          ('env_shade_kernel<forward>', 'env_shade_kernel<false', shade_ms),
+                # (S = 64 launches run the shading kernels that queue the light samples across pixels, env_shade_queue_kernel)
+                for label, needle, ms in (('env_shade_kernel<backward>', ('env_shade_queue_kernel<true', 'env_shade_kernel<true'), None), ('env_gen_kernel', 'env_gen_kernel', gen_ms),
+                                          ('env_shade_kernel<forward>', ('env_shade_queue_kernel<false', 'env_shade_kernel<false'), shade_ms),
                                           ('light_grad_block_kernel', 'light_grad_block_kernel', None)):
                     oc = find_kernel(counters, needle)
                     if oc and chunks > 1:

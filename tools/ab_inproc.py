@@ -13,6 +13,8 @@ from tools.gpu_tenancy import snapshot
 res = int(os.environ.get('PROBE_RES', '512'))
 subdiv = int(os.environ.get('PROBE_SUBDIV', '0'))
 nviews = int(os.environ.get('PROBE_VIEWS', '8'))
+n_x = int(os.environ.get('PROBE_N', '8'))                # n_samples_x
+mesh_name = os.environ.get('PROBE_MESH', 'bob')
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 base = _build.LIB
 paths = [('current', base)] + [(p.split('.so.')[-1], p) for p in sorted(glob.glob(os.path.join(_build.BUILD, 'variants', 'libnvdr_hip.so.*')))]
@@ -44,7 +46,7 @@ for tag, path in paths:
         os.environ[k_] = v_
     if tag.startswith('lg_'):
         os.environ['NVDR_LG_MODE'] = '1' if tag == 'lg_perband' else '0'
-    st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
+    st = DirectLightingStep(mesh_name, res, n_x, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
     os.environ.pop('NVDR_TRACE_VARIANT', None)
     os.environ.pop('NVDR_LG_MODE', None)
     for k_ in env_variants.get(tag, {}):
@@ -70,7 +72,7 @@ def run(tag, iters=int(os.environ.get('AB_ITERS', '4'))):
             st.ctx.set_profiling(True)
         g = [t.clone().requires_grad_(True) for t in (st.gb_pos, nrm, kd, ks, L.base.detach())]
         d, s = ou.optix_env_shade(st.ctx, st.mask, ro, g[0], g[1], st.view_pos, g[2], g[3], g[4], L._pdf, L.rows[:, 0], L.cols,
-                                  n_samples_x=8, rnd_seed=it, shadow_scale=1.0)
+                                  n_samples_x=n_x, rnd_seed=it, shadow_scale=1.0)
         torch.autograd.backward([d, s], [torch.ones_like(d), torch.ones_like(s)])
     torch.cuda.synchronize()
     nf, f = st.ctx.stage_times(backward=False)

@@ -166,7 +166,7 @@ struct nvdr_ctx {
     unsigned *dp_split = nullptr;  // [cap] the slot splits the DP chose
     bool oct_dp = true;            // SAH-optimal collapse (false: greedy largest-area, NVDR_OCT_DP=0)
     float oct_c_leaf = 0.45f;      // cost of a triangle test relative to a node step in the collapse DP
-    int shade_queue = 3;           // S == 64: shading kernels that queue the live light samples across pixels (NVDR_SHADE_QUEUE: bit 0 backward, bit 1 forward, bit 2 also with several rounds per pixel)
+    int shade_queue = 3;           // S == 64: shading kernels that queue the live light samples across pixels (NVDR_SHADE_QUEUE: bit 0 backward, bit 1 forward)
     int lg_mode = -1;              // gather work split: -1 by launch size, 0 all bands per workgroup, 1 one set of workgroups per band (NVDR_LG_MODE)
     bool lg_tags_dirty = true;     // the array may hold tags nobody consumed (fresh allocation, a backward pass without gather)
     uint64_t stream_id = 0;        // id of the ray stream currently held in rays/texel/pix_origin/pix_list

@@ -1003,19 +1003,17 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 }
 
 // ---------------------------------------------------------------------------------------------
-// stage 3 for S > 32 (a round of the wavefront = 64 strata of ONE pixel): the LIGHT-sampled rays go through a queue.  Launched where
-// a pixel is one round (32 < S <= 64: the benchmark's 64 spp); see env_shade_launch for the larger S.
+// stage 3 for S == 64 (one pixel per wavefront round, lane = stratum): the LIGHT-sampled rays go through a queue.
 //
 // A light sample under the pixel's horizon is dead (stage 1 marks it; it contributes exactly zero) -- 45 % of them on bob -- while
 // nearly every BSDF sample is live, so the kernel above shades a pixel in one pass with ~35 and one with ~63 busy lanes.  Here the
 // BSDF samples are shaded in place; the live light samples of consecutive pixels are queued in LDS (ray, texel, visibility, stratum,
 // pixel) and shaded 64 at a time, every lane busy: 1.55 instead of 2 passes per pixel.  A queued sample's contribution is ADDED TO ITS
-// OWN STRATUM'S CELL of a result row in LDS (one row per round of 64 strata), which already holds the BSDF sample's; when all samples
-// of a row are done it is summed over the lanes as above, and the rows of a pixel (S > 64) are added up in order.  S = 64, forward: per
-// lane (0 + A) + B = A + B, the same operands -- images bit-identical to the kernel above (S > 64: it adds the rounds per lane first).
+// OWN STRATUM'S CELL of the pixel's result row in LDS, which already holds the BSDF sample's; when all samples of a pixel are done the
+// row is summed over the lanes exactly as above.  Forward: per lane (0 + A) + B = A + B, the same operands -- bit-identical images.
 // Backward: each sample's gradient terms are accumulated from zero before they are added to the cell (the kernel above adds them
 // term by term to the running sums): last-bit differences, and like above no dependence on which pixels share a wavefront or a chunk.
-// The ring holds NVDR_SQ_RING rows (set-up + result cells); a row whose entry is needed again while samples of it still wait
+// The ring holds NVDR_SQ_RING pixels (set-up + result row); a pixel whose entry is needed again while samples of it still wait
 // drains the queue with a partial batch (3 entries: 0.552 passes per pixel for the light samples against 0.547 with no limit).
 #define NVDR_SQ_RING 3u
 #define NVDR_SQ_QCAP 128u
@@ -1027,9 +1025,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     constexpr int NS = BACKWARD ? 21 : 15;      // floats of a pixel's set-up: pos, nrm, view_pos, kd, ks (, dgrad, sgrad)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     reset_trace_queues(p);
-    const unsigned P = chunk_pixels(p);         // L == 64: a group is one pixel
+    const unsigned P = chunk_pixels(p);         // S == 64: a group is one pixel
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
-    const unsigned S = p.S, rounds = (S + 63u) >> 6;
+    const unsigned S = 64u;
     const float sample_frac = 1.0f / (float)(p.n * p.n);
     const bool use_bits = BACKWARD && p.vis_cache != nullptr;
     const bool save_bits = !BACKWARD && p.vis_cache != nullptr;
@@ -1055,7 +1053,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         grp_step = 1;
     }
     // light-gradient records: see env_shade_kernel
-    const unsigned gs = 2u * S;                                         // stream slots of one pixel
+    const unsigned gs = 2u * S;
     unsigned free_ptr = (grp * gs + 127u) & ~127u, free_end = grp * gs;
     unsigned spare_next = p.lg_spare_base + wave_id * p.lg_spw;
     unsigned bpos = 0xFFFFFFFFu, bleft = 0u;
@@ -1094,14 +1092,10 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         }
     };
 
-    // ring state (wave-uniform): row ordinal `it` of this wavefront (a row = one round of 64 strata of a pixel) lives in entry
-    // it % RING until it is finalised (in order)
-    unsigned it = 0, fin = 0, round = 0;
-    unsigned pend0 = 0, pend1 = 0, pend2 = 0;       // queued samples of the entry's row that are not shaded yet
-    int lin0 = 0, lin1 = 0, lin2 = 0;               // its pixel's index in the frame(s); bit 31 set: the pixel's last row
-    float pix_acc[NF];                              // sum of the rows of the pixel being finalised
-#pragma unroll
-    for (int c = 0; c < NF; ++c) pix_acc[c] = 0.0f;
+    // ring state (wave-uniform): pixel ordinal `it` of this wavefront lives in entry it % RING until it is finalised (in order)
+    unsigned it = 0, fin = 0;
+    unsigned pend0 = 0, pend1 = 0, pend2 = 0;       // queued samples of the entry's pixel that are not shaded yet
+    int lin0 = 0, lin1 = 0, lin2 = 0;               // its index in the frame(s)
     unsigned q_head = 0, q_count = 0;
     static_assert(NVDR_SQ_RING == 3u, "the ring state is spelled out for three entries");
 
@@ -1138,18 +1132,14 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     su[12] = ks.x; su[13] = ks.y; su[14] = ks.z;
                     if (BACKWARD) { su[15] = dgrad.x; su[16] = dgrad.y; su[17] = dgrad.z; su[18] = sgrad.x; su[19] = sgrad.y; su[20] = sgrad.z; }
                 }
-                const unsigned base = round << 6, i = base + (unsigned)lane;     // stratum
-                const bool active = i < S;
-                const int64_t rA = (int64_t)pi * 2 * S + (active ? i : 0u), rB = rA + S;
+                const int64_t rA = (int64_t)pi * 2 * S + lane, rB = rA + S;
                 const float4 rdA = p.rays[rA], rdB = p.rays[rB];
-                const unsigned dead = active ? ((__float_as_uint(rdA.w) >> 31) | ((__float_as_uint(rdB.w) >> 31) << 1)) : 3u;
+                const unsigned dead = (__float_as_uint(rdA.w) >> 31) | ((__float_as_uint(rdB.w) >> 31) << 1);
                 unsigned occ = 0;
                 if (use_bits) {
                     const uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
-                    if (active) {
-                        occ |= ((vc[i >> 5] >> (i & 31u)) & 1u);
-                        occ |= ((vc[p.vis_words + (i >> 5)] >> (i & 31u)) & 1u) << 1;
-                    }
+                    occ |= ((vc[lane >> 5] >> (lane & 31)) & 1u);
+                    occ |= ((vc[p.vis_words + (lane >> 5)] >> (lane & 31)) & 1u) << 1;
                 } else {
                     if (!(dead & 1u)) occ |= p.vis[rA] ? 0u : 1u;
                     if (!(dead & 2u)) occ |= p.vis[rB] ? 0u : 2u;
@@ -1158,12 +1148,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
                     if (lane == 0) {
                         uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
-                        const int w0 = 2 * (int)round;
-                        vc[w0] = (uint32_t)ba;
-                        vc[p.vis_words + w0] = (uint32_t)bb;
-                        if (w0 + 1 < p.vis_words) {
-                            vc[w0 + 1] = (uint32_t)(ba >> 32);
-                            vc[p.vis_words + w0 + 1] = (uint32_t)(bb >> 32);
+                        vc[0] = (uint32_t)ba;
+                        vc[p.vis_words] = (uint32_t)bb;
+                        if (1 < p.vis_words) {
+                            vc[1] = (uint32_t)(ba >> 32);
+                            vc[p.vis_words + 1] = (uint32_t)(bb >> 32);
                         }
                     }
                 }
@@ -1178,17 +1167,10 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 }
                 const unsigned pushed = (unsigned)__popcll(mq);
                 q_count += pushed;
-                const bool last_row = round + 1u == rounds;
-                const int lin_tag = lin | (last_row ? (int)0x80000000u : 0);
-                if (ent == 0u) { pend0 = pushed; lin0 = lin_tag; } else if (ent == 1u) { pend1 = pushed; lin1 = lin_tag; } else { pend2 = pushed; lin2 = lin_tag; }
+                if (ent == 0u) { pend0 = pushed; lin0 = lin; } else if (ent == 1u) { pend1 = pushed; lin1 = lin; } else { pend2 = pushed; lin2 = lin; }
                 ++it;
-                if (last_row) {
-                    if (BACKWARD) free_end = (grp + 1u) * gs;   // the rays of this pixel have all been read: its slots may hold records now
-                    grp += grp_step;
-                    round = 0;
-                } else {
-                    ++round;
-                }
+                if (BACKWARD) free_end = (grp + 1u) * gs;   // the rays of this pixel have all been read: its slots may hold records now
+                grp += grp_step;
                 // ... and the BSDF sample of this lane's stratum is shaded in place
                 has = !(dead & 2u);
                 rd = rdB;
@@ -1280,16 +1262,12 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             const unsigned e = fin % NVDR_SQ_RING;
             const unsigned pend = e == 0u ? pend0 : (e == 1u ? pend1 : pend2);
             if (pend != 0u) break;
-            const int lin_tag = e == 0u ? lin0 : (e == 1u ? lin1 : lin2);
-            const int lin = lin_tag & 0x7fffffff;
+            const int lin = e == 0u ? lin0 : (e == 1u ? lin1 : lin2);
             __builtin_amdgcn_wave_barrier();
             float v[NF];
 #pragma unroll
-            for (int c = 0; c < NF; ++c) {
-                v[c] = pix_acc[c] + group_sum(res[e][c][lane], 64);     // (first row: 0 + the row's sum)
-                pix_acc[c] = lin_tag < 0 ? 0.0f : v[c];
-            }
-            if (lane == 0 && lin_tag < 0) {
+            for (int c = 0; c < NF; ++c) v[c] = group_sum(res[e][c][lane], 64);
+            if (lane == 0) {
                 if (BACKWARD) {
                     float *o = p.g_kd + (int64_t)lin * 3;
                     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
@@ -1713,16 +1691,16 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             lg_grid_y = per_band ? n_bands : 1;
         }
     }
-    // S > 32 (L == 64: one pixel per wavefront round): the shading kernels that queue the live light samples across pixels
+    // S == 64 (one pixel per wavefront round, lane = stratum): the shading kernels that queue the live light samples across pixels
     // (env_shade_queue_kernel; NVDR_SHADE_QUEUE bit 0 backward, bit 1 forward).  The atomics fallback of the light gradient and the
     // contention experiment (NVDR_DEBUG bit 4) stay with the plain kernels.  Decided the same way by the forward and the backward
     // launch (the grid of the backward kernel sizes the spare blocks).  Their workgroups hold 31 / 49 KB of LDS -- 5 / 3 resident per
     // CU -- and a finer split evens out what the pixels cost: forward 15 per CU (0.823 ms per 8-view launch of bob at 64 spp; 5: 0.866,
     // 10: 0.839, 30: 0.825), backward 12 (2.52 ms; 6: 2.60, 9: 2.58, 18: 2.51); one view: 10 and 3 (0.120 / 0.405 ms; 15 and 12: 0.120 / 0.432).
-    // Only where a pixel is ONE round (32 < S <= 64): with several rounds per pixel the plain kernels keep a lane's sums in registers
-    // across the rounds and reduce once per pixel, and win -- 256 spp, 4 views of spot: forward 1.35 against 2.00 ms, backward 5.28
-    // against 5.87 (bit 2 of NVDR_SHADE_QUEUE selects the queue kernels there too, for the tests).
-    const bool queue_ok = L == 64 && (S <= 64 || (c->shade_queue & 4));
+    // Only S == 64: a version of the kernels with one result row per ROUND of a pixel (S = 256: four) was measured and dropped -- the
+    // plain kernels keep a lane's sums in registers across the rounds and won there (256 spp, 4 views of spot: forward 1.35 against
+    // 1.94 ms, backward 5.28 against 5.55), and the generality cost the one-round case 8 % (32 more VGPRs).
+    const bool queue_ok = L == 64 && S == 64;
     const bool queue_fwd = (c->shade_queue & 2) && queue_ok;
     const bool queue_bwd = (c->shade_queue & 1) && queue_ok && lg_records && !(c->debug & 4u);
     if (!c->per_cu_user) {

@@ -425,13 +425,12 @@ def test_light_gradient_records_vs_atomics_over_shapes(probe, n, res, mode, dev,
     assert_close(lg2, lg, 1e-4, floor=1e-3 * la.abs().max().item())
 
 
-@pytest.mark.parametrize('cache_vis,n,res', [(False, 8, 160), (True, 8, 160), (False, 16, 64), (True, 12, 64), (False, 6, 96)],
-                         ids=['retrace', 'cached_visibility', 'four_rounds', 'partial_round_cached', 'one_short_round'])
-def test_queue_shading_kernels_equal_the_plain_ones(cache_vis, n, res, dev, monkeypatch):
-    """The shading kernels that queue the live light samples across pixels (env_shade_queue_kernel; the default for 32 < S <= 64, forced
-    here for the larger S too) against the plain ones (NVDR_SHADE_QUEUE=0).  n_samples_x = 8 (S = 64): images bit for bit (per lane the same two addends); several rounds per pixel
-    (S = 256, S = 144 with a partial last round) or a short round (S = 36): up to the order the rounds are added in.  Per-pixel gradients
-    up to the order in which a sample's own terms are added, the light gradient up to the order of the records."""
+@pytest.mark.parametrize('cache_vis', [False, True], ids=['retrace', 'cached_visibility'])
+def test_queue_shading_kernels_equal_the_plain_ones(cache_vis, dev, monkeypatch):
+    """n_samples_x = 8 (S = 64): the shading kernels that queue the live light samples across pixels (env_shade_queue_kernel, the
+    default there) against the plain ones (NVDR_SHADE_QUEUE=0): images bit for bit (per lane the same two addends), per-pixel
+    gradients up to the order in which a sample's own terms are added, the light gradient up to the order of the records."""
+    n, res = 8, 160
     from nvdiffrecmc_amd import optixutils as ou
     seed, nv = 12, 3
     views = [_gpu_scene('bob', res, n, dev, view=v) for v in range(nv)]
@@ -455,16 +454,12 @@ def test_queue_shading_kernels_equal_the_plain_ones(cache_vis, n, res, dev, monk
         return d.detach(), s.detach(), {k: leaves[k].grad for k in names}
 
     d0, s0, g0 = run('0')
-    d1, s1, g1 = run('7')
+    d1, s1, g1 = run('3')
     assert d0.abs().sum().item() > 0
-    if n == 8:
-        assert torch.equal(d0, d1) and torch.equal(s0, s1)
-    else:
-        assert_close(d1, d0, 2e-6)
-        assert_close(s1, s0, 2e-6)
+    assert torch.equal(d0, d1) and torch.equal(s0, s1)
     for k in names[:4]:
         assert_close(g1[k], g0[k], 2e-5, floor=1e-5 * g0[k].abs().max().item(), what=k)
     assert_close(g1['light'], g0['light'], 1e-4, floor=1e-3 * g0['light'].abs().max().item())
     # the same launch twice: deterministic
-    d2, s2, g2 = run('7')
+    d2, s2, g2 = run('3')
     assert torch.equal(d1, d2) and all(torch.equal(g1[k], g2[k]) for k in names[:4])

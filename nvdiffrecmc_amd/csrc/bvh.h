@@ -117,7 +117,6 @@ struct nvdr_ctx {
     uint32_t *vals[2] = {nullptr, nullptr};
     int *parent = nullptr;         // [2T]: parents of internal nodes [0,T-1) then of leaves [T, 2T)
     int *flags = nullptr;          // [T] arrival counters of the bottom-up pass
-    int *heights = nullptr;        // [2T] subtree heights of the (left, right) child of every node
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     BvhDeviceInfo *dinfo = nullptr;
@@ -162,7 +161,7 @@ struct nvdr_ctx {
     size_t lg_tags_cap = 0;
     uint16_t *cdf_guide = nullptr; // guide tables of the light's CDF inversion (env_shade.hip), rebuilt per launch
     size_t guide_cap = 0;
-    float *dp_cost = nullptr;      // [2 * cap][7] collapse-DP tables of the two children of every binary node (bvh_fit_kernel)
+    float *dp_cost = nullptr;      // [2 * cap][8] hand-off records of bvh_fit_kernel: collapse-DP table (7) + height of the two children of every binary node
     unsigned *dp_split = nullptr;  // [cap] the slot splits the DP chose
     bool oct_dp = true;            // SAH-optimal collapse (false: greedy largest-area, NVDR_OCT_DP=0)
     float oct_c_leaf = 0.45f;      // cost of a triangle test relative to a node step in the collapse DP

@@ -164,14 +164,36 @@ __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, u
     if (i == 0) parent[0] = -1;
 }
 
-// One thread per leaf: write the triangle record, then climb.  Inter-workgroup hand-off of the
-// sibling box follows the agent-scope release/acquire recipe (cdna_hip_programming.md G16):
-// plain stores -> release fence -> drained vmcnt -> device-scope atomic; the second arriver does
-// one acquire fence and then plain loads.
+// Write-through (sc1) accesses of the hand-off below: they reach / come from the level all XCDs agree on, so no cache has to be
+// written back or invalidated around them.
+typedef unsigned nvdr_u3 __attribute__((ext_vector_type(3)));
+typedef float nvdr_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1(unsigned *p, nvdr_u3 v) { asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_sc1(float *p, nvdr_f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ nvdr_u3 load_sc1_u3(const unsigned *p)
+{
+    nvdr_u3 v;
+    asm volatile("global_load_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ nvdr_f4 load_sc1_f4(const float *p)
+{
+    nvdr_f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// One thread per leaf: write the triangle record, then climb.  The sibling's box, height and collapse-DP table are handed from
+// one workgroup to another through WRITE-THROUGH stores (cdna_hip_programming.md G16, the sc1 variant): sc1 stores -> drained
+// vmcnt -> relaxed agent-scope atomic on the node's counter; the second arriver reads them back with sc1 loads.  (Rounds 1-3 used
+// plain stores between an agent-scope release and acquire fence PER NODE: each release writes back the whole L2 of the XCD and each
+// acquire drops the CU's L1 -- 1.4 M of each on the 684 k-triangle mesh, 7-8 ms for this kernel, and the sample-generation kernel
+// that runs beside it on the other stream, whose stores those write-backs kept flushing, took 10.3 instead of 4 ms.)
+// `xchg`: [2 * n][8] floats, the record of the (left, right) child of every node: cost[0..6] of the collapse DP, then the height.
 __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *__restrict__ tris,
                                const uint32_t *__restrict__ order, int n, float4 *__restrict__ tri_rec, uint4 *nodes,
-                               const int *__restrict__ parent, int *flags, int *heights, BvhDeviceInfo *info,
-                               float *dp_cost, unsigned *dp_split, float c_leaf)
+                               const int *__restrict__ parent, int *flags, BvhDeviceInfo *info,
+                               float *xchg, bool dp, unsigned *dp_split, float c_leaf)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -220,32 +242,30 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
         unsigned *rec = (unsigned *)(nodes + 2 * (int64_t)node);
         const int cl = (int)rec[6];
         const int slot = (cl == me) ? 0 : 1;
-        unsigned *dst = rec + 3 * slot;
-        dst[0] = (unsigned)qmn[0] | ((unsigned)qmn[1] << 16);
-        dst[1] = (unsigned)qmn[2] | ((unsigned)qmx[0] << 16);
-        dst[2] = (unsigned)qmx[1] | ((unsigned)qmx[2] << 16);
-        heights[2 * node + slot] = height;
-        if (dp_cost) {
-            float *dc = dp_cost + 7 * (2 * (int64_t)node + slot);
-#pragma unroll
-            for (int i = 0; i < 7; ++i) dc[i] = cost[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int old = atomicAdd(&flags[node], 1);
+        nvdr_u3 box;
+        box.x = (unsigned)qmn[0] | ((unsigned)qmn[1] << 16);
+        box.y = (unsigned)qmn[2] | ((unsigned)qmx[0] << 16);
+        box.z = (unsigned)qmx[1] | ((unsigned)qmx[2] << 16);
+        store_sc1(rec + 3 * slot, box);
+        float *xc = xchg + 8 * (2 * (int64_t)node + slot);
+        nvdr_f4 x0, x1;
+        x0.x = cost[0]; x0.y = cost[1]; x0.z = cost[2]; x0.w = cost[3];
+        x1.x = cost[4]; x1.y = cost[5]; x1.z = cost[6]; x1.w = __int_as_float(height);
+        store_sc1(xc, x0);
+        store_sc1(xc + 4, x1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the write-through stores have arrived ...
+        const int old = __hip_atomic_fetch_add(&flags[node], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... before the counter moves
         if (old == 0) return; // first arriver: the sibling subtree finishes this node
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const unsigned *src = rec + 3 * (1 - slot);
-        const unsigned s0 = src[0], s1 = src[1], s2 = src[2];
+        const nvdr_u3 sb = load_sc1_u3(rec + 3 * (1 - slot));
+        const float *sx = xchg + 8 * (2 * (int64_t)node + (1 - slot));
+        const nvdr_f4 y0 = load_sc1_f4(sx), y1 = load_sc1_f4(sx + 4);
+        const unsigned s0 = sb.x, s1 = sb.y, s2 = sb.z;
         qmn[0] = min(qmn[0], (int)(s0 & 0xffffu)); qmn[1] = min(qmn[1], (int)(s0 >> 16)); qmn[2] = min(qmn[2], (int)(s1 & 0xffffu));
         qmx[0] = max(qmx[0], (int)(s1 >> 16)); qmx[1] = max(qmx[1], (int)(s2 & 0xffffu)); qmx[2] = max(qmx[2], (int)(s2 >> 16));
-        height = 1 + max(height, heights[2 * node + (1 - slot)]);
-        if (dp_cost) {
+        height = 1 + max(height, __float_as_int(y1.w));
+        if (dp) {
             // (left, right) tables in tree order, whichever of the two this thread carried
-            float sib[7];
-            const float *sc = dp_cost + 7 * (2 * (int64_t)node + (1 - slot));
-#pragma unroll
-            for (int i = 0; i < 7; ++i) sib[i] = sc[i];
+            const float sib[7] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z};
             float Lc[7], Rc[7];
 #pragma unroll
             for (int i = 0; i < 7; ++i) { Lc[i] = slot == 0 ? cost[i] : sib[i]; Rc[i] = slot == 0 ? sib[i] : cost[i]; }
@@ -635,7 +655,7 @@ static int ctx_free_bvh(nvdr_ctx *c)
 {
     ctx_free(c, c->nodes); ctx_free(c, c->wide); ctx_free(c, c->oct); ctx_free(c, c->tris8); ctx_free(c, c->oct_task); ctx_free(c, c->tris);
     ctx_free(c, c->keys[0]); ctx_free(c, c->keys[1]); ctx_free(c, c->vals[0]); ctx_free(c, c->vals[1]);
-    ctx_free(c, c->parent); ctx_free(c, c->flags); ctx_free(c, c->heights); ctx_free(c, c->dp_cost); ctx_free(c, c->dp_split); ctx_free(c, c->sort_tmp);
+    ctx_free(c, c->parent); ctx_free(c, c->flags); ctx_free(c, c->dp_cost); ctx_free(c, c->dp_split); ctx_free(c, c->sort_tmp);
     c->sort_tmp_bytes = 0;
     c->cap_tris = 0;
     return 0;
@@ -757,8 +777,7 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     }
     NVDR_HIP_TRY(ctx_malloc(c, &c->parent, sizeof(int) * 2 * cap));
     NVDR_HIP_TRY(ctx_malloc(c, &c->flags, sizeof(int) * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->heights, sizeof(int) * 2 * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->dp_cost, sizeof(float) * 14 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->dp_cost, sizeof(float) * 16 * cap));
     NVDR_HIP_TRY(ctx_malloc(c, &c->dp_split, sizeof(unsigned) * cap));
     size_t bytes = 0;
     NVDR_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1], (size_t)cap, 0, 30));
@@ -856,7 +875,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     }
     NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
     bvh_fit_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->parent,
-                                                        c->flags, c->heights, c->dinfo, c->oct_dp ? c->dp_cost : nullptr, c->dp_split, c->oct_c_leaf);
+                                                        c->flags, c->dinfo, c->dp_cost, c->oct_dp != 0, c->dp_split, c->oct_c_leaf);
     if (c->trace_variant == 0 && n > 1) {
         if (!c->wide) NVDR_HIP_TRY(ctx_malloc(c, &c->wide, sizeof(uint4) * 4 * c->cap_tris, stream));
         bvh_widen_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->nodes, n - 1, c->wide);

@@ -32,4 +32,6 @@ timeout 600 python bench.py --config dmtet800 --no-cpu-baseline --steps 10 --war
 python -c "import json; d=json.load(open('$O/bench_dmtet800_n1.json')); print('dmtet800', d['ms_per_step'], d['median_ms_per_step'], d['roofline']['kernel_ms_hip_events'], d['roofline']['hbm'])"
 timeout 600 python bench.py --config spot512x256 --no-cpu-baseline --steps 10 --warmup 3 --pmc-keep $O 2>/dev/null | tail -1 > $O/bench_spot512x256_n1.json
 python -c "import json; d=json.load(open('$O/bench_spot512x256_n1.json')); print('spot512x256', d['ms_per_step'], d['median_ms_per_step'], d['roofline']['kernel_ms_hip_events'], d['roofline']['frac'])"
+timeout 600 python bench.py --config hotdog512x256 --no-cpu-baseline --steps 8 --warmup 3 --pmc-keep $O 2>/dev/null | tail -1 > $O/bench_hotdog512x256_n1.json
+python -c "import json; d=json.load(open('$O/bench_hotdog512x256_n1.json')); print('hotdog512x256', d['ms_per_step'], d['median_ms_per_step'], d['roofline']['kernel_ms_hip_events'], d['roofline']['frac'], d['roofline']['hbm'])"
 fi

@@ -2,6 +2,7 @@
 opt-in torch formulations behind use_python=True."""
 import inspect
 import math
+import os
 
 import pytest
 import torch
@@ -9,6 +10,8 @@ import torch
 from nvdiffrecmc_amd import scene as sc
 from oracle import renderutils_ref as rr
 from tests.util import assert_close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_camera_matches_dataset_mesh_convention():
@@ -111,6 +114,47 @@ def test_bench_algorithmic_byte_formula():
     assert 0.0 < v['frac_of_lane_peak'] < 1.0 and abs(v['active_lane_fraction'] - 0.58) < 1e-6
     m = bench.mem_figures({'FETCH_SIZE': 737442.3, 'WRITE_SIZE': 224857.5, 'TCC_REQ_sum': 1.88e8, 'TCC_MISS_sum': 1.2e7}, 4.5)
     assert abs(m['hbm_bytes'] - (2 * 737442.3 + 224857.5) * 1024) < 1 and 0 < m['hbm_frac'] < 1 and 0 < m['l2_frac'] < 1
+    # the shading kernels have two names (64 spp launches run the queue kernels): the first alternative that occurs is taken
+    counters = {'void env_shade_kernel<true>(ShadeParams)': {'x': 1}, 'void env_shade_queue_kernel<false>(ShadeParams)': {'x': 2},
+                'void env_shade_kernel<false>(ShadeParams)': {'x': 3}}
+    assert bench.find_kernel(counters, ('env_shade_queue_kernel<true', 'env_shade_kernel<true'))['x'] == 1
+    assert bench.find_kernel(counters, ('env_shade_queue_kernel<false', 'env_shade_kernel<false'))['x'] == 2
+    assert bench.find_kernel(counters, 'env_gen_kernel') is None
+
+
+def test_rocpd_tools_on_a_synthetic_database(tmp_path):
+    """tools/rocpd_summary.py (kernel table + roctx ranges) and tools/rocpd_iteration.py (timeline of one iteration) against a small
+    database with the columns of rocprofv3's `kernels` and `regions` views."""
+    import sqlite3
+    import subprocess
+    import sys
+    dbp = str(tmp_path / 'r.db')
+    db = sqlite3.connect(dbp)
+    db.execute('create table kernels (name text, start integer, end integer, duration integer, vgpr_count integer, accum_vgpr_count integer,'
+               ' sgpr_count integer, lds_size integer, scratch_size integer, grid_x integer, workgroup_x integer, queue_id integer)')
+    db.execute('create table regions (name text, category text, start integer, end integer, duration integer, extdata text)')
+    t = 0
+    for it in range(6):             # six iterations: anchor, a long kernel on queue 1, a short one on queue 2 overlapping it, a gap
+        for name, dur, q, gap in (('light_rows_kernel(float const*)', 5000, 1, 0), ('env_trace_kernel<false>(TraceLaunch)', 2400000, 1, 1000),
+                                  ('bvh_fit_kernel(float const*)', 160000, 2, -2300000), ('adam_step_kernel(AdamTable)', 30000, 1, 2200000)):
+            t += gap
+            db.execute('insert into kernels values (?,?,?,?,?,?,?,?,?,?,?,?)', (name, t, t + dur, dur, 32, 0, 64, 16384, 0, 524288, 256, q))
+            t += dur
+        db.execute('insert into regions values (?,?,?,?,?,?)', ('roctxThreadRangeA', 'MARKER_CORE_RANGE_API', t, t + 700000, 700000, '{"message":"nvdr_env_shade_fwd"}'))
+        t += 3000000
+    db.commit()
+    db.close()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rocpd_summary.py'), dbp], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert '| void env_trace_kernel' not in out.stdout and '| env_trace_kernel<false>(TraceLaunch) | 6 |' in out.stdout
+    assert '| nvdr_env_shade_fwd | 6 | 4200.0 | 700.00 |' in out.stdout
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'rocpd_iteration.py'), dbp], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0].startswith('iteration of') and '4 dispatches' in lines[0] and 'queue_id' in lines[0]
+    assert 'light_rows_kernel' in lines[2] and float(lines[2].split()[0]) == 0.0
+    fit = [l for l in lines if 'bvh_fit_kernel' in l][0].split()
+    assert fit[3] == '2' and float(fit[2]) == 0.0          # on the other queue, no idle time before it (the traversal is still running)
 
 
 def test_broadcast_pixels_column_sum_and_composite_reference():

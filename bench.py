@@ -627,12 +627,13 @@ def run(args):
                                           ('env_shade_kernel<forward>', ('env_shade_queue_kernel<false', 'env_shade_kernel<false'), shade_ms),
                                           ('light_grad_block_kernel', 'light_grad_block_kernel', None)):
                     oc = find_kernel(counters, needle)
+                    kname = next((nm for nm, cc in counters.items() if cc is oc), None)
                     if oc and chunks > 1:
                         oc = {k: (v_ * chunks if not k.startswith('dispatches_pass') else v_) for k, v_ in oc.items()}
                     if oc:
                         mm = mem_figures(oc, ms)
                         vv = valu_figures(oc, ms) if ms else None
-                        others[label] = {'hbm_bytes': mm.get('hbm_bytes'), 'hbm_GBs': mm.get('hbm_GBs'), 'l2_hit': mm.get('l2_hit'),
+                        others[label] = {'kernel': kname, 'hbm_bytes': mm.get('hbm_bytes'), 'hbm_GBs': mm.get('hbm_GBs'), 'l2_hit': mm.get('l2_hit'),
                                           'valu_wave_instructions': oc.get('SQ_INSTS_VALU'),
                                           'active_lane_fraction': (oc['SQ_THREAD_CYCLES_VALU'] / (64.0 * oc['SQ_ACTIVE_INST_VALU'])
                                                                    if oc.get('SQ_ACTIVE_INST_VALU') else None),

@@ -310,10 +310,7 @@ def large_mesh_object(args, dev):
     step.ctx.set_profiling(False)
     with torch.no_grad():
         m = step.mask[..., None]
-        kd = step.kd_tex[step.texel].view(step.nv, H, H, 3) * m
-        ks = step.ks.view(1, 1, 1, 3) * m
-        nrm = ru.prepare_shading_normal(step.gb_pos, step.view_pos, None, step.gb_smooth_nrm, step.gb_tangent, step.gb_geom_nrm)
-        ro = step.gb_pos + nrm * 0.001
+        _, ro, _, nrm, _, kd, ks = step.shade_inputs()
         L = step.light
         P, n_box, n_tri, n_traced = ou.ops.env_shade_traversal_counts(step.ctx, step.mask, ro, step.gb_pos, nrm, step.view_pos, kd, ks, L.base, L._pdf,
                                                                      L.rows[:, 0], L.cols, n_samples_x=n, rnd_seed=0)
@@ -554,10 +551,7 @@ def run(args):
     with torch.no_grad():
         from nvdiffrecmc_amd import renderutils as ru
         m = step.mask[..., None]
-        kd = step.kd_tex[step.texel].view(step.nv, H, W, 3) * m  # same values as the step's kd image
-        ks = step.ks.view(1, 1, 1, 3) * m
-        nrm = ru.prepare_shading_normal(step.gb_pos, step.view_pos, None, step.gb_smooth_nrm, step.gb_tangent, step.gb_geom_nrm)
-        ro = step.gb_pos + nrm * 0.001
+        _, ro, _, nrm, _, kd, ks = step.shade_inputs()        # the tensors optix_env_shade gets inside the iteration
         P, n_box, n_tri, n_traced = ou.ops.env_shade_traversal_counts(step.ctx, step.mask, ro, step.gb_pos, nrm, step.view_pos, kd, ks,
                                                                      light.base, light._pdf, light.rows[:, 0], light.cols,
                                                                      n_samples_x=n, rnd_seed=0)

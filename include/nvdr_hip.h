@@ -143,6 +143,66 @@ typedef struct nvdr_gbuffer_args {
 } nvdr_gbuffer_args;
 int nvdr_render_gbuffer(nvdr_ctx *ctx, const nvdr_gbuffer_args *args, void *stream);
 
+/* ---- geometry / material gradient route (additive, SURVEY 8 f1 second half): the adjoints of what render_layer takes from
+ * nvdiffrast and render/mesh.py, so that gb_pos_grad / gb_normal_grad of env_shade_bwd and the gradients of
+ * prepare_shading_normal_bwd reach the trained vertices and textures (render/render.py:25,85-99,208-234, render/mesh.py:150-219,
+ * geometry/dlmesh.py:45-55, train.py:171-192).  All pointers are device pointers. */
+
+/* A mesh whose normals and tangents are indexed like its positions (mesh.py:178,219: t_nrm_idx = t_tng_idx = t_pos_idx) plus the
+ * vertex -> (triangle, corner) adjacency that makes its per-vertex sums gathers in a FIXED order (deterministic, no atomics):
+ * adj_corner[adj_start[v] .. adj_start[v+1]) = the values 3*triangle + corner of every corner that references vertex v, ascending.
+ * (numpy: flat = t_pos_idx.reshape(-1); adj_corner = argsort(flat, kind='stable'); adj_start = searchsorted(flat[adj_corner], arange(V+1)).) */
+typedef struct nvdr_mesh_args {
+    const float   *v_pos;      int64_t n_verts;   /* [V,3] */
+    const int32_t *t_pos_idx;  int64_t n_tris;    /* [T,3] */
+    const float   *v_tex;      const int32_t *t_tex_idx;   /* [Vt,2], [T,3] */
+    const int32_t *adj_start;  /* [V+1] */
+    const int32_t *adj_corner; /* [3T] */
+} nvdr_mesh_args;
+/* auto_normals (mesh.py:150-178) + compute_tangents (mesh.py:181-219) in one launch: v_nrm, v_tng f32 [V,3] */
+int nvdr_mesh_frame_fwd(const nvdr_mesh_args *mesh, float *v_nrm, float *v_tng, void *stream);
+/* their adjoint: v_nrm_grad, v_tng_grad f32 [V,3] (either may be NULL = zero) -> v_pos_grad [V,3]; accumulate != 0 adds to what
+ * v_pos_grad holds (the scatter of nvdr_interpolate_bwd), otherwise it is overwritten.  scratch: f32 [V,6]. */
+int nvdr_mesh_frame_bwd(const nvdr_mesh_args *mesh, const float *v_nrm_grad, const float *v_tng_grad, float *scratch,
+                        float *v_pos_grad, int accumulate, void *stream);
+
+/* Adjoint of the attribute interpolation of render_layer (dr.interpolate, render.py:25,208-222) at the pixels of `rast`
+ * (nvdr_render_gbuffer's output: (u, v, z/w, triangle_id + 1)): scatters the per-pixel gradients of gb_pos, gb_geometric_normal
+ * (through safe_normalize(cross(v1 - v0, v2 - v0)), render.py:211-214), gb_normal and gb_tangent into v_pos_grad / v_nrm_grad /
+ * v_tng_grad with fp32 atomics (the caller zero-fills them; any gradient pointer may be NULL).  With cam != NULL the barycentrics
+ * are differentiated as well -- (u, v) of the pixel's FIXED primary ray as a function of the triangle's vertices, the part
+ * nvdiffrast's rasterize backward supplies (same function of the vertices: a projective map keeps barycentrics) -- otherwise they
+ * are held constant.  The silhouette term (dr.antialias, render.py:290) has no counterpart here. */
+typedef struct nvdr_interpolate_bwd_args {
+    const float   *rast;      /* [N,H,W,4] */
+    int32_t        n, h, w;
+    const float   *v_pos;     const int32_t *t_pos_idx;   /* [V,3], [T,3] */
+    const float   *v_nrm;     const float   *v_tng;       /* [V,3] each, indexed by t_pos_idx (needed for the barycentric term) */
+    int64_t        n_verts, n_tris;
+    const float   *cam;       /* [N,4,3] as nvdr_gbuffer_args.cam, or NULL */
+    const float   *gb_pos_grad, *gb_geometric_normal_grad, *gb_normal_grad, *gb_tangent_grad;   /* [N,H,W,3] contiguous or NULL */
+    float         *v_pos_grad, *v_nrm_grad, *v_tng_grad;  /* [V,3], accumulated into */
+} nvdr_interpolate_bwd_args;
+int nvdr_interpolate_bwd(const nvdr_interpolate_bwd_args *args, void *stream);
+
+/* Nearest-texel lookup of up to NVDR_MAX_TEXTURES three-channel textures at the interpolated texture coordinate (stand-in for
+ * Texture2D.sample / dr.texture of render.py:61-68, whose trilinear mip filter lies outside the path): texel (ix, iy) =
+ * (clamp(int(s * R), 0, R - 1), clamp(int((1 - t) * R), 0, R - 1)) of a row-major [R,R,3] texture; pixels with rast.w <= 0 get 0.
+ * texc f32 [P,2], rast f32 [P,4], out[k] f32 [P,3].  The backward zero-fills dtex[k] [R_k,R_k,3] and accumulates with atomics. */
+#define NVDR_MAX_TEXTURES 4
+typedef struct nvdr_texture_args {
+    int32_t        n_tex;
+    int32_t        res[NVDR_MAX_TEXTURES];
+    const float   *tex[NVDR_MAX_TEXTURES];
+    const float   *texc, *rast;
+    int64_t        n_pix;
+    float         *out[NVDR_MAX_TEXTURES];          /* forward */
+    const float   *dout[NVDR_MAX_TEXTURES];         /* backward: [P,3] contiguous */
+    float         *dtex[NVDR_MAX_TEXTURES];
+} nvdr_texture_args;
+int nvdr_texture_lookup_fwd(const nvdr_texture_args *args, void *stream);
+int nvdr_texture_lookup_bwd(const nvdr_texture_args *args, void *stream);
+
 /* ---- env_shade_fwd / env_shade_bwd (torch_bindings.cpp:123-272; raygen program kernel.cu:463-542) */
 #define NVDR_COUNTERS_BVH2 (8 + 2 * 8192)
 #define NVDR_COUNTERS_LEN (NVDR_COUNTERS_BVH2 + 8)
@@ -341,7 +401,7 @@ int nvdr_light_update_pdf(const float *base, int64_t hl, int64_t wl, float *pdf,
 
 /* ---- the parameter update of an iteration in one launch (additive; train.py:439-476: light-gradient scale, torch.optim.Adam
  * without weight decay / amsgrad, parameter clamps).  Per element: g = grad * grad_scale; Adam with bias correction at step
- * state[0] + 1; p = max(min(p, hi), max(lo, lo_vec[e % lo_vec_n])).  state: 32 bytes of device memory, 8-byte aligned,
+ * state[0] + 1; p = clamp(p, max(lo, lo_vec[e % lo_vec_n]), min(hi, hi_vec[e % hi_vec_n])) (a NaN stays a NaN, as torch.clamp).  state: 32 bytes of device memory, 8-byte aligned,
  * zero-initialised by the caller once (int32 [0] = steps taken, [1] = scratch, then two doubles: beta1^step, beta2^step); the
  * launch advances it, so it can be replayed from a HIP graph. */
 #define NVDR_ADAM_MAX_TENSORS 8
@@ -355,6 +415,11 @@ typedef struct nvdr_adam_tensor {
     float lo, hi;           /* -INFINITY / INFINITY for none */
     const float *lo_vec;    /* optional per-channel lower bounds (device), NULL for none */
     int64_t lo_vec_n;
+    const float *hi_vec;    /* optional per-channel upper bounds (device), NULL for none (Texture2D.clamp_, render/texture.py:86-90) */
+    int64_t hi_vec_n;
+    float lr_scale;         /* this tensor's learning rate = lr * lr_scale (train.py:336-338: position / material / light rates); 1 for none */
+    int32_t normalize3;     /* != 0: after the clamps every group of three elements is divided by max(its length, 1e-10)
+                               (Texture2D.normalize_ of the normal map, train.py:473-474) */
 } nvdr_adam_tensor;
 int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps, int *state,
                    void *stream);

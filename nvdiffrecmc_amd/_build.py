@@ -25,6 +25,7 @@ SOURCES = [
     'renderutils.hip',
     'light.hip',
     'gbuffer.hip',
+    'mesh.hip',
     'optim.hip',
 ]
 

@@ -48,6 +48,28 @@ class NvdrGbufferArgs(ctypes.Structure):
                                 'gb_texc_deriv', 'gb_depth')]
 
 
+class NvdrMeshArgs(ctypes.Structure):          # include/nvdr_hip.h: nvdr_mesh_args
+    _fields_ = [('v_pos', c_void_p), ('n_verts', c_int64), ('t_pos_idx', c_void_p), ('n_tris', c_int64),
+                ('v_tex', c_void_p), ('t_tex_idx', c_void_p), ('adj_start', c_void_p), ('adj_corner', c_void_p)]
+
+
+class NvdrInterpolateBwdArgs(ctypes.Structure):   # nvdr_interpolate_bwd_args
+    _fields_ = [('rast', c_void_p), ('n', ctypes.c_int32), ('h', ctypes.c_int32), ('w', ctypes.c_int32),
+                ('v_pos', c_void_p), ('t_pos_idx', c_void_p), ('v_nrm', c_void_p), ('v_tng', c_void_p),
+                ('n_verts', c_int64), ('n_tris', c_int64), ('cam', c_void_p),
+                ('gb_pos_grad', c_void_p), ('gb_geometric_normal_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_tangent_grad', c_void_p),
+                ('v_pos_grad', c_void_p), ('v_nrm_grad', c_void_p), ('v_tng_grad', c_void_p)]
+
+
+MAX_TEXTURES = 4
+
+
+class NvdrTextureArgs(ctypes.Structure):        # nvdr_texture_args
+    _fields_ = [('n_tex', ctypes.c_int32), ('res', ctypes.c_int32 * MAX_TEXTURES), ('tex', c_void_p * MAX_TEXTURES),
+                ('texc', c_void_p), ('rast', c_void_p), ('n_pix', c_int64), ('out', c_void_p * MAX_TEXTURES),
+                ('dout', c_void_p * MAX_TEXTURES), ('dtex', c_void_p * MAX_TEXTURES)]
+
+
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p)     # nvdr_alloc_fn
 FREE_FN = ctypes.CFUNCTYPE(None, c_void_p, c_void_p)                                    # nvdr_free_fn
 
@@ -73,7 +95,8 @@ _T = ctypes.POINTER(NvdrTensor)
 
 class NvdrAdamTensor(ctypes.Structure):     # include/nvdr_hip.h: nvdr_adam_tensor
     _fields_ = [('param', c_void_p), ('grad', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p), ('n', c_int64),
-                ('grad_scale', c_float), ('lo', c_float), ('hi', c_float), ('lo_vec', c_void_p), ('lo_vec_n', c_int64)]
+                ('grad_scale', c_float), ('lo', c_float), ('hi', c_float), ('lo_vec', c_void_p), ('lo_vec_n', c_int64),
+                ('hi_vec', c_void_p), ('hi_vec_n', c_int64), ('lr_scale', c_float), ('normalize3', ctypes.c_int32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -95,6 +118,11 @@ _SIGNATURES = {
     'nvdr_trace_visibility_wide_counted': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
     'nvdr_trace_closest': [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_render_gbuffer': [c_void_p, ctypes.POINTER(NvdrGbufferArgs), c_void_p],
+    'nvdr_mesh_frame_fwd': [ctypes.POINTER(NvdrMeshArgs), c_void_p, c_void_p, c_void_p],
+    'nvdr_mesh_frame_bwd': [ctypes.POINTER(NvdrMeshArgs), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    'nvdr_interpolate_bwd': [ctypes.POINTER(NvdrInterpolateBwdArgs), c_void_p],
+    'nvdr_texture_lookup_fwd': [ctypes.POINTER(NvdrTextureArgs), c_void_p],
+    'nvdr_texture_lookup_bwd': [ctypes.POINTER(NvdrTextureArgs), c_void_p],
     'nvdr_env_shade_fwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_bwd': [c_void_p, ctypes.POINTER(NvdrEnvShadeArgs), c_void_p],
     'nvdr_env_shade_last_pixel_count': [c_void_p, ctypes.POINTER(c_int64), c_void_p],

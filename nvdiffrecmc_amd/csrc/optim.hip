@@ -39,13 +39,41 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
         corr[1] = (float)sqrt(1.0 - b2p);                   // sqrt(bias_correction2)
     }
     __syncthreads();
-    const float step_size = corr[0], bc2_sqrt = corr[1];
+    const float step_size0 = corr[0], bc2_sqrt = corr[1];
     // the tensor of this workgroup (uniform: the table entry is read with scalar loads)
     int k = 0;
     for (int q = 1; q < tab.n; ++q)
         if ((int)blockIdx.x >= tab.first_block[q]) k = q;
     const nvdr_adam_tensor &T = tab.t[k];
+    const float step_size = step_size0 * T.lr_scale;        // this tensor's learning rate (train.py:336-338: position / material / light)
     const int64_t e0 = (int64_t)((int)blockIdx.x - tab.first_block[k]) * 256 * tab.per_thread;
+    if (T.normalize3) {
+        // a unit is a texel of three channels: updated, clamped per channel and then renormalised by one thread
+        // (Texture2D.clamp_ + normalize_ of the normal map, train.py:470-474, render/texture.py:86-96)
+        const int64_t units = T.n / 3;
+        for (int j0 = 0; j0 < tab.per_thread; ++j0) {
+            const int64_t t = e0 + (int64_t)j0 * 256 + threadIdx.x;
+            if (t >= units) break;
+            float q[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int64_t e = 3 * t + c;
+                const float gg = T.grad[e] * T.grad_scale, m0 = T.exp_avg[e], v0 = T.exp_avg_sq[e];
+                const float mm = m0 + (gg - m0) * omb1;
+                const float vv = v0 * beta2 + (omb2 * gg) * gg;
+                const float denom = sqrtf(vv) / bc2_sqrt + eps;
+                float p = T.param[e] - step_size * (mm / denom);
+                float lo = T.lo, hi = T.hi;
+                if (T.lo_vec) lo = fmaxf(lo, T.lo_vec[e % T.lo_vec_n]);
+                if (T.hi_vec) hi = fminf(hi, T.hi_vec[e % T.hi_vec_n]);
+                q[c] = p < lo ? lo : (p > hi ? hi : p);             // keeps a NaN (fmaxf / fminf would turn it into a bound)
+                T.exp_avg[e] = mm;
+                T.exp_avg_sq[e] = vv;
+            }
+            const float len = sqrtf(fmaxf((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2], 1e-20f));     // util.safe_normalize
+            T.param[3 * t] = q[0] / len; T.param[3 * t + 1] = q[1] / len; T.param[3 * t + 2] = q[2] / len;
+        }
+    } else
     for (int j0 = 0; j0 < tab.per_thread; j0 += 4) {        // four elements per round: their twelve loads are in flight together
         float g[4], m[4], v[4], pp[4];
         bool ok[4];
@@ -67,7 +95,8 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
             float p = pp[u] - step_size * (mm / denom);                 // addcdiv_(exp_avg, denom, value = -step_size)
             float lo = T.lo, hi = T.hi;
             if (T.lo_vec) lo = fmaxf(lo, T.lo_vec[e % T.lo_vec_n]);
-            p = fmaxf(fminf(p, hi), lo);
+            if (T.hi_vec) hi = fminf(hi, T.hi_vec[e % T.hi_vec_n]);
+            p = p < lo ? lo : (p > hi ? hi : p);                        // torch.clamp semantics: a NaN parameter stays NaN
             T.exp_avg[e] = mm;
             T.exp_avg_sq[e] = vv;
             T.param[e] = p;
@@ -75,12 +104,16 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int done = __hip_atomic_fetch_add(&state[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // Relaxed: nothing a workgroup WROTE has to be visible to the one that draws the last ticket -- only every workgroup's READ of
+        // the state must precede its update, and a workgroup has consumed what it read (pows / corr above, behind the barrier) before
+        // thread 0 gets here.  (Rounds 1-3 used acq_rel + release: a buffer_wbl2 / buffer_inv pair per workgroup, up to 2 048 L2
+        // write-backs in a 33 us kernel.)  The next launch sees the new state through the kernel boundary.
+        const int done = __hip_atomic_fetch_add(&state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (int)gridDim.x - 1) {
             state[1] = 0;
             ((double *)(state + 2))[0] = pows[0];
             ((double *)(state + 2))[1] = pows[1];
-            __hip_atomic_store(&state[0], step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[0], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -91,7 +124,7 @@ extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, do
     NvdrRange range("nvdr_adam_step");
     NVDR_REQUIRE(tensors && state, "adam_step: NULL argument");
     NVDR_REQUIRE(n_tensors >= 1 && n_tensors <= NVDR_ADAM_MAX_TENSORS, "adam_step: %d tensors (1..%d supported)", n_tensors, NVDR_ADAM_MAX_TENSORS);
-    NVDR_REQUIRE(lr > 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "adam_step: bad hyper-parameters");
+    NVDR_REQUIRE(lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0, "adam_step: bad hyper-parameters");
     AdamTable tab;
     memset(&tab, 0, sizeof(tab));
     tab.n = n_tensors;
@@ -100,6 +133,9 @@ extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, do
         const nvdr_adam_tensor &t = tensors[k];
         NVDR_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq && t.n >= 0, "adam_step: tensor %d has a NULL buffer", k);
         NVDR_REQUIRE(!t.lo_vec || t.lo_vec_n > 0, "adam_step: tensor %d: lo_vec without length", k);
+        NVDR_REQUIRE(!t.hi_vec || t.hi_vec_n > 0, "adam_step: tensor %d: hi_vec without length", k);
+        NVDR_REQUIRE(!t.normalize3 || t.n % 3 == 0, "adam_step: tensor %d: normalize3 needs a multiple of three elements", k);
+        NVDR_REQUIRE(t.lr_scale >= 0.0f, "adam_step: tensor %d: negative lr_scale", k);
         tab.t[k] = t;
         total += t.n;
     }
@@ -111,7 +147,7 @@ extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, do
     int64_t blocks = 0;
     for (int k = 0; k < n_tensors; ++k) {
         tab.first_block[k] = (int)blocks;
-        blocks += div_up(tensors[k].n, 256 * per_thread);
+        blocks += div_up(tensors[k].normalize3 ? tensors[k].n / 3 : tensors[k].n, 256 * per_thread);
     }
     for (int k = n_tensors; k <= NVDR_ADAM_MAX_TENSORS; ++k) tab.first_block[k] = (int)blocks;
     if (blocks < 1) blocks = 1;

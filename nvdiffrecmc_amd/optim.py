@@ -14,11 +14,13 @@ from . import _lib
 
 class FusedAdam:
     """params: list of tensors (requires_grad, contiguous fp32, on one GPU).
-    clamps[i]: None or (lo, hi, lo_vec) with lo / hi floats or None and lo_vec an optional per-channel lower bound (device
-    tensor whose length divides the parameter's innermost extent pattern: element e is bounded by lo_vec[e % len(lo_vec)]).
-    grad_scales[i]: factor applied to the gradient of parameter i inside the update (p.grad itself is left alone)."""
+    clamps[i]: None or (lo, hi[, lo_vec[, hi_vec]]) with lo / hi floats or None and lo_vec / hi_vec optional per-channel bounds
+    (device tensors: element e is bounded by lo_vec[e % len(lo_vec)] / hi_vec[e % len(hi_vec)]; Texture2D.clamp_).
+    grad_scales[i]: factor applied to the gradient of parameter i inside the update (p.grad itself is left alone).
+    lr_scales[i]: learning rate of parameter i relative to lr (the reference runs three Adams with position / material / light
+    rates, train.py:336-356).  normalize3[i]: renormalise every texel of three channels after the clamps (the normal map)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clamps=None, grad_scales=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clamps=None, grad_scales=None, lr_scales=None, normalize3=None):
         self.params = list(params)
         if not 1 <= len(self.params) <= 8:
             raise ValueError('FusedAdam: 1..8 parameter tensors')
@@ -28,6 +30,8 @@ class FusedAdam:
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.clamps = list(clamps) if clamps is not None else [None] * len(self.params)
         self.grad_scales = list(grad_scales) if grad_scales is not None else [1.0] * len(self.params)
+        self.lr_scales = list(lr_scales) if lr_scales is not None else [1.0] * len(self.params)
+        self.normalize3 = list(normalize3) if normalize3 is not None else [False] * len(self.params)
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.state = torch.zeros(8, dtype=torch.int32, device=self.params[0].device)     # steps taken, scratch, beta1^t, beta2^t (doubles)
@@ -51,18 +55,22 @@ class FusedAdam:
                 raise RuntimeError('FusedAdam.step: parameter %d has no gradient' % i)
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             keep.append(g)
-            lo, hi, lo_vec = -math.inf, math.inf, None
+            lo, hi, lo_vec, hi_vec = -math.inf, math.inf, None, None
             if self.clamps[i] is not None:
                 c = self.clamps[i]
                 lo = -math.inf if c[0] is None else float(c[0])
                 hi = math.inf if c[1] is None else float(c[1])
                 lo_vec = c[2] if len(c) > 2 else None
+                hi_vec = c[3] if len(c) > 3 else None
             t = tab[i]
             t.param, t.grad, t.exp_avg, t.exp_avg_sq = p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
             t.n = p.numel()
             t.grad_scale, t.lo, t.hi = float(self.grad_scales[i]), lo, hi
             t.lo_vec = lo_vec.data_ptr() if lo_vec is not None else None
             t.lo_vec_n = lo_vec.numel() if lo_vec is not None else 0
+            t.hi_vec = hi_vec.data_ptr() if hi_vec is not None else None
+            t.hi_vec_n = hi_vec.numel() if hi_vec is not None else 0
+            t.lr_scale, t.normalize3 = float(self.lr_scales[i]), int(bool(self.normalize3[i]))
         with torch.no_grad():
             _lib.check(_lib.load().nvdr_adam_step(tab, len(self.params), self.lr, self.betas[0], self.betas[1], self.eps,
                                                   _lib.ptr(self.state), _lib.stream_ptr()), 'adam_step')

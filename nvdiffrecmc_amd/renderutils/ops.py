@@ -174,28 +174,58 @@ def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng,
     return _finite(out, 'prepare_shading_normal')
 
 
+class _shading_frame_func(torch.autograd.Function):
+    """(shading normal, unit copy, shadow-ray origin) in one launch; the adjoint is prepare_shading_normal's (normal.cu:136-179).
+    The unit copy (the filter's guide: bilateral_denoiser differentiates w.r.t. its colour input only, optixutils/ops.py:119) and
+    the ray origin (optix_env_shade returns no gradient for `ro`, ops.py:105) are declared non-differentiable, as in the reference's
+    graph, so gradients reach the six inputs through the shading normal alone."""
+
+    @staticmethod
+    def forward(ctx, pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading, opengl, ro_eps):
+        ins = (pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm)
+        for name, t in zip(('pos', 'view_pos', 'perturbed_nrm', 'smooth_nrm', 'smooth_tng', 'geom_nrm'), ins):
+            _check4(t, 'shading_frame ' + name, 3)
+        N, H, W = _extent(*ins)
+        out = torch.empty(3, N, H, W, 3, dtype=torch.float32, device=pos.device)
+        keep, refs = _views(*ins)
+        _lib.check(_lib.load().nvdr_shading_frame_fwd(*refs, int(bool(two_sided_shading)), int(bool(opengl)), float(ro_eps), _lib.ptr(out[0]),
+                                                      _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.stream_ptr()), 'shading_frame_fwd')
+        ctx.save_for_backward(*ins)
+        ctx.two_sided_shading, ctx.opengl = two_sided_shading, opengl
+        nrm, unit, ro = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(unit, ro)
+        return nrm, unit, ro
+
+    @staticmethod
+    def backward(ctx, dnrm, _dunit, _dro):
+        ts = ctx.saved_tensors
+        N, H, W = _extent(*ts)
+        dnrm = dnrm.contiguous()
+        grads = torch.empty(6, N, H, W, 3, dtype=torch.float32, device=dnrm.device)
+        keep, refs = _views(*ts, dnrm)
+        _lib.check(_lib.load().nvdr_prepare_shading_normal_bwd(*refs, int(bool(ctx.two_sided_shading)), int(bool(ctx.opengl)),
+                                                               *[_lib.ptr(grads[k]) for k in range(6)], _lib.stream_ptr()), 'shading_frame_bwd')
+        out = []
+        for k, t in enumerate(ts):              # broadcast inputs get their gradient at the full extent: fold it (tensor.h:60-62)
+            g = grads[k] if ctx.needs_input_grad[k] else None
+            if g is not None:
+                for d in range(4):
+                    if t.shape[d] == 1 and g.shape[d] != 1:
+                        g = g.sum(d, keepdim=True)
+            out.append(g)
+        return tuple(out) + (None, None, None)
+
+
 def shading_frame(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True, ro_eps=0.001):
     """(shading normal, its unit copy, shadow-ray origin pos + normal * ro_eps) in one launch -- prepare_shading_normal, the
-    safe_normalize of the denoiser's guide and the offset of render.py:107.  Additive and forward only: with an input that requires a
-    gradient it composes the differentiable ops instead."""
+    safe_normalize of the denoiser's guide and the offset of render.py:107.  Additive.  Differentiable through the shading normal
+    (one launch backward: prepare_shading_normal_bwd); the unit copy and the ray origin carry no gradient (see _shading_frame_func)."""
     if perturbed_nrm is None:
         perturbed_nrm = _UNIT_Z.get(pos.device)
         if perturbed_nrm is None:
             perturbed_nrm = _UNIT_Z[pos.device] = torch.tensor([0, 0, 1], dtype=torch.float32, device=pos.device,
                                                                requires_grad=False)[None, None, None, ...]
-    ins = (pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm)
-    if torch.is_grad_enabled() and any(t.requires_grad for t in ins):
-        nrm = prepare_shading_normal(*ins, two_sided_shading=two_sided_shading, opengl=opengl)
-        unit = nrm / torch.sqrt(torch.clamp(torch.sum(nrm * nrm, -1, keepdim=True), min=1e-20))
-        return nrm, unit, pos + nrm * ro_eps
-    for name, t in zip(('pos', 'view_pos', 'perturbed_nrm', 'smooth_nrm', 'smooth_tng', 'geom_nrm'), ins):
-        _lib.require_cuda_f32(t, name)
-    N, H, W = (max(t.shape[k] for t in ins) for k in range(3))
-    out = torch.empty(3, N, H, W, 3, dtype=torch.float32, device=pos.device)
-    refs = [ctypes.byref(_lib.tensor_view(t)) for t in ins]
-    _lib.check(_lib.load().nvdr_shading_frame_fwd(*refs, int(two_sided_shading), int(opengl), float(ro_eps), _lib.ptr(out[0]), _lib.ptr(out[1]),
-                                                  _lib.ptr(out[2]), _lib.stream_ptr()), 'shading_frame_fwd')
-    return out[0], out[1], out[2]
+    return _shading_frame_func.apply(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading, opengl, ro_eps)
 
 
 # ----------------------------------------------------------------------------------------------

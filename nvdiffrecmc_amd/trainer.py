@@ -14,10 +14,21 @@ the parts that touch the hot path:
     gradient all-reduce (new: one view per GPU)          --                -> parallel.py
     Adam on kd texture, ks, light                        train.py:452-461
 
-What replaces the parts that do not exist on ROCm: the G-buffer comes from ONE HIP kernel (csrc/gbuffer.hip:
-primary rays through the same BVH + the attribute interpolation / tangents / (z/w, |dz|) of render_layer,
-render.py:208-234) instead of nvdiffrast, so it is NOT differentiable w.r.t. geometry; kd is a nearest-texel
-lookup into a trainable texture instead of dr.texture.
+The trained set is the reference's (train.py:171-192, geometry/dlmesh.py:28-38): kd, ks and normal TEXTURES (texture_res of
+the config, 1024^2 each), the light probe and -- optimize_geometry=True, lock_pos false -- the vertex positions:
+
+    texture lookups at gb_texc                           render.py:61-68   -> csrc/mesh.hip (nearest texel, one launch each way)
+    perturbed normal -> prepare_shading_normal           render.py:85-99   -> csrc/renderutils.hip (shading_frame, backward included)
+    auto_normals, compute_tangents                       dlmesh.py:52-54   -> csrc/mesh.hip (optimize_geometry)
+    rasterize + interpolate                              render.py:208-234 -> csrc/gbuffer.hip, adjoint csrc/mesh.hip (optimize_geometry)
+
+What replaces the parts that do not exist on ROCm: the G-buffer comes from ONE HIP kernel (primary rays through the same BVH +
+the attribute interpolation / tangents / (z/w, |dz|) of render_layer) instead of nvdiffrast; its adjoint carries the gradients of
+gb_pos / gb_normal / gb_tangent / the face normal back to the vertices (attribute values and barycentrics), but coverage is not
+differentiated (dr.antialias, render.py:290, has no counterpart).  Textures are sampled at the nearest texel instead of
+dr.texture's trilinear mip filter.  With locked geometry (configs/bob.json:14) the G-buffer of the fixed benchmark views is
+rendered once; with optimize_geometry it is re-rendered every iteration from the moving vertices, like the reference does.
+material_set='r3' keeps round 3's reduced set (kd texture at the asset's resolution + ONE global ks vector, no normal map) for A/B.
 """
 import math
 import os
@@ -30,6 +41,8 @@ from . import scene as sc
 from .denoiser import BilateralDenoiser, _safe_normalize
 from .light import EnvironmentLight
 from .optim import FusedAdam
+from . import mesh as mesh_ops
+from . import render as rd
 from .parallel import allreduce_gradients
 
 
@@ -94,7 +107,8 @@ class _broadcast_pixels(torch.autograd.Function):
 class DirectLightingStep:
     def __init__(self, mesh_name='bob', res=512, n_samples_x=8, view=0, n_views=8, device='cuda', env='E1',
                  probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
-                 denoiser_demodulate=True, light_grad_scale=64.0, use_graph=False):
+                 denoiser_demodulate=True, light_grad_scale=64.0, use_graph=False, material_set='full', tex_res=1024,
+                 optimize_geometry=False, lr_pos=None, lr_light=None, perturb_pos=0.0, ks_min=(0.0, 0.08, 0.0), ks_max=(0.0, 1.0, 1.0)):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
@@ -104,6 +118,11 @@ class DirectLightingStep:
         self.denoiser_demodulate = denoiser_demodulate    # FLAGS.denoiser_demodulate (train.py:525, default True)
         self.light_grad_scale = light_grad_scale          # lgt.base.grad *= 64 (train.py:439-440)
         self.total_views = n_views if isinstance(n_views, int) else len(n_views)
+        if material_set not in ('full', 'r3'):
+            raise ValueError("material_set must be 'full' or 'r3'")
+        if optimize_geometry and material_set != 'full':
+            raise ValueError('optimize_geometry needs material_set="full"')
+        self.material_set, self.optimize_geometry, self.tex_res_train = material_set, bool(optimize_geometry), int(tex_res)
         # use_graph: capture the iteration in HIP graphs (one submit instead of ~110 launches) once it has run a few times
         # eagerly.  What makes that legal: nothing on the path synchronises the host or allocates after warm-up, and the
         # random seed of shade() lives in device memory (OptiXContext.seed_offset), so a replay draws fresh samples.
@@ -125,58 +144,106 @@ class DirectLightingStep:
         views = list(view) if isinstance(view, (list, tuple)) else [view]
         self.views = views
         cams = [sc.camera(vw, n_views) for vw in views]
-        mvp = torch.stack([c[1] for c in cams]).to(self.dev)
-        cam = torch.stack([sc.camera_rays(c[0]) for c in cams]).to(self.dev)
-        gb = ou.render_gbuffer(self.ctx, self.mesh, mvp, cam, (H, W))
+        self.mvp = torch.stack([c[1] for c in cams]).to(self.dev)
+        self.cam = torch.stack([sc.camera_rays(c[0]) for c in cams]).to(self.dev)
         self.nv = len(views)
+        self.view_pos = torch.stack([c[2] for c in cams]).to(self.dev)[:, None, None, :].contiguous()    # [V,1,1,3]
+        self.topo = mesh_ops.MeshTopology(self.mesh['t_pos_idx'], self.mesh['v_pos'].shape[0], self.mesh['v_tex'], self.mesh['t_tex_idx'])
+        self._set_gbuffer(ou.render_gbuffer(self.ctx, self.mesh, self.mvp, self.cam, (H, W)))
+        if material_set == 'r3':
+            # texel addresses of the kd lookup (fixed: geometry is locked, configs/bob.json:14); nearest texel of a trainable
+            # texture instead of dr.texture's trilinear mip lookup (outside the path)
+            R = self.mesh['kd_tex'].shape[0]
+            tc = self.gb_texc
+            ix = (tc[..., 0] * R).long().clamp(0, R - 1)
+            iy = ((1.0 - tc[..., 1]) * R).long().clamp(0, R - 1)
+            self.texel = (iy * R + ix).view(-1)
+            self.tex_res = R
+            # only covered pixels look the texture up (the background would pile ~200k duplicates on one texel)
+            self.cov = self.mask.view(-1).nonzero().view(-1)
+            self.texel_cov = self.texel[self.cov].contiguous()
+            self.texel_or_none = torch.where(self.mask.view(-1) > 0, self.texel, torch.full_like(self.texel, -1)).to(torch.int32).contiguous()
+        kd_true = self.mesh['kd_tex'].reshape(-1, 3)
+
+        # ---- reference ("true") parameters -> target image; trainable parameters start elsewhere
+        self.denoiser = BilateralDenoiser(influence=1.0) if denoise else None
+        light_true = EnvironmentLight(sc.env_map(env, probe_res).to(self.dev))
+        ks_true = self.mesh['ks'].clone()
+        Rt = self.mesh['kd_tex'].shape[0]
+        # the global seed counter of render.py:19,112-116 -- kept in DEVICE memory and added to rnd_seed by the kernels
+        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.ctx.seed_offset = self.seed_dev
+        with torch.no_grad():
+            if material_set == 'r3':
+                self.target = self._render(kd_true, ks_true, light_true).detach()
+            else:       # the asset's own material: kd texture, constant ks (data/bob/bob_tri.mtl:3), no normal map
+                self.target = self._render_full(self.mesh['kd_tex'].contiguous(), ks_true.view(1, 1, 3).expand(Rt, Rt, 3).contiguous(),
+                                                torch.tensor([0.0, 0.0, 1.0], device=self.dev).repeat(Rt, Rt, 1).contiguous(), light_true).detach()
+        self._ks_min = torch.tensor(list(ks_min), device=self.dev)
+        self._ks_max = torch.tensor(list(ks_max), device=self.dev)
+        self.light = EnvironmentLight(torch.full((probe_res, probe_res, 3), 0.5, device=self.dev).requires_grad_(True))
+        lr_light = 3.0 * lr if lr_light is None else lr_light            # learning_rate_lgt = learning_rate * 3.0 (train.py:338)
+        lr_pos = lr if lr_pos is None else lr_pos                          # train.py:336
+        if material_set == 'r3':
+            self.kd_tex = torch.nn.Parameter(torch.full_like(kd_true, 0.5))
+            self.ks = torch.nn.Parameter(torch.tensor([0.0, 0.5, 0.0], device=self.dev))
+            self.params = [self.kd_tex, self.ks, self.light.base]
+            names = ['kd', 'ks', 'light']
+            clamps = [(0.0, 1.0), (None, 1.0, self._ks_min), (0.0, None)]
+            lr_scales, grad_scales, norm3 = [1.0, 1.0, 1.0], [1.0, 1.0, light_grad_scale], [False, False, False]
+        else:
+            # initial_guess_material with random_textures (train.py:171-192): kd flat, ks uniform random per texel inside
+            # [ks_min, ks_max] (ksR in [0, 0.01]), the normal map (0, 0, 1); Texture2D.clamp_ bounds per channel
+            R = self.tex_res_train
+            gen = torch.Generator().manual_seed(1234)
+            ks0 = torch.rand(R, R, 3, generator=gen)
+            lo = torch.tensor([0.0, ks_min[1], ks_min[2]])
+            hi = torch.tensor([0.01, ks_max[1], ks_max[2]])
+            self.kd_tex = torch.nn.Parameter(torch.full((R, R, 3), 0.5, device=self.dev))
+            self.ks_tex = torch.nn.Parameter((lo + ks0 * (hi - lo)).to(self.dev))
+            self.nrm_tex = torch.nn.Parameter(torch.tensor([0.0, 0.0, 1.0], device=self.dev).repeat(R, R, 1).contiguous())
+            self._nrm_min = torch.tensor([-1.0, -1.0, 0.0], device=self.dev)           # FLAGS.nrm_min / nrm_max (train.py:552-553)
+            self._nrm_max = torch.tensor([1.0, 1.0, 1.0], device=self.dev)
+            self.params = [self.kd_tex, self.ks_tex, self.nrm_tex, self.light.base]
+            names = ['kd', 'ks', 'normal', 'light']
+            clamps = [(0.0, 1.0), (None, None, self._ks_min, self._ks_max), (None, None, self._nrm_min, self._nrm_max), (0.01, None)]
+            lr_scales, grad_scales, norm3 = [1.0, 1.0, 1.0, lr_light / lr], [1.0, 1.0, 1.0, light_grad_scale], [False, False, True, False]
+            if self.optimize_geometry:
+                # DLMesh: v_pos is the trained geometry (dlmesh.py:28-38); the target was rendered from the unperturbed mesh above
+                v0 = self.mesh['v_pos'].clone()
+                if perturb_pos:
+                    v0 = v0 + perturb_pos * torch.randn(v0.shape, generator=torch.Generator().manual_seed(77)).to(self.dev)
+                self.v_pos = torch.nn.Parameter(v0.contiguous())
+                self.params.append(self.v_pos)
+                names.append('v_pos')
+                clamps.append(None); lr_scales.append(lr_pos / lr); grad_scales.append(1.0); norm3.append(False)
+        self.param_names = names
+        # The same Adam as the reference (train.py:348-356,452-461: three optimizers that differ in their learning rate).  fused: ONE
+        # launch for the light-gradient scale, the Adam update of every tensor and the clamps / normal-map renormalisation
+        # (csrc/optim.hip; torch's multi-tensor Adam puts the elements on 16 workgroups + a kernel per clamp); otherwise
+        # torch.optim.Adam with parameter groups and the reference's sequence of calls.
+        self._fused_update = bool(fused) and self.dev.type == 'cuda'
+        self._lr_scales = lr_scales
+        if self._fused_update:
+            self.opt = FusedAdam(self.params, lr=lr, grad_scales=grad_scales, clamps=clamps, lr_scales=lr_scales, normalize3=norm3)
+        else:
+            groups = [{'params': [p], 'lr': lr * sc_} for p, sc_ in zip(self.params, lr_scales)]
+            try:
+                self.opt = torch.optim.Adam(groups, lr=lr, fused=self.dev.type == 'cuda', capturable=use_graph)
+            except (RuntimeError, TypeError):
+                self.opt = torch.optim.Adam(groups, lr=lr, capturable=use_graph)
+        self.covered = int(self.mask.sum().item())
+
+    def _set_gbuffer(self, gb):
+        """Adopt a G-buffer dict (optixutils.render_gbuffer / render.gbuffer) as the iteration's inputs."""
+        self.rast = gb['rast']
         self.mask = (gb['rast'][..., 3] > 0).float().contiguous()     # the reference passes rast[..., -1] (triangle id + 1 > 0)
         self.gb_pos = gb['gb_pos']
         self.gb_geom_nrm = gb['gb_geometric_normal']
         self.gb_smooth_nrm = gb['gb_normal']
         self.gb_tangent = gb['gb_tangent']
         self.gb_depth = gb['gb_depth']
-        self.view_pos = torch.stack([c[2] for c in cams]).to(self.dev)[:, None, None, :].contiguous()    # [V,1,1,3]
-        # texel addresses of the kd lookup (fixed: geometry is locked, configs/bob.json:14); nearest texel of a trainable
-        # texture instead of dr.texture's trilinear mip lookup (outside the path)
-        R = self.mesh['kd_tex'].shape[0]
-        tc = gb['gb_texc']
-        ix = (tc[..., 0] * R).long().clamp(0, R - 1)
-        iy = ((1.0 - tc[..., 1]) * R).long().clamp(0, R - 1)
-        self.texel = (iy * R + ix).view(-1)
-        kd_true = self.mesh['kd_tex'].reshape(-1, 3)
-        self.tex_res = R
-        # only covered pixels look the texture up (the background would pile ~200k duplicates on one texel)
-        self.cov = self.mask.view(-1).nonzero().view(-1)
-        self.texel_cov = self.texel[self.cov].contiguous()
-        self.texel_or_none = torch.where(self.mask.view(-1) > 0, self.texel, torch.full_like(self.texel, -1)).to(torch.int32).contiguous()
-
-        # ---- reference ("true") parameters -> target image; trainable parameters start elsewhere
-        self.denoiser = BilateralDenoiser(influence=1.0) if denoise else None
-        light_true = EnvironmentLight(sc.env_map(env, probe_res).to(self.dev))
-        ks_true = self.mesh['ks'].clone()
-        # the global seed counter of render.py:19,112-116 -- kept in DEVICE memory and added to rnd_seed by the kernels
-        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.ctx.seed_offset = self.seed_dev
-        with torch.no_grad():
-            self.target = self._render(kd_true, ks_true, light_true).detach()
-        self.kd_tex = torch.nn.Parameter(torch.full_like(kd_true, 0.5))
-        self.ks = torch.nn.Parameter(torch.tensor([0.0, 0.5, 0.0], device=self.dev))
-        self.light = EnvironmentLight(torch.full((probe_res, probe_res, 3), 0.5, device=self.dev).requires_grad_(True))
-        self._ks_min = torch.tensor([0.0, 0.08, 0.0], device=self.dev)
-        self.params = [self.kd_tex, self.ks, self.light.base]
-        # The same Adam as the reference (train.py:452-461).  fused: ONE launch for the light-gradient scale, the Adam update
-        # of the three tensors and their clamps (csrc/optim.hip; torch's multi-tensor Adam puts the ~1 M elements on 16
-        # workgroups: 45 us + five small kernels); otherwise torch.optim.Adam and the reference's sequence of calls.
-        self._fused_update = bool(fused) and self.dev.type == 'cuda'
-        if self._fused_update:
-            self.opt = FusedAdam(self.params, lr=lr, grad_scales=[1.0, 1.0, light_grad_scale],
-                                 clamps=[(0.0, 1.0), (None, 1.0, self._ks_min), (0.0, None)])
-        else:
-            try:
-                self.opt = torch.optim.Adam(self.params, lr=lr, fused=self.dev.type == 'cuda', capturable=use_graph)
-            except (RuntimeError, TypeError):
-                self.opt = torch.optim.Adam(self.params, lr=lr, capturable=use_graph)
-        self.covered = int(self.mask.sum().item())
+        self.gb_texc = gb['gb_texc']
 
     @property
     def seed(self):
@@ -189,6 +256,21 @@ class DirectLightingStep:
     # rays per pass counted from the actual mask: 2 per stratum per covered pixel
     def rays_per_pass(self):
         return 2 * self.n * self.n * self.covered
+
+    @torch.no_grad()
+    def shade_inputs(self):
+        """(mask, ro, gb_pos, shading normal, view_pos, kd, ks) for the CURRENT parameters: what optix_env_shade receives inside the
+        iteration (counting launches of bench.py, the probes under tools/)."""
+        if self.material_set == 'r3':
+            m = self.mask[..., None]
+            kd = self.kd_tex[self.texel].view(self.nv, self.res, self.res, 3) * m
+            ks = self.ks.view(1, 1, 1, 3) * m
+            pn = None
+        else:
+            kd, ks, pn = rd.texture_lookup((self.kd_tex, self.ks_tex, self.nrm_tex), self.gb_texc, self.rast)
+        nrm = ru.prepare_shading_normal(self.gb_pos, self.view_pos, pn, self.gb_smooth_nrm, self.gb_tangent, self.gb_geom_nrm,
+                                        two_sided_shading=True, opengl=True)
+        return self.mask, (self.gb_pos + nrm * 0.001).contiguous(), self.gb_pos, nrm, self.view_pos, kd.contiguous(), ks.contiguous()
 
     def _render(self, kd_tex, ks_vec, light):
         m = self.mask[..., None]
@@ -239,12 +321,50 @@ class DirectLightingStep:
             spec = self.denoiser.forward(torch.cat((spec, nrm, self.gb_depth), dim=-1))
         return diff * (kd * (1.0 - ks[..., 2:3])) + spec
 
+    def _render_full(self, kd_tex, ks_tex, nrm_tex, light, gb=None):
+        """shade() with the reference's material set (render.py:61-131): kd / ks / perturbed normal from three textures in one
+        lookup launch, shading frame, env-shade, both lights filtered in one pass, composite.  gb: a differentiable G-buffer dict
+        (optimize_geometry) or None = the cached one."""
+        rast = self.rast if gb is None else gb['rast']
+        pos, gnrm, snrm, tng, depth, texc = ((self.gb_pos, self.gb_geom_nrm, self.gb_smooth_nrm, self.gb_tangent, self.gb_depth, self.gb_texc) if gb is None else
+                                             (gb['gb_pos'], gb['gb_geometric_normal'], gb['gb_normal'], gb['gb_tangent'], gb['gb_depth'], gb['gb_texc']))
+        kd, ks, pn = rd.texture_lookup((kd_tex, ks_tex, nrm_tex), texc, rast)
+        nrm, nn, ro = ru.shading_frame(pos, self.view_pos, pn, snrm, tng, gnrm, two_sided_shading=True, opengl=True, ro_eps=0.001)
+        self.ctx.pixel_index_offset = self.pixel_index_offset
+        self.ctx.cache_visibility = not self.retrace_backward
+        # mask = rast[..., -1] as the reference passes it (render.py:113): a strided view, > 0 = covered
+        diff, spec = ou.optix_env_shade(self.ctx, rast[..., 3], ro, pos, nrm, self.view_pos, kd, ks, light.base,
+                                        light._pdf, light.rows[:, 0], light.cols, BSDF='pbr', n_samples_x=self.n,
+                                        rnd_seed=0, shadow_scale=1.0)
+        self.seed_dev += 1
+        if self.denoiser is not None and not self.denoiser_demodulate:
+            shaded = ru.shade_composite(diff, spec, kd, ks)
+            cw = ou.ops._bilateral_denoiser_func.apply(shaded, nn, depth, self.denoiser.sigma)
+            return cw[..., 0:3] / cw[..., 3:4]
+        if self.denoiser is not None:
+            if self.pair_filter:
+                diff, spec = ou.ops._bilateral_denoiser_pair_func.apply(diff, spec, nn, depth, self.denoiser.sigma)
+            else:
+                diff = ou.ops._bilateral_denoiser_func.apply(diff, nn, depth, self.denoiser.sigma)
+                spec = ou.ops._bilateral_denoiser_func.apply(spec, nn, depth, self.denoiser.sigma)
+        return ru.shade_composite(diff, spec, kd, ks)
+
     def forward_backward(self):
         """The differentiable part of the iteration; returns the loss tensor (grads are in .grad)."""
         self.light.update_pdf()
-        ou.optix_build_bvh(self.ctx, self.mesh['v_pos'], self.mesh['t_pos_idx'], rebuild=1)
+        v_pos = self.v_pos if self.optimize_geometry else self.mesh['v_pos']
+        ou.optix_build_bvh(self.ctx, v_pos, self.mesh['t_pos_idx'], rebuild=1)
         self.opt.zero_grad(set_to_none=True)
-        img = self._render(self.kd_tex, self.ks, self.light)
+        if self.material_set == 'r3':
+            img = self._render(self.kd_tex, self.ks, self.light)
+        else:
+            gb = None
+            if self.optimize_geometry:
+                # getMesh (dlmesh.py:45-55) + rasterize / interpolate (render.py:208-234) from the moving vertices
+                v_nrm, v_tng = mesh_ops.mesh_frame(v_pos, self.topo)
+                gb = rd.gbuffer(self.ctx, v_pos, v_nrm, v_tng, self.topo, self.mvp, self.cam, (self.res, self.res))
+                self._set_gbuffer({k: v.detach() for k, v in gb.items()})        # shade_inputs() / mask follow the moving mesh
+            img = self._render_full(self.kd_tex, self.ks_tex, self.nrm_tex, self.light, gb)
         loss = ru.image_loss(img, self.target, loss='l1', tonemapper='log_srgb')
         loss.backward()
         return loss
@@ -259,8 +379,15 @@ class DirectLightingStep:
         self.opt.step()
         with torch.no_grad():
             self.kd_tex.clamp_(0.0, 1.0)
-            self.ks.copy_(torch.maximum(self.ks.clamp(max=1.0), self._ks_min))  # ks_min of configs/bob.json: roughness >= 0.08
-            self.light.base.clamp_(min=0.0)
+            if self.material_set == 'r3':
+                self.ks.copy_(torch.maximum(self.ks.clamp(max=1.0), self._ks_min))  # ks_min of configs/bob.json: roughness >= 0.08
+                self.light.base.clamp_(min=0.0)
+            else:                                       # train.py:467-476: Texture2D.clamp_ per channel, normalize_, lgt.clamp_(min=0.01)
+                for i in range(3):
+                    self.ks_tex[..., i].clamp_(min=float(self._ks_min[i]), max=float(self._ks_max[i]))
+                    self.nrm_tex[..., i].clamp_(min=float(self._nrm_min[i]), max=float(self._nrm_max[i]))
+                self.nrm_tex.copy_(self.nrm_tex / torch.sqrt(torch.clamp((self.nrm_tex * self.nrm_tex).sum(-1, keepdim=True), min=1e-20)))
+                self.light.base.clamp_(min=0.01)
 
     def _capture(self, world_size):
         """Two HIP graphs: (A) update_pdf + BVH rebuild + render + loss + backward, (B) light-gradient scale + Adam + clamps.

@@ -207,6 +207,50 @@ def test_fused_adam_matches_torch_adam_and_clamps(dev):
     assert torch.equal(p_gpu[2].grad.cpu(), grads[2])           # the gradient itself is left alone (the scale is applied inside)
 
 
+def test_fused_adam_material_set(dev):
+    """The update of the reference's full parameter set in one launch (train.py:336-356,452-476): three learning rates (position /
+    material / light), per-channel texture clamps from both sides (Texture2D.clamp_, ks_max = [0, 1, 1]), the normal map's
+    clamp + normalize_, lgt.clamp_(min=0.01); a NaN parameter stays NaN; lr = 0 is a no-op on the parameters."""
+    from nvdiffrecmc_amd.optim import FusedAdam
+    torch.manual_seed(9)
+    shapes = [(40, 40, 3), (40, 40, 3), (40, 40, 3), (16, 16, 3), (211, 3)]          # kd, ks, normal, light, v_pos
+    ks_min, ks_max = torch.tensor([0.0, 0.08, 0.0]), torch.tensor([0.0, 1.0, 1.0])
+    n_min, n_max = torch.tensor([-1.0, -1.0, 0.0]), torch.tensor([1.0, 1.0, 1.0])
+    p_ref = [torch.nn.Parameter(torch.rand(*s) * 0.9 + 0.05) for s in shapes]
+    p_gpu = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in p_ref]
+    lr_mat, lr_lgt, lr_pos = 0.01, 0.03, 0.003
+    opts = [torch.optim.Adam(p_ref[0:3], lr=lr_mat), torch.optim.Adam([p_ref[3]], lr=lr_lgt), torch.optim.Adam([p_ref[4]], lr=lr_pos)]
+    opt_gpu = FusedAdam(p_gpu, lr=lr_mat, grad_scales=[1.0, 1.0, 1.0, 64.0, 1.0], lr_scales=[1.0, 1.0, 1.0, lr_lgt / lr_mat, lr_pos / lr_mat],
+                        clamps=[(0.0, 1.0), (None, None, ks_min.to(dev), ks_max.to(dev)), (None, None, n_min.to(dev), n_max.to(dev)), (0.01, None), None],
+                        normalize3=[False, False, True, False, False])
+    for it in range(10):
+        grads = [torch.randn(*s) * 0.3 for s in shapes]
+        for p, q, g in zip(p_ref, p_gpu, grads):
+            p.grad = g.clone()
+            q.grad = g.clone().to(dev)
+        p_ref[3].grad *= 64.0
+        for o in opts:
+            o.step()
+        with torch.no_grad():
+            p_ref[0].clamp_(0.0, 1.0)
+            for i in range(3):
+                p_ref[1][..., i].clamp_(min=float(ks_min[i]), max=float(ks_max[i]))
+                p_ref[2][..., i].clamp_(min=float(n_min[i]), max=float(n_max[i]))
+            p_ref[2].copy_(p_ref[2] / torch.sqrt(torch.clamp((p_ref[2] * p_ref[2]).sum(-1, keepdim=True), min=1e-20)))
+            p_ref[3].clamp_(min=0.01)
+        opt_gpu.step()
+        for k, (p, q) in enumerate(zip(p_ref, p_gpu)):
+            assert_close(q.detach().cpu(), p.detach(), 2e-6, floor=1.0, what='tensor %d step %d' % (k, it))
+    assert float(p_gpu[1][..., 0].abs().max()) == 0.0                                   # ks.x is pinned to [0, 0]
+    assert_close((p_gpu[2] * p_gpu[2]).sum(-1).cpu(), torch.ones(40, 40), 1e-6, floor=1.0)
+    # NaN stays NaN (fmaxf / fminf would have turned it into a bound); lr = 0 leaves the parameters alone
+    q = torch.nn.Parameter(torch.tensor([0.5, float('nan'), 0.25], device=dev))
+    q.grad = torch.ones(3, device=dev)
+    o2 = FusedAdam([q], lr=0.0, clamps=[(0.0, 1.0)])
+    o2.step()
+    assert torch.isnan(q[1]) and float(q[0]) == 0.5 and float(q[2]) == 0.25
+
+
 def test_shading_frame_equals_the_composed_ops(dev):
     """The fused shading frame (shading normal, unit copy, shadow-ray origin in one launch) against prepare_shading_normal + the
     safe_normalize of the filter's guide + the offset of render.py:107; with an input that requires a gradient it composes them."""
@@ -225,9 +269,24 @@ def test_shading_frame_equals_the_composed_ops(dev):
     ref_unit = ref / torch.sqrt(torch.clamp(torch.sum(ref * ref, -1, keepdim=True), min=1e-20))
     assert torch.equal(unit, ref_unit)          # same association as torch.sum: the filter raises dot products of it to the 128th power
     assert torch.equal(ro, pos + ref * 0.001)
-    p2 = pos.clone().requires_grad_(True)
-    n2, u2, r2 = ru.shading_frame(p2, view, None, sn, st, gn)
-    assert r2.requires_grad and torch.equal(n2.detach(), ref)
+    # differentiable through the shading normal (one launch: prepare_shading_normal_bwd), for every input incl. a per-pixel perturbed
+    # normal and the broadcast view position; the unit copy and the ray origin carry no gradient (the reference's graph has none there)
+    pn = torch.nn.functional.normalize(torch.randn(N, H, W, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0]), dim=-1).to(dev)
+    up = torch.randn(N, H, W, 3, generator=g).to(dev)
+    a = [t.clone().requires_grad_(True) for t in (pos, view, pn, sn, st, gn)]
+    b = [t.clone().requires_grad_(True) for t in (pos, view, pn, sn, st, gn)]
+    n2, u2, r2 = ru.shading_frame(*a)
+    assert n2.requires_grad and not u2.requires_grad and not r2.requires_grad
+    n3 = ru.prepare_shading_normal(*b, two_sided_shading=True, opengl=True)
+    assert torch.equal(n2.detach(), n3.detach())
+    (n2 * up).sum().backward()
+    (n3 * up).sum().backward()
+    for x, y in zip(a, b):
+        assert x.grad.shape == y.grad.shape
+        if x.shape == x.grad.shape and x.shape[1] > 1:
+            assert torch.equal(x.grad, y.grad)
+        else:       # the broadcast view position: its full-extent gradient is folded over H and W, in another order than autograd folds it
+            assert_close(x.grad, y.grad, 1e-5, floor=float(y.grad.abs().max()))
 
 
 def test_lookup_rows_matches_torch_indexing(dev):

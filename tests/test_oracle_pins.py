@@ -256,3 +256,21 @@ def test_filter_output_is_empty_where_the_centre_normal_is_zero(impl):
     assert torch.equal(out[empty][:, 3], torch.full((int(empty.sum()),), 1e-4))
     assert torch.equal(grad[empty], torch.zeros(int(empty.sum()), 3))
     assert out[~empty][:, 3].min().item() > 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- mesh frame (round 4)
+def test_mesh_frame_oracle_vs_reference_module():
+    """oracle/render_layer_ref.py auto_normals + compute_tangents and torch autograd through them against the reference's own
+    render/mesh.py:150-219 (tests/golden/mesh_reference.npz, generated by tools/make_golden.py with the CUDA-only imports stubbed)."""
+    from oracle import render_layer_ref as rl
+    gold = load_npz('mesh_reference.npz')['spot700']
+    c = mg.mesh_case()
+    assert checksum(c['v_pos'], c['t_pos_idx'], c['v_tex'], c['t_tex_idx'], c['g_nrm'], c['g_tng']) == str(gold['v_pos_sha256']), 'regenerated case differs'
+    for dt, tol in ((torch.float32, 1e-6), (torch.float64, 2e-6)):
+        v_pos = c['v_pos'].detach().clone().to(dt).requires_grad_(True)
+        vn = rl.auto_normals(v_pos, c['t_pos_idx'])
+        vt = rl.compute_tangents(v_pos, vn, c['v_tex'], c['t_pos_idx'], c['t_tex_idx'])
+        ((vn * c['g_nrm'].to(dt)).sum() + (vt * c['g_tng'].to(dt)).sum()).backward()
+        assert_close(vn, gold['v_nrm'], tol, floor=1.0, what='v_nrm')
+        assert_close(vt, gold['v_tng'], tol * 10, floor=1.0, what='v_tng')
+        assert_close(v_pos.grad, gold['v_pos_grad'], 2e-4, floor=float(np.abs(gold['v_pos_grad']).max()) * 0.01, what='v_pos_grad')

@@ -54,10 +54,7 @@ for tag, path in paths:
     assert st.ctx.cpp_wrapper.lib is lib
     with torch.no_grad():
         m = st.mask[..., None]
-        kd = (st.kd_tex[st.texel].view(st.nv, res, res, 3) * m).contiguous()
-        ks = (st.ks.view(1, 1, 1, 3) * m).contiguous()
-        nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)
-        ro = st.gb_pos + nrm * 0.001
+        _, ro, _, nrm, _, kd, ks = st.shade_inputs()
     steps[tag] = (st, kd, ks, nrm, ro)
 _build.LIB = base
 

@@ -204,13 +204,65 @@ def gen_light():
     np.savez_compressed(os.path.join(OUT, 'light_reference.npz'), **flat)
 
 
+def mesh_case(name='spot', n_tris=700):
+    """A small sub-mesh (the first n_tris triangles of an asset, vertices compacted in both index spaces) + fixed upstream
+    gradients: the input of the mesh-frame pins."""
+    from nvdiffrecmc_amd import scene as sc
+    m = sc.load_mesh(name)
+    tp, tt = m['t_pos_idx'][:n_tris].long(), m['t_tex_idx'][:n_tris].long()
+    up, ip = torch.unique(tp, return_inverse=True)
+    ut, it = torch.unique(tt, return_inverse=True)
+    g = torch.Generator().manual_seed(7)
+    v_pos = m['v_pos'][up].contiguous()
+    return {'v_pos': v_pos, 't_pos_idx': ip.int().contiguous(), 'v_tex': m['v_tex'][ut].contiguous(), 't_tex_idx': it.int().contiguous(),
+            'g_nrm': torch.randn(v_pos.shape, generator=g), 'g_tng': torch.randn(v_pos.shape, generator=g)}
+
+
+def gen_mesh():
+    """The reference's own auto_normals / compute_tangents (render/mesh.py:150-219, imported unmodified with the CUDA-only imports
+    stubbed and device='cuda' stripped from torch.tensor) and torch autograd through them: values and the gradient w.r.t. v_pos."""
+    import types
+    import importlib
+    for mod in ('nvdiffrast', 'nvdiffrast.torch', 'imageio', 'tinycudann'):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules['nvdiffrast'].torch = sys.modules['nvdiffrast.torch']
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    real_tensor = torch.tensor
+
+    def cpu_tensor(*a, **k):
+        k.pop('device', None)
+        return real_tensor(*a, **k)
+    torch.tensor = cpu_tensor
+    try:
+        rmesh = importlib.import_module('render.mesh')      # /root/reference/render/mesh.py, unmodified
+        c = mesh_case()
+        v_pos = c['v_pos'].clone().requires_grad_(True)
+        im = rmesh.Mesh(v_pos=v_pos, t_pos_idx=c['t_pos_idx'].long(), v_tex=c['v_tex'], t_tex_idx=c['t_tex_idx'].long())
+        im = rmesh.auto_normals(im)
+        im = rmesh.compute_tangents(im)
+        ((im.v_nrm * c['g_nrm']).sum() + (im.v_tng * c['g_tng']).sum()).backward()
+        flat = {'spot700/v_pos_sha256': np.array(checksum(c['v_pos'], c['t_pos_idx'], c['v_tex'], c['t_tex_idx'], c['g_nrm'], c['g_tng'])),
+                'spot700/v_nrm': im.v_nrm.detach().numpy(), 'spot700/v_tng': im.v_tng.detach().numpy(),
+                'spot700/v_pos_grad': v_pos.grad.numpy()}
+        assert torch.equal(im.t_nrm_idx, im.t_pos_idx) and torch.equal(im.t_tng_idx, im.t_pos_idx)     # mesh.py:178,219
+        print('mesh', tuple(im.v_nrm.shape), float(v_pos.grad.abs().max()))
+    finally:
+        torch.tensor = real_tensor
+    np.savez_compressed(os.path.join(OUT, 'mesh_reference.npz'), **flat)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == 'light':
         gen_light()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'mesh':
+        gen_mesh()
+        sys.exit(0)
     gen_renderutils()
     gen_light()
+    gen_mesh()
     gen_env_shade()
     gen_denoiser()
     for f in sorted(os.listdir(OUT)):

@@ -17,10 +17,7 @@ n_bursts = int(os.environ.get('PROBE_BURSTS', '18'))
 st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
 with torch.no_grad():
     m = st.mask[..., None]
-    kd = (st.kd_tex[st.texel].view(st.nv, res, res, 3) * m).contiguous()
-    ks = (st.ks.view(1, 1, 1, 3) * m).contiguous()
-    nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)
-    ro = st.gb_pos + nrm * 0.001
+    _, ro, _, nrm, _, kd, ks = st.shade_inputs()
 L = st.light
 ctx = st.ctx
 f = ou.ops.env_shade_traversal_counts

@@ -11,10 +11,7 @@ mesh = os.environ.get('PROBE_MESH', 'bob')
 st = DirectLightingStep(mesh, res, n, view=0, n_views=8, device='cuda:0')
 m = st.mask[..., None]
 with torch.no_grad():
-    kd = (st.kd_tex[st.texel].view(st.nv, res, res, 3) * m).contiguous()
-    ks = (st.ks.view(1, 1, 1, 3) * m).contiguous()
-    nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)
-    ro = st.gb_pos + nrm * 0.001
+    _, ro, _, nrm, _, kd, ks = st.shade_inputs()
 L = st.light
 rays = st.rays_per_pass()
 

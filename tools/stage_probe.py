@@ -16,11 +16,7 @@ nviews = int(os.environ.get('PROBE_VIEWS', '1'))
 st = DirectLightingStep(mesh, res, n, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
 m = st.mask[..., None]
 with torch.no_grad():
-    kd = (st.kd_tex[st.texel].view(st.nv, res, res, 3) * m).contiguous()
-    import time as _t
-    ks = (st.ks.view(1, 1, 1, 3) * m).contiguous()
-    nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)
-    ro = st.gb_pos + nrm * 0.001
+    _, ro, _, nrm, _, kd, ks = st.shade_inputs()
 L = st.light
 ou.ops._optix_env_shade_func.cache_visibility = False
 

@@ -65,17 +65,25 @@ L2_PEAK_GBS = 34500.0      # aggregate L2 bandwidth, same guide
 N_CUS, SIMDS_PER_CU, LANES_PER_SIMD, CLOCK_GHZ = 256, 4, 32, 2.4
 VALU_PEAK_TLANEOPS = N_CUS * SIMDS_PER_CU * LANES_PER_SIMD * CLOCK_GHZ * 1e9 / 1e12   # 78.6 T lane-ops/s (x2 flop = 157.3 TFLOP/s)
 
+# Position learning rate of the geometry-unlocked presets.  The reference moves v_pos with lr 0.005 (configs/nerf_lego.json:9, second pass) under
+# a Laplacian regulariser and silhouette gradients; this harness has neither, and Adam with a Monte-Carlo-noisy gradient random-walks the
+# vertices by lr per step: at 0.01 the mesh is noise after 30 iterations and the traversal 8 x slower (252 ms per dmtet800 iteration, measured).
+# 1e-5 keeps the mesh a mesh over the few hundred iterations of a bench run (< 0.003 units of drift); the work per iteration does not depend on it.
+BENCH_LR_POS = 1e-5
+
 PRESETS = {
-    'bob512': dict(mesh='bob', res=512, n=8, batch=8, subdiv=0,
+    # lock_pos / tex_res: the config's own keys (configs/bob.json:6,14; spot_metal.json; nerf_lego / nerfactor_hotdog train the geometry:
+    # their second pass runs DLMesh with v_pos as a parameter, geometry/dlmesh.py:28-38)
+    'bob512': dict(mesh='bob', res=512, n=8, batch=8, subdiv=0, lock_pos=True, tex_res=1024,
                    metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 64spp bob mesh)',
                    what='bob.json 512x512, 64 spp (n_samples_x=8)'),
-    'spot512x256': dict(mesh='spot', res=512, n=16, batch=4, subdiv=0,
+    'spot512x256': dict(mesh='spot', res=512, n=16, batch=4, subdiv=0, lock_pos=True, tex_res=1024,
                         metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 256spp spot_metal)',
                         what='spot_metal.json 512x512, 256 spp (n_samples_x=16)'),
-    'dmtet800': dict(mesh='bob', res=800, n=8, batch=8, subdiv=3,
+    'dmtet800': dict(mesh='bob', res=800, n=8, batch=8, subdiv=3, lock_pos=False, tex_res=1024,
                      metric='MC shadow rays/sec (fwd+bwd train iteration, 800x800 64spp, 684k-triangle DMTet-sized mesh)',
                      what='nerf_lego.json stand-in: bob subdivided 3x (684 032 triangles), 800x800, 64 spp (n_samples_x=8)'),
-    'hotdog512x256': dict(mesh='bob', res=512, n=16, batch=8, subdiv=2,
+    'hotdog512x256': dict(mesh='bob', res=512, n=16, batch=8, subdiv=2, lock_pos=False, tex_res=1024,
                           metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 256spp, 171k-triangle DMTet-sized mesh)',
                           what='nerfactor_hotdog.json stand-in: bob subdivided 2x (171 008 triangles, the size DMTet extracts from a 128^3 '
                                'grid), 512x512, 256 spp (n_samples_x=16); geometry fixed (the joint geometry optimisation is outside the path)'),
@@ -178,7 +186,9 @@ def collect_pmc(args, keep_dir=None, config=None, passes=None):
     config = config or args.config
     passes = passes or PMC_PASSES
     child = [sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child', '--config', config, '--steps', '2', '--warmup', '1',
-             '--scaling', args.scaling]
+             '--scaling', args.scaling, '--lock-pos', args.lock_pos, '--material-set', args.material_set]
+    if args.tex_res is not None:
+        child += ['--tex-res', str(args.tex_res)]
     for flag, v in (('--res', args.res), ('--n-samples-x', args.n_samples_x), ('--mesh', args.mesh), ('--subdiv', args.subdiv), ('--batch', args.batch)):
         if v is not None and own:
             child += [flag, str(v)]
@@ -291,7 +301,9 @@ def large_mesh_object(args, dev):
     pre = PRESETS['dmtet800']
     t0 = time.perf_counter()
     H, n, nv = pre['res'], pre['n'], pre['batch']
-    step = DirectLightingStep(pre['mesh'], H, n, view=list(range(nv)), n_views=nv, device=dev, retrace_backward=True, subdiv=pre['subdiv'])
+    step = DirectLightingStep(pre['mesh'], H, n, view=list(range(nv)), n_views=nv, device=dev, retrace_backward=True, subdiv=pre['subdiv'],
+                              material_set=args.material_set, tex_res=pre.get('tex_res', 1024),
+                              optimize_geometry=(args.material_set == 'full' and not pre.get('lock_pos', True) and args.lock_pos != 'on'), lr_pos=BENCH_LR_POS)
     for _ in range(4):
         step.step(1)
     step.ctx.set_profiling(True)
@@ -363,6 +375,11 @@ def parse_args():
     ap.add_argument('--subdiv', type=int, default=None)
     ap.add_argument('--batch', type=int, default=None, help='views per iteration: in total for strong, per GPU for weak scaling')
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='strong')
+    ap.add_argument('--lock-pos', choices=('config', 'on', 'off'), default='config',
+                    help='geometry: config = the preset (bob / spot locked as their configs say, the DMTet stand-ins train v_pos), on = locked, off = trained')
+    ap.add_argument('--material-set', choices=('full', 'r3'), default='full',
+                    help="full = kd + ks + normal textures at the config's texture_res + probe (+ v_pos): the reference's set; r3 = round 3's reduced set (A/B)")
+    ap.add_argument('--tex-res', type=int, default=None, help='override the texture resolution of the preset')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 counter passes (roofline.frac becomes null)')
     ap.add_argument('--pmc-timeout', type=int, default=240)
@@ -453,8 +470,13 @@ def run(args):
     use_graph = args.graph == 'on' or (args.graph == 'auto' and (len(my_views) <= 2 or world > 1))
     if args.pmc_child:
         use_graph = False
+    lock_pos = preset.get('lock_pos', True) if args.lock_pos == 'config' else (args.lock_pos == 'on')
+    if args.material_set == 'r3':
+        lock_pos = True
     step = DirectLightingStep(preset['mesh'], H, n, view=my_views, n_views=n_views, device=dev,
-                              pixel_index_offset=my_views[0] * H * W, retrace_backward=True, subdiv=preset['subdiv'], use_graph=use_graph)
+                              pixel_index_offset=my_views[0] * H * W, retrace_backward=True, subdiv=preset['subdiv'], use_graph=use_graph,
+                              material_set=args.material_set, tex_res=args.tex_res or preset.get('tex_res', 1024), optimize_geometry=not lock_pos,
+                              lr_pos=BENCH_LR_POS)
 
     if args.pmc_child:          # under rocprofv3: a few plain iterations, nothing else
         for _ in range(args.warmup + args.steps):
@@ -661,6 +683,10 @@ def run(args):
                        'dead_samples': '%.1f%% of the queries have dot(n,wi)<=0, are zero through the BSDF gates whatever their visibility and are answered without traversal (outputs bit-identical; NVDR_DEBUG=8 traces them); value counts traversed rays only' % (100.0 * (1.0 - n_traced / max(R, 1))),
                        'views_per_iteration': n_views, 'views_rank0': step.nv, 'probe': '%dx%d E1' % (probe, probe),
                        'backward': 're-traces all shadow rays', 'parallelism': 'dp%d (%d views per GPU)' % (world, step.nv),
+                       'trained_parameters': {nm: list(p.shape) for nm, p in zip(step.param_names, step.params)},
+                       'parameter_bytes': int(sum(p.numel() for p in step.params) * 4),
+                       'geometry': ('locked (lock_pos): G-buffer of the fixed views rendered once, BVH rebuilt every iteration as the reference does' if lock_pos else
+                                    'trained (v_pos, lr %g): BVH, vertex normals / tangents and the G-buffer rebuilt from the moving vertices every iteration; no silhouette (dr.antialias) term' % BENCH_LR_POS),
                        'allreduce_bytes_per_step': getattr(step, 'allreduce_bytes', 0)},
             'roofline': roof,
         }

@@ -423,6 +423,11 @@ typedef struct nvdr_adam_tensor {
 } nvdr_adam_tensor;
 int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps, int *state,
                    void *stream);
+/* The same update for a SUBSET of an iteration's tensors (one chunk of the data-parallel gradient exchange: the update of chunk k
+ * runs while chunk k + 1 is still being reduced).  Every launch of an iteration uses step state[0] + 1; only the one with
+ * advance != 0 -- the iteration's last -- moves the counter. */
+int nvdr_adam_step_partial(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps, int *state,
+                           int advance, void *stream);
 
 /* ---- test hook: evaluate include/nvdr_detmath.h on device.  op: 0 sin, 1 cos, 2 acos, 3 atan2(x,y). */
 int nvdr_test_detmath(int op, const float *x, const float *y, int64_t n, float *out, void *stream);

@@ -163,6 +163,7 @@ _SIGNATURES = {
     'nvdr_gather_rows_bwd': [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p],
     'nvdr_light_update_pdf': [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_adam_step': [ctypes.POINTER(NvdrAdamTensor), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p],
+    'nvdr_adam_step_partial': [ctypes.POINTER(NvdrAdamTensor), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p, c_int, c_void_p],
     'nvdr_test_detmath': [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
 }
 _RESTYPES = {'nvdr_last_error': ctypes.c_char_p, 'nvdr_image_loss_num_partials': c_int64}

@@ -19,7 +19,7 @@ struct AdamTable {
     int n;
 };
 
-__global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr, double beta1d, double beta2d, float eps, int *state)
+__global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr, double beta1d, double beta2d, float eps, int *state, int advance)
 {
     // state[0] = steps taken so far, state[1] = workgroups done with this launch, then two doubles: beta1^step, beta2^step (kept
     // as running products: pow() in double costs a workgroup ~10 us of latency).  Every workgroup reads the state before it takes
@@ -111,15 +111,23 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
         const int done = __hip_atomic_fetch_add(&state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == (int)gridDim.x - 1) {
             state[1] = 0;
-            ((double *)(state + 2))[0] = pows[0];
-            ((double *)(state + 2))[1] = pows[1];
-            __hip_atomic_store(&state[0], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (advance) {              // a partial step (one chunk of the gradient exchange) leaves the counter to the iteration's last launch
+                ((double *)(state + 2))[0] = pows[0];
+                ((double *)(state + 2))[1] = pows[1];
+                __hip_atomic_store(&state[0], step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
 extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps,
                               int *state, void *stream_)
+{
+    return nvdr_adam_step_partial(tensors, n_tensors, lr, beta1, beta2, eps, state, 1, stream_);
+}
+
+extern "C" int nvdr_adam_step_partial(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps,
+                                      int *state, int advance, void *stream_)
 {
     NvdrRange range("nvdr_adam_step");
     NVDR_REQUIRE(tensors && state, "adam_step: NULL argument");
@@ -151,7 +159,7 @@ extern "C" int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, do
     }
     for (int k = n_tensors; k <= NVDR_ADAM_MAX_TENSORS; ++k) tab.first_block[k] = (int)blocks;
     if (blocks < 1) blocks = 1;
-    adam_step_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(tab, lr, beta1, beta2, (float)eps, state);
+    adam_step_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream_>>>(tab, lr, beta1, beta2, (float)eps, state, advance);
     NVDR_LAUNCH_CHECK();
     return 0;
 }

@@ -47,10 +47,15 @@ class FusedAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def step(self):
-        tab = (_lib.NvdrAdamTensor * len(self.params))()
+    def step(self, subset=None, advance=True, grad_mult=1.0):
+        """subset: indices of the tensors to update in this launch (None = all); advance=False leaves the step counter alone (every
+        launch of an iteration but the last, nvdr_adam_step_partial); grad_mult: extra factor on the gradients of this launch (1 / world
+        after a summing all-reduce)."""
+        idx = list(range(len(self.params))) if subset is None else list(subset)
+        tab = (_lib.NvdrAdamTensor * len(idx))()
         keep = []
-        for i, p in enumerate(self.params):
+        for j, i in enumerate(idx):
+            p = self.params[i]
             if p.grad is None:
                 raise RuntimeError('FusedAdam.step: parameter %d has no gradient' % i)
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -62,15 +67,15 @@ class FusedAdam:
                 hi = math.inf if c[1] is None else float(c[1])
                 lo_vec = c[2] if len(c) > 2 else None
                 hi_vec = c[3] if len(c) > 3 else None
-            t = tab[i]
+            t = tab[j]
             t.param, t.grad, t.exp_avg, t.exp_avg_sq = p.data_ptr(), g.data_ptr(), self.exp_avg[i].data_ptr(), self.exp_avg_sq[i].data_ptr()
             t.n = p.numel()
-            t.grad_scale, t.lo, t.hi = float(self.grad_scales[i]), lo, hi
+            t.grad_scale, t.lo, t.hi = float(self.grad_scales[i]) * float(grad_mult), lo, hi
             t.lo_vec = lo_vec.data_ptr() if lo_vec is not None else None
             t.lo_vec_n = lo_vec.numel() if lo_vec is not None else 0
             t.hi_vec = hi_vec.data_ptr() if hi_vec is not None else None
             t.hi_vec_n = hi_vec.numel() if hi_vec is not None else 0
             t.lr_scale, t.normalize3 = float(self.lr_scales[i]), int(bool(self.normalize3[i]))
         with torch.no_grad():
-            _lib.check(_lib.load().nvdr_adam_step(tab, len(self.params), self.lr, self.betas[0], self.betas[1], self.eps,
-                                                  _lib.ptr(self.state), _lib.stream_ptr()), 'adam_step')
+            _lib.check(_lib.load().nvdr_adam_step_partial(tab, len(idx), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                          _lib.ptr(self.state), int(bool(advance)), _lib.stream_ptr()), 'adam_step')

@@ -49,3 +49,73 @@ def allreduce_gradients(params, world_size=None, group=None, average=True, local
             p.grad.copy_(g)
         off += n
     return flat.numel() * 4
+
+
+class GradientExchange:
+    """The per-iteration exchange of the reference-sized parameter set (kd + ks + normal textures at 1024^2 = 37.7 MB, the probe,
+    the vertices) cut into CHUNKS, each one flat fp32 bucket with its own asynchronous all-reduce: while chunk k + 1 is
+    on the wire the caller already runs the parameter update of chunk k (`for k in ex.chunks(): ex.wait(k); adam[k].step()`).
+
+    Zero-copy on the way back: after wait(k) the parameters' .grad ARE views into the reduced bucket (no unpack pass), holding the
+    weighted SUM over the ranks; `scale` (= 1 / total weight, a device scalar in the uneven case folded to a float when every rank
+    renders the same number of views) is what the optimizer multiplies the gradient by (FusedAdam grad_scales).  The pack is one
+    torch.cat per chunk into a preallocated bucket, so nothing allocates after the first iteration (HIP-graph friendly).
+
+    groups: list of lists of parameters (one list per chunk).  local_weight: views this rank renders; equal_shards: every rank has
+    the same local_weight (then no weighting traffic at all: plain sum, scale = 1 / world)."""
+
+    def __init__(self, groups, world_size=None, group=None, local_weight=1, equal_shards=True):
+        self.groups = [list(g) for g in groups]
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = (world_size or (dist.get_world_size(group) if self.active else 1))
+        self.local_weight, self.equal_shards = float(local_weight), bool(equal_shards)
+        self.buckets, self.handles = [], []
+        for g in self.groups:
+            n = sum(p.numel() for p in g)
+            extra = 0 if self.equal_shards else 1                       # the weight rides in the same bucket: still one collective per chunk
+            self.buckets.append(torch.zeros(n + extra, dtype=torch.float32, device=g[0].device))
+        self.bytes_per_step = sum(b.numel() for b in self.buckets) * 4 if (self.active and self.world > 1) else 0
+
+    def chunks(self):
+        return range(len(self.groups))
+
+    def pack(self):
+        """Gather the .grad of every parameter into its chunk's bucket (one cat per chunk; a missing gradient contributes zeros)."""
+        for g, b in zip(self.groups, self.buckets):
+            n = b.numel() - (0 if self.equal_shards else 1)
+            flats = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in g]
+            torch.cat(flats, out=b[:n])
+            if not self.equal_shards:
+                b[:n].mul_(self.local_weight)
+                b[n:].fill_(self.local_weight)
+
+    def start(self, skip_single=True):
+        """Launch the all-reduce of every chunk (asynchronous, in chunk order).  With one rank (and skip_single) nothing is sent."""
+        self.handles = [None] * len(self.buckets)
+        if not self.active or (self.world == 1 and skip_single):
+            return
+        for k, b in enumerate(self.buckets):
+            self.handles[k] = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self, k):
+        """Chunk k has arrived: point the .grad of its parameters at the reduced bucket (views, no copy).  Returns the factor the
+        optimizer must apply to these gradients (float, or a 0-dim device tensor for uneven shards)."""
+        h = self.handles[k] if self.handles else None
+        if h is not None:
+            h.wait()
+        b = self.buckets[k]
+        n = b.numel() - (0 if self.equal_shards else 1)
+        off = 0
+        for p in self.groups[k]:
+            p.grad = b[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        if not self.equal_shards:
+            # uneven shards: one more pass over the bucket (rare: n_views % world != 0); b[n] = sum of the weights (or this rank's own)
+            b[:n].div_(b[n].clamp(min=1.0))
+        return self.grad_mult
+
+    @property
+    def grad_mult(self):
+        """What the optimizer multiplies the .grad views by: 1 / world after a summing all-reduce over even shards, else 1."""
+        return (1.0 / self.world) if (self.equal_shards and self.active and self.world > 1) else 1.0

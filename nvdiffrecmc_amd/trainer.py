@@ -43,7 +43,6 @@ from .light import EnvironmentLight
 from .optim import FusedAdam
 from . import mesh as mesh_ops
 from . import render as rd
-from .parallel import allreduce_gradients
 
 
 class _gather_rows(torch.autograd.Function):
@@ -369,11 +368,31 @@ class DirectLightingStep:
         loss.backward()
         return loss
 
-    def _update(self):
-        """Everything after the gradient exchange: light-gradient scale, Adam, clamps (train.py:439-476)."""
+    def set_lr_scale(self, name, value):
+        """Learning rate of one parameter tensor relative to lr (0 freezes it); names as in .param_names."""
+        i = self.param_names.index(name)
+        self._lr_scales[i] = float(value)
         if self._fused_update:
-            self.opt.step()
+            self.opt.lr_scales[i] = float(value)
+        else:
+            self.opt.param_groups[i]['lr'] = self.opt.defaults['lr'] * float(value)
+
+    def _chunk_indices(self):
+        """The gradient exchange's chunks as lists of parameter indices: [kd, ks] (25 MB at 1024^2) | [normal, light, v_pos]; one
+        chunk for round 3's small set."""
+        n = len(self.params)
+        return [list(range(n))] if (self.material_set == 'r3' or n < 3) else [[0, 1], list(range(2, n))]
+
+    def _update(self, subset=None, advance=True, grad_mult=1.0):
+        """Everything after the gradient exchange: light-gradient scale, Adam, clamps (train.py:439-476); subset = the parameter
+        indices of one exchange chunk (fused path only)."""
+        if self._fused_update:
+            self.opt.step(subset=subset, advance=advance, grad_mult=grad_mult)
             return
+        if grad_mult != 1.0:
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.mul_(grad_mult)
         if self.light.base.grad is not None and self.light_grad_scale != 1.0:
             self.light.base.grad *= self.light_grad_scale       # train.py:439-440
         self.opt.step()
@@ -389,9 +408,36 @@ class DirectLightingStep:
                 self.nrm_tex.copy_(self.nrm_tex / torch.sqrt(torch.clamp((self.nrm_tex * self.nrm_tex).sum(-1, keepdim=True), min=1e-20)))
                 self.light.base.clamp_(min=0.01)
 
+    def _exchange(self, world_size):
+        """The chunked gradient exchange of this step object (created on first use: the process group must exist by then)."""
+        if getattr(self, '_ex', None) is None or self._ex.world != world_size:
+            from .parallel import GradientExchange
+            total = self.total_views
+            even = (total % world_size == 0) and (self.nv * world_size == total)
+            groups = [[self.params[i] for i in idx] for idx in self._chunk_indices()] if self._fused_update else [list(self.params)]
+            self._ex = GradientExchange(groups, world_size, local_weight=self.nv, equal_shards=even)
+        return self._ex
+
+    def _exchange_and_update(self, world_size, packed=False, graphs=None):
+        """all-reduce chunk by chunk; the update of chunk k (one fused launch, or its captured graph) runs while chunk k + 1 is
+        still on the wire.  Returns the bytes this rank put into the collectives."""
+        ex = self._exchange(world_size)
+        if not packed:
+            ex.pack()
+        ex.start()
+        chunks = self._chunk_indices() if self._fused_update else [None]
+        for k in ex.chunks():
+            f = ex.wait(k)
+            if graphs is not None:
+                graphs[k].replay()
+            else:
+                self._update(subset=chunks[k], advance=(k == len(chunks) - 1), grad_mult=f)
+        return ex.bytes_per_step
+
     def _capture(self, world_size):
-        """Two HIP graphs: (A) update_pdf + BVH rebuild + render + loss + backward, (B) light-gradient scale + Adam + clamps.
-        The gradient all-reduce (world > 1) runs between them on the same stream; with one rank A and B are one graph."""
+        """HIP graphs: (A) update_pdf + BVH rebuild + render + loss + backward [+ the pack of the exchange buckets], (B_k) light-gradient
+        scale + Adam + clamps of exchange chunk k.  The all-reduces (world > 1) run between them on the same stream, chunk k + 1
+        under B_k; with one rank A and B are one graph."""
         torch.cuda.synchronize()
         self.opt.zero_grad(set_to_none=True)
         ga = torch.cuda.CUDAGraph()
@@ -399,12 +445,20 @@ class DirectLightingStep:
             self._loss_static = self.forward_backward()
             if world_size == 1:
                 self._update()
-        gb = None
+            else:
+                self._exchange(world_size).pack()
+        gbs = None
         if world_size > 1:
-            gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb, pool=ga.pool()):
-                self._update()
-        self._graphs = (ga, gb)
+            ex = self._exchange(world_size)
+            chunks = self._chunk_indices() if self._fused_update else [None]
+            gbs = []
+            for k in ex.chunks():
+                f = ex.wait(k)              # points the .grad of chunk k at its bucket: what the captured update reads on every replay
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, pool=ga.pool()):
+                    self._update(subset=chunks[k], advance=(k == len(chunks) - 1), grad_mult=f)
+                gbs.append(gk)
+        self._graphs = (ga, gbs)
 
     def step(self, world_size=1):
         if self.use_graph and not self.force_eager and self._graphs is None and self._eager_steps >= 3:
@@ -417,16 +471,18 @@ class DirectLightingStep:
                 torch.cuda.synchronize()
                 self.opt.zero_grad(set_to_none=True)
         if self._graphs is not None and not self.force_eager:
-            ga, gb = self._graphs
+            ga, gbs = self._graphs
             ga.replay()
-            if gb is not None:
-                self.allreduce_bytes = allreduce_gradients(self.params, world_size, local_weight=self.nv)
-                gb.replay()
+            if gbs is not None:
+                self.allreduce_bytes = self._exchange_and_update(world_size, packed=True, graphs=gbs)
             return self._loss_static
         self._eager_steps += 1
         loss = self.forward_backward()
-        # weighted by this rank's share of the batch: the loss is a mean over the views a rank renders, the batch mean
-        # over all ranks needs sum(local_views * grad) / total_views (equal to the plain average for even shards)
-        self.allreduce_bytes = allreduce_gradients(self.params, world_size, local_weight=self.nv)
-        self._update()
+        # Each rank's gradient is the gradient of ITS mean over the views it renders; the batch mean over all ranks is the sum over
+        # ranks of (local views * gradient) / total views -- the plain average when the shards are even (parallel.GradientExchange)
+        if world_size > 1:
+            self.allreduce_bytes = self._exchange_and_update(world_size)
+        else:
+            self.allreduce_bytes = 0
+            self._update()
         return loss

@@ -115,3 +115,59 @@ def test_uneven_shards_keep_the_batch_mean():
     want = torch.full((4,), (1.0 + 10.0 + 100.0) / 3.0)
     for rank, g in got:
         assert torch.allclose(torch.from_numpy(g), want, rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------- the chunked exchange (round 4)
+def _worker_exchange(rank, world, port, q, n_views):
+    """The reference-sized parameter set (three 1024^2 textures = 37.7 MB, the probe, vertices) through GradientExchange: two chunks,
+    the 'update' of chunk 0 done before chunk 1 is waited for, gradients read from the bucket views."""
+    from nvdiffrecmc_amd.parallel import GradientExchange
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    views = shard_views(n_views, rank, world)
+    shapes = [(1024, 1024, 3), (1024, 1024, 3), (1024, 1024, 3), (256, 256, 3), (5344, 3)]
+    params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+    # the gradient of THIS rank's mean over its views; view v contributes (v + 1) * pattern_k
+    local = sum(float(v + 1) for v in views) / len(views)
+    for k, p in enumerate(params[:-1]):
+        p.grad = torch.full(p.shape, local * (k + 1))
+    params[-1].grad = None                                  # a parameter without gradient: zeros in the bucket
+    even = n_views % world == 0
+    ex = GradientExchange([params[0:2], params[2:]], world, local_weight=len(views), equal_shards=even)
+    ex.pack()
+    ex.start()
+    out = []
+    for k in ex.chunks():
+        f = ex.wait(k)
+        for p in ex.groups[k]:
+            assert p.grad.data_ptr() >= ex.buckets[k].data_ptr()           # a view into the bucket, not a copy
+            out.append(float((p.grad * f).double().mean()))
+    q.put((rank, out, ex.bytes_per_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_views', [2, 3])
+def test_chunked_exchange_of_the_reference_sized_bucket(n_views):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, world, port, q, n_views)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    mean_view = sum(float(v + 1) for v in range(n_views)) / n_views       # the batch mean over ALL views, however they were dealt
+    for rank, out, nbytes in got:
+        want = [mean_view * (k + 1) for k in range(4)] + [0.0]
+        assert len(out) == 5
+        for a, b in zip(out, want):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (rank, out, want)
+        n = 3 * 1024 * 1024 * 3 + 256 * 256 * 3 + 5344 * 3
+        assert nbytes == (n + (0 if n_views % world == 0 else 2)) * 4        # >= 38 MB; uneven shards carry one weight per chunk
+        assert nbytes >= 38_000_000

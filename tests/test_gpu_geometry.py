@@ -217,8 +217,8 @@ def test_geometry_unlocked_loss_decreases(dev):
         st.kd_tex.copy_(st.mesh['kd_tex'])
         st.ks_tex.copy_(st.mesh['ks'].view(1, 1, 3).expand_as(st.ks_tex))
         st.light.base.copy_(sc.env_map('E1', 256).to(dev))
-    for i in range(len(st.params) - 1):
-        st.opt.lr_scales[i] = 0.0
+    for name in st.param_names[:-1]:
+        st.set_lr_scale(name, 0.0)
     v_true = st.mesh['v_pos']
     err0 = float((st.v_pos.detach() - v_true).norm())
     losses = [float(st.step().detach()) for _ in range(48)]

@@ -8,8 +8,8 @@ for lr_pos, pert in ((1e-4, 0.004), (3e-4, 0.004), (1e-4, 0.0)):
     st = DirectLightingStep('bob', 160, 4, view=[0, 2, 5], device=dev, tex_res=512, optimize_geometry=True, perturb_pos=pert, lr=0.01, lr_pos=lr_pos)
     with torch.no_grad():
         st.kd_tex.copy_(st.mesh['kd_tex']); st.ks_tex.copy_(st.mesh['ks'].view(1, 1, 3).expand_as(st.ks_tex)); st.light.base.copy_(sc.env_map('E1', 256).to(dev))
-    for i in range(len(st.params) - 1):
-        st.opt.lr_scales[i] = 0.0
+    for name in st.param_names[:-1]:
+        st.set_lr_scale(name, 0.0)
     vt = st.mesh['v_pos']
     out = []
     for k in range(80):

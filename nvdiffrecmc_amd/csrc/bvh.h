@@ -110,16 +110,21 @@ struct nvdr_ctx {
     uint4 *wide = nullptr;         // [4 * cap] four-slot nodes of the round-2 kernel (traversal variant 0; built only when selected)
     uint4 *oct = nullptr;          // [4 * cap] eight-wide nodes collapsed from nodes[] (bvh_oct_build_kernel)
     float4 *tris8 = nullptr;       // [3 * cap] triangle records in oct-leaf order
-    int *oct_task = nullptr;       // [cap] build queue: binary node id of every oct node, -1 until published
-    unsigned *oct_ctl = nullptr;   // [8] build counters: ticket head, nodes allocated, nodes done, triangles placed
+    int *oct_task = nullptr;       // [cap] the wide roots: binary nodes that root an eight-wide node (bvh_oct_budget_kernel)
+    unsigned long long *oct_jump = nullptr;   // [cap] (ancestor, budget map) per binary node: the budget resolution's pointer-jumping state
+    unsigned *oct_wslot = nullptr; // [cap] per wide root: (parent wide root << 3) | position among its internal slots
+    unsigned long long *oct_cnt = nullptr, *oct_scan = nullptr;   // [cap] (internal, leaf) slot counts per binary node and their exclusive prefix sums
+    unsigned *oct_ctl = nullptr;   // build counters, one 128-byte line each: wide roots, oct nodes, nodes written, triangles placed
     float4 *tris = nullptr;        // [3 * cap]
     uint32_t *keys[2] = {nullptr, nullptr};
     uint32_t *vals[2] = {nullptr, nullptr};
-    int *parent = nullptr;         // [2T]: parents of internal nodes [0,T-1) then of leaves [T, 2T)
+    uint2 *up = nullptr;           // [2T]: .x = (parent << 2) | (side << 1) | local of the internal nodes [0,T-1), then of the leaves [T, 2T); .y = collapse-DP record of an internal node
     int *flags = nullptr;          // [T] arrival counters of the bottom-up pass
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     BvhDeviceInfo *dinfo = nullptr;
+    float *bounds_part = nullptr;  // [BVH_BOUNDS_BLOCKS][6] per-workgroup partial AABBs of bvh_bounds_kernel, then its ticket word
+    unsigned *bounds_ticket = nullptr;
     int *spill = nullptr;          // [NVDR_QUERY_MAX_BLOCKS][stack_max - NVDR_STACK_LDS][NVDR_QUERY_BLOCK]
     int stack_max = 0;             // entries per lane the current spill allocation supports (LDS part included)
     int oct_stack_max = 0;         // the same for the oct walk's (group, bits) entries
@@ -162,8 +167,6 @@ struct nvdr_ctx {
     uint16_t *cdf_guide = nullptr; // guide tables of the light's CDF inversion (env_shade.hip), rebuilt per launch
     size_t guide_cap = 0;
     float *dp_cost = nullptr;      // [2 * cap][8] hand-off records of bvh_fit_kernel: collapse-DP table (7) + height of the two children of every binary node
-    unsigned *dp_split = nullptr;  // [cap] the slot splits the DP chose
-    bool oct_dp = true;            // SAH-optimal collapse (false: greedy largest-area, NVDR_OCT_DP=0)
     float oct_c_leaf = 0.45f;      // cost of a triangle test relative to a node step in the collapse DP
     int shade_queue = 3;           // S == 64: shading kernels that queue the live light samples across pixels (NVDR_SHADE_QUEUE: bit 0 backward, bit 1 forward)
     int lg_mode = -1;              // gather work split: -1 by launch size, 0 all bands per workgroup, 1 one set of workgroups per band (NVDR_LG_MODE)

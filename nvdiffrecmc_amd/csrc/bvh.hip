@@ -16,6 +16,13 @@
 
 #include <rocprim/rocprim.hpp>
 
+// rocPRIM's radix_sort_pairs runs a merge sort below 1 M items (one block sort + 2 launches per doubling: 21 launches and 0.27 ms for the
+// 684 k keys of the large benchmark mesh).  Its onesweep radix sort (histogram + one launch per 8 key bits, ~0.1 ms alone) was
+// measured in round 4 and is NOT used: its workgroups spin on their predecessors (decoupled look-back), and beside the persistent
+// sample-generation kernel that fills the GPU while the build runs on its side stream one pass in four took 0.5 ms.  The merge
+// sort has no dependency between the workgroups of a launch.
+using nvdr_sort_config = rocprim::default_config;
+
 // ---------------------------------------------------------------------------------------------
 // kernels
 
@@ -36,39 +43,16 @@ __device__ __host__ __forceinline__ float ordered_to_float(int i)
 #endif
 }
 
-__global__ void bvh_init_info_kernel(BvhDeviceInfo *info)
+// Vertex AABB + quantisation grid + leaf padding in ONE launch: every workgroup reduces its share to six floats in `part`, takes a
+// ticket, and the workgroup that draws the last one reduces the partials and writes the grid (bounds as order-preserving ints, as
+// the Morton kernel reads them).  Rounds 1-3: three launches and six atomicMin / atomicMax per WAVEFRONT on the same six words --
+// 24 k serialised L2 atomics = 0.28 ms for 342 k vertices, during which anything else on the GPU crawled (a 15 us elementwise kernel on
+// the caller's stream took 0.29 ms beside it).
+#define BVH_BOUNDS_BLOCKS 128
+__global__ void __launch_bounds__(256) bvh_bounds_kernel(const float *__restrict__ verts, int64_t n_verts, BvhDeviceInfo *info, float *part, unsigned *ticket)
 {
-    if (threadIdx.x == 0) {
-        info->bounds[0] = info->bounds[1] = info->bounds[2] = 0x7fffffff;
-        info->bounds[3] = info->bounds[4] = info->bounds[5] = (int)0x80000000;
-        info->height = 0;
-        info->root = 0;
-    }
-}
-
-// quantisation grid + leaf padding from the vertex AABB (one thread)
-__global__ void bvh_grid_kernel(BvhDeviceInfo *info)
-{
-    float scale = 0.0f, lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = ordered_to_float(info->bounds[a]);
-        hi[a] = ordered_to_float(info->bounds[3 + a]);
-        scale = fmaxf(scale, fmaxf(hi[a] - lo[a], fmaxf(fabsf(lo[a]), fabsf(hi[a]))));
-    }
-    // conservative padding: the slab test must never cull a triangle the fp32 Moeller-Trumbore
-    // predicate would accept (its acceptance band is a few ulp of the scene scale wide)
-    const float pad = 1e-5f * scale;
-    info->pad = pad;
-    for (int a = 0; a < 3; ++a) {
-        const float g0 = lo[a] - 2.0f * pad, g1 = hi[a] + 2.0f * pad;
-        const float ext = fmaxf(g1 - g0, 1e-6f * scale + 1e-30f);
-        info->g_lo[a] = g0;
-        info->g_scale[a] = NVDR_GRID_MAX / ext;
-    }
-}
-
-__global__ void bvh_bounds_kernel(const float *__restrict__ verts, int64_t n_verts, BvhDeviceInfo *info)
-{
+    __shared__ float red[6][4];
+    __shared__ bool last;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_verts; i += (int64_t)gridDim.x * blockDim.x) {
 #pragma unroll
@@ -78,18 +62,65 @@ __global__ void bvh_bounds_kernel(const float *__restrict__ verts, int64_t n_ver
             mx[a] = fmaxf(mx[a], v);
         }
     }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        for (int o = 32; o >= 1; o >>= 1) {
-            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
-            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
-        }
-    }
-    if ((threadIdx.x & 63) == 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto reduce = [&]() {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&info->bounds[a], float_to_ordered(mn[a]));
-            atomicMax(&info->bounds[3 + a], float_to_ordered(mx[a]));
+            for (int o = 32; o >= 1; o >>= 1) {
+                mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+                mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+            }
+            if (lane == 0) { red[a][wave] = mn[a]; red[3 + a][wave] = mx[a]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(fminf(red[a][0], red[a][1]), fminf(red[a][2], red[a][3]));
+            mx[a] = fmaxf(fmaxf(red[3 + a][0], red[3 + a][1]), fmaxf(red[3 + a][2], red[3 + a][3]));
+        }
+    };
+    reduce();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {   // write-through stores (the hand-off recipe of bvh_fit_kernel: no cache to write back or drop)
+            __hip_atomic_store(&part[6 * blockIdx.x + a], mn[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&part[6 * blockIdx.x + 3 + a], mx[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the partials have arrived before the ticket moves
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; }
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = fminf(mn[a], __hip_atomic_load(&part[6 * b + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            mx[a] = fmaxf(mx[a], __hip_atomic_load(&part[6 * b + 3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
+    __syncthreads();
+    reduce();
+    if (threadIdx.x == 0) {
+        *ticket = 0u;                                                       // ready for the next build
+        float scale = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            info->bounds[a] = float_to_ordered(mn[a]);
+            info->bounds[3 + a] = float_to_ordered(mx[a]);
+            scale = fmaxf(scale, fmaxf(mx[a] - mn[a], fmaxf(fabsf(mn[a]), fabsf(mx[a]))));
+        }
+        info->height = 0;
+        info->root = 0;
+        // conservative padding: the slab test must never cull a triangle the fp32 Moeller-Trumbore
+        // predicate would accept (its acceptance band is a few ulp of the scene scale wide)
+        const float pad = 1e-5f * scale;
+        info->pad = pad;
+        for (int a = 0; a < 3; ++a) {
+            const float g0 = mn[a] - 2.0f * pad, g1 = mx[a] + 2.0f * pad;
+            const float ext = fmaxf(g1 - g0, 1e-6f * scale + 1e-30f);
+            info->g_lo[a] = g0;
+            info->g_scale[a] = NVDR_GRID_MAX / ext;
         }
     }
 }
@@ -132,8 +163,12 @@ __device__ __forceinline__ int lbvh_delta(const uint32_t *__restrict__ keys, int
     return a == b ? 32 + __clz(i ^ j) : __clz(a ^ b);
 }
 
-__global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, uint4 *__restrict__ nodes,
-                                     int *__restrict__ parent)
+// Besides the child links, ONE word per child says everything a climb needs: up[c] = (parent << 2) | (side << 1) | local, c an
+// internal node [0, n - 1) or leaf k at [n + k]; side = 0 left / 1 right; local = the parent's leaf range lies inside one block of
+// NVDR_FIT_BLOCK consecutive leaves, i.e. both of its subtrees are climbed by threads of the same workgroup of bvh_fit_kernel, which
+// then meet in LDS.  (The eight-wide builder's budget walk reads the same words.)
+#define NVDR_FIT_BLOCK 256
+__global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, uint4 *__restrict__ nodes, uint2 *__restrict__ up)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -159,9 +194,10 @@ __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, u
     unsigned *rec = (unsigned *)(nodes + 2 * i);
     rec[6] = (unsigned)left;
     rec[7] = (unsigned)right;
-    if (left < 0) parent[n + gamma] = i; else parent[left] = i;
-    if (right < 0) parent[n + gamma + 1] = i; else parent[right] = i;
-    if (i == 0) parent[0] = -1;
+    const unsigned w = ((unsigned)i << 2) | ((lo / NVDR_FIT_BLOCK) == (hi / NVDR_FIT_BLOCK) ? 1u : 0u);
+    up[left < 0 ? n + gamma : left].x = w;          // (.y of an internal node: its collapse-DP record, written by bvh_fit_kernel --
+    up[right < 0 ? n + gamma + 1 : right].x = w | 2u;   //  one 8-byte load per level serves the budget walk of the eight-wide builder)
+    if (i == 0) up[0].x = 0u;
 }
 
 // Write-through (sc1) accesses of the hand-off below: they reach / come from the level all XCDs agree on, so no cache has to be
@@ -183,18 +219,35 @@ __device__ __forceinline__ nvdr_f4 load_sc1_f4(const float *p)
     return v;
 }
 
-// One thread per leaf: write the triangle record, then climb.  The sibling's box, height and collapse-DP table are handed from
-// one workgroup to another through WRITE-THROUGH stores (cdna_hip_programming.md G16, the sc1 variant): sc1 stores -> drained
-// vmcnt -> relaxed agent-scope atomic on the node's counter; the second arriver reads them back with sc1 loads.  (Rounds 1-3 used
-// plain stores between an agent-scope release and acquire fence PER NODE: each release writes back the whole L2 of the XCD and each
-// acquire drops the CU's L1 -- 1.4 M of each on the 684 k-triangle mesh, 7-8 ms for this kernel, and the sample-generation kernel
-// that runs beside it on the other stream, whose stores those write-backs kept flushing, took 10.3 instead of 4 ms.)
-// `xchg`: [2 * n][8] floats, the record of the (left, right) child of every node: cost[0..6] of the collapse DP, then the height.
-__global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *__restrict__ tris,
-                               const uint32_t *__restrict__ order, int n, float4 *__restrict__ tri_rec, uint4 *nodes,
-                               const int *__restrict__ parent, int *flags, BvhDeviceInfo *info,
-                               float *xchg, bool dp, unsigned *dp_split, float c_leaf)
+// budget a child on side `side` (0 left, 1 right) of a node with DP record `rec` receives when that node holds budget i (1..8)
+__device__ __forceinline__ unsigned oct_child_budget(unsigned rec, unsigned i, int side)
 {
+    const unsigned kr = (rec >> 24) & 7u;
+    const unsigned sp = (i >= 2u && i <= 7u) ? ((rec >> (3u * i)) & 7u) : 0u;     // 0: the node stays one slot = it roots a wide node
+    const unsigned l = sp ? sp : kr, tot = sp ? i : 8u;
+    return side == 0 ? l : tot - l;
+}
+
+// One thread per leaf: write the triangle record, then climb; the thread that arrives second at a node takes it on.  What the two
+// subtrees of a node hand each other -- box, height, collapse-DP table: 44 bytes -- travels
+//   * through LDS when both subtrees belong to this workgroup's 256 consecutive (Morton-sorted) leaves: the bottom ~8-20 levels of
+//     every path, > 99 % of the nodes (round 4; a level costs an LDS round trip instead of three dependent trips to memory);
+//   * through memory otherwise, as WRITE-THROUGH stores (cdna_hip_programming.md G16, the sc1 variant): sc1 stores -> drained vmcnt ->
+//     relaxed agent-scope atomic on the node's counter; the second arriver reads them back with sc1 loads.  (Rounds 1-3 used plain stores
+//     between an agent-scope release and acquire fence PER NODE: each release writes back the whole L2 of the XCD and each acquire
+//     drops the CU's L1 -- 1.4 M of each on the 684 k-triangle mesh, 7-8 ms for this kernel, and the sample-generation kernel that
+//     runs beside it on the other stream, whose stores those write-backs kept flushing, took 10.3 instead of 4 ms.)
+// `xchg`: [2 * n][8] floats, the memory-side record of the (left, right) child of a node: cost[0..6] of the collapse DP, then the height.
+__global__ void __launch_bounds__(NVDR_FIT_BLOCK) bvh_fit_kernel(const float *__restrict__ verts, const int32_t *__restrict__ tris,
+                               const uint32_t *__restrict__ order, int n, float4 *__restrict__ tri_rec, uint4 *nodes,
+                               uint2 *up, int *flags, BvhDeviceInfo *info,
+                               float *xchg, float c_leaf, unsigned long long *jump)
+{
+    __shared__ unsigned l_box[NVDR_FIT_BLOCK][2][3];
+    __shared__ float l_x[NVDR_FIT_BLOCK][2][8];
+    __shared__ int l_flag[NVDR_FIT_BLOCK];
+    l_flag[threadIdx.x] = 0;
+    __syncthreads();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t orig = order[k];
@@ -223,8 +276,7 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
         qmx[a] = min(max((int)ceilf(hi) + 1, 0), 65535);
     }
     int height = 0;
-    int me = ~k;
-    int node = parent[n + k];
+    unsigned w = up[n + k].x;
     // The collapse into eight-wide nodes is chosen by dynamic programming over this same bottom-up pass (Ylitie, Karras, Laine 2017,
     // section 4.1): cost[i - 1] = cheapest representation of the subtree carried by this thread in AT MOST i slots of an ancestor's
     // wide node (i = 1..7), in units of (surface area x cost of one node step); a triangle costs c_leaf of a node step.
@@ -239,33 +291,58 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
         for (int i = 0; i < 7; ++i) cost[i] = leaf;
     }
     while (true) {
+        const int node = (int)(w >> 2), slot = (int)((w >> 1) & 1u);
+        const bool local = (w & 1u) != 0u;
+        const unsigned w_next = up[node].x;                                 // in flight while this level is worked on (up[0].x = 0: unused)
         unsigned *rec = (unsigned *)(nodes + 2 * (int64_t)node);
-        const int cl = (int)rec[6];
-        const int slot = (cl == me) ? 0 : 1;
         nvdr_u3 box;
         box.x = (unsigned)qmn[0] | ((unsigned)qmn[1] << 16);
         box.y = (unsigned)qmn[2] | ((unsigned)qmx[0] << 16);
         box.z = (unsigned)qmx[1] | ((unsigned)qmx[2] << 16);
-        store_sc1(rec + 3 * slot, box);
-        float *xc = xchg + 8 * (2 * (int64_t)node + slot);
-        nvdr_f4 x0, x1;
-        x0.x = cost[0]; x0.y = cost[1]; x0.z = cost[2]; x0.w = cost[3];
-        x1.x = cost[4]; x1.y = cost[5]; x1.z = cost[6]; x1.w = __int_as_float(height);
-        store_sc1(xc, x0);
-        store_sc1(xc + 4, x1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the write-through stores have arrived ...
-        const int old = __hip_atomic_fetch_add(&flags[node], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... before the counter moves
-        if (old == 0) return; // first arriver: the sibling subtree finishes this node
-        const nvdr_u3 sb = load_sc1_u3(rec + 3 * (1 - slot));
-        const float *sx = xchg + 8 * (2 * (int64_t)node + (1 - slot));
-        const nvdr_f4 y0 = load_sc1_f4(sx), y1 = load_sc1_f4(sx + 4);
-        const unsigned s0 = sb.x, s1 = sb.y, s2 = sb.z;
+        unsigned s0, s1, s2;
+        float sib[7];
+        int sib_height;
+        if (local) {
+            // both subtrees are this workgroup's: the node record gets a plain store (nobody reads it in this kernel), the hand-off is LDS
+            rec[3 * slot] = box.x; rec[3 * slot + 1] = box.y; rec[3 * slot + 2] = box.z;
+            const int li = node & (NVDR_FIT_BLOCK - 1);                     // a Karras node lies inside its own leaf range
+            l_box[li][slot][0] = box.x; l_box[li][slot][1] = box.y; l_box[li][slot][2] = box.z;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) l_x[li][slot][i] = cost[i];
+            l_x[li][slot][7] = __int_as_float(height);
+            // LDS-only ordering (s_waitcnt lgkmcnt): a workgroup-scope acq_rel atomic would also drain the global stores above, a trip to
+            // memory per level -- exactly what this path is there to avoid
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            const int old = __hip_atomic_fetch_add(&l_flag[li], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            if (old == 0) return; // first arriver: the sibling subtree finishes this node
+            s0 = l_box[li][1 - slot][0]; s1 = l_box[li][1 - slot][1]; s2 = l_box[li][1 - slot][2];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sib[i] = l_x[li][1 - slot][i];
+            sib_height = __float_as_int(l_x[li][1 - slot][7]);
+        } else {
+            store_sc1(rec + 3 * slot, box);
+            float *xc = xchg + 8 * (2 * (int64_t)node + slot);
+            nvdr_f4 x0, x1;
+            x0.x = cost[0]; x0.y = cost[1]; x0.z = cost[2]; x0.w = cost[3];
+            x1.x = cost[4]; x1.y = cost[5]; x1.z = cost[6]; x1.w = __int_as_float(height);
+            store_sc1(xc, x0);
+            store_sc1(xc + 4, x1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the write-through stores have arrived ...
+            const int old = __hip_atomic_fetch_add(&flags[node], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... before the counter moves
+            if (old == 0) return; // first arriver: the sibling subtree finishes this node
+            const nvdr_u3 sb = load_sc1_u3(rec + 3 * (1 - slot));
+            const float *sx = xchg + 8 * (2 * (int64_t)node + (1 - slot));
+            const nvdr_f4 y0 = load_sc1_f4(sx), y1 = load_sc1_f4(sx + 4);
+            s0 = sb.x; s1 = sb.y; s2 = sb.z;
+            sib[0] = y0.x; sib[1] = y0.y; sib[2] = y0.z; sib[3] = y0.w; sib[4] = y1.x; sib[5] = y1.y; sib[6] = y1.z;
+            sib_height = __float_as_int(y1.w);
+        }
         qmn[0] = min(qmn[0], (int)(s0 & 0xffffu)); qmn[1] = min(qmn[1], (int)(s0 >> 16)); qmn[2] = min(qmn[2], (int)(s1 & 0xffffu));
         qmx[0] = max(qmx[0], (int)(s1 >> 16)); qmx[1] = max(qmx[1], (int)(s2 & 0xffffu)); qmx[2] = max(qmx[2], (int)(s2 >> 16));
-        height = 1 + max(height, __float_as_int(y1.w));
-        if (dp) {
+        height = 1 + max(height, sib_height);
+        {
             // (left, right) tables in tree order, whichever of the two this thread carried
-            const float sib[7] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z};
             float Lc[7], Rc[7];
 #pragma unroll
             for (int i = 0; i < 7; ++i) { Lc[i] = slot == 0 ? cost[i] : sib[i]; Rc[i] = slot == 0 ? sib[i] : cost[i]; }
@@ -293,14 +370,25 @@ __global__ void bvh_fit_kernel(const float *__restrict__ verts, const int32_t *_
                 cost[i - 1] = bi;
                 packed |= ki << (3 * i);
             }
-            dp_split[node] = packed;                        // bits 3i..3i+2: slots for the left child at budget i (0: stay one slot); 24..26: the root split
+            up[node].y = packed;                            // bits 3i..3i+2: slots for the left child at budget i (0: stay one slot); 24..26: the root split
+            // starting point of the eight-wide builder's budget resolution (bvh_oct_budget_kernel): for every internal child c,
+            // jump[c] = (this node, F) with F[i - 1] = budget of c when this node holds budget i (a nibble each)
+            const int cl = (int)rec[6], cr = (int)rec[7];
+            unsigned Fl = 0u, Fr = 0u;
+#pragma unroll
+            for (unsigned i = 1; i <= 8; ++i) {
+                Fl |= oct_child_budget(packed, i, 0) << (4u * (i - 1u));
+                Fr |= oct_child_budget(packed, i, 1) << (4u * (i - 1u));
+            }
+            if (cl >= 0) jump[cl] = ((unsigned long long)Fl << 32) | (unsigned)node;
+            if (cr >= 0) jump[cr] = ((unsigned long long)Fr << 32) | (unsigned)node;
+            if (node == 0) jump[0] = 0x8888888800000000ull;         // the tree root holds budget 8 whatever is asked
         }
         if (node == 0) {
             info->height = height;
             return;
         }
-        me = node;
-        node = parent[node];
+        w = w_next;
     }
 }
 
@@ -380,24 +468,30 @@ __global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal
 
 
 // ---------------------------------------------------------------------------------------------
-// Eight-wide nodes (layout: bvh.h "oct").  Top-down collapse of the fitted binary tree, one THREAD per oct node, driven by a
-// ticket queue so that the whole tree is built by ONE launch whatever its depth:
-//   * oct node m is described by task[m] = the binary node it is rooted at; task[0] = 0 (the root), every other entry is -1 until
-//     the thread that builds the parent publishes it (relaxed agent-scope store; the only cross-thread payload is that one int:
-//     the binary tree itself was written by earlier kernels);
-//   * a thread draws tickets m = 0, 1, 2, ... from one counter and polls task[m].  A ticket's parent always has a smaller ticket,
-//     drawn earlier by a thread that is running (it holds the ticket), so every wait ends: no assumption about residency or
-//     dispatch order.  Polling and building are the two arms of ONE loop iteration, never a nested spin: lanes of one wavefront
-//     may wait for each other's output;
-//   * done == allocated (read in this order) <=> nothing is in flight and nothing more will be published: everybody leaves.
-// Collapse rule: the slots start as the two children; the internal slot with the largest (world-space) surface area is replaced by
-// its two children until eight slots are taken or only leaves remain.  Slots are then ordered internal-first (so the children
-// sit contiguously in oct[] and need no per-slot index) and their 16-bit boxes re-quantised to 8 bits in the node's own frame.
+// Eight-wide nodes (layout: bvh.h "oct"): the collapse of the fitted binary tree the dynamic programme of bvh_fit_kernel chose,
+// built WITHOUT any dependency between threads (round 4; rounds 2-3 built it top-down, one thread per oct node behind a ticket
+// queue: every oct level waited for the one above -- 0.73 ms for 684 k triangles, 0.2 ms for bob on 11 workgroups, and ~130 k
+// resident threads polling their task word):
+//   1. budgets.   Whether binary node v becomes the root of a wide node, or a slot of an ancestor's that is split further, depends on
+//      the BUDGET b(v) in 1..7 its parent hands it: b(child) = F_child(b(parent)) with F read off the parent's DP record (root split
+//      if the parent is a wide root -- budget 1, or its record says "stay one slot" --, else the split for that budget).  The maps
+//      (8 entries of 4 bits) compose; every node resolves its budget by lock-free pointer jumping over (ancestor, map) pairs until its
+//      map is constant -- budgets fall by at least one per level inside a wide node, so most maps are constant after a few levels,
+//      and the jumps double for the rest.  Wide roots are appended to a list.
+//   2. count.     Every wide root expands its slots (as the old builder did) and counts its internal / leaf slots.
+//   3. scan.      Exclusive prefix sum of the counts over the binary node index = where every wide node's children block and
+//      triangle block start.  The layout is therefore a function of the tree alone (the ticket builder's depended on thread timing),
+//      and follows the Karras numbering, i.e. the Morton order of the triangles.
+//   4. emit.      Every wide root expands again, finds its own index (parent's block + its position, recorded in step 2) and writes
+//      its 64-byte node and its triangles.
+// Slots are ordered internal-first (children contiguous in oct[], no per-slot index), the internal ones by rising surface area (the walk
+// takes a group's children lowest index first, and an any-hit ray is done at its first hit), and their 16-bit boxes re-quantised to
+// 8 bits in the node's own frame.
 
-#define OCT_CTL_TICKET 0
-#define OCT_CTL_ALLOC 32
-#define OCT_CTL_DONE 64
-#define OCT_CTL_TRIS 96
+#define OCT_CTL_ROOTS 0         // wide roots found (step 1)
+#define OCT_CTL_ALLOC 32        // oct nodes (written by the emit step: 1 + sum of the internal slots)
+#define OCT_CTL_DONE 64         // oct nodes written
+#define OCT_CTL_TRIS 96         // triangles placed
 #define OCT_CTL_WORDS 128
 
 #ifndef NVDR_OCT_ORDER
@@ -408,19 +502,21 @@ struct OctBuildArgs {
     const float4 *tris;     // triangle records in Morton order
     uint4 *oct;
     float4 *tris8;
-    int *task;
-    int *fault;             // the context's host-mapped flag word: bit 1 is raised if the build gives up waiting
-    unsigned *ctl;          // four counters, one 128-byte line each (OCT_CTL_*): next ticket, oct nodes allocated, oct nodes finished, triangles placed
+    unsigned long long *jump;   // [n] per binary node: (ancestor, budget map) of the budget resolution, see bvh_oct_budget_kernel
+    const uint2 *up;        // per binary node: .x = (parent << 2) | (side << 1) | local (bvh_hierarchy_kernel), .y = the slot splits the collapse DP chose (bvh_fit_kernel)
+    int *roots;             // [n] the wide roots (binary node ids), in no particular order
+    unsigned *wslot;        // [n] per wide root: (parent wide root << 3) | position among the parent's internal slots
+    unsigned long long *cnt;    // [n] per binary node: (internal slots << 32) | leaf slots of the wide node rooted there, 0 elsewhere
+    unsigned long long *scan;   // [n] exclusive prefix sum of cnt
+    unsigned *ctl;
     const BvhDeviceInfo *info;
-    int cap;                // entries of task[] / oct nodes that fit (>= n_tris)
-    const unsigned *dp_split;   // per binary node: the slot split chosen by the collapse DP of bvh_fit_kernel (NULL: greedy largest-area collapse)
+    int n_int_nodes;        // n_tris - 1
 };
 
 __global__ void bvh_oct_init_kernel(OctBuildArgs a, int n_tris)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.cap; i += gridDim.x * blockDim.x) a.task[i] = i == 0 && n_tris > 1 ? 0 : -1;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        a.ctl[OCT_CTL_TICKET] = 0u;
+        a.ctl[OCT_CTL_ROOTS] = 0u;
         a.ctl[OCT_CTL_ALLOC] = 1u;
         a.ctl[OCT_CTL_DONE] = n_tris > 1 ? 0u : 1u;
         a.ctl[OCT_CTL_TRIS] = n_tris > 1 ? 0u : 1u;
@@ -433,6 +529,55 @@ __global__ void bvh_oct_init_kernel(OctBuildArgs a, int n_tris)
             a.tris8[0] = a.tris[0]; a.tris8[1] = a.tris[1]; a.tris8[2] = a.tris[2];
         }
     }
+}
+
+__global__ void __launch_bounds__(1024) bvh_oct_budget_kernel(OctBuildArgs a)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_root = false;
+    if (v < a.n_int_nodes) {
+        // jump[v] = (anc, G): "v holds budget G[i - 1] when its ancestor anc holds budget i" (a nibble per i = 1..8).  bvh_fit_kernel left
+        // (parent, F_v) there; the tree root's entry is the constant 8.  Lock-free pointer jumping: compose with the ancestor's CURRENT
+        // entry -- whatever it has reached by now is a true statement about it -- publish the longer jump for the nodes below, repeat
+        // until G is constant.  (The first version of this kernel walked up one level at a time until the composition became constant:
+        // a handful of levels for most nodes, but all the way to the root for some, and the longest walk x the latency of a
+        // dependent load was the kernel's time whatever the loads cost: 0.13 ms on 684 k triangles.)
+        unsigned long long e = a.jump[v];
+        unsigned G = (unsigned)(e >> 32), anc = (unsigned)e;
+        while (G != (G & 15u) * 0x11111111u) {
+            const unsigned long long t = __hip_atomic_load(&a.jump[anc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned G2 = (unsigned)(t >> 32);
+            unsigned H = 0u;
+#pragma unroll
+            for (unsigned i = 0; i < 8; ++i) {
+                const unsigned mid = (G2 >> (4u * i)) & 15u;                // what anc holds when ITS ancestor holds i + 1 ...
+                H |= ((G >> (4u * (mid - 1u))) & 15u) << (4u * i);          // ... and what v holds then
+            }
+            G = H;
+            anc = (unsigned)t;
+            __hip_atomic_store(&a.jump[v], ((unsigned long long)G << 32) | anc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned b = G & 15u;
+        const unsigned own = a.up[v].y;
+        const unsigned rec = own;
+        is_root = v == 0 || b == 1u || (b <= 7u && ((rec >> (3u * b)) & 7u) == 0u);
+        a.cnt[v] = 0ull;
+    }
+    // append the wide roots: ONE atomic per workgroup of 1 024 threads.  (One per wavefront -- 10.7 k atomics on the same word for 684 k
+    // triangles -- was 0.13 ms whatever the rest of the kernel did: same-address atomics retire one every ~12 ns.)
+    __shared__ unsigned wave_cnt[16], wave_base[16];
+    const unsigned long long m = __ballot(is_root);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) { wave_base[w2] = tot; tot += wave_cnt[w2]; }
+        const unsigned base = tot ? atomicAdd(&a.ctl[OCT_CTL_ROOTS], tot) : 0u;
+        for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) wave_base[w2] += base;
+    }
+    __syncthreads();
+    if (is_root) a.roots[wave_base[wave] + __popcll(m & ((1ull << lane) - 1ull))] = v;
 }
 
 // A thread's eight slots live in LDS, field-major (field f of slot k of thread t at ((k * 7 + f) * 256 + t): consecutive threads hit
@@ -452,59 +597,41 @@ __device__ __forceinline__ void oct_load_children(const uint4 *__restrict__ node
     OCT_SL(kr, 4) = q.x >> 16; OCT_SL(kr, 5) = q.y & 0xffff; OCT_SL(kr, 6) = q.y >> 16;
 }
 
-__device__ void oct_build_node(const OctBuildArgs &a, int b, int m, int *sl)
+// the slots of the wide node rooted at binary node b: n of them in LDS, `perm` = their order (4 bits per position: internal slots
+// first, smaller surface area first, then the leaves)
+__device__ __forceinline__ void oct_expand(const OctBuildArgs &a, int b, int *sl, int &n, unsigned &perm, int &n_int, int &n_leaf)
 {
-    int n = 2;
+    n = 2;
     oct_load_children(a.nodes, b, sl, 0, 1);
     const float wx = 1.0f / a.info->g_scale[0], wy = 1.0f / a.info->g_scale[1], wz = 1.0f / a.info->g_scale[2];
-    if (a.dp_split) {
-        // the split the DP chose: slot k carries a budget; an internal child with budget i > 1 whose table says "give s of them to my
-        // left child" is replaced by its two children with budgets (s, i - s)
-        int budget[8];
-        {
-            const unsigned root = a.dp_split[b] >> 24;
-            budget[0] = (int)root;
-            budget[1] = 8 - (int)root;
-        }
-        bool again = true;
-        while (again) {
-            again = false;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (k >= n) continue;
-                const int c = OCT_SL(k, 0);
-                if (c < 0 || budget[k] < 2) continue;
-                const unsigned sp = (a.dp_split[c] >> (3 * budget[k])) & 7u;
-                if (sp == 0u) { budget[k] = 1; continue; }         // stays one slot (decided once)
-                const int bl = (int)sp, br = budget[k] - (int)sp;
-                oct_load_children(a.nodes, c, sl, k, n);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { if (j == k) budget[j] = bl; if (j == n) budget[j] = br; }
-                n++;
-                again = true;
-            }
-        }
-    } else
-    while (n < 8) {
-        int best = -1;
-        float best_area = -1.0f;
+    // the split the DP chose: slot k carries a budget; an internal child with budget i > 1 whose table says "give s of them to my
+    // left child" is replaced by its two children with budgets (s, i - s)
+    int budget[8];
+    {
+        const unsigned root = a.up[b].y >> 24;
+        budget[0] = (int)root;
+        budget[1] = 8 - (int)root;
+    }
+    bool again = true;
+    while (again) {
+        again = false;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (k >= n || OCT_SL(k, 0) < 0) continue;
-            const float ex = (float)(OCT_SL(k, 4) - OCT_SL(k, 1)) * wx, ey = (float)(OCT_SL(k, 5) - OCT_SL(k, 2)) * wy,
-                        ez = (float)(OCT_SL(k, 6) - OCT_SL(k, 3)) * wz;
-            const float area = ex * ey + ey * ez + ez * ex;
-            if (area > best_area) { best_area = area; best = k; }
+            if (k >= n) continue;
+            const int c = OCT_SL(k, 0);
+            if (c < 0 || budget[k] < 2) continue;
+            const unsigned sp = (a.up[c].y >> (3 * budget[k])) & 7u;
+            if (sp == 0u) { budget[k] = 1; continue; }         // stays one slot (decided once)
+            const int bl = (int)sp, br = budget[k] - (int)sp;
+            oct_load_children(a.nodes, c, sl, k, n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { if (j == k) budget[j] = bl; if (j == n) budget[j] = br; }
+            n++;
+            again = true;
         }
-        if (best < 0) break;
-        oct_load_children(a.nodes, OCT_SL(best, 0), sl, best, n);
-        n++;
     }
-    // order: internal children first, then leaves -- as a 4-bit-per-position permutation of the slots.  The walk takes the children of
-    // a group lowest index first, and an any-hit ray is done at its first hit: the internal children with the smaller surface area go
-    // first (insertion sort on the packed permutation; -0.8 ... -1.4 % traversal time, session 23).
-    unsigned perm = 0u;
-    int n_int = 0, n_leaf = 0;
+    perm = 0u;
+    n_int = 0; n_leaf = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (k < n && OCT_SL(k, 0) >= 0) perm |= (unsigned)k << (4 * n_int++);
@@ -532,83 +659,161 @@ __device__ void oct_build_node(const OctBuildArgs &a, int b, int m, int *sl)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (k < n && OCT_SL(k, 0) < 0) perm |= (unsigned)k << (4 * (n_int + n_leaf++));
-    // the children first: they are what the next level is waiting for
-    unsigned cb = 0, tb = 0;
-    if (n_int) cb = atomicAdd(&a.ctl[OCT_CTL_ALLOC], (unsigned)n_int);
-    if (n_leaf) tb = atomicAdd(&a.ctl[OCT_CTL_TRIS], (unsigned)n_leaf);
-    for (int p = 0; p < n_int; ++p)
-        if ((int)(cb + p) < a.cap)
-            __hip_atomic_store(&a.task[cb + p], OCT_SL((perm >> (4 * p)) & 15u, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the node's frame: lower corner + one power-of-two cell per axis such that the extent fits 8 bits
-    int org[3], e[3];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        int lo = 65535, hi = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < n) { lo = min(lo, OCT_SL(k, 1 + ax)); hi = max(hi, OCT_SL(k, 4 + ax)); }
-        org[ax] = lo;
-        int ee = 0;
-        while ((((hi - lo) + (1 << ee) - 1) >> ee) > 255) ++ee;
-        e[ax] = ee;
-    }
-    unsigned planes[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // lo.x[2], lo.y[2], lo.z[2], hi.x[2], hi.y[2], hi.z[2]
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        if (p >= n) continue;
-        const int k = (int)((perm >> (4 * p)) & 15u);
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            const unsigned qlo = (unsigned)((OCT_SL(k, 1 + ax) - org[ax]) >> e[ax]);                              // floor
-            const unsigned qhi = (unsigned)(((OCT_SL(k, 4 + ax) - org[ax]) + (1 << e[ax]) - 1) >> e[ax]);          // ceil
-            planes[2 * ax + (p >> 2)] |= qlo << (8 * (p & 3));
-            planes[6 + 2 * ax + (p >> 2)] |= qhi << (8 * (p & 3));
-        }
-    }
-    uint4 *o = a.oct + 4 * (int64_t)m;
-    o[0] = make_uint4((unsigned)org[0] | ((unsigned)org[1] << 16),
-                      (unsigned)org[2] | ((unsigned)e[0] << 16) | ((unsigned)e[1] << 20) | ((unsigned)e[2] << 24),
-                      cb | ((unsigned)n_int << 28), tb | ((unsigned)n_leaf << 28));
-    o[1] = make_uint4(planes[0], planes[1], planes[2], planes[3]);
-    o[2] = make_uint4(planes[4], planes[5], planes[6], planes[7]);
-    o[3] = make_uint4(planes[8], planes[9], planes[10], planes[11]);
-    for (int j = 0; j < n_leaf; ++j) {
-        const int k = (int)((perm >> (4 * (n_int + j))) & 15u);
-        const int64_t src = 3 * (int64_t)(~OCT_SL(k, 0)), dst = 3 * (int64_t)(tb + j);
-        a.tris8[dst] = a.tris[src]; a.tris8[dst + 1] = a.tris[src + 1]; a.tris8[dst + 2] = a.tris[src + 2];
-    }
 }
 
-__global__ void __launch_bounds__(256) bvh_oct_build_kernel(OctBuildArgs a)
+__global__ void __launch_bounds__(256) bvh_oct_count_kernel(OctBuildArgs a)
 {
     __shared__ int slots[8 * OCT_SLOT_FIELDS * 256];
     int *sl = slots + threadIdx.x;
-    int ticket = -1;
-    unsigned waited = 0;
-    while (true) {
-        if (ticket < 0) ticket = (int)atomicAdd(&a.ctl[OCT_CTL_TICKET], 1u);
-        const int b = ticket < a.cap ? __hip_atomic_load(&a.task[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        if (b >= 0) {
-            oct_build_node(a, b, ticket, sl);
-            atomicAdd(&a.ctl[OCT_CTL_DONE], 1u);
-            ticket = -1;
-        } else {
-            // The waiting threads poll their OWN task word; the shared counters only every 8th time (they sit on the lines the
-            // builders' atomics go to).  `done` first, `allocated` second: equal values then mean they were equal when `done` was
-            // read (both only grow, done <= allocated), i.e. every published node is finished and nobody can publish another one
-            if ((++waited & 7u) == 0u) {
-                const unsigned done = __hip_atomic_load(&a.ctl[OCT_CTL_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned alloc = __hip_atomic_load(&a.ctl[OCT_CTL_ALLOC], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (done == alloc) break;
+    const unsigned n_roots = a.ctl[OCT_CTL_ROOTS];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_roots; i += gridDim.x * blockDim.x) {
+        const int b = a.roots[i];
+        int n, n_int, n_leaf;
+        unsigned perm;
+        oct_expand(a, b, sl, n, perm, n_int, n_leaf);
+        a.cnt[b] = ((unsigned long long)n_int << 32) | (unsigned long long)n_leaf;
+        for (int p = 0; p < n_int; ++p) a.wslot[OCT_SL((perm >> (4 * p)) & 15u, 0)] = ((unsigned)b << 3) | (unsigned)p;
+    }
+}
+
+// Exclusive prefix sum of cnt[] in three launches without any dependency between workgroups (reduce per 2 048 elements -> one
+// workgroup scans the partials -> every workgroup scans its elements from its offset).  (rocPRIM's single-pass scan spins on its
+// predecessors -- decoupled look-back -- and, sharing the GPU with the persistent sample-generation kernel, 2 builds in 51 waited
+// 0.2-0.3 ms for it.)  Both halves of the packed (internal, leaf) counters are summed at once: neither can carry into the other
+// (< 2^29 each).
+#define OCT_SCAN_TILE 2048
+__global__ void __launch_bounds__(256) bvh_oct_scan_reduce_kernel(const unsigned long long *__restrict__ cnt, int n, unsigned long long *__restrict__ part)
+{
+    __shared__ unsigned long long red[4];
+    const int base = blockIdx.x * OCT_SCAN_TILE;
+    unsigned long long sum = 0ull;
+#pragma unroll
+    for (int j = 0; j < OCT_SCAN_TILE / 256; ++j) {
+        const int i = base + j * 256 + threadIdx.x;
+        if (i < n) sum += cnt[i];
+    }
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(1024) bvh_oct_scan_partials_kernel(unsigned long long *part, int n_part, unsigned *ctl)
+{
+    // one workgroup, exclusive scan in place, 1 024 partials per round with a running carry
+    __shared__ unsigned long long wave_sum[16];
+    __shared__ unsigned long long carry_s;
+    if (threadIdx.x == 0) carry_s = 0ull;
+    __syncthreads();
+    for (int base = 0; base < n_part; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned long long v = i < n_part ? part[i] : 0ull;
+        unsigned long long inc = v;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wave_sum[wave] = inc;
+        __syncthreads();
+        unsigned long long before = carry_s;
+        for (int w2 = 0; w2 < wave; ++w2) before += wave_sum[w2];
+        if (i < n_part) part[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    // the grand totals: oct nodes = the root + every internal slot, triangles placed = every leaf slot
+    if (threadIdx.x == 0) { ctl[OCT_CTL_ALLOC] = 1u + (unsigned)(carry_s >> 32); ctl[OCT_CTL_TRIS] = (unsigned)(carry_s & 0xffffffffull); }
+}
+
+__global__ void __launch_bounds__(256) bvh_oct_scan_apply_kernel(const unsigned long long *__restrict__ cnt, int n, const unsigned long long *__restrict__ part,
+                                                                  unsigned long long *__restrict__ scan)
+{
+    __shared__ unsigned long long wave_sum[4];
+    const int base = blockIdx.x * OCT_SCAN_TILE + threadIdx.x * (OCT_SCAN_TILE / 256);     // eight consecutive elements per thread
+    unsigned long long v[OCT_SCAN_TILE / 256], sum = 0ull;
+#pragma unroll
+    for (int j = 0; j < OCT_SCAN_TILE / 256; ++j) {
+        v[j] = base + j < n ? cnt[base + j] : 0ull;
+        sum += v[j];
+    }
+    unsigned long long inc = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    unsigned long long run = part[blockIdx.x] + inc - sum;
+    for (int w2 = 0; w2 < wave; ++w2) run += wave_sum[w2];
+#pragma unroll
+    for (int j = 0; j < OCT_SCAN_TILE / 256; ++j) {
+        if (base + j < n) scan[base + j] = run;
+        run += v[j];
+    }
+}
+
+__global__ void __launch_bounds__(256) bvh_oct_emit_kernel(OctBuildArgs a)
+{
+    __shared__ int slots[8 * OCT_SLOT_FIELDS * 256];
+    int *sl = slots + threadIdx.x;
+    const unsigned n_roots = a.ctl[OCT_CTL_ROOTS];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_roots; i += gridDim.x * blockDim.x) {
+        const int b = a.roots[i];
+        int n, n_int, n_leaf;
+        unsigned perm;
+        oct_expand(a, b, sl, n, perm, n_int, n_leaf);
+        const unsigned long long sc = a.scan[b];
+        const unsigned cb = 1u + (unsigned)(sc >> 32), tb = (unsigned)(sc & 0xffffffffull);
+        unsigned m = 0u;
+        if (b != 0) {
+            const unsigned ws = a.wslot[b];
+            m = 1u + (unsigned)(a.scan[ws >> 3] >> 32) + (ws & 7u);
+        }
+        // the node's frame: lower corner + one power-of-two cell per axis such that the extent fits 8 bits
+        int org[3], e[3];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            int lo = 65535, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < n) { lo = min(lo, OCT_SL(k, 1 + ax)); hi = max(hi, OCT_SL(k, 4 + ax)); }
+            org[ax] = lo;
+            int ee = 0;
+            while ((((hi - lo) + (1 << ee) - 1) >> ee) > 255) ++ee;
+            e[ax] = ee;
+        }
+        unsigned planes[12] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // lo.x[2], lo.y[2], lo.z[2], hi.x[2], hi.y[2], hi.z[2]
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (p >= n) continue;
+            const int k = (int)((perm >> (4 * p)) & 15u);
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const unsigned qlo = (unsigned)((OCT_SL(k, 1 + ax) - org[ax]) >> e[ax]);                              // floor
+                const unsigned qhi = (unsigned)(((OCT_SL(k, 4 + ax) - org[ax]) + (1 << e[ax]) - 1) >> e[ax]);          // ceil
+                planes[2 * ax + (p >> 2)] |= qlo << (8 * (p & 3));
+                planes[6 + 2 * ax + (p >> 2)] |= qhi << (8 * (p & 3));
             }
-            // every wait ends (see above); the bound only turns a bug into an error report instead of a hung GPU (~1 s of polling)
-            if (waited > (1u << 22)) {
-                atomicOr(a.fault, 2);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
+        }
+        uint4 *o = a.oct + 4 * (int64_t)m;
+        o[0] = make_uint4((unsigned)org[0] | ((unsigned)org[1] << 16),
+                          (unsigned)org[2] | ((unsigned)e[0] << 16) | ((unsigned)e[1] << 20) | ((unsigned)e[2] << 24),
+                          cb | ((unsigned)n_int << 28), tb | ((unsigned)n_leaf << 28));
+        o[1] = make_uint4(planes[0], planes[1], planes[2], planes[3]);
+        o[2] = make_uint4(planes[4], planes[5], planes[6], planes[7]);
+        o[3] = make_uint4(planes[8], planes[9], planes[10], planes[11]);
+        for (int j = 0; j < n_leaf; ++j) {
+            const int k = (int)((perm >> (4 * (n_int + j))) & 15u);
+            const int64_t src = 3 * (int64_t)(~OCT_SL(k, 0)), dst = 3 * (int64_t)(tb + j);
+            a.tris8[dst] = a.tris[src]; a.tris8[dst + 1] = a.tris[src + 1]; a.tris8[dst + 2] = a.tris[src + 2];
         }
     }
+    // (counters for the export / the structural checks: nodes written = wide roots; the totals of the internal and the leaf slots
+    // come out of the prefix sum, bvh_oct_scan_partials_kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[OCT_CTL_DONE] = n_roots;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -655,7 +860,8 @@ static int ctx_free_bvh(nvdr_ctx *c)
 {
     ctx_free(c, c->nodes); ctx_free(c, c->wide); ctx_free(c, c->oct); ctx_free(c, c->tris8); ctx_free(c, c->oct_task); ctx_free(c, c->tris);
     ctx_free(c, c->keys[0]); ctx_free(c, c->keys[1]); ctx_free(c, c->vals[0]); ctx_free(c, c->vals[1]);
-    ctx_free(c, c->parent); ctx_free(c, c->flags); ctx_free(c, c->dp_cost); ctx_free(c, c->dp_split); ctx_free(c, c->sort_tmp);
+    ctx_free(c, c->up); ctx_free(c, c->flags); ctx_free(c, c->dp_cost); ctx_free(c, c->sort_tmp);
+    ctx_free(c, c->oct_wslot); ctx_free(c, c->oct_jump); ctx_free(c, c->oct_cnt); ctx_free(c, c->oct_scan);
     c->sort_tmp_bytes = 0;
     c->cap_tris = 0;
     return 0;
@@ -683,6 +889,8 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     if (e == hipSuccess) e = hipMalloc((void **)&c->chunk_counts, sizeof(unsigned) * NVDR_MAX_CHUNKS);
     if (e == hipSuccess) e = hipMalloc((void **)&c->queues, sizeof(unsigned) * 32 * 256);
     if (e == hipSuccess) e = hipMalloc((void **)&c->oct_ctl, sizeof(unsigned) * OCT_CTL_WORDS);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->bounds_part, sizeof(float) * 6 * BVH_BOUNDS_BLOCKS + 128);
+    if (e == hipSuccess) { c->bounds_ticket = (unsigned *)(c->bounds_part + 6 * BVH_BOUNDS_BLOCKS); e = hipMemset(c->bounds_ticket, 0, 128); }
     if (e != hipSuccess) {
         hipFree(c->dinfo);
         if (c->ovf_host) hipHostFree(c->ovf_host);
@@ -709,9 +917,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         for (int k = 0; k < 3; ++k) c->per_cu[k] = c->per_cu[k] < 1 ? 1 : (c->per_cu[k] > 16 ? 16 : c->per_cu[k]);
     }
     if (const char *ab = getenv("NVDR_ASYNC_BUILD")) c->async_build = atoi(ab) != 0;
-    // NVDR_OCT_DP=0: greedy largest-area collapse into eight-wide nodes instead of the SAH-optimal one; NVDR_OCT_CLEAF: cost of a
-    // triangle test in units of a node step (experiments)
-    if (const char *od = getenv("NVDR_OCT_DP")) c->oct_dp = atoi(od) != 0;
+    // NVDR_OCT_CLEAF: cost of a triangle test in units of a node step in the collapse DP (experiments)
     if (const char *cl = getenv("NVDR_OCT_CLEAF")) { const float v = (float)atof(cl); if (v > 0.0f) c->oct_c_leaf = v; }
     // NVDR_LG_MODE: work split of the light-gradient gather (env_shade.hip): 0 every workgroup walks all bands, 1 one set of
     // workgroups per band, unset = by launch size
@@ -750,6 +956,7 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     hipFree(c->chunk_counts);
     hipFree(c->queues);
     hipFree(c->oct_ctl);
+    hipFree(c->bounds_part);
     ctx_free(c, c->spill);
     ctx_free(c, c->pix_list);
     ctx_free(c, c->rays); ctx_free(c, c->texel); ctx_free(c, c->vis); ctx_free(c, c->live); ctx_free(c, c->pix_origin); ctx_free(c, c->lg_part); ctx_free(c, c->lg_tags); ctx_free(c, c->cdf_guide);
@@ -775,12 +982,18 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
         NVDR_HIP_TRY(ctx_malloc(c, &c->keys[i], sizeof(uint32_t) * cap));
         NVDR_HIP_TRY(ctx_malloc(c, &c->vals[i], sizeof(uint32_t) * cap));
     }
-    NVDR_HIP_TRY(ctx_malloc(c, &c->parent, sizeof(int) * 2 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->up, sizeof(uint2) * 2 * cap));
     NVDR_HIP_TRY(ctx_malloc(c, &c->flags, sizeof(int) * cap));
     NVDR_HIP_TRY(ctx_malloc(c, &c->dp_cost, sizeof(float) * 16 * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->dp_split, sizeof(unsigned) * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_wslot, sizeof(unsigned) * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_jump, sizeof(unsigned long long) * cap));
+
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_cnt, sizeof(unsigned long long) * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_scan, sizeof(unsigned long long) * cap));
     size_t bytes = 0;
-    NVDR_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1], (size_t)cap, 0, 30));
+    NVDR_HIP_TRY(rocprim::radix_sort_pairs<nvdr_sort_config>(nullptr, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1], (size_t)cap, 0, 30));
+    const size_t bytes2 = sizeof(unsigned long long) * (size_t)(cap / OCT_SCAN_TILE + 2);       // partial sums of the slot-count scan
+    if (bytes2 > bytes) bytes = bytes2;
     NVDR_HIP_TRY(ctx_malloc(c, &c->sort_tmp, bytes + 256));
     c->sort_tmp_bytes = bytes + 256;
     c->cap_tris = cap;
@@ -862,33 +1075,40 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         NVDR_HIP_TRY(hipStreamWaitEvent(c->build_stream, c->ev_inputs, 0));
         stream = c->build_stream;
     }
-    bvh_init_info_kernel<<<1, 64, 0, stream>>>(c->dinfo);
-    bvh_bounds_kernel<<<min(div_up(n_verts, 256), 1024u), 256, 0, stream>>>(verts, n_verts, c->dinfo);
-    bvh_grid_kernel<<<1, 1, 0, stream>>>(c->dinfo);
+    bvh_bounds_kernel<<<min(div_up(n_verts, 1024), (unsigned)BVH_BOUNDS_BLOCKS), 256, 0, stream>>>(verts, n_verts, c->dinfo, c->bounds_part, c->bounds_ticket);
     if (rebuild != 0) {
         bvh_morton_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, n, c->dinfo, c->keys[0], c->vals[0]);
         size_t bytes = c->sort_tmp_bytes;
-        NVDR_HIP_TRY(rocprim::radix_sort_pairs(c->sort_tmp, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1],
-                                               (size_t)n, 0, 30, stream));
+        NVDR_HIP_TRY(rocprim::radix_sort_pairs<nvdr_sort_config>(c->sort_tmp, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1],
+                                                                 (size_t)n, 0, 30, stream));
         if (n > 1)
-            bvh_hierarchy_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->keys[1], n, c->nodes, c->parent);
+            bvh_hierarchy_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->keys[1], n, c->nodes, c->up);
     }
     NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
-    bvh_fit_kernel<<<div_up(n, 256), 256, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->parent,
-                                                        c->flags, c->dinfo, c->dp_cost, c->oct_dp != 0, c->dp_split, c->oct_c_leaf);
+    bvh_fit_kernel<<<div_up(n, NVDR_FIT_BLOCK), NVDR_FIT_BLOCK, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->up,
+                                                                              c->flags, c->dinfo, c->dp_cost, c->oct_c_leaf, c->oct_jump);
     if (c->trace_variant == 0 && n > 1) {
         if (!c->wide) NVDR_HIP_TRY(ctx_malloc(c, &c->wide, sizeof(uint4) * 4 * c->cap_tris, stream));
         bvh_widen_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->nodes, n - 1, c->wide);
     }
     {
-        // eight-wide nodes for the shadow-ray walk: one launch, ticket-driven (see bvh_oct_build_kernel)
+        // eight-wide nodes for the shadow-ray walk: budgets -> counts -> prefix sum -> emit, no inter-thread dependency (see above)
         OctBuildArgs oa;
-        oa.nodes = c->nodes; oa.tris = c->tris; oa.oct = c->oct; oa.tris8 = c->tris8; oa.task = c->oct_task; oa.ctl = c->oct_ctl;
-        oa.info = c->dinfo; oa.cap = n; oa.fault = c->ovf_dev; oa.dp_split = c->oct_dp ? c->dp_split : nullptr;
-        bvh_oct_init_kernel<<<min(div_up(n, 256), 1024u), 256, 0, stream>>>(oa, n);
+        oa.nodes = c->nodes; oa.tris = c->tris; oa.oct = c->oct; oa.tris8 = c->tris8; oa.up = c->up; oa.jump = c->oct_jump;
+        oa.roots = c->oct_task; oa.wslot = c->oct_wslot; oa.cnt = c->oct_cnt; oa.scan = c->oct_scan; oa.ctl = c->oct_ctl;
+        oa.info = c->dinfo; oa.n_int_nodes = n - 1;
+        bvh_oct_init_kernel<<<1, 64, 0, stream>>>(oa, n);
         if (n > 1) {
-            const unsigned blocks = min(div_up((n + 3) / 4, 256), (unsigned)c->n_cus * 4u);
-            bvh_oct_build_kernel<<<blocks < 1u ? 1u : blocks, 256, 0, stream>>>(oa);
+            bvh_oct_budget_kernel<<<div_up(n - 1, 1024), 1024, 0, stream>>>(oa);
+            // wide roots are ~n / 4.9; the grid-stride loops of the two expansion kernels cover whatever the device-side count says
+            const unsigned blocks = min(div_up((n + 3) / 4, 256), (unsigned)c->n_cus * 8u);
+            bvh_oct_count_kernel<<<blocks < 1u ? 1u : blocks, 256, 0, stream>>>(oa);
+            const unsigned tiles = div_up(n - 1, OCT_SCAN_TILE);
+            unsigned long long *part = (unsigned long long *)c->sort_tmp;      // the sort is done with its scratch by now
+            bvh_oct_scan_reduce_kernel<<<tiles, 256, 0, stream>>>(c->oct_cnt, n - 1, part);
+            bvh_oct_scan_partials_kernel<<<1, 1024, 0, stream>>>(part, (int)tiles, c->oct_ctl);
+            bvh_oct_scan_apply_kernel<<<tiles, 256, 0, stream>>>(c->oct_cnt, n - 1, part, c->oct_scan);
+            bvh_oct_emit_kernel<<<blocks < 1u ? 1u : blocks, 256, 0, stream>>>(oa);
         }
     }
     NVDR_LAUNCH_CHECK();

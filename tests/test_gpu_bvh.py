@@ -427,41 +427,48 @@ def _check_oct_tree(ctx, v, t):
         for j in range(n_leaf[node]):
             k, tri = n_int[node] + j, tbase[node] + j
             assert (lo[node, :, k] <= tmin[tri] + 1e-3).all() and (hi[node, :, k] >= tmax[tri] - 1e-3).all(), (node, j)
-    # an internal slot contains every TRIANGLE below the child node it points to (children are allocated after their parents, so
-    # one sweep from the last node to the first sees every child before its parent).  Note that it need not contain the child's
+    # an internal slot contains every TRIANGLE below the child node it points to.  Note that it need not contain the child's
     # own 8-bit slots: those are rounded outward in the child's frame, which may be coarser than what the parent's slot shows.
+    # (The layout follows the Karras numbering of the binary tree, round 4: a child block may lie before or behind its parent, so the
+    # nodes are visited in an order found by walking the tree from the root -- which also shows that every node is reachable once.)
     big = 1 << 30
     sub_lo = np.full((cnt['nodes'], 3), float(big))
     sub_hi = np.full((cnt['nodes'], 3), -float(big))
-    for node in range(cnt['nodes'] - 1, -1, -1):
+    order, seen, stack = [], np.zeros(cnt['nodes'], dtype=bool), [0]
+    while stack:
+        node = stack.pop()
+        assert not seen[node]
+        seen[node] = True
+        order.append(node)
+        stack.extend(range(cbase[node], cbase[node] + n_int[node]))
+    assert seen.all()
+    for node in reversed(order):                    # children before their parents
         for j in range(n_leaf[node]):
             tri = tbase[node] + j
             sub_lo[node] = np.minimum(sub_lo[node], tmin[tri])
             sub_hi[node] = np.maximum(sub_hi[node], tmax[tri])
         for k in range(n_int[node]):
             c = cbase[node] + k
-            assert c > node
             assert (lo[node, :, k] <= sub_lo[c] + 1e-3).all() and (hi[node, :, k] >= sub_hi[c] - 1e-3).all(), (node, k, c)
             sub_lo[node] = np.minimum(sub_lo[node], sub_lo[c])
             sub_hi[node] = np.maximum(sub_hi[node], sub_hi[c])
     return cnt['nodes'], float((n_int + n_leaf).mean())
 
 
-@pytest.mark.parametrize('rule', ['dp', 'greedy'])
-@pytest.mark.parametrize('kind', ['bob', 'spot', 'single', 'pair', 'fan', 'subdiv1'])
-def test_oct_tree_invariants(kind, rule, dev, monkeypatch):
-    """The eight-wide tree built by the ticket-driven collapse (bvh_oct_build_kernel): every triangle placed once, children and
-    leaves stored contiguously, every 8-bit box contains what it stands for -- on regular meshes, degenerate ones, and after a refit;
-    with the SAH-optimal slot choice of the fit kernel's dynamic programme (default) and with the greedy largest-area rule."""
+@pytest.mark.parametrize('kind', ['bob', 'spot', 'single', 'pair', 'fan', 'subdiv1', 'subdiv2'])
+def test_oct_tree_invariants(kind, dev):
+    """The eight-wide tree (budgets -> counts -> prefix sum -> emit, csrc/bvh.hip): every triangle placed once, every node reachable
+    once from the root, children and leaves stored contiguously, every 8-bit box contains what it stands for -- on regular meshes,
+    degenerate ones, and after a refit; the slot choice is the SAH-optimal one of the fit kernel's dynamic programme; the layout is a
+    function of the tree alone (two builds give the same bytes)."""
+    import numpy as np
     from nvdiffrecmc_amd import optixutils as ou
-    if rule == 'greedy':
-        monkeypatch.setenv('NVDR_OCT_DP', '0')          # read when a context is created
     if kind in ('bob', 'spot'):
         m = sc.load_mesh(kind)
         v, t = m['v_pos'], m['t_pos_idx']
-    elif kind == 'subdiv1':
+    elif kind in ('subdiv1', 'subdiv2'):
         m = sc.load_mesh('bob')
-        v, t = sc.subdivide(m['v_pos'], m['t_pos_idx'], 1)
+        v, t = sc.subdivide(m['v_pos'], m['t_pos_idx'], int(kind[-1]))
     elif kind == 'fan':
         v, t = _degenerate_fan(20000, 3)
     else:
@@ -472,20 +479,18 @@ def test_oct_tree_invariants(kind, rule, dev, monkeypatch):
     nodes, fill = _check_oct_tree(ctx, v, t)
     print('\n[%s] %d triangles -> %d oct nodes, %.2f slots used per node' % (kind, t.shape[0], nodes, fill))
     if t.shape[0] > 8:
-        assert nodes < t.shape[0] / 3 and fill > 4.0
-    if rule == 'dp' and kind in ('bob', 'spot'):
-        # the optimal collapse needs fewer, fuller nodes than the greedy one (bob: 2 2xx against 3 283)
-        monkeypatch.setenv('NVDR_OCT_DP', '0')
-        ctx_g = ou.OptiXContext()
-        monkeypatch.delenv('NVDR_OCT_DP')
-        ou.optix_build_bvh(ctx_g, v.to(dev), t.to(dev), rebuild=1)
-        nodes_g, _ = _check_oct_tree(ctx_g, v, t)
-        assert nodes < nodes_g
-        # and both trees answer alike
+        assert nodes < t.shape[0] / 4 and fill > 4.5           # the optimal collapse: ~n / 4.9 nodes (the greedy rule of round 3: n / 3.3)
+    if kind in ('bob', 'spot', 'fan'):
+        # deterministic layout: a second build (another context) gives the same bytes, and the walk through it answers like the binary walk
+        oct_a, tris_a, _ = ctx.bvh_export_oct()
+        ctx_b = ou.OptiXContext()
+        ou.optix_build_bvh(ctx_b, v.to(dev), t.to(dev), rebuild=1)
+        oct_b, tris_b, _ = ctx_b.bvh_export_oct()
+        assert np.array_equal(oct_a, oct_b) and np.array_equal(tris_a, tris_b)
         g0 = torch.Generator().manual_seed(3)
         ro = (torch.rand(20000, 3, generator=g0) * 2 - 1).to(dev) * float(v.abs().max())
         rd = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g0), dim=-1).to(dev)
-        assert torch.equal(ou.ops.trace_visibility_wide(ctx, ro, rd), ou.ops.trace_visibility_wide(ctx_g, ro, rd))
+        assert torch.equal(ou.ops.trace_visibility_wide(ctx, ro, rd), ou.ops.trace_visibility(ctx, ro, rd))
     g = torch.Generator().manual_seed(1)
     v2 = (v * 1.05 + 0.01 * torch.randn(v.shape, generator=g)).contiguous()
     ou.optix_build_bvh(ctx, v2.to(dev), t.to(dev), rebuild=0)                   # refit: the oct tree is rebuilt over the new boxes

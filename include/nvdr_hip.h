@@ -199,6 +199,8 @@ typedef struct nvdr_texture_args {
     float         *out[NVDR_MAX_TEXTURES];          /* forward */
     const float   *dout[NVDR_MAX_TEXTURES];         /* backward: [P,3] contiguous */
     float         *dtex[NVDR_MAX_TEXTURES];
+    int32_t        accumulate;                      /* backward: != 0 adds to what dtex[k] holds instead of zero-filling it first (a persistent
+                                                       gradient buffer that its consumer re-zeroes: nvdr_adam_tensor.zero_grad) */
 } nvdr_texture_args;
 int nvdr_texture_lookup_fwd(const nvdr_texture_args *args, void *stream);
 int nvdr_texture_lookup_bwd(const nvdr_texture_args *args, void *stream);
@@ -266,6 +268,11 @@ typedef struct nvdr_env_shade_args {
        is a launch parameter and would be frozen into a captured HIP graph; with the counter in device memory a replayed
        iteration draws fresh samples (render.py:112-116 increments its seed once per shade() call). */
     const uint32_t *rnd_seed_offset;
+    /* optional, forward only (with rnd_seed_offset): the launch first copies *rnd_seed_offset to *rnd_seed_snapshot, uses THAT value,
+       and then adds rnd_seed_advance to *rnd_seed_offset -- the "rnd_seed += 1" of render.py:116 and the snapshot a later backward
+       pass needs (pass the snapshot as its rnd_seed_offset) without two extra launches per shade() call. */
+    uint32_t *rnd_seed_snapshot;
+    uint32_t  rnd_seed_advance;
 } nvdr_env_shade_args;
 int nvdr_env_shade_fwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
 int nvdr_env_shade_bwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
@@ -315,6 +322,13 @@ int nvdr_image_loss_fwd(const nvdr_tensor *img, const nvdr_tensor *target, int l
                         void *stream);
 int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper,
                         const float *d_partials, float *img_grad, float *target_grad, void *stream);
+/* The same loss as ONE scalar, mean over the N H W pixels (additive: `torch.sum(out) / (N H W)` of renderutils/ops.py:494 folded in):
+ * partials = scratch of nvdr_image_loss_num_partials floats, out_mean f32 [1]; the backward takes the upstream gradient of the mean
+ * as a device scalar d_mean f32 [1]. */
+int nvdr_image_loss_mean_fwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper, float *partials,
+                             float *out_mean, void *stream);
+int nvdr_image_loss_mean_bwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper, const float *d_mean,
+                             float *img_grad, float *target_grad, void *stream);
 
 /* prepare_shading_normal_fwd/bwd (torch_bindings.cpp:148-219, normal.cu:95-179) */
 int nvdr_prepare_shading_normal_fwd(const nvdr_tensor *pos, const nvdr_tensor *view_pos, const nvdr_tensor *perturbed_nrm,
@@ -420,6 +434,10 @@ typedef struct nvdr_adam_tensor {
     float lr_scale;         /* this tensor's learning rate = lr * lr_scale (train.py:336-338: position / material / light rates); 1 for none */
     int32_t normalize3;     /* != 0: after the clamps every group of three elements is divided by max(its length, 1e-10)
                                (Texture2D.normalize_ of the normal map, train.py:473-474) */
+    uint8_t *active;        /* optional (n % 3 == 0): one byte per tile of 64 three-channel texels, zero-initialised by the caller once.  Tiles
+                               whose gradient is all zero and that never had a non-zero one are skipped after step 1 (their update is the
+                               identity): the sparse gradients of a nearest-texel texture lookup.  NULL: every element is updated */
+    int32_t zero_grad;      /* with `active`: the gradient of every updated tile is zeroed behind the update (`grad` is written) */
 } nvdr_adam_tensor;
 int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps, int *state,
                    void *stream);

@@ -36,7 +36,8 @@ class NvdrEnvShadeArgs(ctypes.Structure):
         ('diff', c_void_p), ('spec', c_void_p),
         ('diff_grad', NvdrTensor), ('spec_grad', NvdrTensor),
         ('gb_pos_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_kd_grad', c_void_p), ('gb_ks_grad', c_void_p),
-        ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p), ('reuse_stream_id', ctypes.c_uint64), ('rnd_seed_offset', c_void_p)]
+        ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p), ('reuse_stream_id', ctypes.c_uint64), ('rnd_seed_offset', c_void_p),
+        ('rnd_seed_snapshot', c_void_p), ('rnd_seed_advance', ctypes.c_uint32)]
 
 
 class NvdrGbufferArgs(ctypes.Structure):
@@ -67,7 +68,7 @@ MAX_TEXTURES = 4
 class NvdrTextureArgs(ctypes.Structure):        # nvdr_texture_args
     _fields_ = [('n_tex', ctypes.c_int32), ('res', ctypes.c_int32 * MAX_TEXTURES), ('tex', c_void_p * MAX_TEXTURES),
                 ('texc', c_void_p), ('rast', c_void_p), ('n_pix', c_int64), ('out', c_void_p * MAX_TEXTURES),
-                ('dout', c_void_p * MAX_TEXTURES), ('dtex', c_void_p * MAX_TEXTURES)]
+                ('dout', c_void_p * MAX_TEXTURES), ('dtex', c_void_p * MAX_TEXTURES), ('accumulate', ctypes.c_int32)]
 
 
 ALLOC_FN = ctypes.CFUNCTYPE(c_void_p, ctypes.c_size_t, c_int, c_void_p, c_void_p)     # nvdr_alloc_fn
@@ -96,7 +97,8 @@ _T = ctypes.POINTER(NvdrTensor)
 class NvdrAdamTensor(ctypes.Structure):     # include/nvdr_hip.h: nvdr_adam_tensor
     _fields_ = [('param', c_void_p), ('grad', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p), ('n', c_int64),
                 ('grad_scale', c_float), ('lo', c_float), ('hi', c_float), ('lo_vec', c_void_p), ('lo_vec_n', c_int64),
-                ('hi_vec', c_void_p), ('hi_vec_n', c_int64), ('lr_scale', c_float), ('normalize3', ctypes.c_int32)]
+                ('hi_vec', c_void_p), ('hi_vec_n', c_int64), ('lr_scale', c_float), ('normalize3', ctypes.c_int32),
+                ('active', c_void_p), ('zero_grad', ctypes.c_int32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -136,6 +138,8 @@ _SIGNATURES = {
     'nvdr_image_loss_num_partials': [c_int64, c_int64, c_int64],
     'nvdr_image_loss_fwd': [_T, _T, c_int, c_int, c_void_p, c_void_p],
     'nvdr_image_loss_bwd': [_T, _T, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    'nvdr_image_loss_mean_fwd': [_T, _T, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    'nvdr_image_loss_mean_bwd': [_T, _T, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_prepare_shading_normal_fwd': [_T] * 6 + [c_int, c_int, c_void_p, c_void_p],
     'nvdr_shading_frame_fwd': [_T] * 6 + [c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_prepare_shading_normal_bwd': [_T] * 7 + [c_int, c_int] + [c_void_p] * 6 + [c_void_p],

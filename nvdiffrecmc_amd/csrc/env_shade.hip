@@ -171,8 +171,29 @@ __global__ void __launch_bounds__(256) compact_pixels_kernel(const float *__rest
 // start of an env-shade launch: reset the covered-pixel counter (not when the forward's work list is reused) and the
 // live-ray counters of the chunks -- unless the stored ray stream is going to be reused, which is decided HERE, on the
 // device, because only the device knows whether the forward's covered pixels fitted one chunk
-__global__ void begin_launch_kernel(unsigned *pix_count, unsigned *chunk_counts, int n_chunks, int reuse, unsigned cap)
+// zero-fill of up to four output images in ONE launch (the reference's torch::zeros, torch_bindings.cpp:148-149; the caller's four
+// gradient tensors are separate storages: four memset launches of ~5 us each in a one-view iteration)
+__global__ void __launch_bounds__(256) zero_outputs_kernel(float *b0, float *b1, float *b2, float *b3, int64_t n)
 {
+    float *const b = blockIdx.y == 0 ? b0 : (blockIdx.y == 1 ? b1 : (blockIdx.y == 2 ? b2 : b3));
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 1024) {
+        b[i] = 0.0f;
+        if (i + 256 < n) b[i + 256] = 0.0f;
+        if (i + 512 < n) b[i + 512] = 0.0f;
+        if (i + 768 < n) b[i + 768] = 0.0f;
+    }
+}
+
+__global__ void begin_launch_kernel(unsigned *pix_count, unsigned *chunk_counts, int n_chunks, int reuse, unsigned cap,
+                                    unsigned *seed_counter, unsigned *seed_snapshot, unsigned seed_advance)
+{
+    // the device-resident seed counter of shade() (render.py:112-116): this launch uses the value it finds (kept in the snapshot
+    // for the backward pass), the next one the advanced value
+    if (seed_snapshot && threadIdx.x == 0) {
+        const unsigned s = *seed_counter;
+        *seed_snapshot = s;
+        *seed_counter = s + seed_advance;
+    }
     const bool keep = reuse && *pix_count <= cap;
     __syncthreads();
     if (!reuse && threadIdx.x == 0) *pix_count = 0;
@@ -1631,6 +1652,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     NVDR_REQUIRE(c->n_tris > 0, "env_shade: no BVH built on this context (call optix_build_bvh first)");
     if (int r0 = ctx_check_overflow(c, "env_shade")) return r0;
     NVDR_REQUIRE(a->bsdf <= 2, "env_shade: BSDF index %u out of range", a->bsdf);
+    NVDR_REQUIRE(!a->rnd_seed_snapshot || a->rnd_seed_offset, "env_shade: rnd_seed_snapshot without rnd_seed_offset");
     NVDR_REQUIRE(a->n_samples_x >= 1 && a->n_samples_x <= 256, "env_shade: n_samples_x %u out of range", a->n_samples_x);
     const int64_t N = a->ro.size[0], H = a->ro.size[1], W = a->ro.size[2];
     NVDR_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), "env_shade: bad launch extent");
@@ -1712,6 +1734,11 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     const unsigned lg_spw = lg_records ? (unsigned)(n_bands + (group_slots + 127) / 128 + 2) : 0u;
     const int64_t bwd_waves_max = (int64_t)c->n_cus * (per_cu[2] < 1 ? 1 : per_cu[2]) * waves_per_block;
     const int64_t cap = stream_chunk_pixels(c, npix, S, bwd_waves_max * lg_spw * 128 * 16);
+    // chunk-local slot numbers are 31-bit: stream_chunk_pixels may have RAISED cap to npix / NVDR_MAX_CHUNKS behind its own clamp
+    // (a launch so large that it cannot be cut into NVDR_MAX_CHUNKS chunks below the limit) -- an error, not a silent wrap-around
+    NVDR_REQUIRE(cap * 2ll * (int64_t)S < (1ll << 31), "env_shade: %lld pixels at %u strata need chunks of %lld pixels, beyond the 2^31 "
+                 "ray slots of one chunk of the ray stream (at most %d chunks per launch): render fewer views per launch",
+                 (long long)npix, S, (long long)cap, NVDR_MAX_CHUNKS);
     const int n_chunks = (int)((npix + cap - 1) / cap);
     // the chunk is raised to npix / NVDR_MAX_CHUNKS when the byte budget asks for more chunks than that; chunk-local slot numbers
     // must still fit 31 bits (they are stored as unsigned / int in the live list, the light-gradient keys and the band gather)
@@ -1735,7 +1762,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     p.N = (int)N; p.H = (int)H; p.W = (int)W;
     p.bsdf = a->bsdf; p.n = a->n_samples_x; p.S = S; p.seed = a->rnd_seed; p.pix_offset = a->pixel_index_offset;
     p.shadow_scale = a->shadow_scale;
-    p.seed_dev = a->rnd_seed_offset;
+    p.seed_dev = (!backward && a->rnd_seed_snapshot) ? a->rnd_seed_snapshot : a->rnd_seed_offset;
     p.L = L; p.log2L = lg;
     p.vis_cache = a->vis_cache;
     p.vis_words = (int)((S + 31) / 32);
@@ -1752,8 +1779,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (p.spec == p.diff + 3 * npix) {
             NVDR_HIP_TRY(hipMemsetAsync(p.diff, 0, sizeof(float) * 6 * npix, stream)); // torch::zeros, torch_bindings.cpp:148-149
         } else {
-            NVDR_HIP_TRY(hipMemsetAsync(p.diff, 0, sizeof(float) * 3 * npix, stream));
-            NVDR_HIP_TRY(hipMemsetAsync(p.spec, 0, sizeof(float) * 3 * npix, stream));
+            zero_outputs_kernel<<<dim3(min(div_up(3 * npix, 1024), 2048u), 2), 256, 0, stream>>>(p.diff, p.spec, nullptr, nullptr, 3 * npix);
         }
     } else {
         NVDR_REQUIRE(a->gb_pos_grad && a->gb_normal_grad && a->gb_kd_grad && a->gb_ks_grad && a->light_grad,
@@ -1766,10 +1792,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (p.g_nrm == p.g_pos + 3 * npix && p.g_kd == p.g_nrm + 3 * npix && p.g_ks == p.g_kd + 3 * npix) {
             NVDR_HIP_TRY(hipMemsetAsync(p.g_pos, 0, sizeof(float) * 12 * npix, stream));   // caller packed the four outputs
         } else {
-            NVDR_HIP_TRY(hipMemsetAsync(p.g_pos, 0, sizeof(float) * 3 * npix, stream));
-            NVDR_HIP_TRY(hipMemsetAsync(p.g_nrm, 0, sizeof(float) * 3 * npix, stream));
-            NVDR_HIP_TRY(hipMemsetAsync(p.g_kd, 0, sizeof(float) * 3 * npix, stream));
-            NVDR_HIP_TRY(hipMemsetAsync(p.g_ks, 0, sizeof(float) * 3 * npix, stream));
+            zero_outputs_kernel<<<dim3(min(div_up(3 * npix, 1024), 2048u), 4), 256, 0, stream>>>(p.g_pos, p.g_nrm, p.g_kd, p.g_ks, 3 * npix);
         }
         p.light_elems = 3 * n_texels;
         const size_t need = (size_t)p.light_elems * (size_t)(lg_rows > 8 ? lg_rows : 8);
@@ -1846,7 +1869,8 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         p.guide_log_cols = lc;
     }
     c->stream_id = 0; // invalid while being rewritten
-    begin_launch_kernel<<<1, 256, 0, stream>>>(&c->dinfo->pix_count, c->chunk_counts, n_chunks, p.reuse, p.pix_cap);
+    begin_launch_kernel<<<1, 256, 0, stream>>>(&c->dinfo->pix_count, c->chunk_counts, n_chunks, p.reuse, p.pix_cap,
+                                               const_cast<unsigned *>(a->rnd_seed_offset), backward ? nullptr : a->rnd_seed_snapshot, a->rnd_seed_advance);
     if (!reuse)
         compact_pixels_kernel<<<div_up(npix, 256 * NVDR_COMPACT_ROUNDS), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
                                                                       &c->dinfo->pix_count);

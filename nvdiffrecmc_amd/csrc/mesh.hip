@@ -354,8 +354,9 @@ extern "C" int nvdr_texture_lookup_bwd(const nvdr_texture_args *a, void *stream)
 {
     TexLookup p;
     if (int r = tex_params(a, p, true, "nvdr_texture_lookup_bwd")) return r;
-    for (int k = 0; k < p.n_tex; ++k)
-        NVDR_HIP_TRY(hipMemsetAsync(p.dtex[k], 0, sizeof(float) * 3 * (size_t)p.res[k] * p.res[k], (hipStream_t)stream));
+    if (!a->accumulate)
+        for (int k = 0; k < p.n_tex; ++k)
+            NVDR_HIP_TRY(hipMemsetAsync(p.dtex[k], 0, sizeof(float) * 3 * (size_t)p.res[k] * p.res[k], (hipStream_t)stream));
     if (p.P == 0) return 0;
     texture_lookup_kernel<true><<<div_up(p.P, 256), 256, 0, (hipStream_t)stream>>>(p);
     NVDR_LAUNCH_CHECK();

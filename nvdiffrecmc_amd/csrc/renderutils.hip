@@ -190,12 +190,12 @@ extern "C" int nvdr_image_loss_fwd(const nvdr_tensor *img, const nvdr_tensor *ta
     return 0;
 }
 
-extern "C" int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper,
-                                   const float *d_partials, float *img_grad, float *target_grad, void *stream)
+static int image_loss_bwd_impl(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper,
+                               const float *d_partials, const float *d_mean, float mean_scale, float *img_grad, float *target_grad, void *stream)
 {
     static const char *OP = "image_loss_bwd";
     // target_grad may be NULL (a target that does not require a gradient: the reference image of a training iteration)
-    NVDR_REQUIRE(img && target && d_partials && img_grad, "%s: NULL argument", OP);
+    NVDR_REQUIRE(img && target && (d_partials || d_mean) && img_grad, "%s: NULL argument", OP);
     const Extent e = make_extent(img, target);
     CHECK_VIEW(img, 3);
     CHECK_VIEW(target, 3);
@@ -203,7 +203,8 @@ extern "C" int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *ta
     const int64_t stride = nvdr_image_loss_num_partials(e.N, e.H, e.W) * LOSS_BLOCK;
     return launch_ew(e, (hipStream_t)stream, [=] __device__(int n, int h, int w, int64_t i) {
         // pixel i was summed into partial ((i mod grid span) / block) by the forward kernel
-        const float d_out = d_partials[(i % stride) / LOSS_BLOCK];
+        // (mean variant: every pixel has the same upstream gradient, d(mean) / (N H W), read from ONE device scalar)
+        const float d_out = d_mean ? d_mean[0] * mean_scale : d_partials[(i % stride) / LOSS_BLOCK];
         const F3 a = fetch3(vi, n, h, w), b = fetch3(vt, n, h, w);
         const float av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
         float gi[3], gt[3];
@@ -228,6 +229,46 @@ extern "C" int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *ta
         store3(img_grad, i, f3(gi[0], gi[1], gi[2]));
         if (target_grad) store3(target_grad, i, f3(gt[0], gt[1], gt[2]));
     });
+}
+
+extern "C" int nvdr_image_loss_bwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper,
+                                   const float *d_partials, float *img_grad, float *target_grad, void *stream)
+{
+    return image_loss_bwd_impl(img, target, loss, tonemapper, d_partials, nullptr, 0.0f, img_grad, target_grad, stream);
+}
+
+// ---- the loss as ONE scalar (additive): what `torch.sum(partials) / (N H W)` of renderutils/ops.py:494 and its adjoint cost five
+// small torch kernels for.  Forward: the partial sums + one workgroup that adds them in a fixed order; backward: the upstream
+// gradient is a device scalar, nothing is expanded.
+__global__ void __launch_bounds__(256) image_loss_reduce_kernel(const float *__restrict__ partials, int64_t n, float scale, float *__restrict__ out)
+{
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += partials[i];
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+
+extern "C" int nvdr_image_loss_mean_fwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper, float *partials,
+                                        float *out_mean, void *stream)
+{
+    NVDR_REQUIRE(out_mean, "image_loss_mean_fwd: NULL output");
+    if (int r = nvdr_image_loss_fwd(img, target, loss, tonemapper, partials, stream)) return r;
+    const Extent e = make_extent(img, target);
+    const int64_t n = nvdr_image_loss_num_partials(e.N, e.H, e.W);
+    image_loss_reduce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials, n, 1.0f / (float)((int64_t)e.N * e.H * e.W), out_mean);
+    NVDR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int nvdr_image_loss_mean_bwd(const nvdr_tensor *img, const nvdr_tensor *target, int loss, int tonemapper,
+                                        const float *d_mean, float *img_grad, float *target_grad, void *stream)
+{
+    NVDR_REQUIRE(d_mean, "image_loss_mean_bwd: NULL upstream gradient");
+    const Extent e = make_extent(img, target);
+    return image_loss_bwd_impl(img, target, loss, tonemapper, nullptr, d_mean, 1.0f / (float)((int64_t)e.N * e.H * e.W), img_grad, target_grad, stream);
 }
 
 // =============================================================================================

@@ -18,9 +18,13 @@ class FusedAdam:
     (device tensors: element e is bounded by lo_vec[e % len(lo_vec)] / hi_vec[e % len(hi_vec)]; Texture2D.clamp_).
     grad_scales[i]: factor applied to the gradient of parameter i inside the update (p.grad itself is left alone).
     lr_scales[i]: learning rate of parameter i relative to lr (the reference runs three Adams with position / material / light
-    rates, train.py:336-356).  normalize3[i]: renormalise every texel of three channels after the clamps (the normal map)."""
+    rates, train.py:336-356).  normalize3[i]: renormalise every texel of three channels after the clamps (the normal map).
+    sparse[i]: the tensor is a three-channel texture whose gradient is zero almost everywhere (a nearest-texel lookup): tiles of 64
+    texels without gradient and without history are skipped -- same parameters, a fraction of the traffic (csrc/optim.hip).
+    zero_grad[i] (with sparse): p.grad is zeroed behind the update (a persistent scatter-add buffer then needs no memset)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clamps=None, grad_scales=None, lr_scales=None, normalize3=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, clamps=None, grad_scales=None, lr_scales=None, normalize3=None,
+                 sparse=None, zero_grad=None):
         self.params = list(params)
         if not 1 <= len(self.params) <= 8:
             raise ValueError('FusedAdam: 1..8 parameter tensors')
@@ -32,6 +36,9 @@ class FusedAdam:
         self.grad_scales = list(grad_scales) if grad_scales is not None else [1.0] * len(self.params)
         self.lr_scales = list(lr_scales) if lr_scales is not None else [1.0] * len(self.params)
         self.normalize3 = list(normalize3) if normalize3 is not None else [False] * len(self.params)
+        self.sparse = list(sparse) if sparse is not None else [False] * len(self.params)
+        self.zero_grad_after = list(zero_grad) if zero_grad is not None else [False] * len(self.params)
+        self.active = [torch.zeros((p.numel() // 3 + 63) // 64, dtype=torch.uint8, device=p.device) if sp else None for p, sp in zip(self.params, self.sparse)]
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.state = torch.zeros(8, dtype=torch.int32, device=self.params[0].device)     # steps taken, scratch, beta1^t, beta2^t (doubles)
@@ -76,6 +83,8 @@ class FusedAdam:
             t.hi_vec = hi_vec.data_ptr() if hi_vec is not None else None
             t.hi_vec_n = hi_vec.numel() if hi_vec is not None else 0
             t.lr_scale, t.normalize3 = float(self.lr_scales[i]), int(bool(self.normalize3[i]))
+            t.active = self.active[i].data_ptr() if self.active[i] is not None else None
+            t.zero_grad = int(bool(self.zero_grad_after[i] and self.active[i] is not None))
         with torch.no_grad():
             _lib.check(_lib.load().nvdr_adam_step_partial(tab, len(idx), self.lr, self.betas[0], self.betas[1], self.eps,
                                                           _lib.ptr(self.state), int(bool(advance)), _lib.stream_ptr()), 'adam_step')

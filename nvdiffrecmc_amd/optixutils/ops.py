@@ -68,6 +68,7 @@ class OptiXContext:
         self.cache_visibility = None
         self.pixel_index_offset = None
         self.seed_offset = None
+        self.seed_advance = 0       # != 0 (with seed_offset and a fixed rnd_seed): every forward launch adds this to the device counter itself
 
     def set_stream_budget(self, megabytes):
         """HBM the ray stream between the three env-shade stages may take (default 8192 MB); larger launches are processed
@@ -204,6 +205,7 @@ class _optix_env_shade_func(torch.autograd.Function):
     @staticmethod
     def forward(ctx, optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, BSDF,
                 n_samples_x, rnd_seed, shadow_scale):
+        ctx.set_materialize_grads(False)
         _rnd_seed = np.random.randint(2**31) if rnd_seed is None else rnd_seed
         perms = _perms_for(n_samples_x, ro.device)
         w = optix_ctx.cpp_wrapper
@@ -211,9 +213,17 @@ class _optix_env_shade_func(torch.autograd.Function):
         # the device-resident seed counter is SNAPSHOT here: the caller advances it right after this call (render.py:116),
         # long before backward runs, and backward must repeat the forward's samples (same slots, same cached visibility bits)
         so = getattr(optix_ctx, 'seed_offset', None)
-        seed_snap = so.clone() if (so is not None and rnd_seed is not None) else so
-        a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
-                       BSDF, n_samples_x, _rnd_seed, shadow_scale, off, seed_snap)
+        adv = int(getattr(optix_ctx, 'seed_advance', 0) or 0)
+        if so is not None and rnd_seed is not None and adv:
+            # the launch itself snapshots the counter and advances it (render.py:116 `rnd_seed += 1`): no clone / add kernels
+            seed_snap = torch.empty_like(so)
+            a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
+                           BSDF, n_samples_x, _rnd_seed, shadow_scale, off, so)
+            a.rnd_seed_snapshot, a.rnd_seed_advance = seed_snap.data_ptr(), adv
+        else:
+            seed_snap = so.clone() if (so is not None and rnd_seed is not None) else so
+            a = _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks, light, pdf, rows, cols, perms,
+                           BSDF, n_samples_x, _rnd_seed, shadow_scale, off, seed_snap)
         N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
         # independent storages like the reference's two torch::zeros (torch_bindings.cpp:148-149): views of one packed
         # buffer would make any in-place op on an output an autograd error; the library zero-fills them
@@ -252,6 +262,10 @@ class _optix_env_shade_func(torch.autograd.Function):
                        ctx.BSDF, ctx.n_samples_x, _rnd_seed, ctx.shadow_scale, ctx.pixel_index_offset, ctx.seed_snap)
         N, H, W = ro.shape[0], ro.shape[1], ro.shape[2]
         dev = ro.device
+        if diff_grad is None:
+            diff_grad = torch.zeros(N, H, W, 3, dtype=torch.float32, device=dev)
+        if spec_grad is None:
+            spec_grad = torch.zeros(N, H, W, 3, dtype=torch.float32, device=dev)
         diff_grad, spec_grad = diff_grad.contiguous(), spec_grad.contiguous()
         a.diff_grad = _lib.tensor_view(diff_grad, lead=False)
         a.spec_grad = _lib.tensor_view(spec_grad, lead=False)

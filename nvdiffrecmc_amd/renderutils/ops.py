@@ -182,6 +182,7 @@ class _shading_frame_func(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading, opengl, ro_eps):
+        ctx.set_materialize_grads(False)        # no zero tensors for the two outputs that carry no gradient
         ins = (pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm)
         for name, t in zip(('pos', 'view_pos', 'perturbed_nrm', 'smooth_nrm', 'smooth_tng', 'geom_nrm'), ins):
             _check4(t, 'shading_frame ' + name, 3)
@@ -200,6 +201,8 @@ class _shading_frame_func(torch.autograd.Function):
     def backward(ctx, dnrm, _dunit, _dro):
         ts = ctx.saved_tensors
         N, H, W = _extent(*ts)
+        if dnrm is None:
+            return (None,) * 9
         dnrm = dnrm.contiguous()
         grads = torch.empty(6, N, H, W, 3, dtype=torch.float32, device=dnrm.device)
         keep, refs = _views(*ts, dnrm)
@@ -294,6 +297,42 @@ class _image_loss_func(torch.autograd.Function):
         _lib.check(lib.nvdr_image_loss_bwd(*refs, _LOSS.get(ctx.loss, 0), int(ctx.tonemapper == 'log_srgb'), _lib.ptr(dout),
                                            _lib.ptr(gi), _lib.ptr(gt) if gt is not None else None, _lib.stream_ptr()), 'image_loss_bwd')
         return gi, gt, None, None
+
+
+class _image_loss_mean_func(torch.autograd.Function):
+    """The loss as one scalar in two launches (partials + a fixed-order reduction) and a backward that reads its upstream gradient
+    from a device scalar: replaces `torch.sum(partials) / (N H W)` and the five small kernels of its adjoint."""
+
+    @staticmethod
+    def forward(ctx, img, target, loss, tonemapper):
+        _check4(img, 'img', 3)
+        _check4(target, 'target', 3)
+        ctx.loss, ctx.tonemapper = loss, tonemapper
+        ctx.save_for_backward(img, target)
+        lib = _lib.load()
+        N, H, W = _extent(img, target)
+        part = torch.empty(lib.nvdr_image_loss_num_partials(N, H, W) + 1, dtype=torch.float32, device=img.device)
+        keep, refs = _views(img, target)
+        _lib.check(lib.nvdr_image_loss_mean_fwd(*refs, _LOSS.get(loss, 0), int(tonemapper == 'log_srgb'), _lib.ptr(part[1:]), _lib.ptr(part),
+                                                _lib.stream_ptr()), 'image_loss_mean_fwd')
+        return part[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, target = ctx.saved_tensors
+        N, H, W = _extent(img, target)
+        dout = dout.contiguous().view(1)
+        gi = torch.empty(N, H, W, 3, dtype=torch.float32, device=img.device)
+        gt = torch.empty(N, H, W, 3, dtype=torch.float32, device=img.device) if ctx.needs_input_grad[1] else None
+        keep, refs = _views(img, target)
+        _lib.check(_lib.load().nvdr_image_loss_mean_bwd(*refs, _LOSS.get(ctx.loss, 0), int(ctx.tonemapper == 'log_srgb'), _lib.ptr(dout),
+                                                        _lib.ptr(gi), _lib.ptr(gt) if gt is not None else None, _lib.stream_ptr()), 'image_loss_mean_bwd')
+        return gi, gt, None, None
+
+
+def image_loss_mean(img, target, loss='l1', tonemapper='none'):
+    """image_loss with the mean folded into the kernels (additive; same value up to the order of the final sum)."""
+    return _finite(_image_loss_mean_func.apply(img, target, loss, tonemapper), 'image_loss')
 
 
 def image_loss(img, target, loss='l1', tonemapper='none', use_python=False):

@@ -172,6 +172,7 @@ class DirectLightingStep:
         # the global seed counter of render.py:19,112-116 -- kept in DEVICE memory and added to rnd_seed by the kernels
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.ctx.seed_offset = self.seed_dev
+        self.ctx.seed_advance = 1        # render.py:116 `rnd_seed += 1`, done by the env-shade launch itself
         with torch.no_grad():
             if material_set == 'r3':
                 self.target = self._render(kd_true, ks_true, light_true).detach()
@@ -223,8 +224,13 @@ class DirectLightingStep:
         # torch.optim.Adam with parameter groups and the reference's sequence of calls.
         self._fused_update = bool(fused) and self.dev.type == 'cuda'
         self._lr_scales = lr_scales
+        self._tex_grad, self._tex_grad_dirty = None, False
         if self._fused_update:
-            self.opt = FusedAdam(self.params, lr=lr, grad_scales=grad_scales, clamps=clamps, lr_scales=lr_scales, normalize3=norm3)
+            sparse = [nm in ('kd', 'ks', 'normal') and material_set == 'full' for nm in names]
+            self.opt = FusedAdam(self.params, lr=lr, grad_scales=grad_scales, clamps=clamps, lr_scales=lr_scales, normalize3=norm3,
+                                 sparse=sparse, zero_grad=sparse)
+            if material_set == 'full':
+                self._tex_grad = [torch.zeros_like(p) for p in self.params[:3]]
         else:
             groups = [{'params': [p], 'lr': lr * sc_} for p, sc_ in zip(self.params, lr_scales)]
             try:
@@ -294,7 +300,6 @@ class DirectLightingStep:
         diff, spec = ou.optix_env_shade(self.ctx, self.mask, ro, self.gb_pos, nrm, self.view_pos, kd, ks, light.base,
                                         light._pdf, light.rows[:, 0], light.cols, BSDF='pbr', n_samples_x=self.n,
                                         rnd_seed=0, shadow_scale=1.0)      # effective seed = 0 + the device counter
-        self.seed_dev += 1                                                  # render.py:116, on the device (graph-capturable)
         if self.denoiser is not None and not self.denoiser_demodulate:
             # the non-demodulated branch of shade() (render.py:124-131): ONE filter pass over the combined colour
             shaded = ru.shade_composite(diff, spec, kd, ks) if self.fused else diff * (kd * (1.0 - ks[..., 2:3])) + spec
@@ -320,22 +325,44 @@ class DirectLightingStep:
             spec = self.denoiser.forward(torch.cat((spec, nrm, self.gb_depth), dim=-1))
         return diff * (kd * (1.0 - ks[..., 2:3])) + spec
 
-    def _render_full(self, kd_tex, ks_tex, nrm_tex, light, gb=None):
+    def _render_full(self, kd_tex, ks_tex, nrm_tex, light, gb=None, grad_buffers=None):
         """shade() with the reference's material set (render.py:61-131): kd / ks / perturbed normal from three textures in one
         lookup launch, shading frame, env-shade, both lights filtered in one pass, composite.  gb: a differentiable G-buffer dict
         (optimize_geometry) or None = the cached one."""
         rast = self.rast if gb is None else gb['rast']
         pos, gnrm, snrm, tng, depth, texc = ((self.gb_pos, self.gb_geom_nrm, self.gb_smooth_nrm, self.gb_tangent, self.gb_depth, self.gb_texc) if gb is None else
                                              (gb['gb_pos'], gb['gb_geometric_normal'], gb['gb_normal'], gb['gb_tangent'], gb['gb_depth'], gb['gb_texc']))
-        kd, ks, pn = rd.texture_lookup((kd_tex, ks_tex, nrm_tex), texc, rast)
-        nrm, nn, ro = ru.shading_frame(pos, self.view_pos, pn, snrm, tng, gnrm, two_sided_shading=True, opengl=True, ro_eps=0.001)
         self.ctx.pixel_index_offset = self.pixel_index_offset
+        self.ctx.cache_visibility = not self.retrace_backward
+        if not (self.fused and self.dev.type == 'cuda'):
+            # the same iteration written as the reference writes it (render.py:61-131): torch indexing for the texel lookups, the
+            # operator API for the rest, the 8-channel cat in front of each filter pass, the composite in torch
+            m = (rast[..., 3:4] > 0).float()
+
+            def look(t):
+                R = t.shape[0]
+                ix = (texc[..., 0] * R).long().clamp(0, R - 1)
+                iy = ((1.0 - texc[..., 1]) * R).long().clamp(0, R - 1)
+                return t[iy, ix] * m
+            kd, ks, pn = look(kd_tex), look(ks_tex), look(nrm_tex)
+            nrm = ru.prepare_shading_normal(pos, self.view_pos, pn, snrm, tng, gnrm, two_sided_shading=True, opengl=True)
+            ro = pos + nrm * 0.001
+            diff, spec = ou.optix_env_shade(self.ctx, rast[..., 3], ro, pos, nrm, self.view_pos, kd, ks, light.base,
+                                            light._pdf, light.rows[:, 0], light.cols, BSDF='pbr', n_samples_x=self.n,
+                                            rnd_seed=0, shadow_scale=1.0)
+            if self.denoiser is not None and not self.denoiser_demodulate:
+                return self.denoiser.forward(torch.cat((diff * (kd * (1.0 - ks[..., 2:3])) + spec, nrm, depth), dim=-1))
+            if self.denoiser is not None:
+                diff = self.denoiser.forward(torch.cat((diff, nrm, depth), dim=-1))
+                spec = self.denoiser.forward(torch.cat((spec, nrm, depth), dim=-1))
+            return diff * (kd * (1.0 - ks[..., 2:3])) + spec
+        kd, ks, pn = rd.texture_lookup((kd_tex, ks_tex, nrm_tex), texc, rast, grad_buffers=grad_buffers)
+        nrm, nn, ro = ru.shading_frame(pos, self.view_pos, pn, snrm, tng, gnrm, two_sided_shading=True, opengl=True, ro_eps=0.001)
         self.ctx.cache_visibility = not self.retrace_backward
         # mask = rast[..., -1] as the reference passes it (render.py:113): a strided view, > 0 = covered
         diff, spec = ou.optix_env_shade(self.ctx, rast[..., 3], ro, pos, nrm, self.view_pos, kd, ks, light.base,
                                         light._pdf, light.rows[:, 0], light.cols, BSDF='pbr', n_samples_x=self.n,
                                         rnd_seed=0, shadow_scale=1.0)
-        self.seed_dev += 1
         if self.denoiser is not None and not self.denoiser_demodulate:
             shaded = ru.shade_composite(diff, spec, kd, ks)
             cw = ou.ops._bilateral_denoiser_func.apply(shaded, nn, depth, self.denoiser.sigma)
@@ -354,6 +381,10 @@ class DirectLightingStep:
         v_pos = self.v_pos if self.optimize_geometry else self.mesh['v_pos']
         ou.optix_build_bvh(self.ctx, v_pos, self.mesh['t_pos_idx'], rebuild=1)
         self.opt.zero_grad(set_to_none=True)
+        if self._tex_grad is not None:
+            if self._tex_grad_dirty:            # a backward pass whose gradients no update consumed (forward_backward called on its own)
+                self._zero_tex_grad()
+            self._tex_grad_dirty = True
         if self.material_set == 'r3':
             img = self._render(self.kd_tex, self.ks, self.light)
         else:
@@ -363,8 +394,8 @@ class DirectLightingStep:
                 v_nrm, v_tng = mesh_ops.mesh_frame(v_pos, self.topo)
                 gb = rd.gbuffer(self.ctx, v_pos, v_nrm, v_tng, self.topo, self.mvp, self.cam, (self.res, self.res))
                 self._set_gbuffer({k: v.detach() for k, v in gb.items()})        # shade_inputs() / mask follow the moving mesh
-            img = self._render_full(self.kd_tex, self.ks_tex, self.nrm_tex, self.light, gb)
-        loss = ru.image_loss(img, self.target, loss='l1', tonemapper='log_srgb')
+            img = self._render_full(self.kd_tex, self.ks_tex, self.nrm_tex, self.light, gb, grad_buffers=self._tex_grad if self.fused else None)
+        loss = (ru.image_loss_mean if (self.fused and self.dev.type == 'cuda') else ru.image_loss)(img, self.target, loss='l1', tonemapper='log_srgb')
         loss.backward()
         return loss
 
@@ -424,6 +455,7 @@ class DirectLightingStep:
         ex = self._exchange(world_size)
         if not packed:
             ex.pack()
+            self._zero_tex_grad()
         ex.start()
         chunks = self._chunk_indices() if self._fused_update else [None]
         for k in ex.chunks():
@@ -433,6 +465,24 @@ class DirectLightingStep:
             else:
                 self._update(subset=chunks[k], advance=(k == len(chunks) - 1), grad_mult=f)
         return ex.bytes_per_step
+
+    def _tex_grad_guard(self):
+        """One rank: FusedAdam zeroes the texture gradients it consumed, which clears the persistent scatter-add buffers only if
+        p.grad IS that buffer.  Should autograd have copied instead of adopting (a hook, a second reference), clear them explicitly."""
+        if self._tex_grad is not None:
+            self._tex_grad_dirty = False
+            for p, b in zip(self.params[:3], self._tex_grad):
+                if p.grad is None or p.grad.data_ptr() != b.data_ptr():
+                    self._zero_tex_grad()
+                    return
+
+    def _zero_tex_grad(self):
+        """Several ranks: the optimizer reads (and zeroes) the exchange buckets, not the persistent scatter-add buffers of the texture
+        lookup -- those are cleared here, once their content has been packed."""
+        if self._tex_grad is not None:
+            self._tex_grad_dirty = False
+            for b in self._tex_grad:
+                b.zero_()
 
     def _capture(self, world_size):
         """HIP graphs: (A) update_pdf + BVH rebuild + render + loss + backward [+ the pack of the exchange buckets], (B_k) light-gradient
@@ -445,8 +495,10 @@ class DirectLightingStep:
             self._loss_static = self.forward_backward()
             if world_size == 1:
                 self._update()
+                self._tex_grad_guard()
             else:
                 self._exchange(world_size).pack()
+                self._zero_tex_grad()
         gbs = None
         if world_size > 1:
             ex = self._exchange(world_size)
@@ -485,4 +537,5 @@ class DirectLightingStep:
         else:
             self.allreduce_bytes = 0
             self._update()
+            self._tex_grad_guard()
         return loss

@@ -290,6 +290,101 @@ def mem_figures(c, kernel_ms):
     return out
 
 
+def cpu_baseline_torch():
+    """The literal baseline BASELINE.json configs[0] sketches, in full: bob 128x128, n_samples_x = 2 (4 spp, 8 shadow rays per covered
+    pixel and pass), the shadow test as brute-force PyTorch-CPU ops over all 10 688 triangles (oracle/torch_baseline.py: torch.set_num_threads
+    = the host's cores), forward + re-tracing backward, around the restated raygen program."""
+    import torch
+    from oracle import oracle as orc, scene_cpu, torch_baseline as tb
+    nt = orc.max_threads()
+    inp = scene_cpu.make_inputs('bob', 128, 128, 2, n_threads=nt)
+    kw = scene_cpu.shade_kwargs(inp)
+    g = torch.Generator().manual_seed(0)
+    dg, sg = torch.rand(1, 128, 128, 3, generator=g), torch.rand(1, 128, 128, 3, generator=g)
+    f, b, t = tb.direct_lighting_torch_shadow(inp['mesh'], kw, 2, diff_grad=dg, spec_grad=sg, n_threads=nt)
+    rays = 2 * t['rays_per_pass']
+    return {'value': rays / t['total_s'], 'unit': 'rays/s', 'cores': nt, 'kind': 'port',
+            'sample': 'BASELINE configs[0] in full: bob 128x128, n_samples_x=2, %d covered pixels, %d shadow rays (forward + re-traced backward) against '
+                      '%d triangles by chunked torch ops on the CPU (%.1f s of the %.1f s; the rest is the restated raygen / shading program)'
+                      % (t['covered'], rays, inp['mesh']['t_pos_idx'].shape[0], t['torch_shadow_fwd_s'] + t['bwd_s'], t['total_s']),
+            'seconds': t['total_s']}
+
+
+def other_config_object(name, args, dev):
+    """One of the other BASELINE configs on the same line (rank 0, N = 1): a few timed iterations, rays from the counting launch; no
+    counters (the dedicated `--config <name>` run has them)."""
+    import torch
+    from nvdiffrecmc_amd.trainer import DirectLightingStep
+    from nvdiffrecmc_amd import optixutils as ou
+    pre = PRESETS[name]
+    t0 = time.perf_counter()
+    H, n, nv = pre['res'], pre['n'], pre['batch']
+    lock = pre.get('lock_pos', True) or args.material_set != 'full'
+    step = DirectLightingStep(pre['mesh'], H, n, view=list(range(nv)), n_views=nv, device=dev, retrace_backward=True, subdiv=pre['subdiv'],
+                              material_set=args.material_set, tex_res=pre.get('tex_res', 1024), optimize_geometry=not lock, lr_pos=BENCH_LR_POS)
+    for _ in range(4):
+        step.step(1)
+    K = 6
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    for _ in range(K):
+        step.step(1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - w0
+    with torch.no_grad():
+        L = step.light
+        _, ro, _, nrm, _, kd, ks = step.shade_inputs()
+        P, n_box, n_tri, n_traced = ou.ops.env_shade_traversal_counts(step.ctx, step.mask, ro, step.gb_pos, nrm, step.view_pos, kd, ks, L.base, L._pdf,
+                                                                     L.rows[:, 0], L.cols, n_samples_x=n, rnd_seed=0)
+    out = {'workload': pre['what'] + ', batch of %d views' % nv, 'mesh_triangles': int(step.mesh['t_pos_idx'].shape[0]), 'covered_pixels': P,
+           'rays_traversed_per_pass': n_traced, 'steps': K, 'ms_per_step': dt / K * 1e3, 'rays_per_sec': 2.0 * n_traced * K / dt,
+           'geometry': 'locked' if lock else 'trained', 'seconds': time.perf_counter() - t0}
+    del step
+    torch.cuda.empty_cache()
+    return out
+
+
+def exchange_probe(step, dev):
+    """The gradient exchange of the real parameter set through RCCL with ONE rank (the only N this box offers): pack of the chunk
+    buckets + one asynchronous all-reduce per chunk + waits, HIP-event time per iteration.  What it shows is the fixed cost of the
+    exchange path (a one-rank all-reduce moves nothing over xGMI)."""
+    import torch
+    import torch.distributed as dist
+    from nvdiffrecmc_amd.parallel import GradientExchange
+    own = False
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        with _stdout_to_stderr():
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        own = True
+    try:
+        groups = [[step.params[i] for i in idx] for idx in step._chunk_indices()]
+        src = [torch.zeros_like(p) for p in step.params]
+        ex = GradientExchange(groups, 1)
+        ex.active = True
+        ms = []
+        for it in range(12):
+            for p, g in zip(step.params, src):          # fresh gradients, as a backward pass leaves them (wait() points .grad into the buckets)
+                p.grad = g
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ex.pack()
+            ex.start(skip_single=False)
+            for k in ex.chunks():
+                ex.wait(k)
+            b.record()
+            b.synchronize()
+            if it >= 2:
+                ms.append(a.elapsed_time(b))
+        return {'backend': dist.get_backend(), 'world': 1, 'chunks': len(groups), 'bucket_bytes': int(sum(b.numel() for b in ex.buckets) * 4),
+                'ms_per_iteration': statistics.median(ms)}
+    finally:
+        if own:
+            with _stdout_to_stderr():
+                dist.destroy_process_group()
+
+
 def large_mesh_object(args, dev):
     """The L2-spilling workload on the SAME bench line (rank 0, N = 1): `dmtet800` -- bob subdivided three times, 684 032 triangles
     (9 MB of eight-wide nodes + 33 MB of triangle records against 4 MB of L2 per XCD), 800x800, 64 spp, 8 views -- a few timed
@@ -386,10 +481,32 @@ def parse_args():
     ap.add_argument('--pmc-keep', default=None, help='directory to write the per-kernel counter table of the PMC passes to')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--no-large-mesh', action='store_true', help='skip the `large_mesh` object (dmtet800: 684 k triangles) of the default N = 1 line')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the `other_configs` objects (spot512x256, hotdog512x256) of the default N = 1 line')
     ap.add_argument('--no-extended', action='store_true', help='skip the extended median phase and the cached-visibility loop')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
                     help='capture the iteration in HIP graphs (auto: when a rank renders <= 2 views -- the launch-bound regime -- or there are several ranks)')
     return ap.parse_args()
+
+
+class _stdout_to_stderr:
+    """RCCL announces itself on STDOUT when it is loaded ("Librccl path : ..."); the one JSON line must stay the only thing there."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        try:        # the banner sits in the C library's stdout buffer (a pipe is fully buffered) and would come out at process exit
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
 
 
 def _free_port():
@@ -445,10 +562,11 @@ def run(args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('NVDR_BENCH_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; gloo only for dry runs
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
-        else:
-            dist.init_process_group(backend)
+        with _stdout_to_stderr():
+            if backend == 'nccl':
+                dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+            else:
+                dist.init_process_group(backend)
         world = dist.get_world_size()                 # what the collective library actually initialised
     dev = torch.device('cuda', dev_index)
 
@@ -700,6 +818,27 @@ def run(args):
             out['cpu_baseline']['note'] = ('this is the reference\'s own CUDA raygen program compiled for the host and run under OpenMP on every core '
                                            '(kind "reference"), NOT the brute-force PyTorch-CPU path BASELINE.json sketches: the same arithmetic, a '
                                            'faster CPU implementation of it than torch ops would be')
+        if world == 1 and not args.no_cpu_baseline and args.config == 'bob512':
+            try:
+                out['cpu_baseline_torch'] = cpu_baseline_torch()
+            except Exception as e:
+                out['cpu_baseline_torch'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if world == 1 and not args.pmc_child:
+            try:
+                with _stdout_to_stderr():
+                    out['config']['exchange_world1'] = exchange_probe(step, dev)
+            except Exception as e:
+                out['config']['exchange_world1'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if world == 1 and args.config == 'bob512' and not args.no_other_configs and not args.no_large_mesh and not args.pmc_child and args.res is None and args.subdiv is None \
+                and args.batch is None:
+            out['other_configs'] = {}
+            step = None
+            torch.cuda.empty_cache()
+            for name in ('spot512x256', 'hotdog512x256'):
+                try:
+                    out['other_configs'][name] = other_config_object(name, args, dev)
+                except Exception as e:
+                    out['other_configs'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and args.config == 'bob512' and not args.no_large_mesh and not args.pmc_child and args.res is None and args.subdiv is None:
             try:
                 step = None
@@ -710,7 +849,8 @@ def run(args):
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        with _stdout_to_stderr():
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -274,3 +274,33 @@ def test_mesh_frame_oracle_vs_reference_module():
         assert_close(vn, gold['v_nrm'], tol, floor=1.0, what='v_nrm')
         assert_close(vt, gold['v_tng'], tol * 10, floor=1.0, what='v_tng')
         assert_close(v_pos.grad, gold['v_pos_grad'], 2e-4, floor=float(np.abs(gold['v_pos_grad']).max()) * 0.01, what='v_pos_grad')
+
+
+# ---------------------------------------------------------------------------------------------- the literal torch-CPU baseline
+def test_torch_bruteforce_shadow_path_matches_the_oracle():
+    """BASELINE configs[0]'s "brute-force PyTorch ray-triangle shadow test on CPU" (oracle/torch_baseline.py, timed by bench.py as
+    cpu_baseline_torch): its visibility equals the oracle's bit-defined predicate on every CLEAR ray (no (ray, triangle) pair within
+    1e-5 of a decision boundary), nearly all rays are clear, and the images / gradients it drives equal the oracle's own."""
+    from oracle import scene_cpu, torch_baseline as tb
+    n = 2
+    inp = scene_cpu.make_inputs('bob', 64, 64, n, n_threads=NT)
+    kw = scene_cpu.shade_kwargs(inp)
+    m = inp['mesh']
+    g = torch.Generator().manual_seed(0)
+    dg, sg = torch.rand(1, 64, 64, 3, generator=g), torch.rand(1, 64, 64, 3, generator=g)
+    f, b, t = tb.direct_lighting_torch_shadow(m, kw, n, diff_grad=dg, spec_grad=sg, n_threads=NT, want=True)
+    ref_f = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=0, n_threads=NT, want_vis=True)
+    ref_b = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=0, n_threads=NT, diff_grad=dg, spec_grad=sg)
+    cov = kw['mask'].reshape(-1) > 0
+    assert t['covered'] == int(cov.sum()) == ref_f['covered'] and t['rays_per_pass'] == 2 * n * n * t['covered']
+    ro, rd = t['rays']
+    vis, margin = tb.shadow_rays_bruteforce_torch(m['v_pos'], m['t_pos_idx'], ro, rd, want_margin=True)
+    ov = orc.visibility(m['v_pos'], m['t_pos_idx'], ro, rd, n_threads=NT)
+    clear = margin > 1e-5
+    assert clear.float().mean().item() > 0.98
+    assert torch.equal(vis[clear], ov[clear])                                    # bit for bit on the clear rays
+    assert (vis != ov).float().mean().item() < 2e-3
+    if torch.equal(t['vis'][cov], ref_f['vis'][cov]):                            # (the usual case: no ray on a boundary at all)
+        assert torch.equal(f['diff'], ref_f['diff']) and torch.equal(f['spec'], ref_f['spec'])
+        assert torch.equal(b['gb_kd_grad'], ref_b['gb_kd_grad']) and torch.equal(b['gb_normal_grad'], ref_b['gb_normal_grad'])
+        assert_close(b['light_grad'], ref_b['light_grad'], 1e-5, floor=float(ref_b['light_grad'].abs().max()))     # summed over OpenMP threads

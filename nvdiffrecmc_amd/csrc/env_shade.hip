@@ -535,6 +535,13 @@ __device__ __forceinline__ unsigned flush_live(const unsigned *stage, unsigned s
     return 0;
 }
 
+
+// (Round 4 measured and dropped a pass between stage 1 and stage 2 that ordered every window of 2 048 entries of the live-ray list by
+// the direction octant of its rays -- the "bucket the claim windows by direction" lead of round 3.  Bit-identical outputs, and the
+// traversal kernel 2-11 % SLOWER on bob, 8-15 % slower on 684 k triangles (profiles/r04_ab_live_sort.md): a wavefront's 64 consecutive
+// entries are the rays of ONE pixel -- one origin -- and walk the same nodes around that origin before they part; 64 rays of one
+// octant from sixteen pixels do not.  The list order the generation kernel produces is the coherent one.)
+
 __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -399,6 +399,7 @@ def large_mesh_object(args, dev):
     step = DirectLightingStep(pre['mesh'], H, n, view=list(range(nv)), n_views=nv, device=dev, retrace_backward=True, subdiv=pre['subdiv'],
                               material_set=args.material_set, tex_res=pre.get('tex_res', 1024),
                               optimize_geometry=(args.material_set == 'full' and not pre.get('lock_pos', True) and args.lock_pos != 'on'), lr_pos=BENCH_LR_POS)
+    step_unlocked = step.optimize_geometry
     for _ in range(4):
         step.step(1)
     step.ctx.set_profiling(True)
@@ -449,9 +450,14 @@ def large_mesh_object(args, dev):
                 out['dispatches_per_launch'] = chunks
             mem = mem_figures(c, trace_ms)
             out['hbm'] = {k: mem[k] for k in ('hbm_bytes', 'fetch_bytes_corrected', 'write_bytes', 'hbm_GBs', 'hbm_frac') if k in mem}
+            out['hbm']['note'] = ('L2-miss (fabric) traffic / HBM peak: the working set (9 MB of nodes + 33 MB of triangle records) fits the 256 MB Infinity '
+                                  'Cache, whose hits FETCH_SIZE counts.  2 x FETCH_SIZE is calibrated for this access pattern (profiles/r04_gather64_calibration.md: '
+                                  'a divergent 64-byte gather that misses L2 moves one 128-byte line and is tallied at 64 B); a pure gather kernel reaches 7.9 TB/s '
+                                  'of line traffic on a 42 MB array, 6.9 TB/s on 1 GB')
             out['l2'] = {k: mem[k] for k in ('l2_requests', 'l2_hit', 'l2_GBs_at_64B_per_request', 'l2_frac') if k in mem}
         if note:
             out['pmc_note'] = note
+    out['geometry'] = 'trained (v_pos, lr %g)' % BENCH_LR_POS if step_unlocked else 'locked'
     out['seconds'] = time.perf_counter() - t0
     return out
 

@@ -940,6 +940,8 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
 {
     if (!c) return 0;
     hipSetDevice(c->device);
+    // the buffers go back to the caller's allocator (torch's caching pool): nothing enqueued on ANY stream may still be reading them
+    (void)hipDeviceSynchronize();
     if (c->build_stream) {
         (void)hipStreamSynchronize(c->build_stream);
         (void)hipEventDestroy(c->ev_inputs);
@@ -965,7 +967,7 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     return 0;
 }
 
-static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
+static int ctx_reserve(nvdr_ctx *c, int64_t n_tris, hipStream_t stream)
 {
     if (n_tris <= c->cap_tris) return 0;
     // the reference frees and re-allocates the GAS on every build (torch_bindings.cpp:52,84-95,114);
@@ -973,28 +975,28 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris)
     NVDR_HIP_TRY(hipDeviceSynchronize());
     ctx_free_bvh(c);
     const int64_t cap = n_tris + n_tris / 2 + 64;
-    NVDR_HIP_TRY(ctx_malloc(c, &c->nodes, sizeof(uint4) * 2 * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->oct, sizeof(uint4) * 4 * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->tris8, sizeof(float4) * 3 * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_task, sizeof(int) * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->tris, sizeof(float4) * 3 * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->nodes, sizeof(uint4) * 2 * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct, sizeof(uint4) * 4 * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->tris8, sizeof(float4) * 3 * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_task, sizeof(int) * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->tris, sizeof(float4) * 3 * cap, stream));
     for (int i = 0; i < 2; ++i) {
-        NVDR_HIP_TRY(ctx_malloc(c, &c->keys[i], sizeof(uint32_t) * cap));
-        NVDR_HIP_TRY(ctx_malloc(c, &c->vals[i], sizeof(uint32_t) * cap));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->keys[i], sizeof(uint32_t) * cap, stream));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->vals[i], sizeof(uint32_t) * cap, stream));
     }
-    NVDR_HIP_TRY(ctx_malloc(c, &c->up, sizeof(uint2) * 2 * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->flags, sizeof(int) * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->dp_cost, sizeof(float) * 16 * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_wslot, sizeof(unsigned) * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_jump, sizeof(unsigned long long) * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->up, sizeof(uint2) * 2 * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->flags, sizeof(int) * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->dp_cost, sizeof(float) * 16 * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_wslot, sizeof(unsigned) * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_jump, sizeof(unsigned long long) * cap, stream));
 
-    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_cnt, sizeof(unsigned long long) * cap));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_scan, sizeof(unsigned long long) * cap));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_cnt, sizeof(unsigned long long) * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct_scan, sizeof(unsigned long long) * cap, stream));
     size_t bytes = 0;
     NVDR_HIP_TRY(rocprim::radix_sort_pairs<nvdr_sort_config>(nullptr, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1], (size_t)cap, 0, 30));
     const size_t bytes2 = sizeof(unsigned long long) * (size_t)(cap / OCT_SCAN_TILE + 2);       // partial sums of the slot-count scan
     if (bytes2 > bytes) bytes = bytes2;
-    NVDR_HIP_TRY(ctx_malloc(c, &c->sort_tmp, bytes + 256));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->sort_tmp, bytes + 256, stream));
     c->sort_tmp_bytes = bytes + 256;
     c->cap_tris = cap;
     return 0;
@@ -1019,7 +1021,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
                      "(%lld tris / %lld verts, got %lld / %lld)",
                      (long long)c->n_tris, (long long)c->n_verts, (long long)n_tris, (long long)n_verts);
     } else {
-        int r = ctx_reserve(c, n_tris);
+        int r = ctx_reserve(c, n_tris, (hipStream_t)stream_);
         if (r) return r;
     }
     // spill columns for the proven stack bound of a tree over n_tris triangles (bvh.h); grow-only.  The binary walks keep 4-byte
@@ -1067,6 +1069,8 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
                 c->in_tris_cap = n_tris + n_tris / 2 + 64;
             }
         }
+        // a build that nobody has waited for yet may still be reading the staging copies (two builds in a row, a build then a refit)
+        if (c->built_pending) { if (int rw = ctx_wait_built(c, caller)) return rw; }
         NVDR_HIP_TRY(hipMemcpyAsync(c->in_verts, verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, caller));
         NVDR_HIP_TRY(hipMemcpyAsync(c->in_tris, tris, sizeof(int32_t) * 3 * n_tris, hipMemcpyDeviceToDevice, caller));
         verts = c->in_verts;

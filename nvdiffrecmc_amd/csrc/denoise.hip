@@ -233,7 +233,12 @@ static int launch_bilateral(const nvdr_tensor *col_or_grad, const nvdr_tensor *c
     const size_t lds_tile = (size_t)(DN_BX + 2 * rad) * (by + 2 * rad) * (pair ? 3 : 2) * sizeof(float4);
     dim3 grid(div_up(W, DN_BX), div_up(H, by), (unsigned)N);
     // beyond 64 KB of dynamic LDS a kernel needs the attribute
-    static bool big_lds = false, big_lds_tried = false;
+    // ... per DEVICE (a process that drives several GPUs sets it on each; the first version remembered one process-wide flag)
+    static bool big_lds_dev[64] = {}, big_lds_tried_dev[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    dev_id = dev_id < 0 || dev_id >= 64 ? 0 : dev_id;
+    bool &big_lds = big_lds_dev[dev_id], &big_lds_tried = big_lds_tried_dev[dev_id];
     if (!big_lds_tried) {
         big_lds_tried = true;
         big_lds = hipFuncSetAttribute((const void *)bilateral_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DN_LDS_KB * 1024) == hipSuccess &&

@@ -542,8 +542,11 @@ __device__ __forceinline__ unsigned flush_live(const unsigned *stage, unsigned s
 // entries are the rays of ONE pixel -- one origin -- and walk the same nodes around that origin before they part; 64 rays of one
 // octant from sixteen pixels do not.  The list order the generation kernel produces is the coherent one.)
 
+// DBG: the NVDR_DEBUG experiment switches are compiled INTO a second instantiation only; the production kernels (DBG = false) carry none
+template <bool DBG>
 __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams p)
 {
+    const unsigned dbg = DBG ? p.debug : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = p.L, G = 64 >> p.log2L;
     const int slot = lane >> p.log2L, sub = lane & (L - 1);
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
             int txB, tyB;
             const float pdfB_light = light_pdf(p, dirB, txB, tyB);
             const unsigned rB = pix * 2u * S + S + pb;
-            const unsigned deadB = (!(p.debug & 8u) && !(dot3(N, dirB) > 0.0f)) ? 0x80000000u : 0u;
+            const unsigned deadB = (!(dbg & 8u) && !(dot3(N, dirB) > 0.0f)) ? 0x80000000u : 0u;
             p.rays[rB] = make_float4(dirB.x, dirB.y, dirB.z, __uint_as_float(__float_as_uint(pdfB_light + pdfB_bsdf) | deadB));
             p.texel[rB] = tyB * p.light.n1 + txB;
         }
@@ -716,7 +719,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 // left out of the list of stream slots stage 2 traverses (appended per wavefront; the list order varies from
                 // run to run, the visibility of a slot does not).
                 // NVDR_DEBUG bit 8 switches the culling off (traces every ray like the reference).
-                liveA = (p.debug & 8u) || dot3(nrm, dirA) > 0.0f;
+                liveA = (dbg & 8u) || dot3(nrm, dirA) > 0.0f;
                 // a dead sample's slot only says so (nobody reads its pdfs or its texel); a live one gets them in run_batch
                 if (!liveA) p.rays[rA] = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(0x80000000u));
                 taskA = make_float4(dirA.x, dirA.y, dirA.z, __uint_as_float(pl | (ring_at << 16)));
@@ -789,9 +792,10 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
 // instructions, but gradient errors of 1e-2) -- all 0.87-0.93 ms.  0.37 ms of it is the 8 M float atomics: every one leaves
 // the XCD as a 64-byte write (rocprofv3 WRITE_SIZE = 506 MB per launch), i.e. it is executed at the memory side whatever the
 // scope bits say; non-temporal loads of the ray stream (to keep the accumulators in L2) change nothing either.
-template <bool BACKWARD>
+template <bool BACKWARD, bool DBG>
 __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_kernel(ShadeParams p)
 {
+    const unsigned dbg = DBG ? p.debug : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = p.L, G = 64 >> p.log2L;
     const int slot = lane >> p.log2L, sub = lane & (L - 1);
@@ -966,9 +970,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                     // that spreads hot texels over 8 addresses (measured: a few per cent); what really helped was not
                     // issuing the zero addends.  The atomics of both samples are issued together after the loop over r
                     // (no effect on time, but it keeps them out of the way of the second sample's loads).
-                    const int at = (p.debug & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel;   // bit 4: contention experiment
+                    const int at = (dbg & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel;   // bit 4: contention experiment
                     // adding +-0 never changes an accumulator that started at +0: occluded samples leave no addend
-                    const bool lg_has = !(p.debug & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
+                    const bool lg_has = !(dbg & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
                     if (r == 0) { lg_hasA = lg_has; lg_recA = make_float4(lg.x, lg.y, lg.z, __int_as_float(at)); }
                     else { lg_hasB = lg_has; lg_recB = make_float4(lg.x, lg.y, lg.z, __int_as_float(at)); }
                     if (lg_has && !p.lg_records) emit_light_grad(lg, at);
@@ -1046,9 +1050,10 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 #define NVDR_SQ_RING 3u
 #define NVDR_SQ_QCAP 128u
 
-template <bool BACKWARD>
+template <bool BACKWARD, bool DBG>
 __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_queue_kernel(ShadeParams p)
 {
+    const unsigned dbg = DBG ? p.debug : 0u;
     constexpr int NF = BACKWARD ? 12 : 6;       // floats of a result cell: (diff, spec) or (g_kd, g_ks, g_pos, g_nrm)
     constexpr int NS = BACKWARD ? 21 : 15;      // floats of a pixel's set-up: pos, nrm, view_pos, kd, ks (, dgrad, sgrad)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1249,7 +1254,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
                 if (BACKWARD) {
                     const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
-                    lg_has = !(p.debug & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
+                    lg_has = !(dbg & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
                     lg_rec = make_float4(lg.x, lg.y, lg.z, __int_as_float(texel));
                     const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
                     const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
@@ -1896,7 +1901,8 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         // otherwise the kernel itself decides from the device-side pixel count)
         if (!(reuse && n_chunks == 1)) {
             NvdrRange r("nvdr:gen");
-            env_gen_kernel<<<(unsigned)pb[0], 256, 0, stream>>>(p);
+            if (c->debug) env_gen_kernel<true><<<(unsigned)pb[0], 256, 0, stream>>>(p);
+            else env_gen_kernel<false><<<(unsigned)pb[0], 256, 0, stream>>>(p);
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
         // stage 2 (the first launch of this call that needs the tree: a build may still be running on the context's side stream)
@@ -1916,8 +1922,8 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         // stage 3
         NvdrRange r3(backward ? "nvdr:shade_bwd+light_grad" : "nvdr:shade_fwd");
         if (backward) {
-            if (shade_queue) env_shade_queue_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
-            else env_shade_kernel<true><<<(unsigned)pb[2], 256, 0, stream>>>(p);
+            if (shade_queue) { if (c->debug) env_shade_queue_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_queue_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
+            else { if (c->debug) env_shade_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
             if (p.lg_records && !(c->debug & 2u)) {
                 light_grad_block_kernel<<<dim3((unsigned)lg_rows, (unsigned)lg_grid_y), NVDR_LG_THREADS, lg_lds, stream>>>(
                     c->lg_tags, c->rays, p.pix_count, p.pix_begin, p.pix_cap, (unsigned)G, (unsigned)group_slots, p.lg_spare_base,
@@ -1926,8 +1932,8 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
                                                                                          k > 0 ? 1 : 0, p.pix_count, p.pix_begin);
             }
         } else {
-            if (shade_queue) env_shade_queue_kernel<false><<<(unsigned)pb[1], 256, 0, stream>>>(p);
-            else env_shade_kernel<false><<<(unsigned)pb[1], 256, 0, stream>>>(p);
+            if (shade_queue) { if (c->debug) env_shade_queue_kernel<false, true><<<(unsigned)pb[1], 256, 0, stream>>>(p); else env_shade_queue_kernel<false, false><<<(unsigned)pb[1], 256, 0, stream>>>(p); }
+            else { if (c->debug) env_shade_kernel<false, true><<<(unsigned)pb[1], 256, 0, stream>>>(p); else env_shade_kernel<false, false><<<(unsigned)pb[1], 256, 0, stream>>>(p); }
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));
     }

@@ -5,7 +5,7 @@
 //   gb_pos, gb_geometric_normal, gb_normal, gb_tangent          render.py:208-222  (interpolate of v_pos / face normals / v_nrm / v_tng)
 //   gb_texc, gb_texc_deriv                                      render.py:225-226
 //   gb_depth = (z/w, |dz|)                                      render.py:228-234
-// Here a pixel's primary ray is traced through the LBVH the shadow rays use (closest hit, bvh.h), and the hit is turned into
+// Here a pixel's primary ray is traced through the eight-wide tree the shadow rays use (closest hit, oct_closest_hit below), and the hit is turned into
 // the same per-pixel records nvdiffrast produces:
 //   rast    = (u, v, z/w, triangle_id + 1)     u, v = perspective-correct barycentrics of vertex 0 and 1 (nvdiffrast's
 //             convention: attr = u a0 + v a1 + (1-u-v) a2); 0 for background pixels
@@ -15,8 +15,90 @@
 // quirk that `clip_pos_deriv[..., 2:3]` / `[..., 3:4]` (render.py:232) pick d(clip.y)/dX and d(clip.y)/dY out of nvdiffrast's
 // interleaved (dA/dX, dA/dY) layout rather than the z and w derivatives: the denoiser's depth weight sees the reference's numbers.
 // Not differentiable (the reference gets geometry gradients from dr.antialias + interpolate; out of scope).
-#include "bvh.h"
+#include "trace_kernel.h"
 #include "bsdf_device.h"
+
+// Closest hit through the EIGHT-WIDE tree the shadow rays walk (round 4; rounds 2-3 walked the binary tree here: ~35 dependent
+// 32-byte fetches per primary ray on 684 k triangles, 0.55 ms per 800^2 view).  One ray per lane, the node step of
+// trace_kernel.h (64-byte node, eight children at 17 VALU each) with the current best distance as the far limit; a leaf's
+// triangle is tested in place -- a closest hit needs the distance at once, nothing is deferred.  Children are taken lowest index
+// first (they are ordered by surface area, not by distance): the walk is not front-to-back, the shrinking limit prunes what lies
+// behind a hit.  Same predicate (include/nvdr_raytri.h) and the same conservative boxes as the binary walk of nvdr_trace_closest:
+// the same triangle unless two triangles are hit at exactly the same distance.
+__device__ __forceinline__ int oct_closest_hit(const BvhView &bvh, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               const OctStack &stack, float &best_t, float &best_u, float &best_v)
+{
+    best_t = NVDR_RAY_TMAX;
+    best_u = 0.0f;
+    best_v = 0.0f;
+    int best = -1;
+    const uint4 *__restrict__ oct = bvh.oct;
+    const float4 *__restrict__ tris8 = bvh.tris8;
+    const BvhDeviceInfo *__restrict__ info = bvh.info;
+    OctRay g;
+    g.ix = fminf(fmaxf(__builtin_amdgcn_rcpf(dx * info->g_scale[0]), -1.0e30f), 1.0e30f);
+    g.iy = fminf(fmaxf(__builtin_amdgcn_rcpf(dy * info->g_scale[1]), -1.0e30f), 1.0e30f);
+    g.iz = fminf(fmaxf(__builtin_amdgcn_rcpf(dz * info->g_scale[2]), -1.0e30f), 1.0e30f);
+    g.nx = -((ox - info->g_lo[0]) * info->g_scale[0] + 2.0f) * g.ix;
+    g.ny = -((oy - info->g_lo[1]) * info->g_scale[1] + 2.0f) * g.iy;
+    g.nz = -((oz - info->g_lo[2]) * info->g_scale[2] + 2.0f) * g.iz;
+    unsigned gbase = 0u, gbits = 1u;        // the root is "child 0 of group 0"
+    int sp = 0;
+    for (unsigned iters = 0; iters < (1u << 24); ++iters) {
+        if (gbits == 0u) {
+            if (sp == 0) break;
+            sp--;
+            const unsigned long long top = stack.pop(sp);
+            gbase = (unsigned)top;
+            gbits = (unsigned)(top >> 32);
+        }
+        const int k = __builtin_ctz(gbits);
+        gbits &= gbits - 1u;
+        const uint4 *nd = oct + 4 * (int64_t)(gbase + (unsigned)k);
+        const uint4 h = nd[0], p1 = nd[1], p2 = nd[2], p3 = nd[3];
+        const float ax = __builtin_ldexpf(g.ix, (int)((h.y >> 16) & 15u)), bx = fmaf((float)(h.x & 0xffffu), g.ix, g.nx);
+        const float ay = __builtin_ldexpf(g.iy, (int)((h.y >> 20) & 15u)), by = fmaf((float)(h.x >> 16), g.iy, g.ny);
+        const float az = __builtin_ldexpf(g.iz, (int)((h.y >> 24) & 15u)), bz = fmaf((float)(h.y & 0xffffu), g.iz, g.nz);
+        const bool sx = g.ix < 0.0f, sy = g.iy < 0.0f, sz = g.iz < 0.0f;
+        const unsigned nx0 = sx ? p2.z : p1.x, nx1 = sx ? p2.w : p1.y, fx0 = sx ? p1.x : p2.z, fx1 = sx ? p1.y : p2.w;
+        const unsigned ny0 = sy ? p3.x : p1.z, ny1 = sy ? p3.y : p1.w, fy0 = sy ? p1.z : p3.x, fy1 = sy ? p1.w : p3.y;
+        const unsigned nz0 = sz ? p3.z : p2.x, nz1 = sz ? p3.w : p2.y, fz0 = sz ? p2.x : p3.z, fz1 = sz ? p2.y : p3.w;
+        unsigned miss = 0u;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const unsigned wnx = j < 4 ? nx0 : nx1, wny = j < 4 ? ny0 : ny1, wnz = j < 4 ? nz0 : nz1;
+            const unsigned wfx = j < 4 ? fx0 : fx1, wfy = j < 4 ? fy0 : fy1, wfz = j < 4 ? fz0 : fz1;
+            const float tnx = fmaf(ubyte_f32(wnx, j & 3), ax, bx), tfx = fmaf(ubyte_f32(wfx, j & 3), ax, bx);
+            const float tny = fmaf(ubyte_f32(wny, j & 3), ay, by), tfy = fmaf(ubyte_f32(wfy, j & 3), ay, by);
+            const float tnz = fmaf(ubyte_f32(wnz, j & 3), az, bz), tfz = fmaf(ubyte_f32(wfz, j & 3), az, bz);
+            const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+            const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best_t));        // nothing behind the best hit so far
+            miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);
+        }
+        const unsigned n_int = h.z >> 28, n_leaf = h.w >> 28;
+        const unsigned hits = ~miss & ((1u << (n_int + n_leaf)) - 1u);
+        const unsigned hi = hits & ((1u << n_int) - 1u);
+        unsigned leaf_bits = hits >> n_int;
+        const unsigned leaf_base = h.w & (NVDR_OCT_MAX_INDEX - 1u);
+        while (leaf_bits) {
+            const int j = __builtin_ctz(leaf_bits);
+            leaf_bits &= leaf_bits - 1u;
+            const int slot = (int)(leaf_base + (unsigned)j);
+            const float4 a = tris8[3 * slot + 0], b = tris8[3 * slot + 1], c = tris8[3 * slot + 2];
+            float t, u, v, det;
+            if (nvdr_ray_tri(ox, oy, oz, dx, dy, dz, a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, &t, &u, &v, &det)) {
+                const float tt = t / det;
+                if (tt < best_t) { best_t = tt; best_u = u / det; best_v = v / det; best = __float_as_int(c.y); }
+            }
+        }
+        if (hi != 0u) {
+            if (gbits != 0u) sp = stack.push(sp, pack2(gbase, gbits));
+            gbase = h.z & (NVDR_OCT_MAX_INDEX - 1u);
+            gbits = hi;
+        }
+    }
+    return best;
+}
 
 struct GbufferParams {
     const float *v_pos; const int *t_pos;
@@ -37,7 +119,12 @@ __device__ __forceinline__ F3 interp3(F3 a0, F3 a1, F3 a2, float u, float v) { r
 __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, GbufferParams p, int *spill)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
+    OctStack stack;             // per lane: NVDR_OSTACK_LDS (group, bits) entries in LDS, deeper ones in the context's spill columns
+    stack.lds = (lds_pair_t *)((char *)smem + (threadIdx.x >> 6) * NVDR_OSTACK_LDS * 64 * 8) + (threadIdx.x & 63);
+    stack.gstride = blockDim.x;
+    stack.smax = bvh.oct_stack_max;
+    stack.ovf = bvh.overflow;
+    stack.glb = (glb_pair_t *)spill + (int64_t)blockIdx.x * blockDim.x * max(bvh.oct_stack_max - NVDR_OSTACK_LDS, 0) + threadIdx.x;
     const int64_t total = (int64_t)p.N * p.H * p.W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % p.W), y = (int)((i / p.W) % p.H), z = (int)(i / ((int64_t)p.W * p.H));
@@ -48,7 +135,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, 
         F3 d = (f3(cam[3], cam[4], cam[5]) * X + f3(cam[6], cam[7], cam[8]) * Y) + f3(cam[9], cam[10], cam[11]);
         d = d * (1.0f / sqrtf(dot3(d, d)));
         float t, bu, bv;
-        const int tri = bvh_closest_hit(bvh, eye.x, eye.y, eye.z, d.x, d.y, d.z, stack, t, bu, bv);
+        const int tri = bvh.n_tris > 0 ? oct_closest_hit(bvh, eye.x, eye.y, eye.z, d.x, d.y, d.z, stack, t, bu, bv) : -1;
 
         float4 rast = make_float4(0.f, 0.f, 0.f, 0.f), rdb = make_float4(0.f, 0.f, 0.f, 0.f);
         F3 pos = f3(0.f), gn = f3(0.f), nrm = f3(0.f), tng = f3(0.f);
@@ -141,7 +228,7 @@ extern "C" int nvdr_render_gbuffer(nvdr_ctx *c, const nvdr_gbuffer_args *a, void
     p.gb_tng = a->gb_tangent; p.gb_texc = a->gb_texc; p.gb_texc_db = a->gb_texc_deriv; p.gb_depth = a->gb_depth;
     const int64_t total = (int64_t)p.N * p.H * p.W;
     if (int rw = ctx_wait_built(c, (hipStream_t)stream_)) return rw;
-    gbuffer_kernel<<<query_grid(c, total), NVDR_QUERY_BLOCK, NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK), (hipStream_t)stream_>>>(bvh_view(c), p, c->spill);
+    gbuffer_kernel<<<query_grid(c, total), NVDR_QUERY_BLOCK, (NVDR_QUERY_BLOCK / 64) * NVDR_OSTACK_LDS * 64 * 8, (hipStream_t)stream_>>>(bvh_view(c), p, c->spill);
     NVDR_LAUNCH_CHECK();
     return 0;
 }

@@ -303,7 +303,7 @@ def cpu_baseline_torch():
     dg, sg = torch.rand(1, 128, 128, 3, generator=g), torch.rand(1, 128, 128, 3, generator=g)
     f, b, t = tb.direct_lighting_torch_shadow(inp['mesh'], kw, 2, diff_grad=dg, spec_grad=sg, n_threads=nt)
     rays = 2 * t['rays_per_pass']
-    return {'value': rays / t['total_s'], 'unit': 'rays/s', 'cores': nt, 'kind': 'port',
+    return {'value': rays / t['total_s'], 'unit': 'rays/s', 'cores': t['threads'], 'host_cores': nt, 'kind': 'port',
             'sample': 'BASELINE configs[0] in full: bob 128x128, n_samples_x=2, %d covered pixels, %d shadow rays (forward + re-traced backward) against '
                       '%d triangles by chunked torch ops on the CPU (%.1f s of the %.1f s; the rest is the restated raygen / shading program)'
                       % (t['covered'], rays, inp['mesh']['t_pos_idx'].shape[0], t['torch_shadow_fwd_s'] + t['bwd_s'], t['total_s']),

@@ -305,6 +305,35 @@ def test_config5_dmtet_sized_256spp_sparse_subset_vs_oracle(dev):
     ctx.check()
 
 
+def test_config4_684k_mesh_800_chunked_sparse_subset_vs_oracle(dev):
+    """BASELINE configs[3] stand-in at the benchmarked shape (`bench.py --config dmtet800`): 800x800, n_samples_x = 8 on the 684 032
+    triangle mesh, the launch cut into several chunks of the ray stream as the 8-view benchmark launch is; a sparse pixel subset
+    against the oracle's brute force over every triangle, forward and all five gradients."""
+    res, n, seed = 800, 8, 12
+    mesh, ctx, kw, perms = _gpu_scene('bob', res, n, dev, view=2, subdiv=3)
+    assert ctx.bvh_info()['n_tris'] == 684032
+    sub = torch.zeros_like(kw['mask'])
+    sub[:, 5::13, 9::17] = kw['mask'][:, 5::13, 9::17]
+    kws = dict(kw, mask=sub)
+    ctx.set_stream_budget(1)                   # 1 MB / (128 rays x 25 B + 16 B): 326 pixels per chunk
+    g = torch.Generator().manual_seed(8)
+    dg, sg = torch.rand(1, res, res, 3, generator=g), torch.rand(1, res, res, 3, generator=g)
+    leaves = {k: kws[k].clone().requires_grad_(True) for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')}
+    d, s = _shade(ctx, dict(kws, **leaves), n, seed)
+    ((d * dg.to(dev)).sum() + (s * sg.to(dev)).sum()).backward()
+    cpu = {k: v.detach().cpu().contiguous() for k, v in kws.items()}
+    f = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT)
+    b = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, diff_grad=dg, spec_grad=sg, n_threads=NT)
+    assert 400 < f['covered'] < 1500           # at least two chunks
+    assert_close(d, f['diff'], 2e-6)
+    assert_close(s, f['spec'], 2e-6)
+    for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks'):
+        ref = b[k + '_grad']
+        assert_close(leaves[k].grad, ref, 2e-4, floor=1e-3 * max(ref.abs().max().item(), 1e-3), what=k)
+    assert_close(leaves['light'].grad, b['light_grad'], 1e-4, floor=1e-3 * b['light_grad'].abs().max().item())
+    ctx.check()
+
+
 def test_dmtet_sized_mesh_800(dev):
     """configs[3] stand-in: 800x800, n_samples_x = 8 on a 171k-triangle mesh (bob subdivided twice): finite, deterministic,
     and identical visibility-driven result after a refit to the same vertices."""
@@ -465,3 +494,4 @@ def test_queue_shading_kernels_equal_the_plain_ones(cache_vis, dev, monkeypatch)
     # the same launch twice: deterministic
     d2, s2, g2 = run('3')
     assert torch.equal(d1, d2) and all(torch.equal(g1[k], g2[k]) for k in names[:4])
+

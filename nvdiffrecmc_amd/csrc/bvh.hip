@@ -922,7 +922,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     // NVDR_LG_MODE: work split of the light-gradient gather (env_shade.hip): 0 every workgroup walks all bands, 1 one set of
     // workgroups per band, unset = by launch size
     if (const char *lm = getenv("NVDR_LG_MODE")) c->lg_mode = atoi(lm) ? 1 : 0;
-    if (const char *sq = getenv("NVDR_SHADE_QUEUE")) c->shade_queue = atoi(sq) & 3;
+    if (const char *sq = getenv("NVDR_SHADE_QUEUE")) c->shade_queue = atoi(sq) & 7;
     // NVDR_TRACE_VARIANT=0 selects the round-2 shadow-ray kernel for contexts created while it is set (A/B tools)
     if (const char *tv = getenv("NVDR_TRACE_VARIANT")) {
         if (atoi(tv) == 0) {

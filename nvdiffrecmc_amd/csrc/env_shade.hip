@@ -1326,6 +1326,247 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 }
 
 // ---------------------------------------------------------------------------------------------
+// stage 3 for S > 64 (several rounds of 64 strata per pixel; n_samples_x = 16: four): a PIXEL-LOCAL queue for the light samples.
+//
+// env_shade_kernel shades a round in two passes -- the light-sampled rays with the 55-75 % of the lanes whose sample is above the
+// horizon, the BSDF-sampled ones with nearly all.  Here the BSDF samples are shaded in place and the live light samples of the pixel's
+// rounds go through a queue in LDS (ray, texel, visibility: 20 bytes) that is shaded 64 at a time: ceil(live / 64) passes instead of one
+// per round, 7 instead of 8 for the typical pixel at 256 spp.  Every lane keeps its sums in registers across all passes of the pixel,
+// exactly as env_shade_kernel does (round 3 measured a variant that routed every sample's result to a row per round in LDS: slower
+// than the plain kernel); the queue never crosses a pixel (a pixel's last round drains it), so what a pixel's lanes add up -- and in
+// which order -- depends on that pixel alone, not on its neighbours, the chunking or the rank.  It is NOT the order of
+// env_shade_kernel: a queued sample is shaded by the lane of its queue position, not of its stratum, so the per-lane partial sums
+// differ and the images agree to rounding (1e-6 relative: the tolerance both kernels have against the oracle), not bit for bit.
+// Light-gradient records: one placement pass per (queue batch, in-place pass) pair, as in the kernels above.
+#define NVDR_SL_QCAP 128u
+
+template <bool BACKWARD, bool DBG>
+__global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_local_kernel(ShadeParams p)
+{
+    const unsigned dbg = DBG ? p.debug : 0u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    reset_trace_queues(p);
+    const unsigned P = chunk_pixels(p);         // L == 64: a group is one pixel
+    const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
+    const unsigned S = p.S;
+    const float sample_frac = 1.0f / (float)(p.n * p.n);
+    const bool use_bits = BACKWARD && p.vis_cache != nullptr;
+    const bool save_bits = !BACKWARD && p.vis_cache != nullptr;
+
+    __shared__ float4 q_rd_all[4][NVDR_SL_QCAP];
+    __shared__ int q_tex_all[4][NVDR_SL_QCAP];          // texel | occluded << 31
+    float4 *q_rd = q_rd_all[wave];
+    int *q_tex = q_tex_all[wave];
+
+    // work split and light-gradient records: see env_shade_kernel
+    const unsigned wave_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + wave));
+    unsigned grp_first = wave_id, grp_last = P, grp_step = waves_total;
+    if (BACKWARD) {
+        const unsigned per_wave = (P + waves_total - 1) / waves_total;
+        grp_first = min(wave_id * per_wave, P);
+        grp_last = min(grp_first + per_wave, P);
+        grp_step = 1;
+    }
+    const unsigned gs = 2u * S;
+    unsigned free_ptr = (grp_first * gs + 127u) & ~127u, free_end = grp_first * gs;
+    unsigned spare_next = p.lg_spare_base + wave_id * p.lg_spw;
+    unsigned bpos = 0xFFFFFFFFu, bleft = 0u;
+    auto emit_records = [&](bool hasA, const float4 &recA, bool hasB, const float4 &recB) {      // called in converged control flow
+        const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : -1;
+        const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : -1;
+        unsigned long long remA = __ballot(hasA), remB = __ballot(hasB);
+        while (remA | remB) {
+            const int b = remA ? __builtin_amdgcn_readlane(bandA, __builtin_ctzll(remA)) : __builtin_amdgcn_readlane(bandB, __builtin_ctzll(remB));
+            const unsigned long long mA = __ballot(bandA == b), mB = __ballot(bandB == b);
+            remA &= ~mA;
+            remB &= ~mB;
+            const unsigned nA = (unsigned)__popcll(mA), cnt = nA + (unsigned)__popcll(mB);
+            const unsigned at_slot = (unsigned)__builtin_amdgcn_readlane((int)bpos, b), left = (unsigned)__builtin_amdgcn_readlane((int)bleft, b);
+            unsigned fresh = 0u;
+            if (cnt > left) {
+                unsigned blk;
+                if (free_ptr + 128u <= free_end) { blk = free_ptr >> 7; free_ptr += 128u; }
+                else blk = spare_next++;
+                fresh = blk << 7;
+                if (at_slot != 0xFFFFFFFFu && lane == 0) p.lg_tags[(at_slot + left - 1u) >> 7] = (uint16_t)((unsigned)b | (128u << 8));
+            }
+            const unsigned to_fresh = fresh - left;
+            if (bandA == b) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recA;
+            }
+            if (bandB == b) {
+                const unsigned rank = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recB;
+            }
+            const unsigned at2 = cnt > left ? fresh + (cnt - left) : at_slot + cnt;
+            const unsigned left2 = cnt > left ? 128u - (cnt - left) : left - cnt;
+            bpos = lane == b ? at2 : bpos;
+            bleft = lane == b ? left2 : bleft;
+        }
+    };
+
+    for (unsigned grp = grp_first; grp < grp_last; grp += grp_step) {
+        const unsigned pi = grp;
+        const int lin = p.pix_list[p.pix_begin + pi];
+        const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
+        const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
+        const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
+        F3 dgrad = f3(0.0f), sgrad = f3(0.0f);
+        if (BACKWARD) {
+            dgrad = fetch3(p.dgrad, z, y, x);
+            sgrad = fetch3(p.sgrad, z, y, x);
+        }
+        F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
+        F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
+        unsigned q_head = 0u, q_count = 0u;             // wave-uniform; the queue is empty between pixels
+        const int64_t rbase = (int64_t)pi * 2 * S;
+        for (unsigned base = 0; base < S; base += 64u) {
+            const unsigned i = base + (unsigned)lane;   // stratum
+            const bool active = i < S;
+            const unsigned ii = active ? i : 0u;
+            const int64_t rA = rbase + ii, rB = rbase + S + ii;
+            const float4 rdA = p.rays[rA], rdB = p.rays[rB];
+            const unsigned dead = active ? ((__float_as_uint(rdA.w) >> 31) | ((__float_as_uint(rdB.w) >> 31) << 1)) : 3u;
+            unsigned occ = 0;
+            if (use_bits) {
+                const uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
+                if (active) {
+                    occ |= ((vc[i >> 5] >> (i & 31u)) & 1u);
+                    occ |= ((vc[p.vis_words + (i >> 5)] >> (i & 31u)) & 1u) << 1;
+                }
+            } else {
+                if (!(dead & 1u)) occ |= p.vis[rA] ? 0u : 1u;
+                if (!(dead & 2u)) occ |= p.vis[rB] ? 0u : 2u;
+            }
+            if (save_bits) {
+                const unsigned long long ba = __ballot(occ & 1u), bb = __ballot((occ >> 1) & 1u);
+                if (lane == 0) {
+                    uint32_t *vc = p.vis_cache + (int64_t)lin * 2 * p.vis_words;
+                    const int w0 = 2 * (int)(base >> 6);
+                    vc[w0] = (uint32_t)ba;
+                    vc[p.vis_words + w0] = (uint32_t)bb;
+                    if (w0 + 1 < p.vis_words) {
+                        vc[w0 + 1] = (uint32_t)(ba >> 32);
+                        vc[p.vis_words + w0 + 1] = (uint32_t)(bb >> 32);
+                    }
+                }
+            }
+            // the live light samples of this round wait in the queue
+            const bool liveA = !(dead & 1u);
+            const unsigned long long mq = __ballot(liveA);
+            if (liveA) {
+                const unsigned at = (q_head + q_count + __builtin_amdgcn_mbcnt_hi((unsigned)(mq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mq, 0u))) & (NVDR_SL_QCAP - 1u);
+                q_rd[at] = rdA;
+                q_tex[at] = p.texel[rA] | (int)((occ & 1u) << 31);
+            }
+            q_count += (unsigned)__popcll(mq);
+            const bool last = base + 64u >= S;
+            float4 lg_rec0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            bool lg_has0 = false;
+            // pass 0: the BSDF samples of this round in place; passes 1..: full batches of the queue (whatever is left in the last round)
+#pragma unroll 1
+            for (int k = 0; ; ++k) {
+                bool has, occluded;
+                float4 rd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                int texel = 0;
+                if (k == 0) {
+                    has = !(dead & 2u);
+                    rd = rdB;
+                    occluded = (occ >> 1) & 1u;
+                    if (has) texel = p.texel[rB];
+                } else {
+                    const unsigned cnt = q_count >= 64u ? 64u : (last ? q_count : 0u);
+                    if (cnt == 0u) break;
+                    __builtin_amdgcn_wave_barrier();    // (entries pushed by other lanes)
+                    has = (unsigned)lane < cnt;
+                    const unsigned qi = (q_head + (unsigned)lane) & (NVDR_SL_QCAP - 1u);
+                    int tq = 0;
+                    if (has) {
+                        rd = q_rd[qi];
+                        tq = q_tex[qi];
+                    }
+                    texel = tq & 0x7fffffff;
+                    occluded = tq < 0;
+                    q_head += cnt;
+                    q_count -= cnt;
+                }
+                float4 lg_rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                bool lg_has = false;
+                if (has) {
+                    const F3 dir = f3(rd.x, rd.y, rd.z);
+                    const float pdfSum = rd.w;
+                    const F3 light_col = fetch_light_texel(p.light, texel);
+                    const float mis_weight = 1.0f / fmaxf(pdfSum, 0.0001f);
+                    F3 _diff = f3(0.0f), _spec = f3(0.0f);
+                    if (p.bsdf == 1 || p.bsdf == 2)
+                        _diff = f3(fwd_lambert(nrm, dir));
+                    else
+                        fwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, _diff, _spec);
+                    const float vis = occluded ? 0.0f : 1.0f;
+                    const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
+                    if (BACKWARD) {
+                        const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
+                        lg_has = !(dbg & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
+                        lg_rec = make_float4(lg.x, lg.y, lg.z, __int_as_float(texel));
+                        const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
+                        const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
+                        if (p.bsdf == 1 || p.bsdf == 2) {
+                            F3 d_wi = f3(0.0f);
+                            bwd_lambert(nrm, dir, g_nrm, d_wi, sum3(_dg));
+                        } else {
+                            bwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
+                        }
+                    } else {
+                        diffAccum += (((_diff * light_col) * V) * mis_weight) * sample_frac;
+                        specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
+                    }
+                }
+                if (BACKWARD) {
+                    if (k == 0) {
+                        lg_rec0 = lg_rec;
+                        lg_has0 = lg_has;
+                    } else {
+                        emit_records(lg_has, lg_rec, lg_has0, lg_rec0);     // light-sampled records first, as above
+                        lg_has0 = false;
+                    }
+                }
+            }
+            if (BACKWARD) emit_records(false, lg_rec0, lg_has0, lg_rec0);   // (nothing left to place if a queue batch took them along)
+        }
+        if (BACKWARD) free_end = (grp + 1u) * gs;       // the rays of this pixel have all been read: its slots may hold records now
+
+        if (!BACKWARD) {
+            diffAccum = group_sum3(diffAccum, 64);
+            specAccum = group_sum3(specAccum, 64);
+            if (lane == 0) {
+                float *o = p.diff + (int64_t)lin * 3;
+                o[0] = diffAccum.x; o[1] = diffAccum.y; o[2] = diffAccum.z;
+                o = p.spec + (int64_t)lin * 3;
+                o[0] = specAccum.x; o[1] = specAccum.y; o[2] = specAccum.z;
+            }
+        } else {
+            g_pos = group_sum3(g_pos, 64);
+            g_nrm = group_sum3(g_nrm, 64);
+            g_kd = group_sum3(g_kd, 64);
+            g_ks = group_sum3(g_ks, 64);
+            if (lane == 0) {
+                float *o = p.g_pos + (int64_t)lin * 3;
+                o[0] = g_pos.x; o[1] = g_pos.y; o[2] = g_pos.z;
+                o = p.g_nrm + (int64_t)lin * 3;
+                o[0] = g_nrm.x; o[1] = g_nrm.y; o[2] = g_nrm.z;
+                o = p.g_kd + (int64_t)lin * 3;
+                o[0] = g_kd.x; o[1] = g_kd.y; o[2] = g_kd.z;
+                o = p.g_ks + (int64_t)lin * 3;
+                o[0] = g_ks.x; o[1] = g_ks.y; o[2] = g_ks.z;
+            }
+        }
+    }
+    if (BACKWARD && bpos != 0xFFFFFFFFu)
+        p.lg_tags[(bpos + bleft - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - bleft) << 8));
+}
+
+// ---------------------------------------------------------------------------------------------
 // light gradient (eval_light_bwd, kernel.cu:203-211) without global atomics: BAND-SORTED RECORD BLOCKS + LDS GATHER.
 //
 // The reference adds every sample's addend to light_grad[texel] with three atomicAdds.  On MI355X fp32 atomics are
@@ -1694,7 +1935,10 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     // wavefront mean many half-empty batches: 0.301 vs 0.315 ms for one view; 8 per CU is 3 % better for eight views)
     int per_cu_launch[3] = {c->per_cu[0], c->per_cu[1], c->per_cu[2]};
     if (!c->per_cu_user && npix <= (1ll << 20)) {
-        per_cu_launch[0] = 4;
+        // (one view: 3 -- the generation kernel's workgroups take a quarter of a CU's registers and LDS each, and with all four resident
+        // the BVH build on the side stream cannot place a workgroup until they exit: generation 0.262 -> 0.287 ms, the traversal's wait
+        // for the tree 0.458 -> 0.423 ms from launch to end, iteration 2.062 -> 2.042 ms; 2: 0.334 / 0.389 / 2.076)
+        per_cu_launch[0] = npix <= (1ll << 18) ? 3 : 4;
         per_cu_launch[2] = 8;        // (backward shading of one view: 0.465 vs 0.483 ms with 8 instead of 6 workgroups per CU; 8 views: +1.5 %)
     }
     const int *per_cu = per_cu_launch;   // blocks per CU of the three per-pixel kernels (generation, forward shading, backward shading): {10, 6, 6},
@@ -1737,6 +1981,12 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     const bool queue_ok = L == 64 && S == 64;
     const bool queue_fwd = (c->shade_queue & 2) && queue_ok;
     const bool queue_bwd = (c->shade_queue & 1) && queue_ok && lg_records && !(c->debug & 4u);
+    // S > 64 (several rounds per pixel): the kernels with a pixel-local queue (env_shade_local_kernel).  Backward by default (bit 0): 256 spp,
+    // 4 views of spot 5.45 -> 4.58 ms, 8 views of the 171 k-triangle mesh 9.94 -> 8.08 ms per launch.  The forward kernel gains nothing from
+    // the fuller passes (1.26 -> 1.27 ms, 2.39 -> 2.51: it waits for its loads, not for its lanes) and stays plain unless bit 2 is set.
+    const bool local_ok = L == 64 && S > 64;
+    const bool local_fwd = (c->shade_queue & 4) && local_ok;
+    const bool local_bwd = (c->shade_queue & 1) && local_ok && lg_records && !(c->debug & 4u);
     if (!c->per_cu_user) {
         if (queue_fwd) per_cu_launch[1] = npix <= (1ll << 18) ? 10 : 15;
         if (queue_bwd) per_cu_launch[2] = npix <= (1ll << 18) ? 3 : (npix <= (1ll << 20) ? 9 : 12);     // (2 / 4 views: 9: 0.78 / 1.33 ms, 3: 0.78 / 1.39, 12: 0.79 / 1.37)
@@ -1783,6 +2033,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
 
     p.lg_records = backward ? lg_records : 0;
     const bool shade_queue = backward ? queue_bwd : queue_fwd;
+    const bool shade_local = backward ? local_bwd : local_fwd;
     p.lg_shift = lg_shift;
 
     if (!backward) {
@@ -1923,6 +2174,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         NvdrRange r3(backward ? "nvdr:shade_bwd+light_grad" : "nvdr:shade_fwd");
         if (backward) {
             if (shade_queue) { if (c->debug) env_shade_queue_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_queue_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
+            else if (shade_local) { if (c->debug) env_shade_local_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_local_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
             else { if (c->debug) env_shade_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
             if (p.lg_records && !(c->debug & 2u)) {
                 light_grad_block_kernel<<<dim3((unsigned)lg_rows, (unsigned)lg_grid_y), NVDR_LG_THREADS, lg_lds, stream>>>(
@@ -1933,6 +2185,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             }
         } else {
             if (shade_queue) { if (c->debug) env_shade_queue_kernel<false, true><<<(unsigned)pb[1], 256, 0, stream>>>(p); else env_shade_queue_kernel<false, false><<<(unsigned)pb[1], 256, 0, stream>>>(p); }
+            else if (shade_local) { if (c->debug) env_shade_local_kernel<false, true><<<(unsigned)pb[1], 256, 0, stream>>>(p); else env_shade_local_kernel<false, false><<<(unsigned)pb[1], 256, 0, stream>>>(p); }
             else { if (c->debug) env_shade_kernel<false, true><<<(unsigned)pb[1], 256, 0, stream>>>(p); else env_shade_kernel<false, false><<<(unsigned)pb[1], 256, 0, stream>>>(p); }
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));

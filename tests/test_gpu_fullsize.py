@@ -495,3 +495,54 @@ def test_queue_shading_kernels_equal_the_plain_ones(cache_vis, dev, monkeypatch)
     d2, s2, g2 = run('3')
     assert torch.equal(d1, d2) and all(torch.equal(g1[k], g2[k]) for k in names[:4])
 
+
+
+@pytest.mark.parametrize('n', [16, 12], ids=['S256', 'S144'])
+@pytest.mark.parametrize('cache_vis', [False, True], ids=['retrace', 'cached_visibility'])
+def test_local_queue_shading_kernels_vs_the_plain_ones(n, cache_vis, dev, monkeypatch):
+    """n_samples_x = 16 / 12 (S = 256 / 144: four / three rounds of 64 lanes per pixel, the last one of S = 144 partial): the shading
+    kernels that pack a pixel's live light samples into full 64-lane passes (env_shade_local_kernel; NVDR_SHADE_QUEUE bit 0: backward,
+    the default there; bit 2: forward) against the plain ones (NVDR_SHADE_QUEUE=0).  Same samples, same visibility; a queued sample is summed by another lane, so images and
+    gradients agree to the rounding of 2 S float additions (the tolerance both have against the oracle), and the result of a pixel does
+    not depend on the launch it is part of (one view alone == the same view inside a batch, bit for bit)."""
+    res = 96
+    from nvdiffrecmc_amd import optixutils as ou
+    seed, nv = 7, 2
+    views = [_gpu_scene('bob', res, n, dev, view=v) for v in range(nv)]
+    mesh = views[0][0]
+    kw = {k: torch.cat([v[2][k] for v in views], 0).contiguous() for k in ('mask', 'ro', 'gb_pos', 'gb_normal', 'gb_view_pos', 'gb_kd', 'gb_ks')}
+    kw.update({k: views[0][2][k] for k in ('light', 'pdf', 'rows', 'cols')})
+    g = torch.Generator().manual_seed(3)
+    dg, sg = torch.rand(nv, res, res, 3, generator=g).to(dev), torch.rand(nv, res, res, 3, generator=g).to(dev)
+    names = ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')
+
+    def run(flag, first=0, count=nv, offset=0):
+        monkeypatch.setenv('NVDR_SHADE_QUEUE', flag)
+        ctx = ou.OptiXContext()
+        monkeypatch.delenv('NVDR_SHADE_QUEUE')
+        ou.optix_build_bvh(ctx, mesh['v_pos'].to(dev), mesh['t_pos_idx'].to(dev), 1)
+        ctx.cache_visibility = cache_vis
+        ctx.pixel_index_offset = offset
+        sl = slice(first, first + count)
+        kv = {k: (v[sl].contiguous() if k in ('mask', 'ro', 'gb_pos', 'gb_normal', 'gb_view_pos', 'gb_kd', 'gb_ks') else v) for k, v in kw.items()}
+        leaves = {k: kv[k].clone().requires_grad_(True) for k in names}
+        d, s = _shade(ctx, dict(kv, **leaves), n, seed)
+        ((d * dg[sl]).sum() + (s * sg[sl]).sum()).backward()
+        ctx.check()
+        return d.detach(), s.detach(), {k: leaves[k].grad for k in names}
+
+    d0, s0, g0 = run('0')
+    d1, s1, g1 = run('7')
+    assert d0.abs().sum().item() > 0
+    assert_close(d1, d0, 2e-6)
+    assert_close(s1, s0, 2e-6)
+    for k in names[:4]:        # (sums of large terms of both signs: half of the 2e-4 both kernels are allowed against the oracle)
+        assert_close(g1[k], g0[k], 1e-4, floor=1e-5 * g0[k].abs().max().item(), what=k)
+    assert_close(g1['light'], g0['light'], 1e-4, floor=1e-3 * g0['light'].abs().max().item())
+    # deterministic, and a pixel's result is its own: the second view alone (offset seeds) == the second view of the batch
+    d2, s2, g2 = run('7')
+    assert torch.equal(d1, d2) and all(torch.equal(g1[k], g2[k]) for k in names[:4])
+    d3, s3, g3 = run('7', first=1, count=1, offset=res * res)
+    assert torch.equal(d3[0], d1[1]) and torch.equal(s3[0], s1[1])
+    for k in names[:4]:
+        assert torch.equal(g3[k][0], g1[k][1]), k

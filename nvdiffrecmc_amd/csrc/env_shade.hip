@@ -1990,6 +1990,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     if (!c->per_cu_user) {
         if (queue_fwd) per_cu_launch[1] = npix <= (1ll << 18) ? 10 : 15;
         if (queue_bwd) per_cu_launch[2] = npix <= (1ll << 18) ? 3 : (npix <= (1ll << 20) ? 9 : 12);     // (2 / 4 views: 9: 0.78 / 1.33 ms, 3: 0.78 / 1.39, 12: 0.79 / 1.37)
+        if (local_bwd && npix > (1ll << 18)) per_cu_launch[2] = 12;     // (4 views of spot at 256 spp: 3: 4.87 ms, 6: 4.72, 9: 4.65, 12: 4.61)
     }
     // spare blocks per wavefront of the backward shading kernel: one open block per band + the records of the first group (nothing
     // consumed yet) + the alignment of its range to 128 slots + the round in flight (env_shade_kernel<true>)

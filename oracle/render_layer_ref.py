@@ -152,3 +152,13 @@ def texture_lookup(tex, texc, rast):
     ix = (texc[..., 0] * R).long().clamp(0, R - 1)
     iy = ((1.0 - texc[..., 1]) * R).long().clamp(0, R - 1)
     return tex[iy, ix] * (rast[..., 3:4] > 0).to(tex.dtype)
+
+
+def shade_composite(diff, spec, kd, ks, bsdf='pbr'):
+    """Final colour of shade() from the two accumulated (or filtered) light images: render/render.py:119-127; a 4-channel input is the
+    (sum w c, sum w) pair of the bilateral filter, divided as bilateral_denoiser does (render/optixutils/ops.py:139-141)."""
+    d = diff[..., 0:3] / diff[..., 3:4] if diff.shape[-1] == 4 else diff
+    s = spec[..., 0:3] / spec[..., 3:4] if spec.shape[-1] == 4 else spec
+    if bsdf in ('white', 'diffuse'):
+        return d * kd
+    return d * (kd * (1.0 - ks[..., 2:3])) + s

@@ -21,6 +21,7 @@ from . import optixutils as ou
 class _gbuffer_func(torch.autograd.Function):
     @staticmethod
     def forward(ctx, optix_ctx, v_pos, v_nrm, v_tng, topo, mvp, cam, resolution, bary_grad):
+        ctx.set_materialize_grads(False)         # (an attribute nobody differentiated arrives as None below, not as an image of zeros)
         mesh = {'v_pos': v_pos.contiguous(), 't_pos_idx': topo.t_pos_idx, 'v_nrm': v_nrm.contiguous(), 't_nrm_idx': topo.t_pos_idx,
                 'v_tng': v_tng.contiguous(), 't_tng_idx': topo.t_pos_idx, 'v_tex': topo.v_tex, 't_tex_idx': topo.t_tex_idx}
         gb = ou.render_gbuffer(optix_ctx, mesh, mvp, cam, resolution)

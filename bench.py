@@ -762,9 +762,9 @@ def run(args):
                 roof['traffic_source'] = 'rocprofv3 --kernel-trace --pmc passes of this run (bench.py --pmc-child, %d dispatches)' % int(c.get('dispatches_pass1', 0))
                 # the other env-shade kernels from the same passes (durations: HIP-event stage times, backward stage 3 includes the gather)
                 others = {}
-                # (S = 64 launches run the shading kernels that queue the light samples across pixels, env_shade_queue_kernel)
-                for label, needle, ms in (('env_shade_kernel<backward>', ('env_shade_queue_kernel<true', 'env_shade_kernel<true'), None), ('env_gen_kernel', 'env_gen_kernel', gen_ms),
-                                          ('env_shade_kernel<forward>', ('env_shade_queue_kernel<false', 'env_shade_kernel<false'), shade_ms),
+                # (S = 64 launches run the shading kernels that queue the light samples across pixels, env_shade_queue_kernel; S > 64 backward env_shade_local_kernel)
+                for label, needle, ms in (('env_shade_kernel<backward>', ('env_shade_queue_kernel<true', 'env_shade_local_kernel<true', 'env_shade_kernel<true'), None), ('env_gen_kernel', 'env_gen_kernel', gen_ms),
+                                          ('env_shade_kernel<forward>', ('env_shade_queue_kernel<false', 'env_shade_local_kernel<false', 'env_shade_kernel<false'), shade_ms),
                                           ('light_grad_block_kernel', 'light_grad_block_kernel', None)):
                     oc = find_kernel(counters, needle)
                     kname = next((nm for nm, cc in counters.items() if cc is oc), None)

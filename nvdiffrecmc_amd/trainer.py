@@ -396,7 +396,9 @@ class DirectLightingStep:
                 self._set_gbuffer({k: v.detach() for k, v in gb.items()})        # shade_inputs() / mask follow the moving mesh
             img = self._render_full(self.kd_tex, self.ks_tex, self.nrm_tex, self.light, gb, grad_buffers=self._tex_grad if self.fused else None)
         loss = (ru.image_loss_mean if (self.fused and self.dev.type == 'cuda') else ru.image_loss)(img, self.target, loss='l1', tonemapper='log_srgb')
-        loss.backward()
+        if getattr(self, '_one', None) is None or self._one.shape != loss.shape or self._one.device != loss.device:
+            self._one = torch.ones_like(loss)
+        loss.backward(gradient=self._one)       # (a resident seed: no fill launch per iteration)
         return loss
 
     def set_lr_scale(self, name, value):

@@ -784,6 +784,70 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
 // ---------------------------------------------------------------------------------------------
 // stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
 
+// Light-gradient records of ONE WAVEFRONT of a backward shading kernel, sorted by band as they are written (light_grad_block_kernel reads
+// them).  A record = (rgb addend, texel); records of one band are packed into BLOCKS of 128 stream slots, and a block is tagged with
+// (band, fill) once it is complete.  Where the blocks come from: the ray stream itself.  The rays of a group of pixels are dead once the
+// wavefront has read them, and a group emits at most as many records as it has slots, so the wavefront carves blocks out of the range
+// it has already consumed (free_ptr .. free_end); until enough is consumed -- the first group, the up to n_bands blocks that are open at
+// any time, the alignment of the range to 128 slots -- it draws on lg_spw spare blocks of its own behind the chunk.  Per-band state
+// lives in the lanes of two registers (lane b: next slot to write / slots left in the open block of band b).
+struct RecordBlocks {
+    unsigned free_ptr, free_end, spare_next, bpos, bleft;
+
+    // first_slot: the first stream slot this wavefront is going to consume; spare_first: its first spare block
+    __device__ __forceinline__ void init(unsigned first_slot, unsigned spare_first)
+    {
+        free_ptr = (first_slot + 127u) & ~127u;
+        free_end = first_slot;
+        spare_next = spare_first;
+        bpos = 0xFFFFFFFFu;
+        bleft = 0u;
+    }
+    // both record sets of a pass pair at once (A first: the light-sampled ones): one placement round per band present in either.
+    // Called in converged control flow.
+    __device__ __forceinline__ void emit(const ShadeParams &p, int lane, bool hasA, const float4 &recA, bool hasB, const float4 &recB)
+    {
+        const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : -1;
+        const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : -1;
+        unsigned long long remA = __ballot(hasA), remB = __ballot(hasB);
+        while (remA | remB) {
+            // the band of the first record still to place
+            const int b = remA ? __builtin_amdgcn_readlane(bandA, __builtin_ctzll(remA)) : __builtin_amdgcn_readlane(bandB, __builtin_ctzll(remB));
+            const unsigned long long mA = __ballot(bandA == b), mB = __ballot(bandB == b);
+            remA &= ~mA;
+            remB &= ~mB;
+            const unsigned nA = (unsigned)__popcll(mA), cnt = nA + (unsigned)__popcll(mB);
+            const unsigned at_slot = (unsigned)__builtin_amdgcn_readlane((int)bpos, b), left = (unsigned)__builtin_amdgcn_readlane((int)bleft, b);
+            unsigned fresh = 0u;
+            if (cnt > left) {                                           // the open block fills up: `left` records complete it, the rest open a new one
+                unsigned blk;
+                if (free_ptr + 128u <= free_end) { blk = free_ptr >> 7; free_ptr += 128u; }
+                else blk = spare_next++;
+                fresh = blk << 7;
+                if (at_slot != 0xFFFFFFFFu && lane == 0) p.lg_tags[(at_slot + left - 1u) >> 7] = (uint16_t)((unsigned)b | (128u << 8));
+            }
+            const unsigned to_fresh = fresh - left;                     // (wraps; only used by ranks >= left)
+            if (bandA == b) {
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recA;
+            }
+            if (bandB == b) {
+                const unsigned rank = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recB;
+            }
+            const unsigned at2 = cnt > left ? fresh + (cnt - left) : at_slot + cnt;
+            const unsigned left2 = cnt > left ? 128u - (cnt - left) : left - cnt;
+            bpos = lane == b ? at2 : bpos;
+            bleft = lane == b ? left2 : bleft;
+        }
+    }
+    // the blocks still open when the wavefront runs out of pixels: lane b tags the one of band b with its fill
+    __device__ __forceinline__ void finish(const ShadeParams &p, int lane) const
+    {
+        if (bpos != 0xFFFFFFFFu) p.lg_tags[(bpos + bleft - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - bleft) << 8));
+    }
+};
+
 // Tried in round 3 and dropped (session 29): fetching the next pixel's list entry one iteration ahead, and starting both samples'
 // texel -> radiance load chains before the arithmetic: forward +1 ... +2.6 %, backward +5 ... +8 % (the registers they hold cost more than
 // the latency they hide at 3 waves per SIMD).
@@ -821,53 +885,10 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         grp_last = min(grp_first + per_wave, n_groups);
         grp_step = 1;
     }
-    // Light-gradient records, sorted by band as they are written (light_grad_block_kernel reads them).  A record = (rgb addend, texel);
-    // records of one band are packed into BLOCKS of 128 stream slots, and a block is tagged with (band, fill) once it is complete.
-    // Where the blocks come from: the ray stream itself.  The rays of a group are dead once this wavefront has read them, and a
-    // group emits at most as many records as it has slots, so the wavefront carves blocks out of the range it has already consumed
-    // (free_ptr .. free_end); until enough is consumed -- the first group, the up to n_bands blocks that are open at any time, the
-    // alignment of the range to 128 slots -- it draws on lg_spw spare blocks of its own behind the chunk.  Per-band state lives in
-    // the lanes of two registers (lane b: next slot to write / slots left in the open block of band b).
+    // light-gradient records of this wavefront (RecordBlocks above)
     const unsigned gs = (unsigned)G * 2u * S;                           // stream slots of one group
-    unsigned free_ptr = (grp_first * gs + 127u) & ~127u, free_end = grp_first * gs;
-    unsigned spare_next = p.lg_spare_base + wave_id * p.lg_spw;
-    unsigned bpos = 0xFFFFFFFFu, bleft = 0u;
-    // both samples of the lanes' strata at once (A: light-sampled, B: BSDF-sampled): one pass over the bands present in either
-    auto emit_records = [&](bool hasA, const float4 &recA, bool hasB, const float4 &recB) {      // called in converged control flow
-        const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : -1;
-        const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : -1;
-        unsigned long long remA = __ballot(hasA), remB = __ballot(hasB);
-        while (remA | remB) {
-            // the band of the first record still to place
-            const int b = remA ? __builtin_amdgcn_readlane(bandA, __builtin_ctzll(remA)) : __builtin_amdgcn_readlane(bandB, __builtin_ctzll(remB));
-            const unsigned long long mA = __ballot(bandA == b), mB = __ballot(bandB == b);
-            remA &= ~mA;
-            remB &= ~mB;
-            const unsigned nA = (unsigned)__popcll(mA), cnt = nA + (unsigned)__popcll(mB);
-            const unsigned at_slot = (unsigned)__builtin_amdgcn_readlane((int)bpos, b), left = (unsigned)__builtin_amdgcn_readlane((int)bleft, b);
-            unsigned fresh = 0u;
-            if (cnt > left) {                                           // the open block fills up: `left` records complete it, the rest open a new one
-                unsigned blk;
-                if (free_ptr + 128u <= free_end) { blk = free_ptr >> 7; free_ptr += 128u; }
-                else blk = spare_next++;
-                fresh = blk << 7;
-                if (at_slot != 0xFFFFFFFFu && lane == 0) p.lg_tags[(at_slot + left - 1u) >> 7] = (uint16_t)((unsigned)b | (128u << 8));
-            }
-            const unsigned to_fresh = fresh - left;                     // (wraps; only used by ranks >= left)
-            if (bandA == b) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
-                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recA;
-            }
-            if (bandB == b) {
-                const unsigned rank = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
-                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recB;
-            }
-            const unsigned at2 = cnt > left ? fresh + (cnt - left) : at_slot + cnt;
-            const unsigned left2 = cnt > left ? 128u - (cnt - left) : left - cnt;
-            bpos = lane == b ? at2 : bpos;
-            bleft = lane == b ? left2 : bleft;
-        }
-    };
+    RecordBlocks rb;
+    rb.init(grp_first * gs, p.lg_spare_base + wave_id * p.lg_spw);
 
     for (unsigned grp = grp_first; grp < grp_last; grp += grp_step) {
         const unsigned pi = grp * G + slot;
@@ -993,7 +1014,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             // No atomic leaves the workgroup in records mode (21 M addends per 8-view launch were 63 M memory-side fp32 atomics):
             // the addends of this round go to the band blocks, light-sampled ones first, in lane order
 #if NVDR_LG_EXPERIMENT == 0
-            if (BACKWARD && p.lg_records) emit_records(lg_hasA, lg_recA, lg_hasB, lg_recB);
+            if (BACKWARD && p.lg_records) rb.emit(p, lane, lg_hasA, lg_recA, lg_hasB, lg_recB);
 #elif NVDR_LG_EXPERIMENT == 3           // records written in place, unsorted (what the shading kernel cost before the band blocks)
             if (BACKWARD && p.lg_records) {
                 if (lg_hasA) p.rays[rA] = lg_recA;
@@ -1001,7 +1022,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             }
 #endif
         }
-        if (BACKWARD) free_end = (grp + 1u) * gs;       // the rays of this group have all been read: its slots may hold records now
+        if (BACKWARD) rb.free_end = (grp + 1u) * gs;    // the rays of this group have all been read: its slots may hold records now
 
         if (!BACKWARD) {
             diffAccum = group_sum3(diffAccum, L);
@@ -1029,9 +1050,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             }
         }
     }
-    // the blocks still open when the wavefront runs out of pixels: lane b tags the one of band b with its fill
-    if (BACKWARD && p.lg_records && bpos != 0xFFFFFFFFu)
-        p.lg_tags[(bpos + bleft - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - bleft) << 8));
+    if (BACKWARD && p.lg_records) rb.finish(p, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1085,45 +1104,10 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         grp_last = min(grp + per_wave, P);
         grp_step = 1;
     }
-    // light-gradient records: see env_shade_kernel
+    // light-gradient records of this wavefront (RecordBlocks above)
     const unsigned gs = 2u * S;
-    unsigned free_ptr = (grp * gs + 127u) & ~127u, free_end = grp * gs;
-    unsigned spare_next = p.lg_spare_base + wave_id * p.lg_spw;
-    unsigned bpos = 0xFFFFFFFFu, bleft = 0u;
-    auto emit_records = [&](bool hasA, const float4 &recA, bool hasB, const float4 &recB) {      // called in converged control flow
-        const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : -1;
-        const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : -1;
-        unsigned long long remA = __ballot(hasA), remB = __ballot(hasB);
-        while (remA | remB) {
-            const int b = remA ? __builtin_amdgcn_readlane(bandA, __builtin_ctzll(remA)) : __builtin_amdgcn_readlane(bandB, __builtin_ctzll(remB));
-            const unsigned long long mA = __ballot(bandA == b), mB = __ballot(bandB == b);
-            remA &= ~mA;
-            remB &= ~mB;
-            const unsigned nA = (unsigned)__popcll(mA), cnt = nA + (unsigned)__popcll(mB);
-            const unsigned at_slot = (unsigned)__builtin_amdgcn_readlane((int)bpos, b), left = (unsigned)__builtin_amdgcn_readlane((int)bleft, b);
-            unsigned fresh = 0u;
-            if (cnt > left) {
-                unsigned blk;
-                if (free_ptr + 128u <= free_end) { blk = free_ptr >> 7; free_ptr += 128u; }
-                else blk = spare_next++;
-                fresh = blk << 7;
-                if (at_slot != 0xFFFFFFFFu && lane == 0) p.lg_tags[(at_slot + left - 1u) >> 7] = (uint16_t)((unsigned)b | (128u << 8));
-            }
-            const unsigned to_fresh = fresh - left;
-            if (bandA == b) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
-                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recA;
-            }
-            if (bandB == b) {
-                const unsigned rank = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
-                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recB;
-            }
-            const unsigned at2 = cnt > left ? fresh + (cnt - left) : at_slot + cnt;
-            const unsigned left2 = cnt > left ? 128u - (cnt - left) : left - cnt;
-            bpos = lane == b ? at2 : bpos;
-            bleft = lane == b ? left2 : bleft;
-        }
-    };
+    RecordBlocks rb;
+    rb.init(grp * gs, p.lg_spare_base + wave_id * p.lg_spw);
 
     // ring state (wave-uniform): pixel ordinal `it` of this wavefront lives in entry it % RING until it is finalised (in order)
     unsigned it = 0, fin = 0;
@@ -1202,7 +1186,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 q_count += pushed;
                 if (ent == 0u) { pend0 = pushed; lin0 = lin; } else if (ent == 1u) { pend1 = pushed; lin1 = lin; } else { pend2 = pushed; lin2 = lin; }
                 ++it;
-                if (BACKWARD) free_end = (grp + 1u) * gs;   // the rays of this pixel have all been read: its slots may hold records now
+                if (BACKWARD) rb.free_end = (grp + 1u) * gs;    // the rays of this pixel have all been read: its slots may hold records now
                 grp += grp_step;
                 // ... and the BSDF sample of this lane's stratum is shaded in place
                 has = !(dead & 2u);
@@ -1289,7 +1273,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 lg_has1 = lg_has;
             }
         }
-        if (BACKWARD && p.lg_records) emit_records(lg_has1, lg_rec1, lg_has0, lg_rec0);     // light-sampled records first, as above
+        if (BACKWARD && p.lg_records) rb.emit(p, lane, lg_has1, lg_rec1, lg_has0, lg_rec0);     // light-sampled records first, as above
         // pixels whose samples are all shaded, in order: the row is summed over the lanes and written
         while (fin < it) {
             const unsigned e = fin % NVDR_SQ_RING;
@@ -1321,8 +1305,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             ++fin;
         }
     }
-    if (BACKWARD && p.lg_records && bpos != 0xFFFFFFFFu)
-        p.lg_tags[(bpos + bleft - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - bleft) << 8));
+    if (BACKWARD && p.lg_records) rb.finish(p, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1368,43 +1351,8 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         grp_step = 1;
     }
     const unsigned gs = 2u * S;
-    unsigned free_ptr = (grp_first * gs + 127u) & ~127u, free_end = grp_first * gs;
-    unsigned spare_next = p.lg_spare_base + wave_id * p.lg_spw;
-    unsigned bpos = 0xFFFFFFFFu, bleft = 0u;
-    auto emit_records = [&](bool hasA, const float4 &recA, bool hasB, const float4 &recB) {      // called in converged control flow
-        const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : -1;
-        const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : -1;
-        unsigned long long remA = __ballot(hasA), remB = __ballot(hasB);
-        while (remA | remB) {
-            const int b = remA ? __builtin_amdgcn_readlane(bandA, __builtin_ctzll(remA)) : __builtin_amdgcn_readlane(bandB, __builtin_ctzll(remB));
-            const unsigned long long mA = __ballot(bandA == b), mB = __ballot(bandB == b);
-            remA &= ~mA;
-            remB &= ~mB;
-            const unsigned nA = (unsigned)__popcll(mA), cnt = nA + (unsigned)__popcll(mB);
-            const unsigned at_slot = (unsigned)__builtin_amdgcn_readlane((int)bpos, b), left = (unsigned)__builtin_amdgcn_readlane((int)bleft, b);
-            unsigned fresh = 0u;
-            if (cnt > left) {
-                unsigned blk;
-                if (free_ptr + 128u <= free_end) { blk = free_ptr >> 7; free_ptr += 128u; }
-                else blk = spare_next++;
-                fresh = blk << 7;
-                if (at_slot != 0xFFFFFFFFu && lane == 0) p.lg_tags[(at_slot + left - 1u) >> 7] = (uint16_t)((unsigned)b | (128u << 8));
-            }
-            const unsigned to_fresh = fresh - left;
-            if (bandA == b) {
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
-                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recA;
-            }
-            if (bandB == b) {
-                const unsigned rank = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
-                p.rays[rank + (rank < left ? at_slot : to_fresh)] = recB;
-            }
-            const unsigned at2 = cnt > left ? fresh + (cnt - left) : at_slot + cnt;
-            const unsigned left2 = cnt > left ? 128u - (cnt - left) : left - cnt;
-            bpos = lane == b ? at2 : bpos;
-            bleft = lane == b ? left2 : bleft;
-        }
-    };
+    RecordBlocks rb;
+    rb.init(grp_first * gs, p.lg_spare_base + wave_id * p.lg_spw);
 
     for (unsigned grp = grp_first; grp < grp_last; grp += grp_step) {
         const unsigned pi = grp;
@@ -1527,14 +1475,14 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                         lg_rec0 = lg_rec;
                         lg_has0 = lg_has;
                     } else {
-                        emit_records(lg_has, lg_rec, lg_has0, lg_rec0);     // light-sampled records first, as above
+                        rb.emit(p, lane, lg_has, lg_rec, lg_has0, lg_rec0);     // light-sampled records first, as above
                         lg_has0 = false;
                     }
                 }
             }
-            if (BACKWARD) emit_records(false, lg_rec0, lg_has0, lg_rec0);   // (nothing left to place if a queue batch took them along)
+            if (BACKWARD) rb.emit(p, lane, false, lg_rec0, lg_has0, lg_rec0);   // (nothing left to place if a queue batch took them along)
         }
-        if (BACKWARD) free_end = (grp + 1u) * gs;       // the rays of this pixel have all been read: its slots may hold records now
+        if (BACKWARD) rb.free_end = (grp + 1u) * gs;    // the rays of this pixel have all been read: its slots may hold records now
 
         if (!BACKWARD) {
             diffAccum = group_sum3(diffAccum, 64);
@@ -1562,8 +1510,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             }
         }
     }
-    if (BACKWARD && bpos != 0xFFFFFFFFu)
-        p.lg_tags[(bpos + bleft - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - bleft) << 8));
+    if (BACKWARD) rb.finish(p, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1576,7 +1523,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 //     of one workgroup (96 KB -> 8 bands at 256x256);
 //   * the backward shading kernel writes a 16-byte RECORD (rgb, texel) per non-zero addend, and it writes the records SORTED BY
 //     BAND: every wavefront keeps one open block of 128 stream slots per band (carved out of the part of the ray stream it has
-//     already consumed) and tags a block with (band, fill) when it is complete -- env_shade_kernel<true>, emit_records;
+//     already consumed) and tags a block with (band, fill) when it is complete -- RecordBlocks::emit;
 //   * workgroup (g, band) of this kernel walks the tag array (2 B per 128 slots), reads the blocks of its band as plain
 //     coalesced 2 KB loads -- every lane a record, every fetched byte used -- and adds them into LDS with ds_add_f32 (hot sun
 //     texels serialise inside the LDS atomic unit, not on the fabric); it leaves the tags it consumed reset to 0xFFFF;

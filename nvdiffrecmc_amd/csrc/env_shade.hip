@@ -784,6 +784,48 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
 // ---------------------------------------------------------------------------------------------
 // stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
 
+// The G-buffer values of one pixel that every sample of it is shaded with (, and the incoming gradients of the backward pass)
+struct PixelSetup {
+    F3 pos, nrm, view_pos, kd, ks, dgrad, sgrad;
+};
+
+// One sample of process_sample (kernel.cu:403-461) -- ray direction and pdf sum `rd`, light texel, visibility -- shaded for pixel `px`.
+// Forward: its contribution is ADDED to (diff, spec).  Backward: its gradient terms are ADDED to (g_kd, g_ks, g_pos, g_nrm) in the order
+// the reference's adjoint code forms them, and its light-gradient addend (eval_light_bwd, kernel.cu:203-211) is returned in lg.
+// The three stage-3 kernels differ in which lane shades which sample and where the sums live, not in this arithmetic.
+template <bool BACKWARD>
+__device__ __forceinline__ void shade_sample(const ShadeParams &p, const PixelSetup &px, const float4 &rd, int texel, bool occluded, float sample_frac,
+                                             F3 &diff, F3 &spec, F3 &g_kd, F3 &g_ks, F3 &g_pos, F3 &g_nrm, F3 &lg)
+{
+    const F3 dir = f3(rd.x, rd.y, rd.z);
+    const float pdfSum = rd.w;
+    const F3 light_col = fetch_light_texel(p.light, texel);
+    // (float)(1.0 / (double)f) of the reference == the IEEE float quotient 1.0f / f: rounding a double quotient of two floats
+    // to float is innocuous double rounding (53 >= 2 * 24 + 2 bits)
+    const float mis_weight = 1.0f / fmaxf(pdfSum, 0.0001f);
+    F3 _diff = f3(0.0f), _spec = f3(0.0f);
+    if (p.bsdf == 1 || p.bsdf == 2)
+        _diff = f3(fwd_lambert(px.nrm, dir));
+    else
+        fwd_pbr_bsdf_shader(px.kd, px.ks, px.pos, px.nrm, px.view_pos, dir, 0.08f, _diff, _spec);
+    const float vis = occluded ? 0.0f : 1.0f;
+    const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
+    if (BACKWARD) {
+        lg = (((px.dgrad * _diff + px.sgrad * _spec) * V) * mis_weight) * sample_frac;
+        const F3 _dg = (((px.dgrad * light_col) * V) * mis_weight) * sample_frac;
+        const F3 _sg = (((px.sgrad * light_col) * V) * mis_weight) * sample_frac;
+        if (p.bsdf == 1 || p.bsdf == 2) {
+            F3 d_wi = f3(0.0f);
+            bwd_lambert(px.nrm, dir, g_nrm, d_wi, sum3(_dg));
+        } else {
+            bwd_pbr_bsdf_shader(px.kd, px.ks, px.pos, px.nrm, px.view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
+        }
+    } else {
+        diff += (((_diff * light_col) * V) * mis_weight) * sample_frac;
+        spec += (((_spec * light_col) * V) * mis_weight) * sample_frac;
+    }
+}
+
 // Light-gradient records of ONE WAVEFRONT of a backward shading kernel, sorted by band as they are written (light_grad_block_kernel reads
 // them).  A record = (rgb addend, texel); records of one band are packed into BLOCKS of 128 stream slots, and a block is tagged with
 // (band, fill) once it is complete.  Where the blocks come from: the ray stream itself.  The rays of a group of pixels are dead once the
@@ -902,6 +944,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             dgrad = fetch3(p.dgrad, z, y, x);
             sgrad = fetch3(p.sgrad, z, y, x);
         }
+        const PixelSetup px = {pos, nrm, view_pos, kd, ks, dgrad, sgrad};
         F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
         F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
         // Stage 1 stored the pixel's samples BY STRATUM (slot s = the light-sampled ray of stratum s, slot S + s the
@@ -969,45 +1012,21 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 const int64_t ri = r == 0 ? rA : rB;
                 const float4 rd = r == 0 ? rdA : rdB;
                 const int texel = p.texel[ri];
-                const F3 dir = f3(rd.x, rd.y, rd.z);
-                const float pdfSum = rd.w;
-                const F3 light_col = fetch_light_texel(p.light, texel);
-                // (float)(1.0 / (double)f) of the reference == the IEEE float quotient 1.0f / f: rounding a double quotient of two floats
-                // to float is innocuous double rounding (53 >= 2 * 24 + 2 bits)
-                const float mis_weight = 1.0f / fmaxf(pdfSum, 0.0001f);
-                F3 _diff = f3(0.0f), _spec = f3(0.0f);
-                if (p.bsdf == 1 || p.bsdf == 2)
-                    _diff = f3(fwd_lambert(nrm, dir));
-                else
-                    fwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, _diff, _spec);
-                const float vis = ((occ >> r) & 1u) ? 0.0f : 1.0f;
-                const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
+                F3 lg = f3(0.0f);
+                shade_sample<BACKWARD>(p, px, rd, texel, (occ >> r) & 1u, sample_frac, diffAccum, specAccum, g_kd, g_ks, g_pos, g_nrm, lg);
                 if (BACKWARD) {
-                    const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
                     // light gradient (eval_light_bwd, kernel.cu:203-211).  fp32 atomics are executed at the memory side on
                     // MI355X (rocprofv3: one 64-byte write leaves the XCD per atomic, whatever the scope bits say), ~25 G
                     // of them per second.  Each XCD accumulates into ITS OWN copy (picked by the XCC id the wave actually
                     // runs on, so the result does not depend on workgroup placement) and a tiny kernel sums the 8 copies:
                     // that spreads hot texels over 8 addresses (measured: a few per cent); what really helped was not
-                    // issuing the zero addends.  The atomics of both samples are issued together after the loop over r
-                    // (no effect on time, but it keeps them out of the way of the second sample's loads).
+                    // issuing the zero addends.
                     const int at = (dbg & 4u) ? (int)((ri * 2654435761u) % (unsigned)(p.light_elems / 3)) : texel;   // bit 4: contention experiment
                     // adding +-0 never changes an accumulator that started at +0: occluded samples leave no addend
                     const bool lg_has = !(dbg & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
                     if (r == 0) { lg_hasA = lg_has; lg_recA = make_float4(lg.x, lg.y, lg.z, __int_as_float(at)); }
                     else { lg_hasB = lg_has; lg_recB = make_float4(lg.x, lg.y, lg.z, __int_as_float(at)); }
                     if (lg_has && !p.lg_records) emit_light_grad(lg, at);
-                    const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
-                    const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
-                    if (p.bsdf == 1 || p.bsdf == 2) {
-                        F3 d_wi = f3(0.0f);
-                        bwd_lambert(nrm, dir, g_nrm, d_wi, sum3(_dg));
-                    } else {
-                        bwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
-                    }
-                } else {
-                    diffAccum += (((_diff * light_col) * V) * mis_weight) * sample_frac;
-                    specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
                 }
               }
             }
@@ -1225,35 +1244,16 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             float4 lg_rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             bool lg_has = false;
             if (has) {
-                const F3 dir = f3(rd.x, rd.y, rd.z);
-                const float pdfSum = rd.w;
-                const F3 light_col = fetch_light_texel(p.light, texel);
-                const float mis_weight = 1.0f / fmaxf(pdfSum, 0.0001f);
-                F3 _diff = f3(0.0f), _spec = f3(0.0f);
-                if (p.bsdf == 1 || p.bsdf == 2)
-                    _diff = f3(fwd_lambert(nrm, dir));
-                else
-                    fwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, _diff, _spec);
-                const float vis = occluded ? 0.0f : 1.0f;
-                const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
+                // (a sample's gradient terms are accumulated from zero before they are added to its cell)
+                const PixelSetup px = {pos, nrm, view_pos, kd, ks, dgrad, sgrad};
+                F3 d = f3(0.0f), sp = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f), g_pos = f3(0.0f), g_nrm = f3(0.0f), lg = f3(0.0f);
+                shade_sample<BACKWARD>(p, px, rd, texel, occluded, sample_frac, d, sp, g_kd, g_ks, g_pos, g_nrm, lg);
                 if (BACKWARD) {
-                    const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
                     lg_has = !(dbg & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
                     lg_rec = make_float4(lg.x, lg.y, lg.z, __int_as_float(texel));
-                    const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
-                    const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
-                    F3 g_kd = f3(0.0f), g_ks = f3(0.0f), g_pos = f3(0.0f), g_nrm = f3(0.0f);
-                    if (p.bsdf == 1 || p.bsdf == 2) {
-                        F3 d_wi = f3(0.0f);
-                        bwd_lambert(nrm, dir, g_nrm, d_wi, sum3(_dg));
-                    } else {
-                        bwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
-                    }
                     out[0] = g_kd.x; out[1] = g_kd.y; out[2] = g_kd.z; out[3] = g_ks.x; out[4] = g_ks.y; out[5] = g_ks.z;
                     out[6] = g_pos.x; out[7] = g_pos.y; out[8] = g_pos.z; out[9] = g_nrm.x; out[10] = g_nrm.y; out[11] = g_nrm.z;
                 } else {
-                    const F3 d = (((_diff * light_col) * V) * mis_weight) * sample_frac;
-                    const F3 sp = (((_spec * light_col) * V) * mis_weight) * sample_frac;
                     out[0] = d.x; out[1] = d.y; out[2] = d.z; out[3] = sp.x; out[4] = sp.y; out[5] = sp.z;
                 }
             }
@@ -1365,6 +1365,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             dgrad = fetch3(p.dgrad, z, y, x);
             sgrad = fetch3(p.sgrad, z, y, x);
         }
+        const PixelSetup px = {pos, nrm, view_pos, kd, ks, dgrad, sgrad};
         F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
         F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
         unsigned q_head = 0u, q_count = 0u;             // wave-uniform; the queue is empty between pixels
@@ -1442,32 +1443,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 float4 lg_rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 bool lg_has = false;
                 if (has) {
-                    const F3 dir = f3(rd.x, rd.y, rd.z);
-                    const float pdfSum = rd.w;
-                    const F3 light_col = fetch_light_texel(p.light, texel);
-                    const float mis_weight = 1.0f / fmaxf(pdfSum, 0.0001f);
-                    F3 _diff = f3(0.0f), _spec = f3(0.0f);
-                    if (p.bsdf == 1 || p.bsdf == 2)
-                        _diff = f3(fwd_lambert(nrm, dir));
-                    else
-                        fwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, _diff, _spec);
-                    const float vis = occluded ? 0.0f : 1.0f;
-                    const float V = vis * p.shadow_scale + (1 - p.shadow_scale);
+                    F3 lg = f3(0.0f);
+                    shade_sample<BACKWARD>(p, px, rd, texel, occluded, sample_frac, diffAccum, specAccum, g_kd, g_ks, g_pos, g_nrm, lg);
                     if (BACKWARD) {
-                        const F3 lg = (((dgrad * _diff + sgrad * _spec) * V) * mis_weight) * sample_frac;
                         lg_has = !(dbg & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
                         lg_rec = make_float4(lg.x, lg.y, lg.z, __int_as_float(texel));
-                        const F3 _dg = (((dgrad * light_col) * V) * mis_weight) * sample_frac;
-                        const F3 _sg = (((sgrad * light_col) * V) * mis_weight) * sample_frac;
-                        if (p.bsdf == 1 || p.bsdf == 2) {
-                            F3 d_wi = f3(0.0f);
-                            bwd_lambert(nrm, dir, g_nrm, d_wi, sum3(_dg));
-                        } else {
-                            bwd_pbr_bsdf_shader(kd, ks, pos, nrm, view_pos, dir, 0.08f, g_kd, g_ks, g_pos, g_nrm, _dg, _sg);
-                        }
-                    } else {
-                        diffAccum += (((_diff * light_col) * V) * mis_weight) * sample_frac;
-                        specAccum += (((_spec * light_col) * V) * mis_weight) * sample_frac;
                     }
                 }
                 if (BACKWARD) {

@@ -17,9 +17,10 @@
 //       lines twice as often costs +65 %.  Two lookups per node instead of four is the lever.
 //       The ray is transformed into grid space once (o' = (o - g_lo) * g_scale, d' = d * g_scale), which
 //       leaves the ray parameter t unchanged, so the slab test runs directly on the decoded integers.
-//   oct[m]    : 4 x uint4 = 64 B per EIGHT-WIDE node (what the shadow-ray traversal of env-shade walks; csrc/trace_kernel.h).  Built from
-//       nodes[] after the fit by a top-down collapse (bvh_oct_build_kernel: a node's slots start as its two children and the
-//       internal slot with the largest surface area is replaced by ITS two children until eight slots are taken).  Slots are
+//   oct[m]    : 4 x uint4 = 64 B per EIGHT-WIDE node (what the shadow-ray traversal of env-shade walks; csrc/trace_kernel.h).  Collapsed
+//       from nodes[] after the fit (bvh.hip: the SAH-optimal treelets chosen by the dynamic programme of bvh_fit_kernel, resolved
+//       into per-node slot budgets by pointer jumping, counted, prefix-summed and emitted -- bvh_oct_budget / count / emit kernels;
+//       the layout is a function of the tree alone).  Slots are
 //       ordered internal children first (n_int of them, stored CONTIGUOUSLY in oct[] from child_base: no per-child index), then
 //       leaves (n_leaf triangles, stored contiguously in tris8[] from tri_base), then empty slots.  Child boxes are re-quantised
 //       to 8 bits in the NODE'S OWN frame -- origin = the node's lower corner on the 16-bit grid, one power-of-two cell size
@@ -108,7 +109,7 @@ struct nvdr_ctx {
     int64_t n_verts = 0;
     uint4 *nodes = nullptr;        // [2 * cap]
     uint4 *wide = nullptr;         // [4 * cap] four-slot nodes of the round-2 kernel (traversal variant 0; built only when selected)
-    uint4 *oct = nullptr;          // [4 * cap] eight-wide nodes collapsed from nodes[] (bvh_oct_build_kernel)
+    uint4 *oct = nullptr;          // [4 * cap] eight-wide nodes collapsed from nodes[] (bvh_oct_emit_kernel)
     float4 *tris8 = nullptr;       // [3 * cap] triangle records in oct-leaf order
     int *oct_task = nullptr;       // [cap] the wide roots: binary nodes that root an eight-wide node (bvh_oct_budget_kernel)
     unsigned long long *oct_jump = nullptr;   // [cap] (ancestor, budget map) per binary node: the budget resolution's pointer-jumping state

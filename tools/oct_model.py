@@ -1,4 +1,4 @@
-"""CPU model of the round-3 shadow-ray walk: the eight-wide collapse of bvh_oct_build_kernel (csrc/bvh.hip) over the LBVH of
+"""CPU model of the round-3 shadow-ray walk: the eight-wide collapse (round 3: bvh_oct_build_kernel, greedy; `dp`: the SAH-optimal one of csrc/bvh.hip) over the LBVH of
 tools/tree_quality_probe.py, the 8-bit node-local quantisation, and the unordered group walk of csrc/trace_kernel.h with deferred
 triangle tests -- in numpy, float32 where the kernel computes in float32.  Prints what the design costs per ray (node steps, box
 tests, triangle tests, stack depth) beside the four-slot walk of round 2, and checks its visibility against brute force.

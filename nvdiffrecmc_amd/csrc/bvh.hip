@@ -168,10 +168,22 @@ __device__ __forceinline__ int lbvh_delta(const uint32_t *__restrict__ keys, int
 // NVDR_FIT_BLOCK consecutive leaves, i.e. both of its subtrees are climbed by threads of the same workgroup of bvh_fit_kernel, which
 // then meet in LDS.  (The eight-wide builder's budget walk reads the same words.)
 #define NVDR_FIT_BLOCK 256
-__global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, uint4 *__restrict__ nodes, uint2 *__restrict__ up)
+// control words of the eight-wide collapse (below), one 128-byte line each
+#define OCT_CTL_ROOTS 0         // wide roots found (step 1)
+#define OCT_CTL_ALLOC 32        // oct nodes (written by the emit step: 1 + sum of the internal slots)
+#define OCT_CTL_DONE 64         // oct nodes written
+#define OCT_CTL_TRIS 96         // triangles placed
+#define OCT_CTL_WORDS 128
+// (Also clears what the two stages behind it start from -- the arrival counters of the fit, the control words of the eight-wide collapse:
+// two 5-us launches less per rebuild; a refit, which does not come through here, keeps them.)
+__global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, uint4 *__restrict__ nodes, uint2 *__restrict__ up, int *__restrict__ flags,
+                                     unsigned *__restrict__ oct_ctl)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
+    flags[i] = 0;
+    if (i == n - 2) flags[n - 1] = 0;
+    if (i == 0) { oct_ctl[OCT_CTL_ROOTS] = 0u; oct_ctl[OCT_CTL_ALLOC] = 1u; oct_ctl[OCT_CTL_DONE] = 0u; oct_ctl[OCT_CTL_TRIS] = 0u; }
     const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
     const int dmin = lbvh_delta(keys, n, i, i - d);
     int lmax = 2;
@@ -488,11 +500,6 @@ __global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal
 // takes a group's children lowest index first, and an any-hit ray is done at its first hit), and their 16-bit boxes re-quantised to
 // 8 bits in the node's own frame.
 
-#define OCT_CTL_ROOTS 0         // wide roots found (step 1)
-#define OCT_CTL_ALLOC 32        // oct nodes (written by the emit step: 1 + sum of the internal slots)
-#define OCT_CTL_DONE 64         // oct nodes written
-#define OCT_CTL_TRIS 96         // triangles placed
-#define OCT_CTL_WORDS 128
 
 #ifndef NVDR_OCT_ORDER
 #define NVDR_OCT_ORDER 1        // internal children of a wide node: smaller surface area first (0: slot order; A/B)
@@ -753,6 +760,38 @@ __global__ void __launch_bounds__(256) bvh_oct_scan_apply_kernel(const unsigned 
         if (base + j < n) scan[base + j] = run;
         run += v[j];
     }
+}
+
+// the three launches above in one workgroup, for trees of up to OCT_SCAN_SMALL binary nodes (the headline mesh has 10 687)
+#define OCT_SCAN_SMALL 16384
+__global__ void __launch_bounds__(1024) bvh_oct_scan_small_kernel(const unsigned long long *__restrict__ cnt, int n, unsigned long long *__restrict__ scan,
+                                                                   unsigned *ctl)
+{
+    __shared__ unsigned long long wave_sum[16];
+    constexpr int PER = OCT_SCAN_SMALL / 1024;
+    const int base = threadIdx.x * PER;
+    unsigned long long v[PER], sum = 0ull;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        v[j] = base + j < n ? cnt[base + j] : 0ull;
+        sum += v[j];
+    }
+    unsigned long long inc = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    unsigned long long run = inc - sum;
+    for (int w2 = 0; w2 < wave; ++w2) run += wave_sum[w2];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        if (base + j < n) scan[base + j] = run;
+        run += v[j];
+    }
+    if (threadIdx.x == 1023) { ctl[OCT_CTL_ALLOC] = 1u + (unsigned)(run >> 32); ctl[OCT_CTL_TRIS] = (unsigned)(run & 0xffffffffull); }
 }
 
 __global__ void __launch_bounds__(256) bvh_oct_emit_kernel(OctBuildArgs a)
@@ -1086,9 +1125,10 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         NVDR_HIP_TRY(rocprim::radix_sort_pairs<nvdr_sort_config>(c->sort_tmp, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1],
                                                                  (size_t)n, 0, 30, stream));
         if (n > 1)
-            bvh_hierarchy_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->keys[1], n, c->nodes, c->up);
+            bvh_hierarchy_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->keys[1], n, c->nodes, c->up, c->flags, c->oct_ctl);
     }
-    NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
+    const bool cleared = rebuild != 0 && n > 1;        // (the hierarchy kernel has cleared the counters and the control words)
+    if (!cleared) NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
     bvh_fit_kernel<<<div_up(n, NVDR_FIT_BLOCK), NVDR_FIT_BLOCK, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->up,
                                                                               c->flags, c->dinfo, c->dp_cost, c->oct_c_leaf, c->oct_jump);
     if (c->trace_variant == 0 && n > 1) {
@@ -1101,7 +1141,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         oa.nodes = c->nodes; oa.tris = c->tris; oa.oct = c->oct; oa.tris8 = c->tris8; oa.up = c->up; oa.jump = c->oct_jump;
         oa.roots = c->oct_task; oa.wslot = c->oct_wslot; oa.cnt = c->oct_cnt; oa.scan = c->oct_scan; oa.ctl = c->oct_ctl;
         oa.info = c->dinfo; oa.n_int_nodes = n - 1;
-        bvh_oct_init_kernel<<<1, 64, 0, stream>>>(oa, n);
+        if (!cleared) bvh_oct_init_kernel<<<1, 64, 0, stream>>>(oa, n);
         if (n > 1) {
             bvh_oct_budget_kernel<<<div_up(n - 1, 1024), 1024, 0, stream>>>(oa);
             // wide roots are ~n / 4.9; the grid-stride loops of the two expansion kernels cover whatever the device-side count says
@@ -1109,9 +1149,13 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
             bvh_oct_count_kernel<<<blocks < 1u ? 1u : blocks, 256, 0, stream>>>(oa);
             const unsigned tiles = div_up(n - 1, OCT_SCAN_TILE);
             unsigned long long *part = (unsigned long long *)c->sort_tmp;      // the sort is done with its scratch by now
-            bvh_oct_scan_reduce_kernel<<<tiles, 256, 0, stream>>>(c->oct_cnt, n - 1, part);
-            bvh_oct_scan_partials_kernel<<<1, 1024, 0, stream>>>(part, (int)tiles, c->oct_ctl);
-            bvh_oct_scan_apply_kernel<<<tiles, 256, 0, stream>>>(c->oct_cnt, n - 1, part, c->oct_scan);
+            if (n - 1 <= OCT_SCAN_SMALL) {
+                bvh_oct_scan_small_kernel<<<1, 1024, 0, stream>>>(c->oct_cnt, n - 1, c->oct_scan, c->oct_ctl);
+            } else {
+                bvh_oct_scan_reduce_kernel<<<tiles, 256, 0, stream>>>(c->oct_cnt, n - 1, part);
+                bvh_oct_scan_partials_kernel<<<1, 1024, 0, stream>>>(part, (int)tiles, c->oct_ctl);
+                bvh_oct_scan_apply_kernel<<<tiles, 256, 0, stream>>>(c->oct_cnt, n - 1, part, c->oct_scan);
+            }
             bvh_oct_emit_kernel<<<blocks < 1u ? 1u : blocks, 256, 0, stream>>>(oa);
         }
     }

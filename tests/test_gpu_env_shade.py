@@ -29,7 +29,7 @@ BWD_RTOL = 2e-4
     ('bob', 64, 64, 4, 'diffuse', 7),
     ('bob', 64, 64, 2, 'white', 8),
     ('bob', 32, 32, 16, 'diffuse', 9),     # S = 256: the pixel-local queue kernel on the Lambert arm
-    ('spot', 24, 24, 16, 'pbr', 10),       # S = 256, metal
+    ('spot', 32, 32, 16, 'pbr', 10),       # S = 256, metal
 ])
 def test_env_shade_fwd_bwd_vs_oracle(mesh, H, W, n, bsdf, seed, dev):
     inp = scene_cpu.make_inputs(mesh, H, W, n, view=seed % 8, probe_res=128, n_threads=NT)

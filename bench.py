@@ -364,9 +364,12 @@ def exchange_probe(step, dev):
         ex = GradientExchange(groups, 1)
         ex.active = True
         ms = []
+        resident = [ex.slot(p) if (i < 3 and step.material_set == 'full') else None for i, p in enumerate(step.params)]
         for it in range(12):
-            for p, g in zip(step.params, src):          # fresh gradients, as a backward pass leaves them (wait() points .grad into the buckets)
-                p.grad = g
+            # gradients as a backward pass of a multi-rank run leaves them: the texture gradients inside the buckets (the lookup's adjoint
+            # scatter-adds there, trainer._exchange), the probe's and the vertices' in tensors of their own
+            for p, g, r in zip(step.params, src, resident):
+                p.grad = r if r is not None else g
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             ex.pack()
@@ -378,7 +381,7 @@ def exchange_probe(step, dev):
             if it >= 2:
                 ms.append(a.elapsed_time(b))
         return {'backend': dist.get_backend(), 'world': 1, 'chunks': len(groups), 'bucket_bytes': int(sum(b.numel() for b in ex.buckets) * 4),
-                'ms_per_iteration': statistics.median(ms)}
+                'ms_per_iteration': statistics.median(ms), 'resident_bytes': int(sum(r.numel() for r in resident if r is not None) * 4)}
     finally:
         if own:
             with _stdout_to_stderr():

@@ -176,15 +176,23 @@ def _fill_args(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_pos, gb_kd, gb_ks
     return a
 
 
+PERM_TABLE_SEED = 0x5EED      # seed of the default permutation tables (_perms_for)
+
+
 def _perms_for(n_samples_x, device):
     """(32k) table of random permutations that decorrelate the BSDF and light strata: one per (device, n_samples_x),
     created lazily and cached for the process (ops.py:79,84-86; the reference keys by n_samples_x only -- it runs one
-    device per process).  Tests inject a seeded CPU-generated table through set_permutation_table()."""
+    device per process).  Drawn from a generator of its own with a FIXED seed (the reference draws from the global CUDA generator):
+    the ranks of a data-parallel run are separate processes, and a view rendered on rank r equals the same view inside the one-GPU
+    batch launch only if both stratify with the same table -- and so does every run.  PERM_TABLE_SEED / set_permutation_table()
+    choose another table; the parity tests inject a CPU-generated one."""
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), n_samples_x)
     t = _optix_env_shade_func._random_perm.get(key)
     if t is None:
-        t = torch.argsort(torch.rand(32768, n_samples_x * n_samples_x, device=device), dim=-1).int()
+        g = torch.Generator(device=device)
+        g.manual_seed(PERM_TABLE_SEED + n_samples_x)
+        t = torch.argsort(torch.rand(32768, n_samples_x * n_samples_x, device=device, generator=g), dim=-1).int()
         _optix_env_shade_func._random_perm[key] = t
     return t
 

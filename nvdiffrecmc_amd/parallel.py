@@ -58,8 +58,9 @@ class GradientExchange:
 
     Zero-copy on the way back: after wait(k) the parameters' .grad ARE views into the reduced bucket (no unpack pass), holding the
     weighted SUM over the ranks; `scale` (= 1 / total weight, a device scalar in the uneven case folded to a float when every rank
-    renders the same number of views) is what the optimizer multiplies the gradient by (FusedAdam grad_scales).  The pack is one
-    torch.cat per chunk into a preallocated bucket, so nothing allocates after the first iteration (HIP-graph friendly).
+    renders the same number of views) is what the optimizer multiplies the gradient by (FusedAdam grad_scales).  The pack is a copy
+    per parameter into a preallocated bucket -- or nothing at all for a gradient its producer already wrote into the bucket (slot()) -- so
+    nothing allocates after the first iteration (HIP-graph friendly).
 
     groups: list of lists of parameters (one list per chunk).  local_weight: views this rank renders; equal_shards: every rank has
     the same local_weight (then no weighting traffic at all: plain sum, scale = 1 / world)."""
@@ -80,12 +81,31 @@ class GradientExchange:
     def chunks(self):
         return range(len(self.groups))
 
+    def slot(self, param):
+        """The part of its chunk's bucket reserved for `param`, shaped like it.  A producer that writes (or scatter-adds) the gradient
+        straight into this view -- and hands it to autograd as the gradient -- makes pack() a no-op for that parameter: the gradient
+        is born in the buffer the collective sends."""
+        for g, b in zip(self.groups, self.buckets):
+            off = 0
+            for p in g:
+                if p is param:
+                    return b[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        raise KeyError('parameter is not part of this exchange')
+
     def pack(self):
-        """Gather the .grad of every parameter into its chunk's bucket (one cat per chunk; a missing gradient contributes zeros)."""
+        """Bring the .grad of every parameter into its chunk's bucket: a copy per parameter, nothing for a gradient that already lives
+        there (slot()), zeros for a missing one."""
         for g, b in zip(self.groups, self.buckets):
             n = b.numel() - (0 if self.equal_shards else 1)
-            flats = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in g]
-            torch.cat(flats, out=b[:n])
+            off = 0
+            for p in g:
+                dst = b[off:off + p.numel()]
+                off += p.numel()
+                if p.grad is None:
+                    dst.zero_()
+                elif p.grad.data_ptr() != dst.data_ptr():
+                    dst.copy_(p.grad.reshape(-1))
             if not self.equal_shards:
                 b[:n].mul_(self.local_weight)
                 b[n:].fill_(self.local_weight)

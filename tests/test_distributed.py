@@ -131,12 +131,19 @@ def _worker_exchange(rank, world, port, q, n_views):
     params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
     # the gradient of THIS rank's mean over its views; view v contributes (v + 1) * pattern_k
     local = sum(float(v + 1) for v in views) / len(views)
-    for k, p in enumerate(params[:-1]):
-        p.grad = torch.full(p.shape, local * (k + 1))
-    params[-1].grad = None                                  # a parameter without gradient: zeros in the bucket
     even = n_views % world == 0
     ex = GradientExchange([params[0:2], params[2:]], world, local_weight=len(views), equal_shards=even)
+    for k, p in enumerate(params[:-1]):
+        if k in (0, 2):                                     # produced inside the bucket (the trainer's texture gradients): nothing to pack
+            p.grad = ex.slot(p)
+            p.grad.fill_(local * (k + 1))
+        else:
+            p.grad = torch.full(p.shape, local * (k + 1))
+    params[-1].grad = None                                  # a parameter without gradient: zeros in the bucket
+    before = [b.clone() for b in ex.buckets]
     ex.pack()
+    n0 = params[0].numel()
+    assert torch.equal(ex.buckets[0][:n0], before[0][:n0]) or not even        # a resident gradient is left where it is (weighted: scaled in place)
     ex.start()
     out = []
     for k in ex.chunks():

@@ -93,3 +93,60 @@ def test_bench_refuses_more_ranks_than_gpus(dev):
         pytest.skip('needs fewer than 64 GPUs')
     r = _bench(['--gpus', '64', '--batch', '64'])
     assert r.returncode != 0 and 'visible' in (r.stdout + r.stderr)
+
+
+_TRAIN_SNIPPET = r'''
+import json, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from nvdiffrecmc_amd.trainer import DirectLightingStep
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+if world > 1:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+res, n, views = 96, 4, [0, 1, 2, 3]
+per = len(views) // world
+mine = views[rank * per:(rank + 1) * per]
+st = DirectLightingStep('bob', res, n, view=mine, n_views=len(views), device='cuda:0', lr=0.03, tex_res=256,
+                        pixel_index_offset=mine[0] * res * res, use_graph=(os.environ.get('USE_GRAPH') == '1'))
+losses = []
+for it in range(8):
+    losses.append(float(st.step(world).item()))
+torch.cuda.synchronize()
+kd = st.params[0].detach().double()
+out = {'rank': rank, 'losses': losses, 'kd_sum': float(kd.sum()), 'kd_abs': float(kd.abs().sum()), 'light_sum': float(st.params[3].detach().double().sum()),
+       'resident': bool(getattr(st, '_tex_grad_resident', False)), 'graph': st._graphs is not None}
+print('RESULT ' + json.dumps(out))
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('graph', ['0', '1'], ids=['eager', 'hip_graphs'])
+def test_two_rank_training_follows_the_one_rank_run(graph, dev):
+    """Four views dealt over two ranks (gloo for the collective, both on this GPU) train like four views on one rank: the chunked
+    exchange sums what the ranks' backward passes scatter-added INTO its buckets, the fused Adam of every chunk sees the batch-mean
+    gradient.  Per step the mean of the two ranks' losses is the one-rank loss (each rank's loss is the mean over its own views), and
+    the trained textures and probe agree up to the order of the additions."""
+    def run(world, rank, port):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), USE_GRAPH=graph,
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        return subprocess.Popen([sys.executable, '-c', _TRAIN_SNIPPET % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+
+    def result(p):
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-2000:] + err[-3000:]
+        return json.loads([l for l in out.splitlines() if l.startswith('RESULT ')][-1][7:])
+    one = result(run(1, 0, _free_port()))
+    port = _free_port()
+    procs = [run(2, r, port) for r in range(2)]
+    two = sorted([result(p) for p in procs], key=lambda d: d['rank'])
+    assert two[0]['resident'] and two[1]['resident'] and not one['resident']
+    assert two[0]['graph'] == (graph == '1')
+    for it in range(8):
+        pair = 0.5 * (two[0]['losses'][it] + two[1]['losses'][it])
+        assert abs(pair - one['losses'][it]) <= 2e-4 * abs(one['losses'][it]), (it, pair, one['losses'][it])
+    assert one['losses'][-1] < one['losses'][0]
+    for k in ('kd_sum', 'light_sum'):
+        assert abs(two[0][k] - two[1][k]) <= 1e-9 * abs(two[0][k])             # the ranks hold the same parameters ...
+        assert abs(two[0][k] - one[k]) <= 1e-4 * abs(one[k]), (k, two[0][k], one[k])      # ... and they are the one-rank parameters

@@ -507,6 +507,12 @@ class DirectLightingStep:
         under B_k; with one rank A and B are one graph."""
         torch.cuda.synchronize()
         self.opt.zero_grad(set_to_none=True)
+        # The parameters' gradient accumulators were created on the default stream by the eager iterations; the capture runs on torch's
+        # capture stream.  Every .grad is None here, so an accumulator only ADOPTS the incoming tensor -- it launches nothing that the
+        # capture could miss -- and torch's warning about the stream mismatch does not apply.
+        warn = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if warn is not None:
+            warn(False)
         ga = torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):
             self._loss_static = self.forward_backward()

@@ -1086,6 +1086,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 // The ring holds NVDR_SQ_RING pixels (set-up + result row); a pixel whose entry is needed again while samples of it still wait
 // drains the queue with a partial batch (3 entries: 0.552 passes per pixel for the light samples against 0.547 with no limit).
 #define NVDR_SQ_RING 3u
+#ifndef NVDR_SQ_RING_FWD
+#define NVDR_SQ_RING_FWD 2u        // ring entries of the forward instantiation: 25 instead of 31 KB of LDS per workgroup, six resident per CU (forward shading 0.818 -> 0.800 ms per 8-view launch; 3: A/B)
+#endif
 #define NVDR_SQ_QCAP 128u
 
 template <bool BACKWARD, bool DBG>
@@ -1103,8 +1106,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     const bool use_bits = BACKWARD && p.vis_cache != nullptr;
     const bool save_bits = !BACKWARD && p.vis_cache != nullptr;
 
-    __shared__ float res_all[4][NVDR_SQ_RING][NF][64];
-    __shared__ float setup_all[4][NVDR_SQ_RING][NS + 3];
+    constexpr unsigned RING = BACKWARD ? NVDR_SQ_RING : NVDR_SQ_RING_FWD;
+    __shared__ float res_all[4][RING][NF][64];
+    __shared__ float setup_all[4][RING][NS + 3];
     __shared__ float4 q_rd_all[4][NVDR_SQ_QCAP];
     __shared__ unsigned q_meta_all[4][NVDR_SQ_QCAP];    // stratum | ring entry << 6 | occluded << 8
     __shared__ int q_tex_all[4][NVDR_SQ_QCAP];
@@ -1133,10 +1137,10 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     unsigned pend0 = 0, pend1 = 0, pend2 = 0;       // queued samples of the entry's pixel that are not shaded yet
     int lin0 = 0, lin1 = 0, lin2 = 0;               // its index in the frame(s)
     unsigned q_head = 0, q_count = 0;
-    static_assert(NVDR_SQ_RING == 3u, "the ring state is spelled out for three entries");
+    static_assert(RING == 2u || RING == 3u, "the ring state is spelled out for up to three entries");
 
     while (true) {
-        const bool ring_full = it - fin == NVDR_SQ_RING;
+        const bool ring_full = it - fin == RING;
         const bool do_home = grp < grp_last && !ring_full;
         if (!do_home && q_count == 0u && fin == it) break;
         float4 lg_rec0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), lg_rec1 = lg_rec0;    // [0]: the in-place pass (BSDF samples), [1]: the queue pass
@@ -1152,7 +1156,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             F3 pos, nrm, view_pos, kd, ks, dgrad = f3(0.0f), sgrad = f3(0.0f);     // the set-up of the sample's pixel
             if (k == 0) {
                 if (!do_home) continue;
-                ent = it % NVDR_SQ_RING;
+                ent = it % RING;
                 const unsigned pi = grp;
                 const int lin = p.pix_list[p.pix_begin + pi];
                 const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
@@ -1276,7 +1280,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         if (BACKWARD && p.lg_records) rb.emit(p, lane, lg_has1, lg_rec1, lg_has0, lg_rec0);     // light-sampled records first, as above
         // pixels whose samples are all shaded, in order: the row is summed over the lanes and written
         while (fin < it) {
-            const unsigned e = fin % NVDR_SQ_RING;
+            const unsigned e = fin % RING;
             const unsigned pend = e == 0u ? pend0 : (e == 1u ? pend1 : pend2);
             if (pend != 0u) break;
             const int lin = e == 0u ? lin0 : (e == 1u ? lin1 : lin2);

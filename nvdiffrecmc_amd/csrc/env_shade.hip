@@ -1085,7 +1085,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 // term by term to the running sums): last-bit differences, and like above no dependence on which pixels share a wavefront or a chunk.
 // The ring holds NVDR_SQ_RING pixels (set-up + result row); a pixel whose entry is needed again while samples of it still wait
 // drains the queue with a partial batch (3 entries: 0.552 passes per pixel for the light samples against 0.547 with no limit).
+// (Backward, round 4, in-process A/B: two entries = 38 KB of LDS: +4.1 % -- more partial batches; two entries AND 128 VGPRs (seven dwords
+// spilled) for four workgroups per CU: +1.8 % at eight views, +7.6 % at one.  Three entries at three waves per SIMD stay.)
+#ifndef NVDR_SQ_RING
 #define NVDR_SQ_RING 3u
+#endif
 #ifndef NVDR_SQ_RING_FWD
 #define NVDR_SQ_RING_FWD 2u        // ring entries of the forward instantiation: 25 instead of 31 KB of LDS per workgroup, six resident per CU (forward shading 0.818 -> 0.800 ms per 8-view launch; 3: A/B)
 #endif

@@ -377,9 +377,11 @@ class DirectLightingStep:
 
     def forward_backward(self):
         """The differentiable part of the iteration; returns the loss tensor (grads are in .grad)."""
-        self.light.update_pdf()
+        # the rebuild first: it runs on the context's side stream, and the sooner it starts the less of it is left when the traversal
+        # needs the tree (one view: the light's three small kernels used to run in front of it)
         v_pos = self.v_pos if self.optimize_geometry else self.mesh['v_pos']
         ou.optix_build_bvh(self.ctx, v_pos, self.mesh['t_pos_idx'], rebuild=1)
+        self.light.update_pdf()
         self.opt.zero_grad(set_to_none=True)
         if self._tex_grad is not None:
             if self._tex_grad_dirty:            # a backward pass whose gradients no update consumed (forward_backward called on its own)

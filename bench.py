@@ -16,7 +16,8 @@ Workloads (BASELINE.json `configs`):
   dmtet800    (configs[3] stand-in)  bob subdivided three times = 684 032 triangles (the size of a 128^3 DMTet
               extraction; 43 MB of nodes + triangles: does NOT fit the 4 MB L2s), 800x800, n_samples_x = 8, batch 8.
   hotdog512x256 (configs[4] stand-in)  bob subdivided twice = 171 008 triangles, 512x512, n_samples_x = 16 (256 spp), batch 8
-              (configs/nerfactor_hotdog.json:7-8); geometry fixed -- DMTet's joint geometry optimisation is outside the path.
+              (configs/nerfactor_hotdog.json:7-8); v_pos is trained like the reference's second (DLMesh) pass -- the COST of the geometry
+              gradient, not a converging geometry optimisation (no silhouette term, no regulariser: BENCH_LR_POS).
 One step = one optimisation iteration of nvdiffrecmc_amd/trainer.py: update_pdf + BVH rebuild + shading normal +
 env-shade fwd + 2x bilateral denoiser + composite + log-sRGB L1 image loss + full backward (the env-shade backward
 RE-TRACES every ray, as the reference does) + gradient all-reduce (N > 1) + Adam.  Inputs are resident in HBM before
@@ -74,10 +75,12 @@ BENCH_LR_POS = 1e-5
 PRESETS = {
     # lock_pos / tex_res: the config's own keys (configs/bob.json:6,14; spot_metal.json; nerf_lego / nerfactor_hotdog train the geometry:
     # their second pass runs DLMesh with v_pos as a parameter, geometry/dlmesh.py:28-38)
-    'bob512': dict(mesh='bob', res=512, n=8, batch=8, subdiv=0, lock_pos=True, tex_res=1024,
+    # ks_min: configs/bob.json:10 and spot_metal.json:12 say [0, 0.1, 0]; nerf_lego / nerfactor_hotdog keep the default of train.py:550 (0.08)
+    'bob512': dict(mesh='bob', res=512, n=8, batch=8, subdiv=0, lock_pos=True, tex_res=1024, ks_min=(0.0, 0.1, 0.0),
                    metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 64spp bob mesh)',
                    what='bob.json 512x512, 64 spp (n_samples_x=8)'),
-    'spot512x256': dict(mesh='spot', res=512, n=16, batch=4, subdiv=0, lock_pos=True, tex_res=1024,
+    # spot_metal.json:8,20: texture_res 512, no_perturbed_nrm (no normal map in the trained set)
+    'spot512x256': dict(mesh='spot', res=512, n=16, batch=4, subdiv=0, lock_pos=True, tex_res=512, ks_min=(0.0, 0.1, 0.0), perturbed_nrm=False,
                         metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 256spp spot_metal)',
                         what='spot_metal.json 512x512, 256 spp (n_samples_x=16)'),
     'dmtet800': dict(mesh='bob', res=800, n=8, batch=8, subdiv=3, lock_pos=False, tex_res=1024,
@@ -86,9 +89,23 @@ PRESETS = {
     'hotdog512x256': dict(mesh='bob', res=512, n=16, batch=8, subdiv=2, lock_pos=False, tex_res=1024,
                           metric='MC shadow rays/sec (fwd+bwd train iteration, 512x512 256spp, 171k-triangle DMTet-sized mesh)',
                           what='nerfactor_hotdog.json stand-in: bob subdivided 2x (171 008 triangles, the size DMTet extracts from a 128^3 '
-                               'grid), 512x512, 256 spp (n_samples_x=16); geometry fixed (the joint geometry optimisation is outside the path)'),
+                               'grid), 512x512, 256 spp (n_samples_x=16)'),
 }
 DOMINANT = 'env_trace_kernel<false>'
+GEOMETRY_NOTE = ('v_pos trained at lr %g: this measures the WORK SHAPE of geometry training (BVH / vertex frames / G-buffer rebuilt from the moving vertices, '
+                 'interpolation adjoint, v_pos in the exchange and in Adam), not a converging geometry optimisation -- the reference adds silhouette gradients '
+                 '(dr.antialias, render.py:290) and a Laplacian regulariser (geometry/dlmesh.py:57-76), both outside the path' % BENCH_LR_POS)
+TEXTURE_NOTE = ('trained textures are sampled at the NEAREST texel (render/texture.py:57-68 uses dr.texture linear-mipmap-linear, outside the path): only the '
+                'texels some covered pixel looks up receive gradient, which the tile-sparse Adam and the tile-sparse exchange exploit; with the mip chain of the '
+                'reference every texel would receive gradient -- `adam_dense_ms` / exchange mode "dense" are the like-for-like figures')
+
+
+def make_step(pre, args, dev, views, n_views, lock_pos, **kw):
+    """The iteration object of one preset (trainer.DirectLightingStep) with the config's own keys."""
+    from nvdiffrecmc_amd.trainer import DirectLightingStep
+    return DirectLightingStep(pre['mesh'], pre['res'], pre['n'], view=views, n_views=n_views, device=dev, subdiv=pre['subdiv'],
+                              material_set=args.material_set, tex_res=args.tex_res or pre.get('tex_res', 1024), optimize_geometry=not lock_pos,
+                              lr_pos=BENCH_LR_POS, ks_min=pre.get('ks_min', (0.0, 0.08, 0.0)), perturbed_nrm=pre.get('perturbed_nrm', True), **kw)
 
 
 def algorithmic_bytes(N, H, W, P, S, probe, bvh2_nodes, bvh2_tris, n_traced):
@@ -320,8 +337,7 @@ def other_config_object(name, args, dev):
     t0 = time.perf_counter()
     H, n, nv = pre['res'], pre['n'], pre['batch']
     lock = pre.get('lock_pos', True) or args.material_set != 'full'
-    step = DirectLightingStep(pre['mesh'], H, n, view=list(range(nv)), n_views=nv, device=dev, retrace_backward=True, subdiv=pre['subdiv'],
-                              material_set=args.material_set, tex_res=pre.get('tex_res', 1024), optimize_geometry=not lock, lr_pos=BENCH_LR_POS)
+    step = make_step(pre, args, dev, list(range(nv)), nv, lock, retrace_backward=True)
     for _ in range(4):
         step.step(1)
     K = 6
@@ -338,7 +354,9 @@ def other_config_object(name, args, dev):
                                                                      L.rows[:, 0], L.cols, n_samples_x=n, rnd_seed=0)
     out = {'workload': pre['what'] + ', batch of %d views' % nv, 'mesh_triangles': int(step.mesh['t_pos_idx'].shape[0]), 'covered_pixels': P,
            'rays_traversed_per_pass': n_traced, 'steps': K, 'ms_per_step': dt / K * 1e3, 'rays_per_sec': 2.0 * n_traced * K / dt,
-           'geometry': 'locked' if lock else 'trained', 'seconds': time.perf_counter() - t0}
+           'geometry': 'locked' if lock else 'trained', 'trained_parameters': list(step.param_names), 'seconds': time.perf_counter() - t0}
+    if not lock:
+        out['geometry_note'] = GEOMETRY_NOTE
     del step
     torch.cuda.empty_cache()
     return out
@@ -399,9 +417,8 @@ def large_mesh_object(args, dev):
     pre = PRESETS['dmtet800']
     t0 = time.perf_counter()
     H, n, nv = pre['res'], pre['n'], pre['batch']
-    step = DirectLightingStep(pre['mesh'], H, n, view=list(range(nv)), n_views=nv, device=dev, retrace_backward=True, subdiv=pre['subdiv'],
-                              material_set=args.material_set, tex_res=pre.get('tex_res', 1024),
-                              optimize_geometry=(args.material_set == 'full' and not pre.get('lock_pos', True) and args.lock_pos != 'on'), lr_pos=BENCH_LR_POS)
+    step = make_step(pre, args, dev, list(range(nv)), nv, not (args.material_set == 'full' and not pre.get('lock_pos', True) and args.lock_pos != 'on'),
+                     retrace_backward=True)
     step_unlocked = step.optimize_geometry
     for _ in range(4):
         step.step(1)
@@ -445,8 +462,8 @@ def large_mesh_object(args, dev):
         counters, note = collect_pmc(args, keep_dir=args.pmc_keep, config='dmtet800', passes=[['FETCH_SIZE'], ['TCC_REQ_sum', 'WRITE_SIZE', 'TCC_MISS_sum']])
         c = find_kernel(counters, DOMINANT) if counters else None
         if c:
-            # per DISPATCH -> per pass: this workload's ray stream (3.5 GB) is cut into two chunks by the 2 GiB budget, and the child runs
-            # 7 env-shade passes (see the roofline object below)
+            # per DISPATCH -> per pass: a ray stream larger than the context's byte budget (8 GiB by default) is cut into chunks, one dispatch
+            # each, and the child runs 7 env-shade passes (see the roofline object below)
             chunks = max(1, int(round(c.get('dispatches_pass0', 7) / 7.0)))
             if chunks > 1:
                 c = {k: (v_ * chunks if not k.startswith('dispatches_pass') else v_) for k, v_ in c.items()}
@@ -461,6 +478,8 @@ def large_mesh_object(args, dev):
         if note:
             out['pmc_note'] = note
     out['geometry'] = 'trained (v_pos, lr %g)' % BENCH_LR_POS if step_unlocked else 'locked'
+    if step_unlocked:
+        out['geometry_note'] = GEOMETRY_NOTE
     out['seconds'] = time.perf_counter() - t0
     return out
 
@@ -600,10 +619,7 @@ def run(args):
     lock_pos = preset.get('lock_pos', True) if args.lock_pos == 'config' else (args.lock_pos == 'on')
     if args.material_set == 'r3':
         lock_pos = True
-    step = DirectLightingStep(preset['mesh'], H, n, view=my_views, n_views=n_views, device=dev,
-                              pixel_index_offset=my_views[0] * H * W, retrace_backward=True, subdiv=preset['subdiv'], use_graph=use_graph,
-                              material_set=args.material_set, tex_res=args.tex_res or preset.get('tex_res', 1024), optimize_geometry=not lock_pos,
-                              lr_pos=BENCH_LR_POS)
+    step = make_step(preset, args, dev, my_views, n_views, lock_pos, pixel_index_offset=my_views[0] * H * W, retrace_backward=True, use_graph=use_graph)
 
     if args.pmc_child:          # under rocprofv3: a few plain iterations, nothing else
         for _ in range(args.warmup + args.steps):
@@ -747,7 +763,7 @@ def run(args):
             c = find_kernel(counters, DOMINANT) if counters else None
             if c:
                 # The child ran 3 iterations + the target render = 7 env-shade passes.  A launch whose ray stream is cut into chunks
-                # (spot512x256: 3 GB of stream against the 2 GiB budget) dispatches the kernel once per non-empty chunk and pass;
+                # (larger than the context's byte budget, 8 GiB by default) dispatches the kernel once per non-empty chunk and pass;
                 # the counter sums are per DISPATCH, the HIP-event time is per pass: bring the counters to the pass.
                 chunks = max(1, int(round(c.get('dispatches_pass0', 7) / 7.0)))
                 if chunks > 1:
@@ -809,11 +825,18 @@ def run(args):
                        'shadow_ray_queries_per_pass_rank0': R, 'rays_traversed_per_pass_rank0': n_traced,
                        'dead_samples': '%.1f%% of the queries have dot(n,wi)<=0, are zero through the BSDF gates whatever their visibility and are answered without traversal (outputs bit-identical; NVDR_DEBUG=8 traces them); value counts traversed rays only' % (100.0 * (1.0 - n_traced / max(R, 1))),
                        'views_per_iteration': n_views, 'views_rank0': step.nv, 'probe': '%dx%d E1' % (probe, probe),
-                       'backward': 're-traces all shadow rays', 'parallelism': 'dp%d (%d views per GPU)' % (world, step.nv),
+                       'backward': 're-traces all shadow rays (what the reference\'s backward does; `value` / `ms_per_step` are defined on this iteration)',
+                       # the same iteration with the forward's visibility bits replayed in backward -- exact whenever forward and backward share the seed
+                       # (train.py:547 decorrelated=False, render.py:112-116; per-pixel gradients bit-identical, tests/test_gpu_env_shade.py) and the
+                       # default of trainer.DirectLightingStep; measured after the timed steps, never part of `value`
+                       'ms_per_step_cached_visibility': (dt2 / k2 * 1e3) if dt2 else None,
+                       'iters_per_sec_cached_visibility': (k2 / dt2) if dt2 else None,
+                       'texture_filter': TEXTURE_NOTE,
+                       'parallelism': 'dp%d (%d views per GPU)' % (world, step.nv),
                        'trained_parameters': {nm: list(p.shape) for nm, p in zip(step.param_names, step.params)},
                        'parameter_bytes': int(sum(p.numel() for p in step.params) * 4),
                        'geometry': ('locked (lock_pos): G-buffer of the fixed views rendered once, BVH rebuilt every iteration as the reference does' if lock_pos else
-                                    'trained (v_pos, lr %g): BVH, vertex normals / tangents and the G-buffer rebuilt from the moving vertices every iteration; no silhouette (dr.antialias) term' % BENCH_LR_POS),
+                                    'trained (v_pos, lr %g): BVH, vertex normals / tangents and the G-buffer rebuilt from the moving vertices every iteration; ' % BENCH_LR_POS + GEOMETRY_NOTE),
                        'allreduce_bytes_per_step': getattr(step, 'allreduce_bytes', 0)},
             'roofline': roof,
         }

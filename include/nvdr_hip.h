@@ -67,10 +67,6 @@ int nvdr_ctx_set_stream_budget(nvdr_ctx *ctx, int64_t bytes);
 typedef void *(*nvdr_alloc_fn)(size_t bytes, int device, void *stream, void *user);
 typedef void (*nvdr_free_fn)(void *ptr, void *user);
 int nvdr_ctx_set_allocator(nvdr_ctx *ctx, nvdr_alloc_fn alloc_fn, nvdr_free_fn free_fn, void *user);
-/* Shadow-ray kernel of this context: 1 (default) = round 3 (eight-wide compressed nodes, deferred triangle tests), 0 = the
- * round-2 kernel (four-slot nodes), kept for in-process A/B timing and bit-for-bit cross-checks.  Must be selected before the
- * first nvdr_bvh_build on the context. */
-int nvdr_ctx_set_trace_variant(nvdr_ctx *ctx, int variant);
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
  * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);
  * rebuild == 0: refit the bounds of the existing hierarchy to moved vertices (OPTIX_BUILD_OPERATION_UPDATE). */
@@ -431,14 +427,20 @@ typedef struct nvdr_adam_tensor {
     int64_t lo_vec_n;
     const float *hi_vec;    /* optional per-channel upper bounds (device), NULL for none (Texture2D.clamp_, render/texture.py:86-90) */
     int64_t hi_vec_n;
-    float lr_scale;         /* this tensor's learning rate = lr * lr_scale (train.py:336-338: position / material / light rates); 1 for none */
+    float lr_scale;         /* this tensor's learning rate = lr * lr_scale (train.py:336-338: position / material / light rates); 0 (a
+                               zero-initialised block) means 1.  To freeze a tensor set `frozen`, not a zero rate */
     int32_t normalize3;     /* != 0: after the clamps every group of three elements is divided by max(its length, 1e-10)
                                (Texture2D.normalize_ of the normal map, train.py:473-474) */
     uint8_t *active;        /* optional (n % 3 == 0): one byte per tile of 64 three-channel texels, zero-initialised by the caller once.  Tiles
                                whose gradient is all zero and that never had a non-zero one are skipped after step 1 (their update is the
                                identity): the sparse gradients of a nearest-texel texture lookup.  NULL: every element is updated */
     int32_t zero_grad;      /* with `active`: the gradient of every updated tile is zeroed behind the update (`grad` is written) */
+    int32_t frozen;         /* != 0: the tensor is left alone altogether (parameter, moments and gradient untouched) */
 } nvdr_adam_tensor;
+/* sizeof of the argument blocks as THIS build of the library sees them: a caller compiled (or a ctypes mirror written) against another
+ * revision of this header compares before its first call.  which: 0 nvdr_adam_tensor, 1 nvdr_env_shade_args, 2 nvdr_texture_args,
+ * 3 nvdr_interpolate_bwd_args, 4 nvdr_tensor, 5 nvdr_gbuffer_args, 6 nvdr_mesh_args, 7 nvdr_bvh_info; anything else returns 0. */
+size_t nvdr_abi_sizeof(int which);
 int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps, int *state,
                    void *stream);
 /* The same update for a SUBSET of an iteration's tensors (one chunk of the data-parallel gradient exchange: the update of chunk k
@@ -446,6 +448,18 @@ int nvdr_adam_step(const nvdr_adam_tensor *tensors, int n_tensors, double lr, do
  * advance != 0 -- the iteration's last -- moves the counter. */
 int nvdr_adam_step_partial(const nvdr_adam_tensor *tensors, int n_tensors, double lr, double beta1, double beta2, double eps, int *state,
                            int advance, void *stream);
+
+/* ---- tile-sparse gradient exchange (additive; the reference has no distributed code).  The data-parallel step all-reduces the
+ * gradients of the trained textures; with nearest-texel lookups they are zero outside the tiles (tile_floats contiguous floats, e.g.
+ * 64 texels x 3 channels) a rank's pixels touched.  flags: one byte per tile, 1 = the tile holds a non-zero value (or a NaN).  After a
+ * MAX all-reduce of the flags over the ranks, nvdr_tile_plan lists the flagged tiles in ascending order (list [n_tiles] int32, *count =
+ * how many; device memory, identical on every rank), nvdr_tile_gather copies them into `compact` ([count, tile_floats], what the SUM
+ * all-reduce sends), nvdr_tile_scatter copies the sums back to their places in the dense buffer.  Buffers 16-byte aligned, tile_floats a
+ * multiple of 4; the count is read on the device by gather / scatter. */
+int nvdr_tile_flags(const float *grad, int64_t n_tiles, int tile_floats, uint8_t *flags, void *stream);
+int nvdr_tile_plan(const uint8_t *flags, int64_t n_tiles, int32_t *list, int32_t *count, void *stream);
+int nvdr_tile_gather(const float *dense, const int32_t *list, const int32_t *count, int64_t n_tiles, int tile_floats, float *compact, void *stream);
+int nvdr_tile_scatter(const float *compact, const int32_t *list, const int32_t *count, int64_t n_tiles, int tile_floats, float *dense, void *stream);
 
 /* ---- test hook: evaluate include/nvdr_detmath.h on device.  op: 0 sin, 1 cos, 2 acos, 3 atan2(x,y). */
 int nvdr_test_detmath(int op, const float *x, const float *y, int64_t n, float *out, void *stream);

@@ -27,6 +27,7 @@ SOURCES = [
     'gbuffer.hip',
     'mesh.hip',
     'optim.hip',
+    'exchange.hip',
 ]
 
 # -ffp-contract=off: the sampling math must round exactly like the CPU oracle

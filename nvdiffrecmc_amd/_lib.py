@@ -98,7 +98,7 @@ class NvdrAdamTensor(ctypes.Structure):     # include/nvdr_hip.h: nvdr_adam_tens
     _fields_ = [('param', c_void_p), ('grad', c_void_p), ('exp_avg', c_void_p), ('exp_avg_sq', c_void_p), ('n', c_int64),
                 ('grad_scale', c_float), ('lo', c_float), ('hi', c_float), ('lo_vec', c_void_p), ('lo_vec_n', c_int64),
                 ('hi_vec', c_void_p), ('hi_vec_n', c_int64), ('lr_scale', c_float), ('normalize3', ctypes.c_int32),
-                ('active', c_void_p), ('zero_grad', ctypes.c_int32)]
+                ('active', c_void_p), ('zero_grad', ctypes.c_int32), ('frozen', ctypes.c_int32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -109,7 +109,6 @@ _SIGNATURES = {
     'nvdr_ctx_destroy': [c_void_p],
     'nvdr_ctx_check': [c_void_p, c_void_p],
     'nvdr_ctx_set_stream_budget': [c_void_p, c_int64],
-    'nvdr_ctx_set_trace_variant': [c_void_p, c_int],
     'nvdr_ctx_set_allocator': [c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_bvh_build': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
     'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
@@ -168,13 +167,29 @@ _SIGNATURES = {
     'nvdr_light_update_pdf': [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_adam_step': [ctypes.POINTER(NvdrAdamTensor), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p],
     'nvdr_adam_step_partial': [ctypes.POINTER(NvdrAdamTensor), c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_void_p, c_int, c_void_p],
+    'nvdr_abi_sizeof': [c_int],
+    'nvdr_tile_flags': [c_void_p, c_int64, c_int, c_void_p, c_void_p],
+    'nvdr_tile_plan': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p],
+    'nvdr_tile_gather': [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p],
+    'nvdr_tile_scatter': [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p],
     'nvdr_test_detmath': [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
 }
-_RESTYPES = {'nvdr_last_error': ctypes.c_char_p, 'nvdr_image_loss_num_partials': c_int64}
+_RESTYPES = {'nvdr_last_error': ctypes.c_char_p, 'nvdr_image_loss_num_partials': c_int64, 'nvdr_abi_sizeof': ctypes.c_size_t}
+# nvdr_abi_sizeof(which) -> the ctypes mirror that must have that size (checked once at load: a stale library or a stale mirror is an error)
+_ABI_MIRRORS = {0: 'NvdrAdamTensor', 1: 'NvdrEnvShadeArgs', 2: 'NvdrTextureArgs', 3: 'NvdrInterpolateBwdArgs', 4: 'NvdrTensor', 5: 'NvdrGbufferArgs',
+                6: 'NvdrMeshArgs', 7: 'NvdrBvhInfo'}
 
 EXPORTED_SYMBOLS = sorted(_SIGNATURES)
 
 _lib = None
+
+
+def tuning_env(name, default=None):
+    """Value of an experiment switch (NVDR_RAW_ALLOC, NVDR_PAIR_FILTER, ...): read only when NVDR_TUNING=1 is set as well, like the
+    library's own switches (csrc/core.hip nvdr_tuning_env); a stray variable in a production environment changes nothing."""
+    if os.environ.get('NVDR_TUNING', '0') not in ('', '0'):
+        return os.environ.get(name, default)
+    return default
 
 
 def lib_path():
@@ -196,6 +211,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError here means the library is stale: rebuild
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
+    for which, mirror in _ABI_MIRRORS.items():
+        want, have = int(lib.nvdr_abi_sizeof(which)), ctypes.sizeof(globals()[mirror])
+        if want != have:
+            raise RuntimeError('libnvdr_hip.so and its ctypes mirror disagree on %s (%d vs %d bytes): rebuild the library '
+                               '(__graft_entry__.build()) or update nvdiffrecmc_amd/_lib.py' % (mirror, want, have))
     _lib = lib
     return lib
 

@@ -31,9 +31,6 @@
 //       8 B per child instead of 16 B (four-slot nodes of round 2) and ~n/5 nodes instead of n: bob 0.15 MB instead of 0.68 MB,
 //       684 k triangles 9 MB instead of 44 MB; one dependent 64-B fetch per THREE tree levels.
 //   tris8[k]  : the triangle records in the order the oct nodes refer to them (a node's leaf children are adjacent).
-//   wide[n]   : 4 x uint4 = 64 B per internal node, the four-slot nodes of the ROUND-2 kernel (the node's up to four grandchildren,
-//       one uint4 per slot = 16-bit box + child reference).  Only built when that kernel is selected (nvdr_ctx_set_trace_variant(0):
-//       in-process A/B and cross-checks, csrc/trace_kernel_r2.h).
 //   tris[k]   : 3 x float4 = 48 B per triangle in Morton order, world space, full precision:
 //       (v0.xyz, e1.x) (e1.yz, e2.xy) (e2.z, orig_index_bits, 0, 0) -- the hit predicate itself
 //       (include/nvdr_raytri.h) never sees quantised data.
@@ -108,7 +105,6 @@ struct nvdr_ctx {
     int64_t n_tris = 0;
     int64_t n_verts = 0;
     uint4 *nodes = nullptr;        // [2 * cap]
-    uint4 *wide = nullptr;         // [4 * cap] four-slot nodes of the round-2 kernel (traversal variant 0; built only when selected)
     uint4 *oct = nullptr;          // [4 * cap] eight-wide nodes collapsed from nodes[] (bvh_oct_emit_kernel)
     float4 *tris8 = nullptr;       // [3 * cap] triangle records in oct-leaf order
     int *oct_task = nullptr;       // [cap] the wide roots: binary nodes that root an eight-wide node (bvh_oct_budget_kernel)
@@ -147,7 +143,6 @@ struct nvdr_ctx {
     bool built_pending = false;    // a build is (possibly) still in flight on build_stream
     hipStream_t built_waited = nullptr;   // the caller stream that already waits on ev_built ...
     bool built_waited_valid = false;      // ... if any (the default stream's handle IS the null pointer)
-    int trace_variant = 1;         // shadow-ray kernel: 1 = round 3 (oct nodes, deferred triangle tests), 0 = round 2 (four-slot nodes)
     // env-shade scratch
     int *pix_list = nullptr;       // [N*H*W] compacted indices of the covered pixels of the whole launch
     int64_t pix_cap = 0;
@@ -185,7 +180,6 @@ struct nvdr_ctx {
 
 struct BvhView {
     const uint4 *nodes;
-    const uint4 *wide;
     const uint4 *oct;
     const float4 *tris8;
     int oct_stack_max;
@@ -233,7 +227,6 @@ static inline BvhView bvh_view(const nvdr_ctx *c)
 {
     BvhView v;
     v.nodes = c->nodes;
-    v.wide = c->wide;
     v.oct = c->oct;
     v.tris8 = c->tris8;
     v.oct_stack_max = c->oct_stack_max;

@@ -453,32 +453,6 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_closest_kernel(BvhView
     }
 }
 
-// round-2 kernel only (traversal variant 0): wide[i] = the (up to four) grandchildren of internal node i, see bvh.h
-__global__ void bvh_widen_kernel(const uint4 *__restrict__ nodes, int n_internal, uint4 *__restrict__ wide)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_internal) return;
-    const uint4 a = nodes[2 * i], b = nodes[2 * i + 1];
-    uint4 slot[4];
-    int k = 0;
-    const int child[2] = {(int)b.z, (int)b.w};
-    const uint4 own[2] = {make_uint4(a.x, a.y, a.z, b.z), make_uint4(a.w, b.x, b.y, b.w)};
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        if (child[s] >= 0) {                    // internal child: its two children take a slot each
-            const uint4 ca = nodes[2 * child[s]], cb = nodes[2 * child[s] + 1];
-            slot[k++] = make_uint4(ca.x, ca.y, ca.z, cb.z);
-            slot[k++] = make_uint4(ca.w, cb.x, cb.y, cb.w);
-        } else {
-            slot[k++] = own[s];                 // leaf child: box from this node
-        }
-    }
-    for (; k < 4; ++k) slot[k] = make_uint4(0u, 0u, 0u, 0x7ffffff0u);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wide[4 * (int64_t)i + q] = slot[q];
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // Eight-wide nodes (layout: bvh.h "oct"): the collapse of the fitted binary tree the dynamic programme of bvh_fit_kernel chose,
 // built WITHOUT any dependency between threads (round 4; rounds 2-3 built it top-down, one thread per oct node behind a ticket
@@ -897,7 +871,7 @@ extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
 
 static int ctx_free_bvh(nvdr_ctx *c)
 {
-    ctx_free(c, c->nodes); ctx_free(c, c->wide); ctx_free(c, c->oct); ctx_free(c, c->tris8); ctx_free(c, c->oct_task); ctx_free(c, c->tris);
+    ctx_free(c, c->nodes); ctx_free(c, c->oct); ctx_free(c, c->tris8); ctx_free(c, c->oct_task); ctx_free(c, c->tris);
     ctx_free(c, c->keys[0]); ctx_free(c, c->keys[1]); ctx_free(c, c->vals[0]); ctx_free(c, c->vals[1]);
     ctx_free(c, c->up); ctx_free(c, c->flags); ctx_free(c, c->dp_cost); ctx_free(c, c->sort_tmp);
     ctx_free(c, c->oct_wslot); ctx_free(c, c->oct_jump); ctx_free(c, c->oct_cnt); ctx_free(c, c->oct_scan);
@@ -946,29 +920,22 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     // NVDR_DEBUG (experiments only: 1 skip tracing, 2 skip the light gradient, 8 trace dead samples, 16 light-gradient
     // atomics instead of the band gather, 32 pretend the traversal stacks hold 13 / 2 entries, 64 an explicit reset kernel in
     // front of the traversal kernel) is read ONCE here, not per launch, and announced when set
-    if (const char *dbg = getenv("NVDR_DEBUG")) {
+    if (const char *dbg = nvdr_tuning_env("NVDR_DEBUG")) {
         c->debug = (unsigned)atoi(dbg);
         if (c->debug) fprintf(stderr, "[nvdr] NVDR_DEBUG=%u is active on this context (experiment switches; not for production)\n", c->debug);
     }
-    if (const char *pb = getenv("NVDR_PBLOCKS")) {
+    if (const char *pb = nvdr_tuning_env("NVDR_PBLOCKS")) {
         sscanf(pb, "%d,%d,%d", &c->per_cu[0], &c->per_cu[1], &c->per_cu[2]);
         c->per_cu_user = true;
         for (int k = 0; k < 3; ++k) c->per_cu[k] = c->per_cu[k] < 1 ? 1 : (c->per_cu[k] > 16 ? 16 : c->per_cu[k]);
     }
-    if (const char *ab = getenv("NVDR_ASYNC_BUILD")) c->async_build = atoi(ab) != 0;
+    if (const char *ab = nvdr_tuning_env("NVDR_ASYNC_BUILD")) c->async_build = atoi(ab) != 0;
     // NVDR_OCT_CLEAF: cost of a triangle test in units of a node step in the collapse DP (experiments)
-    if (const char *cl = getenv("NVDR_OCT_CLEAF")) { const float v = (float)atof(cl); if (v > 0.0f) c->oct_c_leaf = v; }
+    if (const char *cl = nvdr_tuning_env("NVDR_OCT_CLEAF")) { const float v = (float)atof(cl); if (v > 0.0f) c->oct_c_leaf = v; }
     // NVDR_LG_MODE: work split of the light-gradient gather (env_shade.hip): 0 every workgroup walks all bands, 1 one set of
     // workgroups per band, unset = by launch size
-    if (const char *lm = getenv("NVDR_LG_MODE")) c->lg_mode = atoi(lm) ? 1 : 0;
-    if (const char *sq = getenv("NVDR_SHADE_QUEUE")) c->shade_queue = atoi(sq) & 7;
-    // NVDR_TRACE_VARIANT=0 selects the round-2 shadow-ray kernel for contexts created while it is set (A/B tools)
-    if (const char *tv = getenv("NVDR_TRACE_VARIANT")) {
-        if (atoi(tv) == 0) {
-            c->trace_variant = 0;
-            fprintf(stderr, "[nvdr] NVDR_TRACE_VARIANT=0: this context runs the round-2 shadow-ray kernel (A/B only)\n");
-        }
-    }
+    if (const char *lm = nvdr_tuning_env("NVDR_LG_MODE")) c->lg_mode = atoi(lm) ? 1 : 0;
+    if (const char *sq = nvdr_tuning_env("NVDR_SHADE_QUEUE")) c->shade_queue = atoi(sq) & 7;
     (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (c->n_cus <= 0) c->n_cus = 256;
     *out = c;
@@ -1131,10 +1098,6 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     if (!cleared) NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
     bvh_fit_kernel<<<div_up(n, NVDR_FIT_BLOCK), NVDR_FIT_BLOCK, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->up,
                                                                               c->flags, c->dinfo, c->dp_cost, c->oct_c_leaf, c->oct_jump);
-    if (c->trace_variant == 0 && n > 1) {
-        if (!c->wide) NVDR_HIP_TRY(ctx_malloc(c, &c->wide, sizeof(uint4) * 4 * c->cap_tris, stream));
-        bvh_widen_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->nodes, n - 1, c->wide);
-    }
     {
         // eight-wide nodes for the shadow-ray walk: budgets -> counts -> prefix sum -> emit, no inter-thread dependency (see above)
         OctBuildArgs oa;
@@ -1225,16 +1188,6 @@ extern "C" int nvdr_ctx_set_allocator(nvdr_ctx *c, nvdr_alloc_fn alloc_fn, nvdr_
     c->alloc_fn = alloc_fn;
     c->free_fn = free_fn;
     c->alloc_user = user;
-    return 0;
-}
-
-extern "C" int nvdr_ctx_set_trace_variant(nvdr_ctx *c, int variant)
-{
-    NVDR_REQUIRE(c, "nvdr_ctx_set_trace_variant: NULL ctx");
-    NVDR_REQUIRE(variant == 0 || variant == 1, "nvdr_ctx_set_trace_variant: variant %d (0 = round-2 kernel, 1 = round-3 kernel)", variant);
-    NVDR_REQUIRE(variant == 1 || c->n_tris == 0, "nvdr_ctx_set_trace_variant: select the round-2 kernel BEFORE the first nvdr_bvh_build "
-                 "(its four-slot nodes are only built when it is selected)");
-    c->trace_variant = variant;
     return 0;
 }
 

@@ -36,6 +36,10 @@ void nvdr_set_error(const char *fmt, ...);
 
 #define NVDR_LAUNCH_CHECK() NVDR_HIP_TRY(hipGetLastError())
 
+// Experiment switches (NVDR_DEBUG, NVDR_PBLOCKS, NVDR_LG_MODE, ...) are read ONLY when NVDR_TUNING=1 is set as well: a stray
+// variable in a production environment changes nothing (it is named once on stderr).  core.hip.
+const char *nvdr_tuning_env(const char *name);
+
 // roctx range for the lifetime of a scope (core.hip; a no-op unless NVDR_ROCTX=1)
 void nvdr_range_push(const char *name);
 void nvdr_range_pop(void);

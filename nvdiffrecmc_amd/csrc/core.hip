@@ -17,6 +17,16 @@ void nvdr_set_error(const char *fmt, ...)
 
 extern "C" const char *nvdr_last_error(void) { return g_err; }
 
+const char *nvdr_tuning_env(const char *name)
+{
+    const char *v = getenv(name);
+    if (!v) return nullptr;
+    const char *t = getenv("NVDR_TUNING");
+    if (t && atoi(t) > 0) return v;
+    fprintf(stderr, "[nvdr] %s is set but ignored: experiment switches need NVDR_TUNING=1\n", name);
+    return nullptr;
+}
+
 // ---------------------------------------------------------------------------------------------
 // roctx ranges around the entry points and their stages (bvh build, gen, trace, shade, light gradient, filter, optimiser): the
 // reference has no tracing at all (train.py:416,481-492 time the iteration on the host).  Off unless NVDR_ROCTX=1; the marker
@@ -47,7 +57,22 @@ bool nvdr_range_enabled(void)
 }
 void nvdr_range_push(const char *name) { if (nvdr_range_enabled()) g_range_push(name); }
 void nvdr_range_pop(void) { if (nvdr_range_enabled()) g_range_pop(); }
-extern "C" int nvdr_version(void) { return 100; }
+extern "C" int nvdr_version(void) { return 101; }
+
+extern "C" size_t nvdr_abi_sizeof(int which)
+{
+    switch (which) {
+    case 0: return sizeof(nvdr_adam_tensor);
+    case 1: return sizeof(nvdr_env_shade_args);
+    case 2: return sizeof(nvdr_texture_args);
+    case 3: return sizeof(nvdr_interpolate_bwd_args);
+    case 4: return sizeof(nvdr_tensor);
+    case 5: return sizeof(nvdr_gbuffer_args);
+    case 6: return sizeof(nvdr_mesh_args);
+    case 7: return sizeof(nvdr_bvh_info);
+    default: return 0;
+    }
+}
 
 __global__ void detmath_kernel(int op, const float *__restrict__ x, const float *__restrict__ y, int64_t n,
                                float *__restrict__ out)

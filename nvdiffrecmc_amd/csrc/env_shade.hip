@@ -28,7 +28,6 @@
 // source and uses include/nvdr_detmath.h for sin/cos/acos/atan2, which makes every
 // discrete decision (texel, lobe, visibility) bit-identical to the CPU oracle.
 #include "trace_kernel.h"
-#include "trace_kernel_r2.h"
 #include "bsdf_device.h"
 
 #define NVDR_PI_DBL 3.14159265358979323846
@@ -772,13 +771,6 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     env_trace_body<COUNT>(a, smem);
-}
-// the round-2 kernel (trace_kernel_r2.h), traversal variant 0: A/B and cross-checks only
-template <bool COUNT>
-__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_kernel_r2(TraceLaunch a)
-{
-    extern __shared__ __attribute__((aligned(16))) int smem[];
-    env_trace_body_r2<COUNT>(a, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1730,14 +1722,6 @@ static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t s
     // reset them -- every traversal launch follows one of those (a backward pass that re-traces the forward's stream follows the
     // forward's stage 3; any other launch in between invalidates that stream).  NVDR_DEBUG bit 64 adds an explicit reset kernel.
     if (c->debug & 64u) zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
-    if (c->trace_variant == 0) {
-        const size_t lds2 = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
-        if (counters)
-            env_trace_kernel_r2<true><<<blocks, NVDR_QUERY_BLOCK, lds2, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
-        else
-            env_trace_kernel_r2<false><<<blocks, NVDR_QUERY_BLOCK, lds2, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
-        return;
-    }
     if (counters)
         env_trace_kernel<true><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
     else
@@ -1821,7 +1805,7 @@ static size_t lg_lds_budget()
     static size_t budget = 0;
     if (budget) return budget;
     size_t kb = 96;
-    if (const char *e = getenv("NVDR_LG_LDS_KB")) kb = (size_t)atoll(e);
+    if (const char *e = nvdr_tuning_env("NVDR_LG_LDS_KB")) kb = (size_t)atoll(e);
     if (kb < 8) kb = 8;
     if (kb > 160) kb = 160;
     size_t want = kb * 1024;

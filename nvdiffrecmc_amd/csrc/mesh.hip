@@ -197,6 +197,7 @@ __device__ __forceinline__ F3 f3d(D3 a) { return f3((float)a.x, (float)a.y, (flo
 
 struct InterpBwd {
     const float *rast; int N, H, W;
+    int64_t n_verts, n_tris;
     const float *v_pos; const int *t_pos; const float *v_nrm; const float *v_tng; const float *cam;
     const float *g_pos, *g_gn, *g_nrm, *g_tng;
     float *o_pos, *o_nrm, *o_tng;
@@ -216,9 +217,13 @@ __global__ void __launch_bounds__(256) interpolate_bwd_kernel(InterpBwd p)
     if (i >= total) return;
     const float4 r = ((const float4 *)p.rast)[i];
     if (!(r.w > 0.0f)) return;
-    const int tri = (int)r.w - 1;
+    const int64_t tri = (int64_t)r.w - 1;
+    // a G-buffer of another topology (a stale `rast`, an index buffer that does not belong to v_pos) must not read or add out of bounds:
+    // such a pixel is skipped, like an uncovered one
+    if (tri >= p.n_tris) return;
     const float u = r.x, v = r.y, w2 = 1.0f - u - v;
     const int i0 = p.t_pos[3 * tri], i1 = p.t_pos[3 * tri + 1], i2 = p.t_pos[3 * tri + 2];
+    if ((unsigned)i0 >= (uint64_t)p.n_verts || (unsigned)i1 >= (uint64_t)p.n_verts || (unsigned)i2 >= (uint64_t)p.n_verts) return;
     const F3 gp = p.g_pos ? ld3(p.g_pos, i) : f3(0.0f);
     const F3 gn = p.g_nrm ? ld3(p.g_nrm, i) : f3(0.0f);
     const F3 gt = p.g_tng ? ld3(p.g_tng, i) : f3(0.0f);
@@ -279,6 +284,7 @@ extern "C" int nvdr_interpolate_bwd(const nvdr_interpolate_bwd_args *a, void *st
     NVDR_REQUIRE(!a->gb_tangent_grad || a->v_tng_grad, "nvdr_interpolate_bwd: gb_tangent_grad without v_tng_grad");
     InterpBwd p;
     p.rast = a->rast; p.N = a->n; p.H = a->h; p.W = a->w;
+    p.n_verts = a->n_verts; p.n_tris = a->n_tris;
     p.v_pos = a->v_pos; p.t_pos = a->t_pos_idx; p.v_nrm = a->v_nrm; p.v_tng = a->v_tng; p.cam = a->cam;
     p.g_pos = a->gb_pos_grad; p.g_gn = a->gb_geometric_normal_grad; p.g_nrm = a->gb_normal_grad; p.g_tng = a->gb_tangent_grad;
     p.o_pos = a->v_pos_grad; p.o_nrm = a->v_nrm_grad; p.o_tng = a->v_tng_grad;

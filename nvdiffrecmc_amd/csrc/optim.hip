@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
     for (int q = 1; q < tab.n; ++q)
         if ((int)blockIdx.x >= tab.first_block[q]) k = q;
     const nvdr_adam_tensor &T = tab.t[k];
-    const float step_size = step_size0 * T.lr_scale;        // this tensor's learning rate (train.py:336-338: position / material / light)
+    if (T.frozen) return;
+    const float step_size = step_size0 * (T.lr_scale == 0.0f ? 1.0f : T.lr_scale);   // (a zero-initialised block: the plain learning rate)        // this tensor's learning rate (train.py:336-338: position / material / light)
     const int64_t e0 = (int64_t)((int)blockIdx.x - tab.first_block[k]) * 256 * tab.per_thread;
     if (T.active) {
         // SPARSE TEXTURE path (round 4).  A trained texture of 1024^2 texels receives gradient only at the texels some covered pixel
@@ -192,7 +193,7 @@ extern "C" int nvdr_adam_step_partial(const nvdr_adam_tensor *tensors, int n_ten
         NVDR_REQUIRE(!t.lo_vec || t.lo_vec_n > 0, "adam_step: tensor %d: lo_vec without length", k);
         NVDR_REQUIRE(!t.hi_vec || t.hi_vec_n > 0, "adam_step: tensor %d: hi_vec without length", k);
         NVDR_REQUIRE(!t.normalize3 || t.n % 3 == 0, "adam_step: tensor %d: normalize3 needs a multiple of three elements", k);
-        NVDR_REQUIRE(t.lr_scale >= 0.0f, "adam_step: tensor %d: negative lr_scale", k);
+        NVDR_REQUIRE(t.lr_scale >= 0.0f, "adam_step: tensor %d: negative lr_scale (0 = the plain rate; `frozen` freezes)", k);
         NVDR_REQUIRE(!t.active || t.n % 3 == 0, "adam_step: tensor %d: the sparse path works on texels of three channels", k);
         NVDR_REQUIRE(!t.zero_grad || t.active, "adam_step: tensor %d: zero_grad needs the sparse path (active)", k);
         tab.t[k] = t;

@@ -82,7 +82,9 @@ class FusedAdam:
             t.lo_vec_n = lo_vec.numel() if lo_vec is not None else 0
             t.hi_vec = hi_vec.data_ptr() if hi_vec is not None else None
             t.hi_vec_n = hi_vec.numel() if hi_vec is not None else 0
-            t.lr_scale, t.normalize3 = float(self.lr_scales[i]), int(bool(self.normalize3[i]))
+            # lr_scales[i] == 0 freezes the tensor (the C block's lr_scale 0 means "the plain rate": a zero-initialised block trains)
+            t.lr_scale, t.normalize3 = float(self.lr_scales[i]) or 1.0, int(bool(self.normalize3[i]))
+            t.frozen = int(float(self.lr_scales[i]) == 0.0)
             t.active = self.active[i].data_ptr() if self.active[i] is not None else None
             t.zero_grad = int(bool(self.zero_grad_after[i] and self.active[i] is not None))
         with torch.no_grad():

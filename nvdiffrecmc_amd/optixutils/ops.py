@@ -38,7 +38,7 @@ class _HipContext:
         # scratch (ray stream, stack spill, BVH buffers) comes from torch's caching allocator: visible in torch.cuda.memory_*
         # and returned to its pool when the context dies.  NVDR_RAW_ALLOC=1 keeps the library on hipMalloc (A/B, debugging).
         self._alloc_cb = None
-        if not os.environ.get('NVDR_RAW_ALLOC'):
+        if not _lib.tuning_env('NVDR_RAW_ALLOC'):
             self._alloc_cb = _lib.torch_allocator()
             _lib.check(self.lib.nvdr_ctx_set_allocator(h, ctypes.cast(self._alloc_cb[0], ctypes.c_void_p),
                                                        ctypes.cast(self._alloc_cb[1], ctypes.c_void_p), None), 'nvdr_ctx_set_allocator')
@@ -75,12 +75,6 @@ class OptiXContext:
         in chunks of covered pixels with identical results."""
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')
-
-    def set_trace_variant(self, variant):
-        """Shadow-ray kernel: 1 (default) = eight-wide nodes + deferred triangle tests, 0 = the round-2 kernel (A/B and
-        cross-checks).  Before the first optix_build_bvh on this context."""
-        w = self.cpp_wrapper
-        _lib.check(w.lib.nvdr_ctx_set_trace_variant(w.handle, int(variant)), 'nvdr_ctx_set_trace_variant')
 
     def check(self):
         """Synchronise and raise if any traversal launch on this context ever overflowed its stack (never silent)."""

@@ -1,54 +1,104 @@
-"""Data-parallel plumbing for the one-view-per-GPU sharding: no collective on the data
-path, ONE flattened fp32 all-reduce of the shared-parameter gradients per iteration (RCCL over xGMI
-when the backend is "nccl"; gloo in the CPU tests).  The reference has no distributed code at all.
+"""Data-parallel plumbing for the one-view-per-GPU sharding: no collective on the data path, the gradients of the
+shared parameters all-reduced once per iteration (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).  The
+reference has no distributed code at all.
+
+GradientExchange cuts the parameter set into CHUNKS ordered by when the NEXT iteration needs them:
+
+    chunk 0  light probe (+ vertex positions)   dense, 0.8-4.9 MB   needed first: update_pdf, BVH build, vertex frames, G-buffer
+    chunk 1  kd / ks / normal textures          25-37.7 MB dense, or TILE-SPARSE: only the 768-byte tiles some rank's pixels touched
+
+so that the caller can start the next iteration's geometry stage while the texture chunk is still on the wire and wait for it
+only in front of the texture lookup (trainer.DirectLightingStep pipelines exactly that).  The tile-sparse mode sends the same
+addends through the same SUM collective -- untouched tiles are zero on every rank and stay home -- so its sums are the dense
+exchange's sums; it costs one small MAX all-reduce of the tile flags and one host read of the union's size.
 """
 import torch
 import torch.distributed as dist
 
+TILE_FLOATS = 192        # 64 texels x 3 channels = 768 contiguous bytes: the tile of the sparse Adam path (csrc/optim.hip)
+
 
 def shard_views(n_views, rank, world_size):
     """Views owned by `rank`: contiguous blocks, one view per rank when n_views == world_size.  Uneven shards
-    (n_views % world_size != 0) are allowed -- allreduce_gradients(local_weight=len(shard)) keeps the batch mean exact --
+    (n_views % world_size != 0) are allowed -- GradientExchange(local_weight=len(shard), equal_shards=False) keeps the batch mean exact --
     but an empty shard (n_views < world_size) is the caller's error to handle."""
     per = (n_views + world_size - 1) // world_size
     return list(range(rank * per, min(n_views, (rank + 1) * per)))
 
 
 def allreduce_gradients(params, world_size=None, group=None, average=True, local_weight=None, skip_single=True):
-    """Sum (or average: the loss is a mean over the batch of views, renderutils/ops.py:494) the .grad of
-    `params` across ranks through ONE flat bucket.  Parameters without a gradient contribute zeros, so
-    every rank sends the same layout.
+    """Sum (or average: the loss is a mean over the batch of views, renderutils/ops.py:494) the .grad of `params` across ranks
+    through ONE flat bucket: a one-chunk GradientExchange, written back into the parameters' own .grad tensors.  Parameters
+    without a gradient contribute zeros, so every rank sends the same layout.
 
-    local_weight: number of views this rank rendered.  Each rank's gradient is the gradient of ITS mean over
-    local_weight views; the batch mean is sum_r(w_r * g_r) / sum_r(w_r), which differs from the plain average
-    whenever shard_views deals uneven shards (n_views % world != 0).  The weight travels as one extra element
-    of the same bucket, so it is still one collective.  None = equal weights (plain average)."""
+    local_weight: number of views this rank rendered.  Each rank's gradient is the gradient of ITS mean over local_weight views; the
+    batch mean is sum_r(w_r * g_r) / sum_r(w_r), which differs from the plain average whenever shard_views deals uneven shards; the
+    weight travels as one extra element of the same bucket, so it is still one collective.  None = equal weights (plain average).
+    Returns the bytes put into the collective (0 when nothing was sent)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 0
     ws = world_size or dist.get_world_size(group)
     if ws == 1 and skip_single:      # skip_single=False: run the collective anyway (single-rank RCCL smoke test)
         return 0
-    grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params]
+    params = list(params)
     weighted = average and local_weight is not None
-    if weighted:
-        w = float(local_weight)
-        grads = [g * w for g in grads] + [torch.full((1,), w, dtype=torch.float32, device=grads[0].device)]
-    flat = torch.cat(grads) if len(grads) > 1 else grads[0].clone()
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if weighted:
-        flat = flat[:-1] / flat[-1].clamp(min=1.0)
-    elif average:
-        flat.div_(ws)
-    off = 0
-    for p in params:
-        n = p.numel()
-        g = flat[off:off + n].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
+    ex = GradientExchange([params], ws, group=group, local_weight=(local_weight if weighted else 1), equal_shards=not weighted)
+    ex.active = True
+    own = [p.grad for p in params]
+    ex.pack()
+    ex.start(skip_single=False)
+    f = ex.wait(0)
+    if not average:
+        f = 1.0
+    for p, g in zip(params, own):       # the caller's tensors keep their identity: copy out of the bucket view
+        red = p.grad if f == 1.0 else p.grad * f
+        if g is None:
+            p.grad = red.clone()
         else:
-            p.grad.copy_(g)
-        off += n
-    return flat.numel() * 4
+            g.copy_(red)
+            p.grad = g
+    return sum(b.numel() for b in ex.buckets) * 4
+
+
+class _TileOps:
+    """flags / plan / gather / scatter of the tile-sparse exchange: the HIP kernels of csrc/exchange.hip for GPU tensors; plain torch
+    indexing for CPU tensors (the gloo tests of this file's logic -- the trainer never holds CPU tensors)."""
+
+    @staticmethod
+    def flags(bucket, n_tiles, tile_floats, out):
+        if bucket.is_cuda:
+            from . import _lib
+            _lib.check(_lib.load().nvdr_tile_flags(bucket.data_ptr(), n_tiles, tile_floats, out.data_ptr(), _lib.stream_ptr()), 'nvdr_tile_flags')
+        else:
+            out.copy_((bucket[:n_tiles * tile_floats].view(n_tiles, tile_floats) != 0).any(1).to(torch.uint8))
+
+    @staticmethod
+    def plan(flags, n_tiles, tile_list, count):
+        if flags.is_cuda:
+            from . import _lib
+            _lib.check(_lib.load().nvdr_tile_plan(flags.data_ptr(), n_tiles, tile_list.data_ptr(), count.data_ptr(), _lib.stream_ptr()), 'nvdr_tile_plan')
+        else:
+            idx = flags.nonzero().view(-1).to(torch.int32)
+            tile_list[:idx.numel()] = idx
+            count.fill_(idx.numel())
+
+    @staticmethod
+    def move(dense, compact, tile_list, count, n_tiles, tile_floats, gather):
+        if dense.is_cuda:
+            from . import _lib
+            lib = _lib.load()
+            if gather:
+                _lib.check(lib.nvdr_tile_gather(dense.data_ptr(), tile_list.data_ptr(), count.data_ptr(), n_tiles, tile_floats, compact.data_ptr(), _lib.stream_ptr()), 'nvdr_tile_gather')
+            else:
+                _lib.check(lib.nvdr_tile_scatter(compact.data_ptr(), tile_list.data_ptr(), count.data_ptr(), n_tiles, tile_floats, dense.data_ptr(), _lib.stream_ptr()), 'nvdr_tile_scatter')
+        else:
+            k = int(count.item())
+            idx = tile_list[:k].long()
+            d, c = dense[:n_tiles * tile_floats].view(n_tiles, tile_floats), compact[:k * tile_floats].view(k, tile_floats)
+            if gather:
+                c.copy_(d.index_select(0, idx))
+            else:
+                d.index_copy_(0, idx, c)
 
 
 class GradientExchange:
@@ -57,15 +107,25 @@ class GradientExchange:
     on the wire the caller already runs the parameter update of chunk k (`for k in ex.chunks(): ex.wait(k); adam[k].step()`).
 
     Zero-copy on the way back: after wait(k) the parameters' .grad ARE views into the reduced bucket (no unpack pass), holding the
-    weighted SUM over the ranks; `scale` (= 1 / total weight, a device scalar in the uneven case folded to a float when every rank
-    renders the same number of views) is what the optimizer multiplies the gradient by (FusedAdam grad_scales).  The pack is a copy
-    per parameter into a preallocated bucket -- or nothing at all for a gradient its producer already wrote into the bucket (slot()) -- so
-    nothing allocates after the first iteration (HIP-graph friendly).
+    weighted SUM over the ranks; `grad_mult` (= 1 / world over even shards) is what the optimizer multiplies the gradient by
+    (FusedAdam grad_scales).  The pack is a copy per parameter into a preallocated bucket -- or nothing at all for a gradient its
+    producer already wrote into the bucket (slot()) -- so nothing allocates after the first iteration (HIP-graph friendly).
 
-    groups: list of lists of parameters (one list per chunk).  local_weight: views this rank renders; equal_shards: every rank has
-    the same local_weight (then no weighting traffic at all: plain sum, scale = 1 / world)."""
+    groups: list of lists of parameters (one list per chunk, in the order the next iteration needs them).  local_weight: views this
+    rank renders; equal_shards: every rank has the same local_weight (then no weighting traffic at all: plain sum).
 
-    def __init__(self, groups, world_size=None, group=None, local_weight=1, equal_shards=True):
+    sparse: None, or one bool per chunk.  A sparse chunk is exchanged tile by tile (TILE_FLOATS floats):
+        compute_flags()   after pack(): which tiles of this rank's bucket are non-zero (one HIP launch; capturable in a HIP graph)
+        start()           MAX all-reduce of the flag bytes (asynchronous), beside the dense chunks' SUM all-reduces
+        send(k)           union list (one launch) -> its size read by the host -> gather -> SUM all-reduce of the compacted tiles (asynchronous);
+                          runs on a SIDE stream that waits for the flags only, so whatever the caller enqueued on the main stream in between
+                          (the next iteration's geometry stage) is not waited for
+        wait(k)           scatter the sums back into the dense bucket; .grad views as for a dense chunk
+    When the union exceeds `sparse_max_fraction` of the tiles the dense bucket is all-reduced instead (every rank sees the same count,
+    so every rank takes the same branch).  Uneven shards and chunks whose parameters are not whole tiles fall back to dense."""
+
+    def __init__(self, groups, world_size=None, group=None, local_weight=1, equal_shards=True, sparse=None, tile_floats=TILE_FLOATS,
+                 sparse_max_fraction=0.5):
         self.groups = [list(g) for g in groups]
         self.group = group
         self.active = dist.is_available() and dist.is_initialized()
@@ -76,8 +136,29 @@ class GradientExchange:
             n = sum(p.numel() for p in g)
             extra = 0 if self.equal_shards else 1                       # the weight rides in the same bucket: still one collective per chunk
             self.buckets.append(torch.zeros(n + extra, dtype=torch.float32, device=g[0].device))
-        self.bytes_per_step = sum(b.numel() for b in self.buckets) * 4 if (self.active and self.world > 1) else 0
+        self.tile_floats = int(tile_floats)
+        self.sparse_max_fraction = float(sparse_max_fraction)
+        sparse = list(sparse) if sparse is not None else [False] * len(self.groups)
+        self.sparse = [bool(s) and self.equal_shards and all(p.numel() % self.tile_floats == 0 for p in g) for s, g in zip(sparse, self.groups)]
+        self._sp = {}
+        for k, (s, b) in enumerate(zip(self.sparse, self.buckets)):
+            if s:
+                n_tiles = b.numel() // self.tile_floats
+                dev = b.device
+                self._sp[k] = {'n_tiles': n_tiles,
+                               'flags': torch.zeros(n_tiles, dtype=torch.uint8, device=dev),
+                               'list': torch.zeros(max(n_tiles, 1), dtype=torch.int32, device=dev),
+                               'count': torch.zeros(1, dtype=torch.int32, device=dev),
+                               'count_host': (torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else torch.zeros(1, dtype=torch.int32)),
+                               'compact': torch.zeros_like(b),          # worst case: every tile (288 GB of HBM: 38 MB is nothing)
+                               'flags_handle': None, 'state': 'idle', 'mode': 'dense', 'tiles': 0}
+        self._side, self._ev_start = None, None      # the side stream of send() and the point of the main stream it is ordered behind (GPU tensors)
+        self._sends = self.active and self.world > 1
+        self.bytes_dense = sum(b.numel() for b in self.buckets) * 4
+        self.bytes_per_step = self.bytes_dense if self._sends else 0     # what the last start()/send() round put into collectives
+        self._bytes_round = 0
 
+    # ------------------------------------------------------------------------------------------------------------------ layout
     def chunks(self):
         return range(len(self.groups))
 
@@ -110,21 +191,97 @@ class GradientExchange:
                 b[:n].mul_(self.local_weight)
                 b[n:].fill_(self.local_weight)
 
+    def compute_flags(self):
+        """Sparse chunks: flag the non-zero tiles of this rank's bucket (after pack(); one launch per sparse chunk, capturable)."""
+        for k, sp in self._sp.items():
+            _TileOps.flags(self.buckets[k], sp['n_tiles'], self.tile_floats, sp['flags'])
+
+    # ------------------------------------------------------------------------------------------------------------- collectives
+    def _all_reduce(self, t, op):
+        return dist.all_reduce(t, op=op, group=self.group, async_op=True)
+
     def start(self, skip_single=True):
-        """Launch the all-reduce of every chunk (asynchronous, in chunk order).  With one rank (and skip_single) nothing is sent."""
+        """Launch what can be launched right after the backward pass, in chunk order: the SUM all-reduce of every dense chunk, the MAX
+        all-reduce of every sparse chunk's tile flags (all asynchronous).  With one rank (and skip_single) nothing is sent."""
         self.handles = [None] * len(self.buckets)
-        if not self.active or (self.world == 1 and skip_single):
-            return
+        self._bytes_round = 0
+        live = self.active and not (self.world == 1 and skip_single)
         for k, b in enumerate(self.buckets):
-            self.handles[k] = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if k in self._sp:
+                sp = self._sp[k]
+                sp['state'], sp['flags_handle'] = 'flagged', None
+                if live:
+                    sp['flags_handle'] = self._all_reduce(sp['flags'], dist.ReduceOp.MAX)
+                    self._bytes_round += sp['flags'].numel()
+            elif live:
+                self.handles[k] = self._all_reduce(b, dist.ReduceOp.SUM)
+                self._bytes_round += b.numel() * 4
+        self._live = live
+        if self._sp and self.buckets[0].is_cuda:
+            # send() runs on a side stream ordered behind THIS point of the main stream (the buckets and flags are complete here), not
+            # behind whatever the caller enqueues between start() and send()
+            self._ev_start = torch.cuda.Event()
+            self._ev_start.record()
+        if not self._sp:
+            self.bytes_per_step = self._bytes_round
+
+    def send(self, k):
+        """Second stage of a sparse chunk (a no-op for a dense one): the union's tile list, its size to the host, the gather and the
+        asynchronous SUM all-reduce of the compacted tiles.  Blocks the host until the flags of chunk k have been reduced -- not until
+        the main stream has drained: GPU work enqueued after start() keeps running."""
+        sp = self._sp.get(k)
+        if sp is None or sp['state'] != 'flagged':
+            return
+        b = self.buckets[k]
+        cuda = b.is_cuda
+        if cuda and self._side is None:
+            self._side = torch.cuda.Stream(device=b.device)
+        if cuda:
+            self._side.wait_event(self._ev_start)        # the main stream as of start(), not as of now
+        ctx = torch.cuda.stream(self._side) if cuda else _null_context()
+        with ctx:
+            if sp['flags_handle'] is not None:
+                sp['flags_handle'].wait()
+            _TileOps.plan(sp['flags'], sp['n_tiles'], sp['list'], sp['count'])
+            if cuda:
+                sp['count_host'].copy_(sp['count'], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                ev.synchronize()
+                n = int(sp['count_host'][0])
+            else:
+                n = int(sp['count'].item())
+            sp['tiles'] = n
+            if n > self.sparse_max_fraction * sp['n_tiles']:
+                sp['mode'] = 'dense'
+                if self._live:
+                    self.handles[k] = self._all_reduce(b, dist.ReduceOp.SUM)
+                    self._bytes_round += b.numel() * 4
+            else:
+                sp['mode'] = 'sparse'
+                _TileOps.move(b, sp['compact'], sp['list'], sp['count'], sp['n_tiles'], self.tile_floats, gather=True)
+                if self._live and n > 0:
+                    self.handles[k] = self._all_reduce(sp['compact'][:n * self.tile_floats], dist.ReduceOp.SUM)
+                    self._bytes_round += n * self.tile_floats * 4
+        sp['state'] = 'sent'
+        self.bytes_per_step = self._bytes_round
 
     def wait(self, k):
         """Chunk k has arrived: point the .grad of its parameters at the reduced bucket (views, no copy).  Returns the factor the
         optimizer must apply to these gradients (float, or a 0-dim device tensor for uneven shards)."""
+        sp = self._sp.get(k)
+        if sp is not None and sp['state'] == 'flagged':
+            self.send(k)
         h = self.handles[k] if self.handles else None
         if h is not None:
             h.wait()
         b = self.buckets[k]
+        if sp is not None and sp['state'] == 'sent':
+            if b.is_cuda:
+                torch.cuda.current_stream(b.device).wait_stream(self._side)    # (the gather / a one-rank run: no collective handle to wait on)
+            if sp['mode'] == 'sparse':
+                _TileOps.move(b, sp['compact'], sp['list'], sp['count'], sp['n_tiles'], self.tile_floats, gather=False)
+            sp['state'] = 'idle'
         n = b.numel() - (0 if self.equal_shards else 1)
         off = 0
         for p in self.groups[k]:
@@ -139,3 +296,19 @@ class GradientExchange:
     def grad_mult(self):
         """What the optimizer multiplies the .grad views by: 1 / world after a summing all-reduce over even shards, else 1."""
         return (1.0 / self.world) if (self.equal_shards and self.active and self.world > 1) else 1.0
+
+    def report(self):
+        """What the last round sent: {mode, bytes_dense, bytes_sent, tiles_touched, tiles_total} (bench.py config.exchange)."""
+        modes = [self._sp[k]['mode'] if k in self._sp else 'dense' for k in self.chunks()]
+        return {'mode': 'sparse' if 'sparse' in modes else 'dense', 'chunk_modes': modes, 'chunk_bytes_dense': [b.numel() * 4 for b in self.buckets],
+                'bytes_dense': self.bytes_dense, 'bytes_sent': int(self.bytes_per_step),
+                'tiles_touched': int(sum(sp['tiles'] for sp in self._sp.values())), 'tiles_total': int(sum(sp['n_tiles'] for sp in self._sp.values())),
+                'tile_bytes': self.tile_floats * 4}
+
+
+class _null_context:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False

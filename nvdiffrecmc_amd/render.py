@@ -77,6 +77,8 @@ class _texture_lookup_func(torch.autograd.Function):
         _lib.require_cuda_f32(rast, 'rast')
         texc, rast = texc.contiguous(), rast.contiguous()
         P = rast.numel() // 4
+        if rast.shape[-1] != 4 or texc.shape[-1] != 2 or texc.numel() != 2 * P:
+            raise RuntimeError('texture_lookup: gb_texc %s must hold one (s, t) pair per pixel of rast %s' % (tuple(texc.shape), tuple(rast.shape)))
         a = _lib.NvdrTextureArgs()
         a.n_tex, a.texc, a.rast, a.n_pix = n, texc.data_ptr(), rast.data_ptr(), P
         outs, keep = [], []

@@ -43,6 +43,7 @@ from .light import EnvironmentLight
 from .optim import FusedAdam
 from . import mesh as mesh_ops
 from . import render as rd
+from . import _lib
 
 
 class _gather_rows(torch.autograd.Function):
@@ -105,15 +106,23 @@ class _broadcast_pixels(torch.autograd.Function):
 
 class DirectLightingStep:
     def __init__(self, mesh_name='bob', res=512, n_samples_x=8, view=0, n_views=8, device='cuda', env='E1',
-                 probe_res=256, denoise=True, retrace_backward=True, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
+                 probe_res=256, denoise=True, retrace_backward=False, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
                  denoiser_demodulate=True, light_grad_scale=64.0, use_graph=False, material_set='full', tex_res=1024,
-                 optimize_geometry=False, lr_pos=None, lr_light=None, perturb_pos=0.0, ks_min=(0.0, 0.08, 0.0), ks_max=(0.0, 1.0, 1.0)):
+                 optimize_geometry=False, lr_pos=None, lr_light=None, perturb_pos=0.0, ks_min=(0.0, 0.08, 0.0), ks_max=(0.0, 1.0, 1.0),
+                 perturbed_nrm=True):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
+        # retrace_backward=False (default): the forward pass and its backward pass draw the same samples (train.py:547 `decorrelated = False`,
+        # render.py:112-116: one rnd_seed for both), so the backward pass replays the forward's visibility bits instead of traversing the same
+        # rays again -- per-pixel gradients bit-identical (tests/test_gpu_env_shade.py), one traversal launch less.  True = what the
+        # reference's backward does (optixTrace again): the iteration bench.py's `value` is defined on.
         self.retrace_backward = retrace_backward
+        # perturbed_nrm=False: FLAGS.no_perturbed_nrm (configs/spot_metal.json:20, render.py:92-93): no normal-map lookup; the normal texture
+        # stays in the optimizer's list (train.py:185-197) but never receives a gradient, i.e. is never updated -- it is left out of the set here
+        self.perturbed_nrm = bool(perturbed_nrm)
         self.fused = fused
-        self.pair_filter = os.environ.get('NVDR_PAIR_FILTER', '1') != '0'      # (A/B switch of the harness)
+        self.pair_filter = _lib.tuning_env('NVDR_PAIR_FILTER', '1') != '0'      # (A/B switch of the harness)
         self.denoiser_demodulate = denoiser_demodulate    # FLAGS.denoiser_demodulate (train.py:525, default True)
         self.light_grad_scale = light_grad_scale          # lgt.base.grad *= 64 (train.py:439-440)
         self.total_views = n_views if isinstance(n_views, int) else len(n_views)
@@ -178,7 +187,8 @@ class DirectLightingStep:
                 self.target = self._render(kd_true, ks_true, light_true).detach()
             else:       # the asset's own material: kd texture, constant ks (data/bob/bob_tri.mtl:3), no normal map
                 self.target = self._render_full(self.mesh['kd_tex'].contiguous(), ks_true.view(1, 1, 3).expand(Rt, Rt, 3).contiguous(),
-                                                torch.tensor([0.0, 0.0, 1.0], device=self.dev).repeat(Rt, Rt, 1).contiguous(), light_true).detach()
+                                                torch.tensor([0.0, 0.0, 1.0], device=self.dev).repeat(Rt, Rt, 1).contiguous() if self.perturbed_nrm else None,
+                                                light_true).detach()
         self._ks_min = torch.tensor(list(ks_min), device=self.dev)
         self._ks_max = torch.tensor(list(ks_max), device=self.dev)
         self.light = EnvironmentLight(torch.full((probe_res, probe_res, 3), 0.5, device=self.dev).requires_grad_(True))
@@ -201,13 +211,21 @@ class DirectLightingStep:
             hi = torch.tensor([0.01, ks_max[1], ks_max[2]])
             self.kd_tex = torch.nn.Parameter(torch.full((R, R, 3), 0.5, device=self.dev))
             self.ks_tex = torch.nn.Parameter((lo + ks0 * (hi - lo)).to(self.dev))
-            self.nrm_tex = torch.nn.Parameter(torch.tensor([0.0, 0.0, 1.0], device=self.dev).repeat(R, R, 1).contiguous())
             self._nrm_min = torch.tensor([-1.0, -1.0, 0.0], device=self.dev)           # FLAGS.nrm_min / nrm_max (train.py:552-553)
             self._nrm_max = torch.tensor([1.0, 1.0, 1.0], device=self.dev)
-            self.params = [self.kd_tex, self.ks_tex, self.nrm_tex, self.light.base]
-            names = ['kd', 'ks', 'normal', 'light']
-            clamps = [(0.0, 1.0), (None, None, self._ks_min, self._ks_max), (None, None, self._nrm_min, self._nrm_max), (0.01, None)]
-            lr_scales, grad_scales, norm3 = [1.0, 1.0, 1.0, lr_light / lr], [1.0, 1.0, 1.0, light_grad_scale], [False, False, True, False]
+            self.params = [self.kd_tex, self.ks_tex]
+            names = ['kd', 'ks']
+            clamps = [(0.0, 1.0), (None, None, self._ks_min, self._ks_max)]
+            lr_scales, grad_scales, norm3 = [1.0, 1.0], [1.0, 1.0], [False, False]
+            self.nrm_tex = None
+            if self.perturbed_nrm:
+                self.nrm_tex = torch.nn.Parameter(torch.tensor([0.0, 0.0, 1.0], device=self.dev).repeat(R, R, 1).contiguous())
+                self.params.append(self.nrm_tex)
+                names.append('normal')
+                clamps.append((None, None, self._nrm_min, self._nrm_max)); lr_scales.append(1.0); grad_scales.append(1.0); norm3.append(True)
+            self.params.append(self.light.base)
+            names.append('light')
+            clamps.append((0.01, None)); lr_scales.append(lr_light / lr); grad_scales.append(light_grad_scale); norm3.append(False)
             if self.optimize_geometry:
                 # DLMesh: v_pos is the trained geometry (dlmesh.py:28-38); the target was rendered from the unperturbed mesh above
                 v0 = self.mesh['v_pos'].clone()
@@ -218,6 +236,7 @@ class DirectLightingStep:
                 names.append('v_pos')
                 clamps.append(None); lr_scales.append(lr_pos / lr); grad_scales.append(1.0); norm3.append(False)
         self.param_names = names
+        self.n_tex = sum(1 for nm in names if nm in ('kd', 'ks', 'normal')) if material_set == 'full' else 0     # the leading texture parameters
         # The same Adam as the reference (train.py:348-356,452-461: three optimizers that differ in their learning rate).  fused: ONE
         # launch for the light-gradient scale, the Adam update of every tensor and the clamps / normal-map renormalisation
         # (csrc/optim.hip; torch's multi-tensor Adam puts the elements on 16 workgroups + a kernel per clamp); otherwise
@@ -230,7 +249,7 @@ class DirectLightingStep:
             self.opt = FusedAdam(self.params, lr=lr, grad_scales=grad_scales, clamps=clamps, lr_scales=lr_scales, normalize3=norm3,
                                  sparse=sparse, zero_grad=sparse)
             if material_set == 'full':
-                self._tex_grad = [torch.zeros_like(p) for p in self.params[:3]]
+                self._tex_grad = [torch.zeros_like(p) for p in self.params[:self.n_tex]]
         else:
             groups = [{'params': [p], 'lr': lr * sc_} for p, sc_ in zip(self.params, lr_scales)]
             try:
@@ -272,7 +291,7 @@ class DirectLightingStep:
             ks = self.ks.view(1, 1, 1, 3) * m
             pn = None
         else:
-            kd, ks, pn = rd.texture_lookup((self.kd_tex, self.ks_tex, self.nrm_tex), self.gb_texc, self.rast)
+            kd, ks, pn = self._lookup(self.kd_tex, self.ks_tex, self.nrm_tex, self.gb_texc, self.rast)
         nrm = ru.prepare_shading_normal(self.gb_pos, self.view_pos, pn, self.gb_smooth_nrm, self.gb_tangent, self.gb_geom_nrm,
                                         two_sided_shading=True, opengl=True)
         return self.mask, (self.gb_pos + nrm * 0.001).contiguous(), self.gb_pos, nrm, self.view_pos, kd.contiguous(), ks.contiguous()
@@ -325,6 +344,14 @@ class DirectLightingStep:
             spec = self.denoiser.forward(torch.cat((spec, nrm, self.gb_depth), dim=-1))
         return diff * (kd * (1.0 - ks[..., 2:3])) + spec
 
+    @staticmethod
+    def _lookup(kd_tex, ks_tex, nrm_tex, texc, rast, grad_buffers=None):
+        """kd, ks and the perturbed normal (None without a normal map: no_perturbed_nrm) of every pixel in one launch."""
+        if nrm_tex is None:
+            kd, ks = rd.texture_lookup((kd_tex, ks_tex), texc, rast, grad_buffers=grad_buffers)
+            return kd, ks, None
+        return rd.texture_lookup((kd_tex, ks_tex, nrm_tex), texc, rast, grad_buffers=grad_buffers)
+
     def _render_full(self, kd_tex, ks_tex, nrm_tex, light, gb=None, grad_buffers=None):
         """shade() with the reference's material set (render.py:61-131): kd / ks / perturbed normal from three textures in one
         lookup launch, shading frame, env-shade, both lights filtered in one pass, composite.  gb: a differentiable G-buffer dict
@@ -344,7 +371,7 @@ class DirectLightingStep:
                 ix = (texc[..., 0] * R).long().clamp(0, R - 1)
                 iy = ((1.0 - texc[..., 1]) * R).long().clamp(0, R - 1)
                 return t[iy, ix] * m
-            kd, ks, pn = look(kd_tex), look(ks_tex), look(nrm_tex)
+            kd, ks, pn = look(kd_tex), look(ks_tex), (look(nrm_tex) if nrm_tex is not None else None)
             nrm = ru.prepare_shading_normal(pos, self.view_pos, pn, snrm, tng, gnrm, two_sided_shading=True, opengl=True)
             ro = pos + nrm * 0.001
             diff, spec = ou.optix_env_shade(self.ctx, rast[..., 3], ro, pos, nrm, self.view_pos, kd, ks, light.base,
@@ -356,7 +383,7 @@ class DirectLightingStep:
                 diff = self.denoiser.forward(torch.cat((diff, nrm, depth), dim=-1))
                 spec = self.denoiser.forward(torch.cat((spec, nrm, depth), dim=-1))
             return diff * (kd * (1.0 - ks[..., 2:3])) + spec
-        kd, ks, pn = rd.texture_lookup((kd_tex, ks_tex, nrm_tex), texc, rast, grad_buffers=grad_buffers)
+        kd, ks, pn = self._lookup(kd_tex, ks_tex, nrm_tex, texc, rast, grad_buffers=grad_buffers)
         nrm, nn, ro = ru.shading_frame(pos, self.view_pos, pn, snrm, tng, gnrm, two_sided_shading=True, opengl=True, ro_eps=0.001)
         self.ctx.cache_visibility = not self.retrace_backward
         # mask = rast[..., -1] as the reference passes it (render.py:113): a strided view, > 0 = covered
@@ -439,8 +466,10 @@ class DirectLightingStep:
             else:                                       # train.py:467-476: Texture2D.clamp_ per channel, normalize_, lgt.clamp_(min=0.01)
                 for i in range(3):
                     self.ks_tex[..., i].clamp_(min=float(self._ks_min[i]), max=float(self._ks_max[i]))
-                    self.nrm_tex[..., i].clamp_(min=float(self._nrm_min[i]), max=float(self._nrm_max[i]))
-                self.nrm_tex.copy_(self.nrm_tex / torch.sqrt(torch.clamp((self.nrm_tex * self.nrm_tex).sum(-1, keepdim=True), min=1e-20)))
+                    if self.nrm_tex is not None:
+                        self.nrm_tex[..., i].clamp_(min=float(self._nrm_min[i]), max=float(self._nrm_max[i]))
+                if self.nrm_tex is not None:
+                    self.nrm_tex.copy_(self.nrm_tex / torch.sqrt(torch.clamp((self.nrm_tex * self.nrm_tex).sum(-1, keepdim=True), min=1e-20)))
                 self.light.base.clamp_(min=0.01)
 
     def _exchange(self, world_size):
@@ -456,7 +485,7 @@ class DirectLightingStep:
             # 37.7 MB of texture gradients are neither packed nor cleared: one copy and three memsets less per iteration and rank.
             self._tex_grad_resident = False
             if self._tex_grad is not None and world_size > 1:
-                self._tex_grad = [self._ex.slot(p) for p in self.params[:3]]
+                self._tex_grad = [self._ex.slot(p) for p in self.params[:self.n_tex]]
                 self._tex_grad_resident = True
         return self._ex
 
@@ -482,7 +511,7 @@ class DirectLightingStep:
         p.grad IS that buffer.  Should autograd have copied instead of adopting (a hook, a second reference), clear them explicitly."""
         if self._tex_grad is not None:
             self._tex_grad_dirty = False
-            for p, b in zip(self.params[:3], self._tex_grad):
+            for p, b in zip(self.params[:self.n_tex], self._tex_grad):
                 if p.grad is None or p.grad.data_ptr() != b.data_ptr():
                     self._zero_tex_grad()
                     return

@@ -178,3 +178,79 @@ def test_chunked_exchange_of_the_reference_sized_bucket(n_views):
         n = 3 * 1024 * 1024 * 3 + 256 * 256 * 3 + 5344 * 3
         assert nbytes == (n + (0 if n_views % world == 0 else 2)) * 4        # >= 38 MB; uneven shards carry one weight per chunk
         assert nbytes >= 38_000_000
+
+
+# ---------------------------------------------------------------------------------------------- the tile-sparse exchange (round 5)
+def _worker_sparse(rank, world, port, q, density):
+    """kd / ks / normal textures with gradient at a few texels per rank (a nearest-texel lookup's adjoint) through the exchange in both
+    modes: probe + vertices first (dense), then the textures dense resp. tile-sparse."""
+    from nvdiffrecmc_amd.parallel import GradientExchange, TILE_FLOATS
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    R = 128
+    shapes = [(R, R, 3), (R, R, 3), (R, R, 3), (16, 16, 3), (37, 3)]
+    gen = torch.Generator().manual_seed(100 + rank)
+    grads = []
+    for s in shapes[:3]:
+        g = torch.zeros(*s)
+        n = int(density * R * R)
+        for _ in range(4):                                  # four runs of neighbouring texels: what a view's pixels touch is clustered
+            first = int(torch.randint(0, R * R - n // 4, (1,), generator=gen))
+            g.view(-1, 3)[first:first + n // 4] = torch.randn(n // 4, 3, generator=gen)
+        grads.append(g)
+    grads += [torch.randn(16, 16, 3, generator=gen), torch.randn(37, 3, generator=gen)]
+    results = {}
+    for mode in ('dense', 'sparse'):
+        params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+        ex = GradientExchange([params[3:], params[:3]], world, local_weight=1, equal_shards=True, sparse=[False, mode == 'sparse'])
+        assert ex.sparse == [False, mode == 'sparse']
+        for p, g in zip(params[:3], grads[:3]):             # born in the bucket, as the trainer's lookup adjoint leaves them
+            p.grad = ex.slot(p)
+            p.grad.copy_(g)
+        params[3].grad, params[4].grad = grads[3].clone(), grads[4].clone()
+        ex.pack()
+        ex.compute_flags()
+        ex.start()
+        f = ex.wait(0)                                      # probe + vertices: the next iteration's geometry stage could start here
+        early = [(p.grad * f).clone() for p in params[3:]]
+        ex.send(1)
+        f = ex.wait(1)
+        tex = [(p.grad * f).clone() for p in params[:3]]
+        results[mode] = (early + tex, ex.report())
+    dd, ds = results['dense'][0], results['sparse'][0]
+    same = all(torch.equal(a, b) for a, b in zip(dd, ds))   # the same addends through the same collective: bit for bit
+    rep = results['sparse'][1]
+    q.put((rank, same, rep, [t.double().sum().item() for t in ds], results['dense'][1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('density', [0.04, 0.9], ids=['sparse_4pct', 'falls_back_to_dense'])
+def test_tile_sparse_exchange_equals_the_dense_one(density):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sparse, args=(r, world, port, q, density)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, rep, sums, rep_dense in got:
+        assert same, 'sparse and dense exchange differ on rank %d' % rank
+        assert rep['bytes_dense'] == rep_dense['bytes_dense'] == rep_dense['bytes_sent'] == (3 * 128 * 128 * 3 + 16 * 16 * 3 + 37 * 3) * 4
+        assert rep['tiles_total'] == 3 * 128 * 128 // 64
+        if density < 0.5:
+            assert rep['mode'] == 'sparse' and 0 < rep['tiles_touched'] < 0.5 * rep['tiles_total']
+            # flags (1 B per tile) + the dense probe / vertex chunk + the touched tiles
+            assert rep['bytes_sent'] == rep['tiles_total'] + (16 * 16 * 3 + 37 * 3) * 4 + rep['tiles_touched'] * 768
+            assert rep['bytes_sent'] < 0.6 * rep['bytes_dense']
+        else:
+            assert rep['mode'] == 'dense' and rep['tiles_touched'] > 0.5 * rep['tiles_total']       # the union is large: the dense bucket travels
+            assert rep['bytes_sent'] == rep['bytes_dense'] + rep['tiles_total']
+    assert got[0][3] == got[1][3]                           # both ranks hold the same sums
+    assert got[0][2]['tiles_touched'] == got[1][2]['tiles_touched']

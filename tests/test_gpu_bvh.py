@@ -496,28 +496,3 @@ def test_oct_tree_invariants(kind, dev):
     ou.optix_build_bvh(ctx, v2.to(dev), t.to(dev), rebuild=0)                   # refit: the oct tree is rebuilt over the new boxes
     _check_oct_tree(ctx, v2, t)
     ctx.check()
-
-
-def test_round2_and_round3_kernels_agree(dev):
-    """The round-2 shadow-ray kernel (four-slot nodes, kept as traversal variant 0 for A/B timing) and the round-3 kernel
-    (eight-wide compressed nodes, deferred triangle tests) answer identically, ray for ray and image for image."""
-    from nvdiffrecmc_amd import optixutils as ou
-    from tests.test_gpu_fullsize import _gpu_scene, _shade
-    mesh = sc.load_mesh('bob')
-    ctx3 = make_ctx(mesh, dev)
-    ctx2 = ou.OptiXContext()
-    ctx2.set_trace_variant(0)
-    ou.optix_build_bvh(ctx2, mesh['v_pos'].to(dev), mesh['t_pos_idx'].to(dev), rebuild=1)
-    ro, rd = _rays(300000, 5, 0.35)
-    ro, rd = ro.to(dev), rd.to(dev)
-    a, b = ou.trace_visibility_wide(ctx3, ro, rd), ou.trace_visibility_wide(ctx2, ro, rd)
-    assert torch.equal(a, b) and 0.05 < a.float().mean().item() < 0.95
-    with pytest.raises(RuntimeError, match='BEFORE'):
-        ctx3.set_trace_variant(0)
-    res, n = 160, 8
-    _, c3, kw, perms = _gpu_scene('bob', res, n, dev, view=3)
-    d3, s3 = _shade(c3, kw, n, 7)
-    d2, s2 = _shade(ctx2, kw, n, 7)
-    assert torch.equal(d3, d2) and torch.equal(s3, s2)
-    ctx2.check()
-    ctx3.check()

@@ -147,12 +147,13 @@ def test_whole_frame_vs_oracle_with_gpu_visibility(dev):
     ctx.check()
 
 
-def test_batched_views_equal_single_view_launches(dev):
-    """The benchmarked launch shape -- N = 8 views in ONE launch (configs/bob.json:8) -- against eight one-view launches whose
-    pixel index is offset by view * H * W (the data-parallel split, kernel.cu:504): images and per-pixel gradients bit for bit,
-    the light gradient (a sum over all views) up to addition order."""
+@pytest.mark.parametrize('res', [128, 512], ids=['128', 'benchmarked_8x512'])
+def test_batched_views_equal_single_view_launches(res, dev):
+    """The benchmarked launch shape -- N = 8 views in ONE launch (configs/bob.json:8), at 128^2 and at the 8 x 512^2 the bench line is
+    quoted on -- against eight one-view launches whose pixel index is offset by view * H * W (the data-parallel split, kernel.cu:504):
+    images and per-pixel gradients bit for bit, the light gradient (a sum over all views) up to addition order.  Needs no oracle."""
     from nvdiffrecmc_amd import optixutils as ou
-    res, n, seed, nv = 128, 8, 6, 8
+    n, seed, nv = 8, 6, 8
     views = [_gpu_scene('bob', res, n, dev, view=v) for v in range(nv)]
     mesh, ctx = views[0][0], views[0][1]
     cat = {k: torch.cat([v[2][k] for v in views], 0).contiguous() for k in ('mask', 'ro', 'gb_pos', 'gb_normal', 'gb_view_pos', 'gb_kd', 'gb_ks')}

@@ -2,6 +2,7 @@
 is loaded side by side (separate dlopen handles, separate globals), gets its own DirectLightingStep, and the variants are timed
 in interleaved rounds -- fresh processes differ by +-8 % on identical code, which buries most kernel experiments.
     PROBE_VIEWS=8 python tools/ab_inproc.py [rounds]"""
+import os as _os; _os.environ.setdefault('NVDR_TUNING', '1')
 import ctypes, glob, os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +28,6 @@ for spec in filter(None, os.environ.get('AB_ENV', '').split('|')):
 if os.environ.get('AB_LG', '0') != '0':
     paths.append(('lg_all', base))         # light-gradient gather: every workgroup walks all bands (NVDR_LG_MODE=0)
     paths.append(('lg_perband', base))     # one set of workgroups per band (NVDR_LG_MODE=1)
-if os.environ.get('AB_R2', '1') != '0':
-    paths.append(('r2kernel', base))       # the same library with the round-2 shadow-ray kernel selected (NVDR_TRACE_VARIANT=0)
 only = os.environ.get('AB_ONLY')
 if only:
     paths = [pp for pp in paths if pp[0] in only.split(',') or pp[0] == 'current']
@@ -38,16 +37,11 @@ for tag, path in paths:
     _lib._lib = None
     _build.LIB = path                      # _lib.load() binds the signatures of whatever this points to
     lib = _lib.load()
-    if tag == 'r2kernel':
-        os.environ['NVDR_TRACE_VARIANT'] = '0'
-    else:
-        os.environ.pop('NVDR_TRACE_VARIANT', None)
     for k_, v_ in env_variants.get(tag, {}).items():
         os.environ[k_] = v_
     if tag.startswith('lg_'):
         os.environ['NVDR_LG_MODE'] = '1' if tag == 'lg_perband' else '0'
-    st = DirectLightingStep(mesh_name, res, n_x, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
-    os.environ.pop('NVDR_TRACE_VARIANT', None)
+    st = DirectLightingStep(mesh_name, res, n_x, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv, retrace_backward=True)
     os.environ.pop('NVDR_LG_MODE', None)
     for k_ in env_variants.get(tag, {}):
         os.environ.pop(k_, None)

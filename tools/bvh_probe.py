@@ -3,6 +3,7 @@ caller's stream.  usage: bvh_probe.py [mesh] [subdiv] [reps]   (under rocprofv3 
 import os
 import sys
 
+os.environ.setdefault('NVDR_TUNING', '1')
 os.environ.setdefault('NVDR_ASYNC_BUILD', '0')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402

@@ -4,7 +4,7 @@ import cProfile, pstats, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nvdiffrecmc_amd.trainer import DirectLightingStep
-st = DirectLightingStep('bob', 512, 8, view=0, n_views=8, device='cuda:0')
+st = DirectLightingStep('bob', 512, 8, view=0, n_views=8, device='cuda:0', retrace_backward=True)
 for _ in range(5): st.step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()

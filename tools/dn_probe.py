@@ -18,7 +18,7 @@ if only:
     paths = [pp for pp in paths if pp[0] in only.split(',') or pp[0] == 'current']
 _build.LIB = base
 _lib._lib = None
-st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0')
+st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', retrace_backward=True)
 with torch.no_grad():
     nrm = ru.prepare_shading_normal(st.gb_pos, st.view_pos, None, st.gb_smooth_nrm, st.gb_tangent, st.gb_geom_nrm)
     nn = _safe_normalize(nrm).contiguous()

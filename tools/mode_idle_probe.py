@@ -14,7 +14,7 @@ nviews = int(os.environ.get('PROBE_VIEWS', '1'))
 burst = int(os.environ.get('PROBE_BURST', '30'))
 gaps = [float(v) for v in os.environ.get('PROBE_GAPS', '0,0.05,0.2,0.5,1,2').split(',')]
 n_bursts = int(os.environ.get('PROBE_BURSTS', '18'))
-st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
+st = DirectLightingStep('bob', res, 8, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv, retrace_backward=True)
 with torch.no_grad():
     m = st.mask[..., None]
     _, ro, _, nrm, _, kd, ks = st.shade_inputs()

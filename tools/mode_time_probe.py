@@ -12,7 +12,7 @@ res = int(os.environ.get('PROBE_RES', '800'))
 subdiv = int(os.environ.get('PROBE_SUBDIV', '3'))
 gb = float(os.environ.get('PROBE_CHILD_GB', '8'))
 t_start = time.perf_counter()
-st = DirectLightingStep('bob', res, 8, view=[0], n_views=8, device='cuda:0', subdiv=subdiv)
+st = DirectLightingStep('bob', res, 8, view=[0], n_views=8, device='cuda:0', subdiv=subdiv, retrace_backward=True)
 with torch.no_grad():
     m = st.mask[..., None]
     _, ro, _, nrm, _, kd, ks = st.shade_inputs()

@@ -1,4 +1,5 @@
 """Kernel-level timing probe of the env-shade op on the benchmark workload (bob 512^2, n=8) with the NVDR_DEBUG knobs."""
+import os as _os; _os.environ.setdefault('NVDR_TUNING', '1')
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,7 @@ from nvdiffrecmc_amd import optixutils as ou, renderutils as ru
 n = int(os.environ.get('PROBE_N', '8'))
 res = int(os.environ.get('PROBE_RES', '512'))
 mesh = os.environ.get('PROBE_MESH', 'bob')
-st = DirectLightingStep(mesh, res, n, view=0, n_views=8, device='cuda:0')
+st = DirectLightingStep(mesh, res, n, view=0, n_views=8, device='cuda:0', retrace_backward=True)
 m = st.mask[..., None]
 with torch.no_grad():
     _, ro, _, nrm, _, kd, ks = st.shade_inputs()

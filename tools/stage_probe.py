@@ -1,5 +1,6 @@
 """Per-stage HIP-event times of the env-shade op (gen / trace / shade, forward and backward) on the benchmark workload,
 for a list of NVDR_PBLOCKS / NVDR_DEBUG settings given as argv: e.g.  stage_probe.py 4,4,4 6,4,5 'dbg=8'"""
+import os as _os; _os.environ.setdefault('NVDR_TUNING', '1')
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,7 @@ res = int(os.environ.get('PROBE_RES', '512'))
 mesh = os.environ.get('PROBE_MESH', 'bob')
 subdiv = int(os.environ.get('PROBE_SUBDIV', '0'))
 nviews = int(os.environ.get('PROBE_VIEWS', '1'))
-st = DirectLightingStep(mesh, res, n, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv)
+st = DirectLightingStep(mesh, res, n, view=list(range(nviews)), n_views=8, device='cuda:0', subdiv=subdiv, retrace_backward=True)
 m = st.mask[..., None]
 with torch.no_grad():
     _, ro, _, nrm, _, kd, ks = st.shade_inputs()

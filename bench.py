@@ -105,7 +105,8 @@ def make_step(pre, args, dev, views, n_views, lock_pos, **kw):
     from nvdiffrecmc_amd.trainer import DirectLightingStep
     return DirectLightingStep(pre['mesh'], pre['res'], pre['n'], view=views, n_views=n_views, device=dev, subdiv=pre['subdiv'],
                               material_set=args.material_set, tex_res=args.tex_res or pre.get('tex_res', 1024), optimize_geometry=not lock_pos,
-                              lr_pos=BENCH_LR_POS, ks_min=pre.get('ks_min', (0.0, 0.08, 0.0)), perturbed_nrm=pre.get('perturbed_nrm', True), **kw)
+                              lr_pos=BENCH_LR_POS, ks_min=pre.get('ks_min', (0.0, 0.08, 0.0)), perturbed_nrm=pre.get('perturbed_nrm', True),
+                              **dict(dict(exchange_mode=args.exchange, pipeline=not args.no_pipeline), **kw))
 
 
 def algorithmic_bytes(N, H, W, P, S, probe, bvh2_nodes, bvh2_tris, n_traced):
@@ -362,48 +363,81 @@ def other_config_object(name, args, dev):
     return out
 
 
-def exchange_probe(step, dev):
-    """The gradient exchange of the real parameter set through RCCL with ONE rank (the only N this box offers): pack of the chunk
-    buckets + one asynchronous all-reduce per chunk + waits, HIP-event time per iteration.  What it shows is the fixed cost of the
-    exchange path (a one-rank all-reduce moves nothing over xGMI)."""
-    import torch
+def init_world1(dev):
+    """A one-rank RCCL process group on this GPU (the only N a one-GPU box offers): the several-rank schedule then runs its real
+    collectives -- a one-rank all-reduce moves nothing over xGMI, what it shows is the fixed cost of the path."""
     import torch.distributed as dist
-    from nvdiffrecmc_amd.parallel import GradientExchange
-    own = False
-    if not dist.is_initialized():
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', str(_free_port()))
-        with _stdout_to_stderr():
-            dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-        own = True
+    if dist.is_initialized():
+        return False
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(_free_port()))
+    with _stdout_to_stderr():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    return True
+
+
+def exchange_object(step, ms_exposed):
+    """config.exchange of a line that ran the several-rank schedule: what the last round sent and how long the main stream stood still for it."""
+    rep = step._ex.report()
+    rep['pipelined'] = bool(step.pipeline and len(step._ex_chunks) > 1)
+    rep['exposed_ms'] = statistics.median(ms_exposed) if ms_exposed else None
+    rep['exposed_ms_note'] = ('median per iteration of the time the main stream waits on the exchange (HIP events around every wait: collectives not yet '
+                              'finished + the scatter of the reduced tiles); the rest of the exchange runs under the next iteration\'s geometry stage')
+    if getattr(step, '_union_views', None):
+        rep['union_emulated_views'] = len(step._union_views)
+    return rep
+
+
+def one_view_object(args, dev, preset_name, eight_view_ms, lock=None):
+    """The per-GPU share of the 8-GPU run on THIS box (rank 0, N = 1): one view of the batch in HIP graphs under the several-rank schedule
+    (chunks ordered by the next iteration's need, tile-sparse texture chunk, pipelined with the next geometry stage) with a one-rank RCCL
+    group doing the real collectives on the bytes an 8-rank run would send (the tile flags are OR-ed with the tiles ALL eight views touch).
+    No xGMI time is in it -- `projected` prices the wire separately."""
+    import torch
+    pre = dict(PRESETS[preset_name])
+    t0 = time.perf_counter()
+    lock = pre.get('lock_pos', True) if lock is None else lock
+    own = init_world1(dev)
+    out = {'preset': preset_name, 'geometry': 'locked' if lock else 'trained'}
     try:
-        groups = [[step.params[i] for i in idx] for idx in step._chunk_indices()]
-        src = [torch.zeros_like(p) for p in step.params]
-        ex = GradientExchange(groups, 1)
-        ex.active = True
-        ms = []
-        resident = [ex.slot(p) if (i < 3 and step.material_set == 'full') else None for i, p in enumerate(step.params)]
-        for it in range(12):
-            # gradients as a backward pass of a multi-rank run leaves them: the texture gradients inside the buckets (the lookup's adjoint
-            # scatter-adds there, trainer._exchange), the probe's and the vertices' in tensors of their own
-            for p, g, r in zip(step.params, src, resident):
-                p.grad = r if r is not None else g
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            ex.pack()
-            ex.start(skip_single=False)
-            for k in ex.chunks():
-                ex.wait(k)
-            b.record()
-            b.synchronize()
-            if it >= 2:
-                ms.append(a.elapsed_time(b))
-        return {'backend': dist.get_backend(), 'world': 1, 'chunks': len(groups), 'bucket_bytes': int(sum(b.numel() for b in ex.buckets) * 4),
-                'ms_per_iteration': statistics.median(ms), 'resident_bytes': int(sum(r.numel() for r in resident if r is not None) * 4)}
+        for mode in ('sparse', 'dense'):
+            step = make_step(pre, args, dev, [0], pre['batch'], lock, retrace_backward=True, use_graph=True, force_exchange=True, exchange_mode=mode,
+                             union_views=list(range(pre['batch'])))
+            for _ in range(12):
+                step.step(1)
+            step.measure_exposed = True
+            K = 40
+            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            for _ in range(K):
+                step.step(1)
+            step.finish()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - w0
+            ex = exchange_object(step, step.exposed_ms())
+            out[mode] = {'ms_per_step': dt / K * 1e3, 'hip_graph': step._graphs is not None, 'exchange': ex}
+            del step
+            torch.cuda.empty_cache()
+        # the wire, priced: ring all-reduce of S bytes over 8 GPUs moves 2 * 7/8 * S per GPU; bus bandwidth 150-250 GB/s assumed (xGMI: 7 links x ~153 GB/s
+        # peak per GPU, MI355X_MICROARCH.md); latency floor 30 us per collective.  Only what is NOT hidden under the next geometry stage counts.
+        proj = {}
+        for mode in ('sparse', 'dense'):
+            e = out[mode]['exchange']
+            early = e['chunk_bytes_dense'][0] if len(e['chunk_bytes_dense']) > 1 else 0
+            tex = e['bytes_sent'] - early
+            wire = lambda nbytes, bw: 30e-6 + 2.0 * 7.0 / 8.0 * nbytes / (bw * 1e9)
+            lo, hi = [out[mode]['ms_per_step'] + 1e3 * (wire(early, bw) + wire(tex, bw)) for bw in (250.0, 150.0)]
+            proj[mode] = {'ms_per_step_with_wire_nothing_hidden': [lo, hi], 'speedup_vs_8_views_on_one_gpu': [eight_view_ms / hi, eight_view_ms / lo]}
+        out['projected_8gpu'] = dict(proj, eight_views_one_gpu_ms=eight_view_ms,
+                                     note='8 views on one GPU / (one view + exchange machinery measured here + ring all-reduce wire time at 150-250 GB/s bus bandwidth, '
+                                          'none of it assumed hidden); the measured scaling curve is the driver\'s SCALE file when an 8-GPU node exists')
     finally:
         if own:
+            import torch.distributed as dist
             with _stdout_to_stderr():
                 dist.destroy_process_group()
+    out['seconds'] = time.perf_counter() - t0
+    return out
 
 
 def large_mesh_object(args, dev):
@@ -511,6 +545,12 @@ def parse_args():
     ap.add_argument('--no-large-mesh', action='store_true', help='skip the `large_mesh` object (dmtet800: 684 k triangles) of the default N = 1 line')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the `other_configs` objects (spot512x256, hotdog512x256) of the default N = 1 line')
     ap.add_argument('--no-extended', action='store_true', help='skip the extended median phase and the cached-visibility loop')
+    ap.add_argument('--exchange', choices=('auto', 'dense', 'sparse'), default='auto',
+                    help='gradient exchange of the texture chunk at N > 1: dense = the whole bucket, sparse / auto = the tiles some rank touched (falls back to dense by itself)')
+    ap.add_argument('--no-pipeline', action='store_true', help='N > 1: wait for the texture chunk inside the iteration instead of under the next geometry stage')
+    ap.add_argument('--exchange-world1', action='store_true',
+                    help='N = 1: run the several-rank schedule with a one-rank RCCL group (fixed cost of the exchange path; tile flags OR-ed with the tiles all views of the batch touch)')
+    ap.add_argument('--no-one-view', action='store_true', help='skip the `one_view` object (per-GPU share of the 8-GPU run) of the default N = 1 line')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
                     help='capture the iteration in HIP graphs (auto: when a rank renders <= 2 views -- the launch-bound regime -- or there are several ranks)')
     return ap.parse_args()
@@ -619,7 +659,11 @@ def run(args):
     lock_pos = preset.get('lock_pos', True) if args.lock_pos == 'config' else (args.lock_pos == 'on')
     if args.material_set == 'r3':
         lock_pos = True
-    step = make_step(preset, args, dev, my_views, n_views, lock_pos, pixel_index_offset=my_views[0] * H * W, retrace_backward=True, use_graph=use_graph)
+    forced = bool(args.exchange_world1 and world == 1 and not args.pmc_child)
+    if forced:
+        init_world1(dev)
+    step = make_step(preset, args, dev, my_views, n_views, lock_pos, pixel_index_offset=my_views[0] * H * W, retrace_backward=True, use_graph=use_graph,
+                     force_exchange=forced, union_views=(list(range(n_views)) if forced else None))
 
     if args.pmc_child:          # under rocprofv3: a few plain iterations, nothing else
         for _ in range(args.warmup + args.steps):
@@ -656,6 +700,7 @@ def run(args):
         a.record()
         step.step(world)
         b.record()
+    step.finish()               # (several ranks: the pipelined texture update of the last step belongs to the timed region)
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     step_ms = [a.elapsed_time(b) for a, b in ev]
@@ -668,6 +713,9 @@ def run(args):
     # extended phase: more samples of the same iteration for the median (>= 50 steps and >= 3 s), then the same iteration
     # with the forward's visibility bits replayed in backward (identical gradients, no second traversal; an extra, never `value`)
     ext_ms, dt2, k2 = [], None, 0
+    multi = world > 1 or forced
+    if multi:
+        step.measure_exposed = True
     if not args.no_extended:
         t_ext = time.perf_counter()
         while True:
@@ -684,7 +732,10 @@ def run(args):
                 more = flag.item() != 0.0
             if not more:
                 break
+    exposed = step.exposed_ms() if multi else None
+    step.measure_exposed = False
     if use_graph:                                     # leave graph mode for good: stage times of the same kernels, eagerly
+        step.finish()
         step.force_eager = True
         for _ in range(2):
             step.step(world)
@@ -855,12 +906,17 @@ def run(args):
                 out['cpu_baseline_torch'] = cpu_baseline_torch()
             except Exception as e:
                 out['cpu_baseline_torch'] = {'error': '%s: %s' % (type(e).__name__, e)}
-        if world == 1 and not args.pmc_child:
+        if multi:
+            out['config']['exchange'] = exchange_object(step, exposed)
+        if world == 1 and args.config == 'bob512' and not args.no_one_view and not args.pmc_child and args.res is None and args.subdiv is None and args.batch is None \
+                and not forced:
+            step = None
+            torch.cuda.empty_cache()
             try:
                 with _stdout_to_stderr():
-                    out['config']['exchange_world1'] = exchange_probe(step, dev)
+                    out['config']['one_view'] = one_view_object(args, dev, 'bob512', dt / args.steps * 1e3)
             except Exception as e:
-                out['config']['exchange_world1'] = {'error': '%s: %s' % (type(e).__name__, e)}
+                out['config']['one_view'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and args.config == 'bob512' and not args.no_other_configs and not args.no_large_mesh and not args.pmc_child and args.res is None and args.subdiv is None \
                 and args.batch is None:
             out['other_configs'] = {}

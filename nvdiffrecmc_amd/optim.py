@@ -65,6 +65,9 @@ class FusedAdam:
             p = self.params[i]
             if p.grad is None:
                 raise RuntimeError('FusedAdam.step: parameter %d has no gradient' % i)
+            if self.zero_grad_after[i] and not p.grad.is_contiguous():
+                # a copy would be zeroed instead of the buffer the producer scatter-adds into
+                raise RuntimeError('FusedAdam.step: zero_grad needs a contiguous .grad for parameter %d (the persistent scatter-add buffer itself)' % i)
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             keep.append(g)
             lo, hi, lo_vec, hi_vec = -math.inf, math.inf, None, None

@@ -152,6 +152,7 @@ class GradientExchange:
                                'count_host': (torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else torch.zeros(1, dtype=torch.int32)),
                                'compact': torch.zeros_like(b),          # worst case: every tile (288 GB of HBM: 38 MB is nothing)
                                'flags_handle': None, 'state': 'idle', 'mode': 'dense', 'tiles': 0}
+        self.extra_flags = {}               # chunk -> uint8 flags OR-ed into this rank's (trainer union_views: a one-rank run that moves the bytes of a several-rank one)
         self._side, self._ev_start = None, None      # the side stream of send() and the point of the main stream it is ordered behind (GPU tensors)
         self._sends = self.active and self.world > 1
         self.bytes_dense = sum(b.numel() for b in self.buckets) * 4
@@ -195,6 +196,8 @@ class GradientExchange:
         """Sparse chunks: flag the non-zero tiles of this rank's bucket (after pack(); one launch per sparse chunk, capturable)."""
         for k, sp in self._sp.items():
             _TileOps.flags(self.buckets[k], sp['n_tiles'], self.tile_floats, sp['flags'])
+            if self.extra_flags.get(k) is not None:         # (one-rank dry runs: the tiles the other ranks would have touched)
+                torch.maximum(sp['flags'], self.extra_flags[k], out=sp['flags'])
 
     # ------------------------------------------------------------------------------------------------------------- collectives
     def _all_reduce(self, t, op):

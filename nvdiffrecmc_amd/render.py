@@ -65,6 +65,19 @@ def gbuffer(optix_ctx, v_pos, v_nrm, v_tng, topo, mvp, cam, resolution, bary_gra
     return dict(zip(_GB_NAMES, _gbuffer_func.apply(optix_ctx, v_pos, v_nrm, v_tng, topo, mvp, cam, resolution, bary_grad)))
 
 
+class PersistentGrads(list):
+    """Persistent [R,R,3] buffers the texture lookup's adjoint ADDS into (texture_lookup(grad_buffers=...)), with the contract made
+    explicit: all zero when a backward pass runs, then `dirty` until their consumer has used AND re-zeroed them (FusedAdam zero_grad, or
+    a memset) and says so (`dirty = False`).  A second backward pass into dirty buffers would double-count and raises."""
+
+    def __init__(self, buffers):
+        super().__init__(buffers)
+        for b in self:
+            if not b.is_contiguous():
+                raise ValueError('PersistentGrads: buffers must be contiguous')
+        self.dirty = False
+
+
 class _texture_lookup_func(torch.autograd.Function):
     @staticmethod
     def forward(ctx, texc, rast, grad_buffers, *textures):
@@ -102,6 +115,12 @@ class _texture_lookup_func(torch.autograd.Function):
         a = _lib.NvdrTextureArgs()
         a.n_tex, a.texc, a.rast, a.n_pix = len(ctx.res), texc.data_ptr(), rast.data_ptr(), rast.numel() // 4
         grads, keep = [], []
+        if isinstance(ctx.grad_buffers, PersistentGrads):
+            # (under HIP-graph capture this runs once, at capture time; a replay repeats the launches, not the check)
+            if ctx.grad_buffers.dirty:
+                raise RuntimeError('texture_lookup: the persistent gradient buffers still hold the gradients of an earlier backward pass '
+                                   '(two lookups sharing one set of buffers, or a consumer that did not clear them): they would be counted twice')
+            ctx.grad_buffers.dirty = True
         for k, (R, g) in enumerate(zip(ctx.res, gouts)):
             g = g.contiguous() if g is not None else torch.zeros(*rast.shape[:-1], 3, dtype=torch.float32, device=rast.device)
             keep.append(g)

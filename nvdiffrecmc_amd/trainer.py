@@ -109,7 +109,7 @@ class DirectLightingStep:
                  probe_res=256, denoise=True, retrace_backward=False, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
                  denoiser_demodulate=True, light_grad_scale=64.0, use_graph=False, material_set='full', tex_res=1024,
                  optimize_geometry=False, lr_pos=None, lr_light=None, perturb_pos=0.0, ks_min=(0.0, 0.08, 0.0), ks_max=(0.0, 1.0, 1.0),
-                 perturbed_nrm=True):
+                 perturbed_nrm=True, exchange_mode='auto', pipeline=True, force_exchange=False, union_views=None):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
@@ -121,6 +121,18 @@ class DirectLightingStep:
         # perturbed_nrm=False: FLAGS.no_perturbed_nrm (configs/spot_metal.json:20, render.py:92-93): no normal-map lookup; the normal texture
         # stays in the optimizer's list (train.py:185-197) but never receives a gradient, i.e. is never updated -- it is left out of the set here
         self.perturbed_nrm = bool(perturbed_nrm)
+        # Several ranks (parallel.GradientExchange).  exchange_mode: 'dense' = the whole texture bucket is all-reduced; 'sparse' / 'auto' =
+        # only the 768-byte tiles some rank's pixels touched (falls back to dense by itself when most tiles are touched).  pipeline: the
+        # texture chunk's reduce runs under the NEXT iteration's geometry stage and is waited for in front of the texture lookup.
+        # force_exchange: run the several-rank schedule with ONE rank (the fixed cost of the path; a one-rank RCCL pass when a process group exists).
+        if exchange_mode not in ('auto', 'dense', 'sparse'):
+            raise ValueError("exchange_mode must be 'auto', 'dense' or 'sparse'")
+        self.exchange_mode, self.pipeline, self.force_exchange = exchange_mode, bool(pipeline), bool(force_exchange)
+        # union_views (with force_exchange): the views of the WHOLE batch; the tile flags of this one rank are OR-ed with the tiles those views
+        # touch, so that the one-rank run compacts, sends and scatters the bytes the several-rank run would (bench.py one_view)
+        self._union_views = list(union_views) if (union_views is not None and force_exchange) else None
+        self.measure_exposed, self._exposed_events = False, []
+        self._stage1_ready, self._gb_live, self._pending = False, None, False
         self.fused = fused
         self.pair_filter = _lib.tuning_env('NVDR_PAIR_FILTER', '1') != '0'      # (A/B switch of the harness)
         self.denoiser_demodulate = denoiser_demodulate    # FLAGS.denoiser_demodulate (train.py:525, default True)
@@ -243,13 +255,13 @@ class DirectLightingStep:
         # torch.optim.Adam with parameter groups and the reference's sequence of calls.
         self._fused_update = bool(fused) and self.dev.type == 'cuda'
         self._lr_scales = lr_scales
-        self._tex_grad, self._tex_grad_dirty = None, False
+        self._tex_grad = None
         if self._fused_update:
             sparse = [nm in ('kd', 'ks', 'normal') and material_set == 'full' for nm in names]
             self.opt = FusedAdam(self.params, lr=lr, grad_scales=grad_scales, clamps=clamps, lr_scales=lr_scales, normalize3=norm3,
                                  sparse=sparse, zero_grad=sparse)
             if material_set == 'full':
-                self._tex_grad = [torch.zeros_like(p) for p in self.params[:self.n_tex]]
+                self._tex_grad = rd.PersistentGrads(torch.zeros_like(p) for p in self.params[:self.n_tex])
         else:
             groups = [{'params': [p], 'lr': lr * sc_} for p, sc_ in zip(self.params, lr_scales)]
             try:
@@ -402,33 +414,47 @@ class DirectLightingStep:
                 spec = ou.ops._bilateral_denoiser_func.apply(spec, nn, depth, self.denoiser.sigma)
         return ru.shade_composite(diff, spec, kd, ks)
 
-    def forward_backward(self):
-        """The differentiable part of the iteration; returns the loss tensor (grads are in .grad)."""
+    def _stage1(self):
+        """The geometry stage of an iteration -- everything that needs only the light probe and the vertices, not the textures: BVH
+        rebuild (side stream), update_pdf, and with trained geometry getMesh (dlmesh.py:45-55) + rasterize / interpolate
+        (render.py:208-234) from the moving vertices.  With several ranks it runs while the texture chunk of the previous iteration's
+        gradient exchange is still on the wire (_step_multi)."""
         # the rebuild first: it runs on the context's side stream, and the sooner it starts the less of it is left when the traversal
         # needs the tree (one view: the light's three small kernels used to run in front of it)
         v_pos = self.v_pos if self.optimize_geometry else self.mesh['v_pos']
         ou.optix_build_bvh(self.ctx, v_pos, self.mesh['t_pos_idx'], rebuild=1)
         self.light.update_pdf()
+        self._gb_live = None
+        if self.material_set != 'r3' and self.optimize_geometry:
+            v_nrm, v_tng = mesh_ops.mesh_frame(v_pos, self.topo)
+            gb = rd.gbuffer(self.ctx, v_pos, v_nrm, v_tng, self.topo, self.mvp, self.cam, (self.res, self.res))
+            self._set_gbuffer({k: v.detach() for k, v in gb.items()})        # shade_inputs() / mask follow the moving mesh
+            self._gb_live = gb
+        self._stage1_ready = True
+
+    def _stage2(self, grad_seed=None):
+        """Texture lookups, shading frame, env-shade, filters, composite, loss and the whole backward pass; returns the loss tensor
+        (gradients are in .grad, the texture gradients scatter-added into the persistent buffers / exchange buckets)."""
+        self._stage1_ready = False
         self.opt.zero_grad(set_to_none=True)
-        if self._tex_grad is not None:
-            if self._tex_grad_dirty:            # a backward pass whose gradients no update consumed (forward_backward called on its own)
-                self._zero_tex_grad()
-            self._tex_grad_dirty = True
+        if self._tex_grad is not None and self._tex_grad.dirty:
+            self._zero_tex_grad()           # a backward pass whose gradients no update consumed (forward_backward called on its own)
         if self.material_set == 'r3':
             img = self._render(self.kd_tex, self.ks, self.light)
         else:
-            gb = None
-            if self.optimize_geometry:
-                # getMesh (dlmesh.py:45-55) + rasterize / interpolate (render.py:208-234) from the moving vertices
-                v_nrm, v_tng = mesh_ops.mesh_frame(v_pos, self.topo)
-                gb = rd.gbuffer(self.ctx, v_pos, v_nrm, v_tng, self.topo, self.mvp, self.cam, (self.res, self.res))
-                self._set_gbuffer({k: v.detach() for k, v in gb.items()})        # shade_inputs() / mask follow the moving mesh
-            img = self._render_full(self.kd_tex, self.ks_tex, self.nrm_tex, self.light, gb, grad_buffers=self._tex_grad if self.fused else None)
+            img = self._render_full(self.kd_tex, self.ks_tex, self.nrm_tex, self.light, self._gb_live, grad_buffers=self._tex_grad if self.fused else None)
         loss = (ru.image_loss_mean if (self.fused and self.dev.type == 'cuda') else ru.image_loss)(img, self.target, loss='l1', tonemapper='log_srgb')
         if getattr(self, '_one', None) is None or self._one.shape != loss.shape or self._one.device != loss.device:
             self._one = torch.ones_like(loss)
         loss.backward(gradient=self._one)       # (a resident seed: no fill launch per iteration)
+        self._gb_live = None
         return loss
+
+    def forward_backward(self):
+        """The differentiable part of the iteration; returns the loss tensor (grads are in .grad)."""
+        if not getattr(self, '_stage1_ready', False):
+            self._stage1()
+        return self._stage2()
 
     def set_lr_scale(self, name, value):
         """Learning rate of one parameter tensor relative to lr (0 freezes it); names as in .param_names."""
@@ -440,10 +466,13 @@ class DirectLightingStep:
             self.opt.param_groups[i]['lr'] = self.opt.defaults['lr'] * float(value)
 
     def _chunk_indices(self):
-        """The gradient exchange's chunks as lists of parameter indices: [kd, ks] (25 MB at 1024^2) | [normal, light, v_pos]; one
-        chunk for round 3's small set."""
+        """The gradient exchange's chunks as lists of parameter indices, in the order the NEXT iteration needs them: [light, v_pos] --
+        update_pdf, BVH build, vertex frames and G-buffer wait for these -- then the textures [kd, ks, normal] (25-38 MB at 1024^2), which
+        only the texture lookup waits for.  One chunk for round 3's small set."""
         n = len(self.params)
-        return [list(range(n))] if (self.material_set == 'r3' or n < 3) else [[0, 1], list(range(2, n))]
+        if self.material_set == 'r3' or self.n_tex == 0 or self.n_tex == n:
+            return [list(range(n))]
+        return [list(range(self.n_tex, n)), list(range(self.n_tex))]
 
     def _update(self, subset=None, advance=True, grad_mult=1.0):
         """Everything after the gradient exchange: light-gradient scale, Adam, clamps (train.py:439-476); subset = the parameter
@@ -478,39 +507,140 @@ class DirectLightingStep:
             from .parallel import GradientExchange
             total = self.total_views
             even = (total % world_size == 0) and (self.nv * world_size == total)
-            groups = [[self.params[i] for i in idx] for idx in self._chunk_indices()] if self._fused_update else [list(self.params)]
-            self._ex = GradientExchange(groups, world_size, local_weight=self.nv, equal_shards=even)
+            chunks = self._chunk_indices() if self._fused_update else [list(range(len(self.params)))]
+            groups = [[self.params[i] for i in idx] for idx in chunks]
+            # tile-sparse: the texture chunk only ('dense' sends the whole bucket; 'sparse' / 'auto' send the touched tiles and fall back to
+            # the dense bucket when more than half of the tiles are touched -- with the reference's mip-mapped textures they all would be)
+            sparse = [self.exchange_mode != 'dense' and len(chunks) == 2 and k == 1 for k in range(len(chunks))]
+            self._ex = GradientExchange(groups, world_size, local_weight=self.nv, equal_shards=even, sparse=sparse)
+            self._ex_chunks = chunks if self._fused_update else [None]
             # Several ranks: the texture lookup's adjoint scatter-adds straight into the exchange buckets (they are what the persistent
             # gradient buffers were: all zero between iterations, re-zeroed tile by tile by the optimizer that consumes them), so the
             # 37.7 MB of texture gradients are neither packed nor cleared: one copy and three memsets less per iteration and rank.
             self._tex_grad_resident = False
-            if self._tex_grad is not None and world_size > 1:
-                self._tex_grad = [self._ex.slot(p) for p in self.params[:self.n_tex]]
+            if self._tex_grad is not None and (world_size > 1 or self.force_exchange):
+                self._tex_grad = rd.PersistentGrads(self._ex.slot(p) for p in self.params[:self.n_tex])
                 self._tex_grad_resident = True
+            self._pending = False
+            if self._union_views and any(self._ex.sparse):
+                self._ex.extra_flags[self._ex.sparse.index(True)] = self._union_flags()
         return self._ex
 
-    def _exchange_and_update(self, world_size, packed=False, graphs=None):
-        """all-reduce chunk by chunk; the update of chunk k (one fused launch, or its captured graph) runs while chunk k + 1 is
-        still on the wire.  Returns the bytes this rank put into the collectives."""
+    @torch.no_grad()
+    def _union_flags(self):
+        """One byte per 64-texel tile of the texture chunk: 1 where some covered pixel of the union views looks a texel of that tile up."""
+        from .parallel import TILE_FLOATS
+        cams = [sc.camera(vw, self.total_views) for vw in self._union_views]
+        mvp = torch.stack([c[1] for c in cams]).to(self.dev)
+        cam = torch.stack([sc.camera_rays(c[0]) for c in cams]).to(self.dev)
+        gb = ou.render_gbuffer(self.ctx, self.mesh, mvp, cam, (self.res, self.res))
+        cov = gb['rast'][..., 3].reshape(-1) > 0
+        tc = gb['gb_texc'].reshape(-1, 2)[cov]
+        out = []
+        for p in self.params[:self.n_tex]:
+            R = p.shape[0]
+            ix = (tc[:, 0] * R).long().clamp(0, R - 1)
+            iy = ((1.0 - tc[:, 1]) * R).long().clamp(0, R - 1)
+            f = torch.zeros(p.numel() // TILE_FLOATS, dtype=torch.uint8, device=self.dev)
+            f[(iy * R + ix) // (TILE_FLOATS // 3)] = 1
+            out.append(f)
+        return torch.cat(out)
+
+    # ---- several ranks (or force_exchange): the exchange is pipelined with the next iteration ---------------------------------------
+    #
+    #   step i:      stage 2 (lookups ... backward, pack, tile flags) | all-reduce [light, v_pos] ; all-reduce tile flags
+    #                Adam [light, v_pos]  ->  stage 1 of step i + 1 (BVH rebuild, update_pdf, vertex frames, G-buffer)     <- main stream
+    #                texture chunk: union list, gather, all-reduce                                                         <- side stream + RCCL
+    #   step i + 1:  wait(textures) -> scatter -> Adam [kd, ks, normal] -> stage 2 ...
+    #
+    # The textures' update completes before the next texture lookup, so every iteration sees exactly the parameters of the unpipelined
+    # schedule; finish() completes the last one.
+
+    def _wait(self, k):
+        """ex.wait(k) with the time the MAIN stream stands still for it measured by a pair of events (measure_exposed)."""
+        ex = self._ex
+        if not self.measure_exposed:
+            return ex.wait(k)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        f = ex.wait(k)
+        b.record()
+        self._exposed_events.append((a, b))
+        return f
+
+    def exposed_ms(self):
+        """Per-iteration time the main stream waited on the exchange (collectives + scatter) since measure_exposed was set, as a list; clears it."""
+        torch.cuda.synchronize()
+        per_wait = [a.elapsed_time(b) for a, b in self._exposed_events]
+        self._exposed_events = []
+        n = max(1, len(self._ex_chunks))
+        return [sum(per_wait[i:i + n]) for i in range(0, len(per_wait) - n + 1, n)]
+
+    def _finish_pending(self, graphs=None):
+        """The texture chunk of the previous iteration: wait for its all-reduce, scatter, Adam + clamps."""
+        if not getattr(self, '_pending', False):
+            return
+        k = len(self._ex_chunks) - 1
+        f = self._wait(k)
+        if graphs is not None:
+            graphs[k].replay()
+        else:
+            self._update(subset=self._ex_chunks[k], advance=True, grad_mult=f)
+        self._pending = False
+
+    def finish(self):
+        """Complete the parameter update of the last iteration (the pipelined texture chunk).  Call once after the last step()."""
+        if getattr(self, '_pending', False):
+            g = self._graphs[1] if (self._graphs is not None and not self.force_eager) else None
+            self._finish_pending(g)
+
+    def _step_multi(self, world_size):
         ex = self._exchange(world_size)
-        if not packed:
+        chunks = self._ex_chunks
+        graphs = self._graphs if (self._graphs is not None and not self.force_eager) else None
+        if graphs is None and self._graphs is not None and not getattr(self, '_left_graphs', False):
+            self._left_graphs, self._stage1_ready = True, False        # force_eager: the geometry stage is redone eagerly (its autograd graph too)
+        last = len(chunks) - 1
+        self._finish_pending(graphs[1] if graphs else None)
+        if graphs:
+            g1, gb, g2 = graphs[0], graphs[1], graphs[2]
+            if not self._stage1_ready:
+                g1.replay()
+                self._stage1_ready = True
+            g2.replay()
+            self._stage1_ready = False
+            loss = self._loss_static
+        else:
+            self._eager_steps += 1
+            loss = self.forward_backward()
             ex.pack()
             self._packed_tex_grad()
-        ex.start()
-        chunks = self._chunk_indices() if self._fused_update else [None]
-        for k in ex.chunks():
-            f = ex.wait(k)
-            if graphs is not None:
-                graphs[k].replay()
+            ex.compute_flags()
+        ex.start(skip_single=not self.force_exchange)
+        for k in range(last):                       # the early chunks: their update, then the next iteration's geometry stage can go
+            f = self._wait(k)
+            if graphs:
+                gb[k].replay()
             else:
-                self._update(subset=chunks[k], advance=(k == len(chunks) - 1), grad_mult=f)
-        return ex.bytes_per_step
+                self._update(subset=chunks[k], advance=False, grad_mult=f)
+        if self.pipeline and last > 0:
+            if graphs:
+                graphs[0].replay()
+                self._stage1_ready = True
+            else:
+                self._stage1()
+        ex.send(last)                               # sparse: the host reads the union's size here -- the GPU is busy with stage 1 meanwhile
+        self._pending = True
+        if not (self.pipeline and last > 0):
+            self._finish_pending(graphs[1] if graphs else None)
+        self.allreduce_bytes = ex.bytes_per_step
+        return loss
 
     def _tex_grad_guard(self):
         """One rank: FusedAdam zeroes the texture gradients it consumed, which clears the persistent scatter-add buffers only if
         p.grad IS that buffer.  Should autograd have copied instead of adopting (a hook, a second reference), clear them explicitly."""
         if self._tex_grad is not None:
-            self._tex_grad_dirty = False
+            self._tex_grad.dirty = False
             for p, b in zip(self.params[:self.n_tex], self._tex_grad):
                 if p.grad is None or p.grad.data_ptr() != b.data_ptr():
                     self._zero_tex_grad()
@@ -520,7 +650,7 @@ class DirectLightingStep:
         """The gradients are in the exchange buckets: clear the persistent scatter-add buffers of the texture lookup -- unless they ARE
         the buckets (_exchange), which the optimizer re-zeroes as it consumes them."""
         if getattr(self, '_tex_grad_resident', False):
-            self._tex_grad_dirty = False
+            self._tex_grad.dirty = False
         else:
             self._zero_tex_grad()
 
@@ -528,14 +658,14 @@ class DirectLightingStep:
         """Several ranks: the optimizer reads (and zeroes) the exchange buckets, not the persistent scatter-add buffers of the texture
         lookup -- those are cleared here, once their content has been packed."""
         if self._tex_grad is not None:
-            self._tex_grad_dirty = False
+            self._tex_grad.dirty = False
             for b in self._tex_grad:
                 b.zero_()
 
     def _capture(self, world_size):
-        """HIP graphs: (A) update_pdf + BVH rebuild + render + loss + backward [+ the pack of the exchange buckets], (B_k) light-gradient
-        scale + Adam + clamps of exchange chunk k.  The all-reduces (world > 1) run between them on the same stream, chunk k + 1
-        under B_k; with one rank A and B are one graph."""
+        """HIP graphs.  One rank: ONE graph -- update_pdf + BVH rebuild + render + loss + backward + light-gradient scale + Adam + clamps.
+        Several ranks: G1 (stage 1: the geometry stage), G2 (stage 2 + bucket pack + tile flags), B_k (Adam + clamps of exchange chunk k);
+        the collectives run between the replays, on RCCL's stream."""
         torch.cuda.synchronize()
         self.opt.zero_grad(set_to_none=True)
         # The parameters' gradient accumulators were created on the default stream by the eager iterations; the capture runs on torch's
@@ -544,54 +674,91 @@ class DirectLightingStep:
         warn = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
         if warn is not None:
             warn(False)
-        ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            self._loss_static = self.forward_backward()
-            if world_size == 1:
+        multi = world_size > 1 or self.force_exchange
+        if not multi:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._stage1_ready = False
+                self._loss_static = self.forward_backward()
                 self._update()
                 self._tex_grad_guard()
-            else:
-                self._exchange(world_size).pack()
-                self._packed_tex_grad()
-        gbs = None
-        if world_size > 1:
-            ex = self._exchange(world_size)
-            chunks = self._chunk_indices() if self._fused_update else [None]
-            gbs = []
-            for k in ex.chunks():
-                f = ex.wait(k)              # points the .grad of chunk k at its bucket: what the captured update reads on every replay
-                gk = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gk, pool=ga.pool()):
-                    self._update(subset=chunks[k], advance=(k == len(chunks) - 1), grad_mult=f)
-                gbs.append(gk)
-        self._graphs = (ga, gbs)
+            self._graphs = (ga, None, None)
+            return
+        ex = self._exchange(world_size)
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            self._stage1()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, pool=g1.pool()):
+            self._loss_static = self._stage2()
+            ex.pack()
+            self._packed_tex_grad()
+            ex.compute_flags()
+        gbs = []
+        n = len(self._ex_chunks)
+        for k in range(n):
+            f = self._point_grads(k)        # the .grad of chunk k = views into its bucket: what the captured update reads on every replay
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk, pool=g1.pool()):
+                self._update(subset=self._ex_chunks[k], advance=(k == n - 1), grad_mult=f)
+            gbs.append(gk)
+        self._graphs = (g1, gbs, g2)
+        self._stage1_ready = False
+
+    def _point_grads(self, k):
+        """.grad of the parameters of chunk k = views into its bucket (what GradientExchange.wait leaves), without touching the exchange's state."""
+        ex = self._ex
+        off = 0
+        for p in ex.groups[k]:
+            p.grad = ex.buckets[k][off:off + p.numel()].view_as(p)
+            off += p.numel()
+        return ex.grad_mult
+
+    def _agree_on_graphs(self, ok, world_size):
+        """Every rank must run the same schedule: if the capture failed anywhere, every rank raises (a rank that silently fell back to eager
+        launches would still be correct, but the run would no longer be what its bench line says)."""
+        if world_size > 1 and _dist_ready():
+            import torch.distributed as dist
+            t = torch.tensor([1.0 if ok else 0.0], device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
+        return ok
 
     def step(self, world_size=1):
+        multi = world_size > 1 or self.force_exchange
         if self.use_graph and not self.force_eager and self._graphs is None and self._eager_steps >= 3:
+            err = None
+            if multi:
+                self._exchange(world_size)
+                self._finish_pending()
             try:
                 self._capture(world_size)
-            except Exception as e:      # a runtime that cannot capture this iteration keeps running it eagerly (same results)
+            except Exception as e:
+                err = e
+            if multi:
+                if not self._agree_on_graphs(err is None, world_size):
+                    raise RuntimeError('HIP-graph capture of the iteration failed on at least one rank (this rank: %s); the ranks must '
+                                       'all run captured or all eager -- rerun with use_graph=False' % (repr(err) if err else 'ok'))
+            elif err is not None:      # one rank: a runtime that cannot capture this iteration keeps running it eagerly (same results)
                 import warnings
-                warnings.warn('HIP-graph capture of the iteration failed (%s: %s); continuing eagerly' % (type(e).__name__, e))
+                warnings.warn('HIP-graph capture of the iteration failed (%s: %s); continuing eagerly' % (type(err).__name__, err))
                 self.use_graph, self._graphs = False, None
                 torch.cuda.synchronize()
                 self.opt.zero_grad(set_to_none=True)
+                self._stage1_ready = False
+        if multi:
+            return self._step_multi(world_size)
         if self._graphs is not None and not self.force_eager:
-            ga, gbs = self._graphs
-            ga.replay()
-            if gbs is not None:
-                self.allreduce_bytes = self._exchange_and_update(world_size, packed=True, graphs=gbs)
+            self._graphs[0].replay()
             return self._loss_static
         self._eager_steps += 1
-        if world_size > 1:
-            self._exchange(world_size)          # (before the first backward: the texture gradients are produced inside its buckets)
         loss = self.forward_backward()
-        # Each rank's gradient is the gradient of ITS mean over the views it renders; the batch mean over all ranks is the sum over
-        # ranks of (local views * gradient) / total views -- the plain average when the shards are even (parallel.GradientExchange)
-        if world_size > 1:
-            self.allreduce_bytes = self._exchange_and_update(world_size)
-        else:
-            self.allreduce_bytes = 0
-            self._update()
-            self._tex_grad_guard()
+        self.allreduce_bytes = 0
+        self._update()
+        self._tex_grad_guard()
         return loss
+
+
+def _dist_ready():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()

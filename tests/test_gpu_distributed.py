@@ -106,15 +106,19 @@ if world > 1:
 res, n, views = 96, 4, [0, 1, 2, 3]
 per = len(views) // world
 mine = views[rank * per:(rank + 1) * per]
-st = DirectLightingStep('bob', res, n, view=mine, n_views=len(views), device='cuda:0', lr=0.03, tex_res=256,
-                        pixel_index_offset=mine[0] * res * res, use_graph=(os.environ.get('USE_GRAPH') == '1'))
+st = DirectLightingStep('bob', res, n, view=mine, n_views=len(views), device='cuda:0', lr=0.03, tex_res=512,
+                        pixel_index_offset=mine[0] * res * res, use_graph=(os.environ.get('USE_GRAPH') == '1'),
+                        exchange_mode=os.environ.get('EXCHANGE', 'auto'), pipeline=(os.environ.get('PIPELINE', '1') == '1'))
 losses = []
 for it in range(8):
     losses.append(float(st.step(world).item()))
+st.finish()                 # the pipelined texture update of the last step
 torch.cuda.synchronize()
 kd = st.params[0].detach().double()
+rep = st._ex.report() if world > 1 else {}
 out = {'rank': rank, 'losses': losses, 'kd_sum': float(kd.sum()), 'kd_abs': float(kd.abs().sum()), 'light_sum': float(st.params[3].detach().double().sum()),
-       'resident': bool(getattr(st, '_tex_grad_resident', False)), 'graph': st._graphs is not None}
+       'nrm_sum': float(st.params[2].detach().double().sum()), 'ks_sum': float(st.params[1].detach().double().sum()),
+       'resident': bool(getattr(st, '_tex_grad_resident', False)), 'graph': st._graphs is not None, 'exchange': rep}
 print('RESULT ' + json.dumps(out))
 if world > 1:
     dist.barrier()
@@ -122,15 +126,16 @@ if world > 1:
 '''
 
 
+@pytest.mark.parametrize('exchange,pipeline', [('dense', '0'), ('dense', '1'), ('sparse', '1')], ids=['dense_unpipelined', 'dense_pipelined', 'sparse_pipelined'])
 @pytest.mark.parametrize('graph', ['0', '1'], ids=['eager', 'hip_graphs'])
-def test_two_rank_training_follows_the_one_rank_run(graph, dev):
+def test_two_rank_training_follows_the_one_rank_run(graph, exchange, pipeline, dev):
     """Four views dealt over two ranks (gloo for the collective, both on this GPU) train like four views on one rank: the chunked
     exchange sums what the ranks' backward passes scatter-added INTO its buckets, the fused Adam of every chunk sees the batch-mean
     gradient.  Per step the mean of the two ranks' losses is the one-rank loss (each rank's loss is the mean over its own views), and
     the trained textures and probe agree up to the order of the additions."""
     def run(world, rank, port):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), USE_GRAPH=graph,
-                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   EXCHANGE=exchange, PIPELINE=pipeline, HSA_ENABLE_IPC_MODE_LEGACY='0')
         return subprocess.Popen([sys.executable, '-c', _TRAIN_SNIPPET % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
 
     def result(p):
@@ -147,6 +152,52 @@ def test_two_rank_training_follows_the_one_rank_run(graph, dev):
         pair = 0.5 * (two[0]['losses'][it] + two[1]['losses'][it])
         assert abs(pair - one['losses'][it]) <= 2e-4 * abs(one['losses'][it]), (it, pair, one['losses'][it])
     assert one['losses'][-1] < one['losses'][0]
-    for k in ('kd_sum', 'light_sum'):
+    for k in ('kd_sum', 'ks_sum', 'nrm_sum', 'light_sum'):
         assert abs(two[0][k] - two[1][k]) <= 1e-9 * abs(two[0][k])             # the ranks hold the same parameters ...
         assert abs(two[0][k] - one[k]) <= 1e-4 * abs(one[k]), (k, two[0][k], one[k])      # ... and they are the one-rank parameters
+    ex = two[0]['exchange']
+    assert ex['mode'] == exchange and ex['chunk_modes'][0] == 'dense'          # [probe] first, dense; then the textures
+    if exchange == 'sparse':
+        assert 0 < ex['tiles_touched'] < 0.5 * ex['tiles_total'] and ex['bytes_sent'] < 0.6 * ex['bytes_dense']
+        assert two[0]['exchange']['tiles_touched'] == two[1]['exchange']['tiles_touched']
+    else:
+        assert ex['bytes_sent'] == ex['bytes_dense']
+
+
+_FORCED_SNIPPET = r'''
+import json, os, sys, torch
+sys.path.insert(0, %r)
+from nvdiffrecmc_amd.trainer import DirectLightingStep
+res, n = 96, 4
+out = {}
+for tag, kw in (('plain', {}), ('forced', {'force_exchange': True, 'exchange_mode': 'sparse', 'union_views': [0, 1, 2, 3]})):
+    st = DirectLightingStep('bob', res, n, view=[1], n_views=4, device='cuda:0', lr=0.03, tex_res=512, pixel_index_offset=res * res,
+                            use_graph=(os.environ.get('USE_GRAPH') == '1'), **kw)
+    losses = [float(st.step(1).item()) for _ in range(7)]
+    st.finish()
+    torch.cuda.synchronize()
+    out[tag] = {'losses': losses, 'sums': [float(p.detach().double().sum()) for p in st.params], 'graph': st._graphs is not None,
+                'exchange': st._ex.report() if kw else None}
+print('RESULT ' + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize('graph', ['0', '1'], ids=['eager', 'hip_graphs'])
+def test_the_several_rank_schedule_with_one_rank_is_the_plain_iteration(graph, dev):
+    """force_exchange: stage 2 | exchange of [probe] | its Adam | stage 1 of the NEXT iteration | tile-sparse texture chunk (flags, union list,
+    gather, scatter) | texture Adam in front of the next lookup -- with one rank and no collective this must train exactly like the plain
+    iteration: the same losses step by step and the same parameters up to the order of atomic additions (the pipelining moves launches, not arithmetic)."""
+    env = dict(os.environ, USE_GRAPH=graph, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', _FORCED_SNIPPET % ROOT], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('RESULT ')][-1][7:])
+    a, b = out['plain'], out['forced']
+    assert a['graph'] == b['graph'] == (graph == '1')
+    for x, y in zip(a['losses'], b['losses']):         # (up to the order of the lookup adjoint's atomic additions)
+        assert abs(x - y) <= 2e-5 * abs(x), (a['losses'], b['losses'])
+    for x, y in zip(a['sums'], b['sums']):
+        assert abs(x - y) <= 1e-5 * abs(x), (a['sums'], b['sums'])
+    assert a['losses'][-1] < a['losses'][0]
+    ex = b['exchange']
+    assert ex['mode'] == 'sparse'
+    assert 0 < ex['tiles_touched'] < ex['tiles_total']          # the union of the four views' tiles, not only this view's

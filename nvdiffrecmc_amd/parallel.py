@@ -57,7 +57,7 @@ def allreduce_gradients(params, world_size=None, group=None, average=True, local
         else:
             g.copy_(red)
             p.grad = g
-    return sum(b.numel() for b in ex.buckets) * 4
+    return sum(p.numel() for p in params) * 4          # the payload (a weighted bucket carries one more element)
 
 
 class _TileOps:

@@ -414,15 +414,24 @@ class DirectLightingStep:
                 spec = ou.ops._bilateral_denoiser_func.apply(spec, nn, depth, self.denoiser.sigma)
         return ru.shade_composite(diff, spec, kd, ks)
 
-    def _stage1(self):
+    def _build_bvh(self):
+        v_pos = self.v_pos if self.optimize_geometry else self.mesh['v_pos']
+        ou.optix_build_bvh(self.ctx, v_pos, self.mesh['t_pos_idx'], rebuild=1)
+        self._build_deferred = False
+        return v_pos
+
+    def _stage1(self, defer_build=False):
         """The geometry stage of an iteration -- everything that needs only the light probe and the vertices, not the textures: BVH
         rebuild (side stream), update_pdf, and with trained geometry getMesh (dlmesh.py:45-55) + rasterize / interpolate
         (render.py:208-234) from the moving vertices.  With several ranks it runs while the texture chunk of the previous iteration's
-        gradient exchange is still on the wire (_step_multi)."""
+        gradient exchange is still on the wire (_step_multi).
+        defer_build (the several-rank schedule with LOCKED geometry): the rebuild is left to the start of stage 2, where it runs beside the
+        sample generation as in the one-rank iteration -- nothing in this stage would consume the tree, and a HIP graph of this stage alone
+        could not end with the side stream's work unjoined."""
         # the rebuild first: it runs on the context's side stream, and the sooner it starts the less of it is left when the traversal
         # needs the tree (one view: the light's three small kernels used to run in front of it)
-        v_pos = self.v_pos if self.optimize_geometry else self.mesh['v_pos']
-        ou.optix_build_bvh(self.ctx, v_pos, self.mesh['t_pos_idx'], rebuild=1)
+        self._build_deferred = bool(defer_build) and not self.optimize_geometry
+        v_pos = self.mesh['v_pos'] if self._build_deferred else self._build_bvh()
         self.light.update_pdf()
         self._gb_live = None
         if self.material_set != 'r3' and self.optimize_geometry:
@@ -436,6 +445,8 @@ class DirectLightingStep:
         """Texture lookups, shading frame, env-shade, filters, composite, loss and the whole backward pass; returns the loss tensor
         (gradients are in .grad, the texture gradients scatter-added into the persistent buffers / exchange buckets)."""
         self._stage1_ready = False
+        if getattr(self, '_build_deferred', False):
+            self._build_bvh()
         self.opt.zero_grad(set_to_none=True)
         if self._tex_grad is not None and self._tex_grad.dirty:
             self._zero_tex_grad()           # a backward pass whose gradients no update consumed (forward_backward called on its own)
@@ -612,7 +623,9 @@ class DirectLightingStep:
             loss = self._loss_static
         else:
             self._eager_steps += 1
-            loss = self.forward_backward()
+            if not self._stage1_ready:
+                self._stage1(defer_build=True)
+            loss = self._stage2()
             ex.pack()
             self._packed_tex_grad()
             ex.compute_flags()
@@ -628,7 +641,7 @@ class DirectLightingStep:
                 graphs[0].replay()
                 self._stage1_ready = True
             else:
-                self._stage1()
+                self._stage1(defer_build=True)
         ex.send(last)                               # sparse: the host reads the union's size here -- the GPU is busy with stage 1 meanwhile
         self._pending = True
         if not (self.pipeline and last > 0):
@@ -687,7 +700,7 @@ class DirectLightingStep:
         ex = self._exchange(world_size)
         g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g1):
-            self._stage1()
+            self._stage1(defer_build=True)
         g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g2, pool=g1.pool()):
             self._loss_static = self._stage2()

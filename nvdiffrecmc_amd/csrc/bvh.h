@@ -140,6 +140,10 @@ struct nvdr_ctx {
     float *in_verts = nullptr;     // the build's own copy of the caller's geometry (taken on the caller's stream: the caller may
     int32_t *in_tris = nullptr;    // overwrite or free its tensors as soon as nvdr_bvh_build has returned)
     int64_t in_verts_cap = 0, in_tris_cap = 0;
+    bool build_deferred = false;   // nvdr_ctx_set_build_mode(2): the build's launches wait for the first consumer of the tree
+    bool queued = false;           // a prepared build whose kernels have not been launched yet (ctx_launch_build)
+    const float *queued_verts = nullptr; const int32_t *queued_tris = nullptr;
+    int queued_rebuild = 0; int64_t queued_n_verts = 0, queued_n_tris = 0;
     bool built_pending = false;    // a build is (possibly) still in flight on build_stream
     hipStream_t built_waited = nullptr;   // the caller stream that already waits on ev_built ...
     bool built_waited_valid = false;      // ... if any (the default stream's handle IS the null pointer)
@@ -191,6 +195,7 @@ struct BvhView {
 };
 
 int ctx_check_overflow(nvdr_ctx *c, const char *who);   // bvh.hip
+int ctx_launch_build(nvdr_ctx *c, hipStream_t stream);  // bvh.hip: the kernels of a prepared (possibly deferred) build
 int ctx_wait_built(nvdr_ctx *c, hipStream_t stream);    // bvh.hip: make `stream` wait for the context's last BVH build
 
 // every device buffer the context owns beyond its few fixed control words goes through these two

@@ -853,6 +853,7 @@ int ctx_check_overflow(nvdr_ctx *c, const char *who)
 // Every consumer of the tree calls this before its first launch that reads it: the build may still be running on the side stream.
 int ctx_wait_built(nvdr_ctx *c, hipStream_t stream)
 {
+    if (c->queued) { if (int r = ctx_launch_build(c, stream)) return r; }      // (a deferred build: launched now, on the side stream)
     if (!c->built_pending || (c->built_waited_valid && c->built_waited == stream)) return 0;
     NVDR_HIP_TRY(hipStreamWaitEvent(stream, c->ev_built, 0));
     c->built_waited = stream;
@@ -864,6 +865,7 @@ extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
 {
     NVDR_REQUIRE(c != nullptr, "nvdr_ctx_check: ctx is NULL");
     NVDR_HIP_TRY(hipSetDevice(c->device));
+    if (c->queued) { if (int rq = ctx_launch_build(c, (hipStream_t)stream_)) return rq; }
     if (c->build_stream) NVDR_HIP_TRY(hipStreamSynchronize(c->build_stream));
     NVDR_HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
     return ctx_check_overflow(c, "nvdr_ctx_check");
@@ -1008,6 +1010,27 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris, hipStream_t stream)
     return 0;
 }
 
+// the build's own copy of the caller's vertices and indices, both in one launch
+__global__ void __launch_bounds__(256) bvh_copy_inputs_kernel(const float *__restrict__ v, int64_t nv, float *__restrict__ vo,
+                                                              const int32_t *__restrict__ t, int64_t nt, int32_t *__restrict__ to)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv || i < nt; i += stride) {
+        if (i < nv) vo[i] = v[i];
+        if (i < nt) to[i] = t[i];
+    }
+}
+
+extern "C" int nvdr_ctx_set_build_mode(nvdr_ctx *c, int mode)
+{
+    NVDR_REQUIRE(c, "nvdr_ctx_set_build_mode: NULL ctx");
+    NVDR_REQUIRE(mode >= 0 && mode <= 2, "nvdr_ctx_set_build_mode: mode %d (0 caller's stream, 1 side stream, 2 side stream with deferred launches)", mode);
+    NVDR_REQUIRE(!c->queued, "nvdr_ctx_set_build_mode: a deferred build is waiting for its consumer on this context");
+    c->async_build = mode != 0;
+    c->build_deferred = mode == 2;
+    return 0;
+}
+
 extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, const int32_t *tris, int64_t n_tris,
                               int rebuild, void *stream_)
 {
@@ -1021,6 +1044,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     NVDR_HIP_TRY(hipSetDevice(c->device));
     // a context whose traversal stack overflowed (or whose build / walk gave up) is unusable: say so before touching any buffer
     if (int r0 = ctx_check_overflow(c, "nvdr_bvh_build")) return r0;
+    if (c->queued) { if (int rq = ctx_launch_build(c, stream)) return rq; }      // a deferred build nobody consumed: a refit may follow it
     if (rebuild == 0) {
         NVDR_REQUIRE(c->n_tris == n_tris && c->n_verts == n_verts,
                      "nvdr_bvh_build: refit (rebuild=0) needs the topology of the last full build "
@@ -1077,11 +1101,42 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         }
         // a build that nobody has waited for yet may still be reading the staging copies (two builds in a row, a build then a refit)
         if (c->built_pending) { if (int rw = ctx_wait_built(c, caller)) return rw; }
-        NVDR_HIP_TRY(hipMemcpyAsync(c->in_verts, verts, sizeof(float) * 3 * n_verts, hipMemcpyDeviceToDevice, caller));
-        NVDR_HIP_TRY(hipMemcpyAsync(c->in_tris, tris, sizeof(int32_t) * 3 * n_tris, hipMemcpyDeviceToDevice, caller));
+        // ONE copy launch for both buffers (two hipMemcpyAsync nodes cost a captured HIP graph ~15 us each on this runtime)
+        {
+            const int64_t nv3 = 3 * n_verts, nt3 = 3 * n_tris, most = nv3 > nt3 ? nv3 : nt3;
+            bvh_copy_inputs_kernel<<<min(div_up(most, 256 * 4), 2048u), 256, 0, caller>>>(verts, nv3, c->in_verts, tris, nt3, c->in_tris);
+        }
         verts = c->in_verts;
         tris = c->in_tris;
         NVDR_HIP_TRY(hipEventRecord(c->ev_inputs, caller));
+        stream = c->build_stream;
+    }
+    c->queued_verts = verts; c->queued_tris = tris; c->queued_rebuild = rebuild; c->queued_n_verts = n_verts; c->queued_n_tris = n_tris;
+    c->queued = true;
+    c->n_tris = n_tris;
+    c->n_verts = n_verts;
+    c->stream_id = 0; // a ray stream traced against the old geometry must not be reused
+    if (c->async_build) {
+        c->built_pending = true;        // (consumers call ctx_wait_built, which launches a deferred build first)
+        c->built_waited_valid = false;
+    }
+    // build_mode 2: the launches wait for the first consumer of the tree (ctx_wait_built) -- in program order BEHIND whatever the caller
+    // enqueues in between (env-shade: pixel compaction, sample generation), so that in a captured HIP graph those nodes come first
+    if (c->async_build && c->build_deferred) return 0;
+    return ctx_launch_build(c, stream);
+}
+
+// the kernels of a prepared build (nvdr_bvh_build), on the context's side stream -- or the caller's, without one
+int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
+{
+    if (!c->queued) return 0;
+    c->queued = false;
+    const float *verts = c->queued_verts;
+    const int32_t *tris = c->queued_tris;
+    const int rebuild = c->queued_rebuild;
+    const int64_t n_verts = c->queued_n_verts;
+    const int n = (int)c->queued_n_tris;
+    if (c->async_build) {
         NVDR_HIP_TRY(hipStreamWaitEvent(c->build_stream, c->ev_inputs, 0));
         stream = c->build_stream;
     }
@@ -1123,14 +1178,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
         }
     }
     NVDR_LAUNCH_CHECK();
-    if (c->async_build) {
-        NVDR_HIP_TRY(hipEventRecord(c->ev_built, c->build_stream));
-        c->built_pending = true;
-        c->built_waited_valid = false;
-    }
-    c->n_tris = n_tris;
-    c->n_verts = n_verts;
-    c->stream_id = 0; // a ray stream traced against the old geometry must not be reused
+    if (c->async_build) NVDR_HIP_TRY(hipEventRecord(c->ev_built, c->build_stream));
     return 0;
 }
 

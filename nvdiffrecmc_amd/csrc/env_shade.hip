@@ -131,8 +131,11 @@ __device__ __forceinline__ unsigned chunk_pixels(const ShadeParams &p) { return 
 // A wavefront looks at NVDR_COMPACT_ROUNDS x 64 consecutive pixels and claims list space for all of them with ONE atomic (the
 // counter is a single address: with one claim per 64 pixels the 32 k claims of an 8-view launch serialised into 113 us).
 #define NVDR_COMPACT_ROUNDS 16
+// zero_a / zero_b (forward launches): the two output images are zero-filled HERE at the pixels that are not covered -- the shading kernel stores
+// every covered pixel -- instead of by a memset of their own (one node less in front of the generation kernel of a launch-bound iteration)
 __global__ void __launch_bounds__(256) compact_pixels_kernel(const float *__restrict__ mask, int64_t ms0, int64_t ms1, int64_t ms2, int N, int H,
-                                                             int W, int *__restrict__ list, unsigned *count)
+                                                             int W, int *__restrict__ list, unsigned *count, float *__restrict__ zero_a,
+                                                             float *__restrict__ zero_b)
 {
     const unsigned total = (unsigned)(N * H * W);           // < 2^31 (checked by the launcher)
     const int lane = threadIdx.x & 63;
@@ -155,6 +158,11 @@ __global__ void __launch_bounds__(256) compact_pixels_kernel(const float *__rest
         }
         bits[k] = __ballot(on);
         n += (unsigned)__popcll(bits[k]);
+        if (zero_a && i < total && !on) {
+            float *za = zero_a + 3 * (int64_t)i, *zb = zero_b + 3 * (int64_t)i;
+            za[0] = 0.0f; za[1] = 0.0f; za[2] = 0.0f;
+            zb[0] = 0.0f; zb[1] = 0.0f; zb[2] = 0.0f;
+        }
     }
     if (n == 0) return;
     unsigned base = 0;
@@ -1960,12 +1968,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
 
     if (!backward) {
         NVDR_REQUIRE(a->diff && a->spec, "env_shade_fwd: NULL output");
-        p.diff = a->diff; p.spec = a->spec;
-        if (p.spec == p.diff + 3 * npix) {
-            NVDR_HIP_TRY(hipMemsetAsync(p.diff, 0, sizeof(float) * 6 * npix, stream)); // torch::zeros, torch_bindings.cpp:148-149
-        } else {
-            zero_outputs_kernel<<<dim3(min(div_up(3 * npix, 1024), 2048u), 2), 256, 0, stream>>>(p.diff, p.spec, nullptr, nullptr, 3 * npix);
-        }
+        p.diff = a->diff; p.spec = a->spec;       // torch::zeros (torch_bindings.cpp:148-149): the uncovered pixels are zeroed by compact_pixels_kernel below
     } else {
         NVDR_REQUIRE(a->gb_pos_grad && a->gb_normal_grad && a->gb_kd_grad && a->gb_ks_grad && a->light_grad,
                      "env_shade_bwd: NULL output");
@@ -2058,7 +2061,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
                                                const_cast<unsigned *>(a->rnd_seed_offset), backward ? nullptr : a->rnd_seed_snapshot, a->rnd_seed_advance);
     if (!reuse)
         compact_pixels_kernel<<<div_up(npix, 256 * NVDR_COMPACT_ROUNDS), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
-                                                                      &c->dinfo->pix_count);
+                                                                      &c->dinfo->pix_count, backward ? nullptr : p.diff, backward ? nullptr : p.spec);
     for (int k = 0; k < n_chunks; ++k) {
         p.pix_begin = (unsigned)((int64_t)k * cap);
         p.ray_count = c->chunk_counts + k;

@@ -76,6 +76,12 @@ class OptiXContext:
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')
 
+    def set_build_mode(self, mode):
+        """Where optix_build_bvh runs: 1 (default) side stream, 0 the caller's stream, 2 side stream with the launches deferred to the
+        first consumer of the tree (HIP graphs of launch-bound iterations: the caller's own front nodes come first)."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_ctx_set_build_mode(w.handle, int(mode)), 'nvdr_ctx_set_build_mode')
+
     def check(self):
         """Synchronise and raise if any traversal launch on this context ever overflowed its stack (never silent)."""
         w = self.cpp_wrapper

@@ -187,7 +187,10 @@ class GradientExchange:
                 if p.grad is None:
                     dst.zero_()
                 elif p.grad.data_ptr() != dst.data_ptr():
-                    dst.copy_(p.grad.reshape(-1))
+                    if dst.is_cuda:     # an elementwise KERNEL, not copy_(): a device-to-device memcpy node stalls a replayed HIP graph for ~30 us on this runtime
+                        torch.mul(p.grad.reshape(-1), 1.0, out=dst)
+                    else:
+                        dst.copy_(p.grad.reshape(-1))
             if not self.equal_shards:
                 b[:n].mul_(self.local_weight)
                 b[n:].fill_(self.local_weight)

@@ -109,7 +109,7 @@ class DirectLightingStep:
                  probe_res=256, denoise=True, retrace_backward=False, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
                  denoiser_demodulate=True, light_grad_scale=64.0, use_graph=False, material_set='full', tex_res=1024,
                  optimize_geometry=False, lr_pos=None, lr_light=None, perturb_pos=0.0, ks_min=(0.0, 0.08, 0.0), ks_max=(0.0, 1.0, 1.0),
-                 perturbed_nrm=True, exchange_mode='auto', pipeline=True, force_exchange=False, union_views=None):
+                 perturbed_nrm=True, exchange_mode='auto', pipeline=True, force_exchange=False, union_views=None, build_mode=None):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
@@ -156,6 +156,7 @@ class DirectLightingStep:
         self.mesh = {k: (v.to(self.dev) if isinstance(v, torch.Tensor) else v) for k, v in mesh.items()}
         self.ctx = ou.OptiXContext()
         ou.optix_build_bvh(self.ctx, self.mesh['v_pos'], self.mesh['t_pos_idx'], rebuild=1)
+        self._build_mode = build_mode
 
         # ---- G-buffers of this rank's views in ONE kernel launch (csrc/gbuffer.hip): primary rays through the same BVH +
         # the attribute interpolation, face normal, tangents and (z/w, |dz|) pair of render_layer (render.py:208-234); stands
@@ -269,6 +270,14 @@ class DirectLightingStep:
             except (RuntimeError, TypeError):
                 self.opt = torch.optim.Adam(groups, lr=lr, capturable=use_graph)
         self.covered = int(self.mask.sum().item())
+        # Where the per-iteration BVH rebuild runs (OptiXContext.set_build_mode).  Launch-bound iterations captured in HIP graphs (one or two
+        # views per rank) defer the build's launches behind the sample generation's: the graph's front nodes are then the iteration's own.
+        mode = self._build_mode
+        if mode is None:
+            env = _lib.tuning_env('NVDR_BUILD_MODE')
+            mode = int(env) if env is not None else (2 if (use_graph and self.nv <= 2 and not self.optimize_geometry) else 1)
+        self.ctx.check()                 # (the construction-time build and G-buffer are done: no build in flight)
+        self.ctx.set_build_mode(mode)
 
     def _set_gbuffer(self, gb):
         """Adopt a G-buffer dict (optixutils.render_gbuffer / render.gbuffer) as the iteration's inputs."""

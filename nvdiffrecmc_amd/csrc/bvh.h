@@ -50,7 +50,9 @@
 // keys give delta = 32 + clz(i ^ j) with i, j < n (at most ceil(log2 n) values): a root-to-leaf path holds at most
 // h_max = 30 + ceil(log2 n) <= 60 internal nodes whatever the mesh (100 k triangles on one centroid: a balanced tree over
 // the index bits).  The binary walk holds <= h_max entries.  Every level of the oct tree descends at least one binary level, and
-// the oct walk pushes at most one entry per level of its path, so it holds <= h_max entries too.  nvdr_bvh_build sizes the spill
+// the oct walk pushes at most one entry per level of its path, so it holds <= h_max entries too.  (Round 5: the bottom subtrees of up to
+// 64 leaves are rebuilt by agglomerative clustering, bvh.hip TREELETS; a rebuilt treelet is committed only if it has at most
+// NVDR_TREELET_CAP levels, so a path holds <= h_max + NVDR_TREELET_CAP internal nodes.)  nvdr_bvh_build sizes the spill
 // columns from this bound (nvdr_stack_bound); a push beyond it -- unreachable unless the bound is wrong -- raises the context's
 // overflow flag (host-mapped memory), which every later call on the context and nvdr_ctx_check() turn into an error instead
 // of a silently wrong visibility (tests/test_gpu_bvh.py feeds degenerate meshes).
@@ -58,6 +60,7 @@
 #define NVDR_STACK_LDS 12
 #endif
 #define NVDR_STACK_MAX 104
+#define NVDR_TREELET_CAP 16                  // levels of a rebuilt treelet (bvh.hip); deeper ones keep their Karras subtree
 #define NVDR_QUERY_BLOCK 256                 // threads per workgroup of every traversal kernel
 #ifndef NVDR_QUERY_MAX_BLOCKS
 #define NVDR_QUERY_MAX_BLOCKS 2048           // persistent / grid-stride launches never exceed this
@@ -85,7 +88,7 @@ static inline int nvdr_stack_bound(int64_t n_tris)
 {
     int lg = 0;
     while ((1ll << lg) < n_tris) ++lg;
-    const int h_max = 30 + lg;
+    const int h_max = 30 + lg + NVDR_TREELET_CAP;      // (+ the levels a rebuilt treelet may add below a Karras node, bvh.hip)
     return h_max < NVDR_STACK_MAX ? h_max : NVDR_STACK_MAX;
 }
 

@@ -173,17 +173,18 @@ __device__ __forceinline__ int lbvh_delta(const uint32_t *__restrict__ keys, int
 #define OCT_CTL_ALLOC 32        // oct nodes (written by the emit step: 1 + sum of the internal slots)
 #define OCT_CTL_DONE 64         // oct nodes written
 #define OCT_CTL_TRIS 96         // triangles placed
-#define OCT_CTL_WORDS 128
+#define OCT_CTL_TREELETS 128    // treelet roots listed (bvh_treelet_mark_kernel)
+#define OCT_CTL_WORDS 160
 // (Also clears what the two stages behind it start from -- the arrival counters of the fit, the control words of the eight-wide collapse:
 // two 5-us launches less per rebuild; a refit, which does not come through here, keeps them.)
 __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, uint4 *__restrict__ nodes, uint2 *__restrict__ up, int *__restrict__ flags,
-                                     unsigned *__restrict__ oct_ctl)
+                                     unsigned *__restrict__ oct_ctl, uint2 *__restrict__ range)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     flags[i] = 0;
     if (i == n - 2) flags[n - 1] = 0;
-    if (i == 0) { oct_ctl[OCT_CTL_ROOTS] = 0u; oct_ctl[OCT_CTL_ALLOC] = 1u; oct_ctl[OCT_CTL_DONE] = 0u; oct_ctl[OCT_CTL_TRIS] = 0u; }
+    if (i == 0) { oct_ctl[OCT_CTL_ROOTS] = 0u; oct_ctl[OCT_CTL_ALLOC] = 1u; oct_ctl[OCT_CTL_DONE] = 0u; oct_ctl[OCT_CTL_TRIS] = 0u; oct_ctl[OCT_CTL_TREELETS] = 0u; }
     const int d = (lbvh_delta(keys, n, i, i + 1) - lbvh_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
     const int dmin = lbvh_delta(keys, n, i, i - d);
     int lmax = 2;
@@ -201,6 +202,7 @@ __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, u
     } while (t > 1);
     const int gamma = i + s * d + min(d, 0);
     const int lo = min(i, j), hi = max(i, j);
+    range[i] = make_uint2((unsigned)lo, (unsigned)hi);      // the node's leaves: positions lo .. hi of the Morton order (bvh_treelet_*_kernel)
     const int left = (lo == gamma) ? ~gamma : gamma;
     const int right = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
     unsigned *rec = (unsigned *)(nodes + 2 * i);
@@ -210,6 +212,133 @@ __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, u
     up[left < 0 ? n + gamma : left].x = w;          // (.y of an internal node: its collapse-DP record, written by bvh_fit_kernel --
     up[right < 0 ? n + gamma + 1 : right].x = w | 2u;   //  one 8-byte load per level serves the budget walk of the eight-wide builder)
     if (i == 0) up[0].x = 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TREELETS: the bottom of the Morton tree rebuilt by agglomerative clustering (round 5).
+//
+// A Karras tree splits a key range at its highest differing bit: fine at the top, poor at the bottom, where a handful of triangles
+// that share a Morton cell are paired by the accidents of the Z curve.  On the CPU model (tools/treelet_model.py) rebuilding every
+// maximal subtree of <= 64 leaves by greedy agglomerative clustering -- merge the two clusters whose union has the smallest surface
+// area -- takes 6.0 % of the node steps of a shadow ray off the eight-wide walk on bob (a full binned-SAH build: 8.5 %, a SAH tree
+// over the TOP of the Morton tree: 1-2 %: the loss is at the bottom).  It is local work: ONE WAVEFRONT per treelet, a lane per cluster,
+//   * every round each live cluster looks for the partner with the smallest union (the candidates' boxes come as scalars out of
+//     v_readlane: 6 reads + ~16 VALU per candidate), MUTUAL nearest neighbours merge (Walter et al. 2008 / PLOC, Meister & Bittner 2018:
+//     the closest pair is always mutual, so every round merges at least one pair; ~8 rounds for 64 leaves); ties go to the lower lane,
+//     so the tree is a function of the input alone;
+//   * the new internal nodes take the ids the Karras subtree had -- a Karras subtree over the leaves lo .. hi owns the ids lo + 1 .. hi - 1
+//     and its root id (lo or hi) -- so nothing outside the treelet changes, and "a node lies inside its own leaf range", which the
+//     LDS hand-off of bvh_fit_kernel indexes by, still holds;
+//   * treelets never straddle a block of NVDR_FIT_BLOCK leaves (a straddling subtree is split further), so every node in them is "local";
+//   * a rebuilt treelet deeper than NVDR_TREELET_CAP levels is not committed (never seen: the deepest of bob's 380 has 8 levels), which
+//     keeps the proven stack bound: h_max + NVDR_TREELET_CAP (bvh.h).
+// Refits (rebuild = 0) keep whatever topology the last build left.
+#ifndef NVDR_TREELET_W
+#define NVDR_TREELET_W 64           // leaves per treelet, <= 64 (0: plain Karras tree, A/B)
+#endif
+
+__device__ __forceinline__ bool treelet_ok(uint2 r) { return r.y - r.x < (unsigned)NVDR_TREELET_W && (r.x / NVDR_FIT_BLOCK) == (r.y / NVDR_FIT_BLOCK); }
+
+// list the maximal subtrees that fit a treelet (>= 3 leaves: two leaves have one tree)
+__global__ void __launch_bounds__(1024) bvh_treelet_mark_kernel(const uint2 *__restrict__ range, const uint2 *__restrict__ up, int n_int, int *__restrict__ list,
+                                                                unsigned *__restrict__ ctl)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_root = false;
+    if (v < n_int) {
+        const uint2 r = range[v];
+        is_root = treelet_ok(r) && r.y - r.x >= 2u && (v == 0 || !treelet_ok(range[up[v].x >> 2]));
+    }
+    __shared__ unsigned wave_cnt[16], wave_base[16];
+    const unsigned long long m = __ballot(is_root);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) { wave_base[w2] = tot; tot += wave_cnt[w2]; }
+        const unsigned base = tot ? atomicAdd(&ctl[OCT_CTL_TREELETS], tot) : 0u;
+        for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) wave_base[w2] += base;
+    }
+    __syncthreads();
+    if (is_root) list[wave_base[wave] + __popcll(m & ((1ull << lane) - 1ull))] = v;
+}
+
+__global__ void __launch_bounds__(256) bvh_treelet_kernel(const float *__restrict__ verts, const int32_t *__restrict__ tris, const uint32_t *__restrict__ order, int n,
+                                                          const uint2 *__restrict__ range, uint4 *__restrict__ nodes, uint2 *__restrict__ up,
+                                                          const int *__restrict__ list, const unsigned *__restrict__ ctl)
+{
+    __shared__ int m_id[4][64], m_l[4][64], m_r[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned count = ctl[OCT_CTL_TREELETS];
+    const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
+    for (unsigned e = blockIdx.x * (blockDim.x >> 6) + wave; e < count; e += waves_total) {
+        const int root = list[e];
+        const uint2 rg = range[root];
+        const int lo = (int)rg.x, k = (int)(rg.y - rg.x) + 1;
+        bool active = lane < k;
+        int ref = ~(lo + lane), depth = 0;
+        float bx0 = 0.0f, by0 = 0.0f, bz0 = 0.0f, bx1 = 0.0f, by1 = 0.0f, bz1 = 0.0f;
+        if (active) {
+            const uint32_t t = order[lo + lane];
+            const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
+            const float ax = verts[3 * i0], ay = verts[3 * i0 + 1], az = verts[3 * i0 + 2];
+            const float bx = verts[3 * i1], by = verts[3 * i1 + 1], bz = verts[3 * i1 + 2];
+            const float cx = verts[3 * i2], cy = verts[3 * i2 + 1], cz = verts[3 * i2 + 2];
+            bx0 = fminf(ax, fminf(bx, cx)); by0 = fminf(ay, fminf(by, cy)); bz0 = fminf(az, fminf(bz, cz));
+            bx1 = fmaxf(ax, fmaxf(bx, cx)); by1 = fmaxf(ay, fmaxf(by, cy)); bz1 = fmaxf(az, fmaxf(bz, cz));
+        }
+        int created = 0, n_act = k;
+        while (n_act > 1) {
+            // nearest neighbour by the surface area of the union; candidates in rising lane order, strict <: ties go to the lower lane
+            float best = 3.0e38f;
+            int best_j = lane;
+            for (unsigned long long mm = __ballot(active); mm; mm &= mm - 1ull) {
+                const int j = __builtin_ctzll(mm);
+                const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx0), j)), y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by0), j));
+                const float z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz0), j)), x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx1), j));
+                const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by1), j)), z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz1), j));
+                const float ex = fmaxf(bx1, x1) - fminf(bx0, x0), ey = fmaxf(by1, y1) - fminf(by0, y0), ez = fmaxf(bz1, z1) - fminf(bz0, z0);
+                const float a = (ex * ey + ey * ez) + ez * ex;
+                if (j != lane && a < best) { best = a; best_j = j; }
+            }
+            // the partner's choice and state (every lane takes part in the permutes; an inactive lane reads itself)
+            const int src = active ? best_j : lane;
+            const int their = __shfl(best_j, src);
+            const bool mutual = active && best_j != lane && their == lane && __shfl((int)active, src) != 0;
+            const bool merger = mutual && lane < best_j;
+            const int p_ref = __shfl(ref, src), p_depth = __shfl(depth, src);
+            const float px0 = __shfl(bx0, src), py0 = __shfl(by0, src), pz0 = __shfl(bz0, src);
+            const float px1 = __shfl(bx1, src), py1 = __shfl(by1, src), pz1 = __shfl(bz1, src);
+            const unsigned long long mg = __ballot(merger);
+            const int merges = __popcll(mg);
+            if (merger) {
+                const int idx = created + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, 0u));
+                const int nid = n_act == 2 ? root : lo + 1 + idx;       // the last merge is the treelet's root; the others take the ids lo + 1 .. hi - 1
+                m_id[wave][idx] = nid; m_l[wave][idx] = ref; m_r[wave][idx] = p_ref;
+                ref = nid;
+                depth = 1 + max(depth, p_depth);
+                bx0 = fminf(bx0, px0); by0 = fminf(by0, py0); bz0 = fminf(bz0, pz0);
+                bx1 = fmaxf(bx1, px1); by1 = fmaxf(by1, py1); bz1 = fmaxf(bz1, pz1);
+            }
+            if (mutual && lane > best_j) active = false;
+            created += merges;
+            n_act -= merges;
+            if (merges == 0) break;             // (cannot happen: the closest pair is mutual; a NaN box would land here and keep the Karras subtree)
+        }
+        const unsigned long long last = __ballot(active);
+        const int top_depth = __builtin_amdgcn_readlane(depth, __builtin_ctzll(last | (1ull << 63)));
+        __builtin_amdgcn_wave_barrier();
+        if (n_act == 1 && top_depth <= NVDR_TREELET_CAP && lane < k - 1) {
+            const int nid = m_id[wave][lane], l = m_l[wave][lane], r = m_r[wave][lane];
+            unsigned *rec = (unsigned *)(nodes + 2 * (int64_t)nid);
+            rec[6] = (unsigned)l;
+            rec[7] = (unsigned)r;
+            up[l < 0 ? n + ~l : l].x = ((unsigned)nid << 2) | 1u;                // (every node of a treelet is local: treelet_ok)
+            up[r < 0 ? n + ~r : r].x = ((unsigned)nid << 2) | 3u;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // Write-through (sc1) accesses of the hand-off below: they reach / come from the level all XCDs agree on, so no cache has to be
@@ -476,7 +605,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) trace_closest_kernel(BvhView
 
 
 #ifndef NVDR_OCT_ORDER
-#define NVDR_OCT_ORDER 1        // internal children of a wide node: smaller surface area first (0: slot order; A/B)
+#define NVDR_OCT_ORDER 1        // internal children of a wide node: smaller surface area first (0: slot order, 2: larger first; A/B)
 #endif
 struct OctBuildArgs {
     const uint4 *nodes;     // fitted binary nodes
@@ -632,7 +761,11 @@ __device__ __forceinline__ void oct_expand(const OctBuildArgs &a, int b, int *sl
         for (int i = 1; i < n_int; ++i)
             for (int j = i; j > 0; --j) {
                 const unsigned a = (perm >> (4 * j)) & 15u, b = (perm >> (4 * (j - 1))) & 15u;
+#if NVDR_OCT_ORDER == 2
+                if (!(area_of(a) > area_of(b))) break;       // larger first (A/B)
+#else
                 if (!(area_of(a) < area_of(b))) break;
+#endif
                 perm = (perm & ~(0xffu << (4 * (j - 1)))) | (a << (4 * (j - 1))) | (b << (4 * j));
             }
     }
@@ -1147,7 +1280,16 @@ int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
         NVDR_HIP_TRY(rocprim::radix_sort_pairs<nvdr_sort_config>(c->sort_tmp, bytes, c->keys[0], c->keys[1], c->vals[0], c->vals[1],
                                                                  (size_t)n, 0, 30, stream));
         if (n > 1)
-            bvh_hierarchy_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->keys[1], n, c->nodes, c->up, c->flags, c->oct_ctl);
+        {
+            bvh_hierarchy_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->keys[1], n, c->nodes, c->up, c->flags, c->oct_ctl, (uint2 *)c->oct_scan);
+#if NVDR_TREELET_W >= 3
+            if (n >= 4) {       // (the ranges live in oct_scan and the list in oct_task until the collapse, which runs behind the fit, takes them over)
+                bvh_treelet_mark_kernel<<<div_up(n - 1, 1024), 1024, 0, stream>>>((const uint2 *)c->oct_scan, c->up, n - 1, c->oct_task, c->oct_ctl);
+                const unsigned tb = min(div_up(n, 4 * 24), (unsigned)c->n_cus * 8u);
+                bvh_treelet_kernel<<<tb < 1u ? 1u : tb, 256, 0, stream>>>(verts, tris, c->vals[1], n, (const uint2 *)c->oct_scan, c->nodes, c->up, c->oct_task, c->oct_ctl);
+            }
+#endif
+        }
     }
     const bool cleared = rebuild != 0 && n > 1;        // (the hierarchy kernel has cleared the counters and the control words)
     if (!cleared) NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));

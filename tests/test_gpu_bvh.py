@@ -212,8 +212,8 @@ def test_degenerate_meshes_match_bruteforce(kind, dev):
     ctx = ou.OptiXContext()
     ou.optix_build_bvh(ctx, v.to(dev), t.to(dev), rebuild=1)
     info = ctx.bvh_info()
-    assert info['height'] <= 30 + 17 and info['stack_max'] >= info['height']     # h <= 30 + ceil(log2 n)
-    assert info['stack_max'] >= 3 * ((info['height'] + 1) // 2 + 1) or info['stack_max'] == 104
+    # h <= 30 + ceil(log2 n) for the Karras tree (+ the 16 levels a rebuilt treelet may add, csrc/bvh.h); the stacks hold the bound
+    assert info['height'] <= 30 + 17 + 16 and info['stack_max'] >= info['height'] and info['stack_max'] == 30 + 17 + 16
     # half random rays (near and far origins), half aimed at interior points of random triangles (certain hits, deep descents)
     ro, rd = _rays(3000, 21, 0.3)
     ro2, rd2 = _rays(3000, 22, 1.5)

@@ -242,11 +242,30 @@ def test_cpu_walk_of_a_bvh2_equals_bruteforce():
 
 
 def test_stack_bound_formula():
-    """nvdr_stack_bound (csrc/bvh.h) restated: h_max = 30 + ceil(log2 n); wide walk <= 3 * (ceil(h_max / 2) + 1) <= 104."""
+    """nvdr_stack_bound (csrc/bvh.h) restated and compiled: h_max = 30 + ceil(log2 n) levels of the Karras tree + the NVDR_TREELET_CAP = 16
+    a rebuilt treelet may add, capped at NVDR_STACK_MAX = 104 (one stack entry per level for the binary and the eight-wide walk alike)."""
     import math
-    for n, expect in ((1, 48), (2, 51), (10688, 69), (171008, 75), (1 << 24, 84), ((1 << 30) - 1, 93)):
-        h = 30 + (0 if n <= 1 else math.ceil(math.log2(n)))
-        assert min(max(3 * ((h + 1) // 2 + 1), h), 104) == expect
+    import subprocess
+    import tempfile
+    cases = ((1, 46), (2, 47), (10688, 60), (171008, 64), (684032, 66), (1 << 24, 70), ((1 << 28) - 1, 74))
+    for n, expect in cases:
+        h = 30 + (0 if n <= 1 else math.ceil(math.log2(n))) + 16
+        assert min(h, 104) == expect
+    # ... and what the header itself computes (host-side inline function, no GPU needed)
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, 'b.cpp')
+        open(src, 'w').write('#include <stdio.h>\n#include <stdint.h>\n#define NVDR_STACK_MAX 104\n#define NVDR_TREELET_CAP 16\n'
+                             + _between(open(os.path.join(ROOT, 'nvdiffrecmc_amd', 'csrc', 'bvh.h')).read(), 'static inline int nvdr_stack_bound', '\n}\n') + '\n}\n'
+                             + 'int main(){long long v[] = {%s}; for (auto x : v) printf("%%d ", nvdr_stack_bound(x)); return 0;}\n' % ', '.join('%dll' % n for n, _ in cases))
+        exe = os.path.join(d, 'b')
+        subprocess.run(['g++', '-std=c++17', src, '-o', exe], check=True)
+        got = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    assert got == [e for _, e in cases]
+
+
+def _between(text, start, end):
+    i = text.index(start)
+    return text[i:text.index(end, i)]
 
 
 def test_render_layer_restatement_interpolates_like_nvdiffrast():

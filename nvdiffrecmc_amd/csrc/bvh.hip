@@ -690,21 +690,29 @@ __global__ void __launch_bounds__(1024) bvh_oct_budget_kernel(OctBuildArgs a)
     if (is_root) a.roots[wave_base[wave] + __popcll(m & ((1ull << lane) - 1ull))] = v;
 }
 
-// A thread's eight slots live in LDS, field-major (field f of slot k of thread t at ((k * 7 + f) * 256 + t): consecutive threads hit
-// consecutive banks).  Private arrays with run-time indices would live in scratch memory: the first version did, and spent
-// 0.3 ms on bob's 3 300 nodes (~30 us per node, ten levels deep).
-#define OCT_SLOT_FIELDS 7       // ref, lo.xyz, hi.xyz
-#define OCT_SL(k, f) sl[((k) * OCT_SLOT_FIELDS + (f)) * 256]
+// A thread's eight slots live in LDS, word-major (word w of slot k of thread t at ((k * 4 + w) * OCT_THREADS + t): consecutive threads
+// hit consecutive banks).  Private arrays with run-time indices would live in scratch memory: the first version did, and spent
+// 0.3 ms on bob's 3 300 nodes (~30 us per node, ten levels deep).  A slot is the four words of a child in the binary node record --
+// reference + the 16-bit box packed in three -- and a workgroup has 128 threads: 16 KB of LDS (rounds 2-4: seven unpacked words x
+// 256 threads = 57 KB, which did not fit beside the sample-generation kernel's workgroups: at one view per GPU, where the build is what
+// the traversal waits for, bvh_oct_count_kernel took 148 us against 27 us alone).
+#define OCT_THREADS 128
+#define OCT_SLOT_WORDS 4        // ref, lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16
+#define OCT_W(k, w) sl[((k) * OCT_SLOT_WORDS + (w)) * OCT_THREADS]
+// field f of slot k: 0 = the reference, 1..3 = lo.xyz, 4..6 = hi.xyz
+#define OCT_SL(k, f) oct_field(sl, (k), (f))
+__device__ __forceinline__ int oct_field(const int *sl, int k, int f)
+{
+    if (f == 0) return OCT_W(k, 0);
+    const unsigned w = (unsigned)OCT_W(k, 1 + ((f - 1) >> 1));
+    return (int)(((f - 1) & 1) ? (w >> 16) : (w & 0xffffu));
+}
 
 __device__ __forceinline__ void oct_load_children(const uint4 *__restrict__ nodes, int b, int *sl, int kl, int kr)
 {
     const uint4 p = nodes[2 * (int64_t)b], q = nodes[2 * (int64_t)b + 1];
-    OCT_SL(kl, 0) = (int)q.z;
-    OCT_SL(kl, 1) = p.x & 0xffff; OCT_SL(kl, 2) = p.x >> 16; OCT_SL(kl, 3) = p.y & 0xffff;
-    OCT_SL(kl, 4) = p.y >> 16; OCT_SL(kl, 5) = p.z & 0xffff; OCT_SL(kl, 6) = p.z >> 16;
-    OCT_SL(kr, 0) = (int)q.w;
-    OCT_SL(kr, 1) = p.w & 0xffff; OCT_SL(kr, 2) = p.w >> 16; OCT_SL(kr, 3) = q.x & 0xffff;
-    OCT_SL(kr, 4) = q.x >> 16; OCT_SL(kr, 5) = q.y & 0xffff; OCT_SL(kr, 6) = q.y >> 16;
+    OCT_W(kl, 0) = (int)q.z; OCT_W(kl, 1) = (int)p.x; OCT_W(kl, 2) = (int)p.y; OCT_W(kl, 3) = (int)p.z;
+    OCT_W(kr, 0) = (int)q.w; OCT_W(kr, 1) = (int)p.w; OCT_W(kr, 2) = (int)q.x; OCT_W(kr, 3) = (int)q.y;
 }
 
 // the slots of the wide node rooted at binary node b: n of them in LDS, `perm` = their order (4 bits per position: internal slots
@@ -775,9 +783,9 @@ __device__ __forceinline__ void oct_expand(const OctBuildArgs &a, int b, int *sl
         if (k < n && OCT_SL(k, 0) < 0) perm |= (unsigned)k << (4 * (n_int + n_leaf++));
 }
 
-__global__ void __launch_bounds__(256) bvh_oct_count_kernel(OctBuildArgs a)
+__global__ void __launch_bounds__(OCT_THREADS) bvh_oct_count_kernel(OctBuildArgs a)
 {
-    __shared__ int slots[8 * OCT_SLOT_FIELDS * 256];
+    __shared__ int slots[8 * OCT_SLOT_WORDS * OCT_THREADS];
     int *sl = slots + threadIdx.x;
     const unsigned n_roots = a.ctl[OCT_CTL_ROOTS];
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_roots; i += gridDim.x * blockDim.x) {
@@ -901,9 +909,9 @@ __global__ void __launch_bounds__(1024) bvh_oct_scan_small_kernel(const unsigned
     if (threadIdx.x == 1023) { ctl[OCT_CTL_ALLOC] = 1u + (unsigned)(run >> 32); ctl[OCT_CTL_TRIS] = (unsigned)(run & 0xffffffffull); }
 }
 
-__global__ void __launch_bounds__(256) bvh_oct_emit_kernel(OctBuildArgs a)
+__global__ void __launch_bounds__(OCT_THREADS) bvh_oct_emit_kernel(OctBuildArgs a)
 {
-    __shared__ int slots[8 * OCT_SLOT_FIELDS * 256];
+    __shared__ int slots[8 * OCT_SLOT_WORDS * OCT_THREADS];
     int *sl = slots + threadIdx.x;
     const unsigned n_roots = a.ctl[OCT_CTL_ROOTS];
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n_roots; i += gridDim.x * blockDim.x) {
@@ -1305,8 +1313,8 @@ int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
         if (n > 1) {
             bvh_oct_budget_kernel<<<div_up(n - 1, 1024), 1024, 0, stream>>>(oa);
             // wide roots are ~n / 4.9; the grid-stride loops of the two expansion kernels cover whatever the device-side count says
-            const unsigned blocks = min(div_up((n + 3) / 4, 256), (unsigned)c->n_cus * 8u);
-            bvh_oct_count_kernel<<<blocks < 1u ? 1u : blocks, 256, 0, stream>>>(oa);
+            const unsigned blocks = min(div_up((n + 3) / 4, OCT_THREADS), (unsigned)c->n_cus * 16u);
+            bvh_oct_count_kernel<<<blocks < 1u ? 1u : blocks, OCT_THREADS, 0, stream>>>(oa);
             const unsigned tiles = div_up(n - 1, OCT_SCAN_TILE);
             unsigned long long *part = (unsigned long long *)c->sort_tmp;      // the sort is done with its scratch by now
             if (n - 1 <= OCT_SCAN_SMALL) {
@@ -1316,7 +1324,7 @@ int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
                 bvh_oct_scan_partials_kernel<<<1, 1024, 0, stream>>>(part, (int)tiles, c->oct_ctl);
                 bvh_oct_scan_apply_kernel<<<tiles, 256, 0, stream>>>(c->oct_cnt, n - 1, part, c->oct_scan);
             }
-            bvh_oct_emit_kernel<<<blocks < 1u ? 1u : blocks, 256, 0, stream>>>(oa);
+            bvh_oct_emit_kernel<<<blocks < 1u ? 1u : blocks, OCT_THREADS, 0, stream>>>(oa);
         }
     }
     NVDR_LAUNCH_CHECK();

@@ -122,10 +122,16 @@ class GradientExchange:
                           (the next iteration's geometry stage) is not waited for
         wait(k)           scatter the sums back into the dense bucket; .grad views as for a dense chunk
     When the union exceeds `sparse_max_fraction` of the tiles the dense bucket is all-reduced instead (every rank sees the same count,
-    so every rank takes the same branch).  Uneven shards and chunks whose parameters are not whole tiles fall back to dense."""
+    so every rank takes the same branch).  Uneven shards and chunks whose parameters are not whole tiles fall back to dense.
+    An entry of `sparse` may also be the string 'auto': the tile machinery costs ~0.1 ms per iteration of its own (flags, union list, host
+    read, gather, scatter), so it only pays when few tiles are touched -- 'auto' PROBES the union every `probe_every` rounds (the first
+    included) and runs the rounds in between sparse if the probe found at most `auto_fraction` of the tiles touched, plainly dense otherwise
+    (no flags, no extra collective).  Measured on the benchmark views: one 512^2 view touches 24 % of the 64-texel tiles of a 1024^2 texture,
+    the union of the batch's eight views 49 % (18 % of the TEXELS; tools/tile_fraction_probe.py) -- and with the reference's mip-mapped
+    lookups every tile would be touched -- so 'auto' settles on dense there."""
 
     def __init__(self, groups, world_size=None, group=None, local_weight=1, equal_shards=True, sparse=None, tile_floats=TILE_FLOATS,
-                 sparse_max_fraction=0.5):
+                 sparse_max_fraction=0.5, auto_fraction=0.25, probe_every=64):
         self.groups = [list(g) for g in groups]
         self.group = group
         self.active = dist.is_available() and dist.is_initialized()
@@ -139,6 +145,9 @@ class GradientExchange:
         self.tile_floats = int(tile_floats)
         self.sparse_max_fraction = float(sparse_max_fraction)
         sparse = list(sparse) if sparse is not None else [False] * len(self.groups)
+        sparse = [False if s in (False, None, 'dense') else s for s in sparse]
+        self.auto = [s == 'auto' for s in sparse]
+        self.auto_fraction, self.probe_every, self._round = float(auto_fraction), int(probe_every), 0
         self.sparse = [bool(s) and self.equal_shards and all(p.numel() % self.tile_floats == 0 for p in g) for s, g in zip(sparse, self.groups)]
         self._sp = {}
         for k, (s, b) in enumerate(zip(self.sparse, self.buckets)):
@@ -151,7 +160,8 @@ class GradientExchange:
                                'count': torch.zeros(1, dtype=torch.int32, device=dev),
                                'count_host': (torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == 'cuda' else torch.zeros(1, dtype=torch.int32)),
                                'compact': torch.zeros_like(b),          # worst case: every tile (288 GB of HBM: 38 MB is nothing)
-                               'flags_handle': None, 'state': 'idle', 'mode': 'dense', 'tiles': 0}
+                               'flags_handle': None, 'state': 'idle', 'mode': 'dense', 'tiles': 0,
+                               'use': True, 'auto_sparse': False}       # this round goes through the tiles / what the last probe of 'auto' decided
         self.extra_flags = {}               # chunk -> uint8 flags OR-ed into this rank's (trainer union_views: a one-rank run that moves the bytes of a several-rank one)
         self._side, self._ev_start = None, None      # the side stream of send() and the point of the main stream it is ordered behind (GPU tensors)
         self._sends = self.active and self.world > 1
@@ -198,6 +208,9 @@ class GradientExchange:
     def compute_flags(self):
         """Sparse chunks: flag the non-zero tiles of this rank's bucket (after pack(); one launch per sparse chunk, capturable)."""
         for k, sp in self._sp.items():
+            sp['use'] = (not self.auto[k]) or sp['auto_sparse'] or self._round % self.probe_every == 0
+            if not sp['use']:
+                continue
             _TileOps.flags(self.buckets[k], sp['n_tiles'], self.tile_floats, sp['flags'])
             if self.extra_flags.get(k) is not None:         # (one-rank dry runs: the tiles the other ranks would have touched)
                 torch.maximum(sp['flags'], self.extra_flags[k], out=sp['flags'])
@@ -212,24 +225,27 @@ class GradientExchange:
         self.handles = [None] * len(self.buckets)
         self._bytes_round = 0
         live = self.active and not (self.world == 1 and skip_single)
+        self._round += 1
         for k, b in enumerate(self.buckets):
-            if k in self._sp:
+            if k in self._sp and self._sp[k]['use']:
                 sp = self._sp[k]
                 sp['state'], sp['flags_handle'] = 'flagged', None
                 if live:
                     sp['flags_handle'] = self._all_reduce(sp['flags'], dist.ReduceOp.MAX)
                     self._bytes_round += sp['flags'].numel()
-            elif live:
-                self.handles[k] = self._all_reduce(b, dist.ReduceOp.SUM)
-                self._bytes_round += b.numel() * 4
+            else:
+                if k in self._sp:
+                    self._sp[k]['state'], self._sp[k]['mode'] = 'idle', 'dense'
+                if live:
+                    self.handles[k] = self._all_reduce(b, dist.ReduceOp.SUM)
+                    self._bytes_round += b.numel() * 4
         self._live = live
         if self._sp and self.buckets[0].is_cuda:
             # send() runs on a side stream ordered behind THIS point of the main stream (the buckets and flags are complete here), not
             # behind whatever the caller enqueues between start() and send()
             self._ev_start = torch.cuda.Event()
             self._ev_start.record()
-        if not self._sp:
-            self.bytes_per_step = self._bytes_round
+        self.bytes_per_step = self._bytes_round        # (send() adds what a sparse chunk's second stage puts on the wire)
 
     def send(self, k):
         """Second stage of a sparse chunk (a no-op for a dense one): the union's tile list, its size to the host, the gather and the
@@ -258,7 +274,9 @@ class GradientExchange:
             else:
                 n = int(sp['count'].item())
             sp['tiles'] = n
-            if n > self.sparse_max_fraction * sp['n_tiles']:
+            limit = self.auto_fraction if self.auto[k] else self.sparse_max_fraction
+            sp['auto_sparse'] = n <= limit * sp['n_tiles']
+            if n > limit * sp['n_tiles']:
                 sp['mode'] = 'dense'
                 if self._live:
                     self.handles[k] = self._all_reduce(b, dist.ReduceOp.SUM)
@@ -306,7 +324,8 @@ class GradientExchange:
     def report(self):
         """What the last round sent: {mode, bytes_dense, bytes_sent, tiles_touched, tiles_total} (bench.py config.exchange)."""
         modes = [self._sp[k]['mode'] if k in self._sp else 'dense' for k in self.chunks()]
-        return {'mode': 'sparse' if 'sparse' in modes else 'dense', 'chunk_modes': modes, 'chunk_bytes_dense': [b.numel() * 4 for b in self.buckets],
+        return {'mode': 'sparse' if 'sparse' in modes else 'dense', 'chunk_modes': modes,
+                'policy': ['auto' if a else ('sparse' if s else 'dense') for a, s in zip(self.auto, self.sparse)], 'chunk_bytes_dense': [b.numel() * 4 for b in self.buckets],
                 'bytes_dense': self.bytes_dense, 'bytes_sent': int(self.bytes_per_step),
                 'tiles_touched': int(sum(sp['tiles'] for sp in self._sp.values())), 'tiles_total': int(sum(sp['n_tiles'] for sp in self._sp.values())),
                 'tile_bytes': self.tile_floats * 4}

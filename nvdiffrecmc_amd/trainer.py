@@ -121,8 +121,9 @@ class DirectLightingStep:
         # perturbed_nrm=False: FLAGS.no_perturbed_nrm (configs/spot_metal.json:20, render.py:92-93): no normal-map lookup; the normal texture
         # stays in the optimizer's list (train.py:185-197) but never receives a gradient, i.e. is never updated -- it is left out of the set here
         self.perturbed_nrm = bool(perturbed_nrm)
-        # Several ranks (parallel.GradientExchange).  exchange_mode: 'dense' = the whole texture bucket is all-reduced; 'sparse' / 'auto' =
-        # only the 768-byte tiles some rank's pixels touched (falls back to dense by itself when most tiles are touched).  pipeline: the
+        # Several ranks (parallel.GradientExchange).  exchange_mode: 'dense' = the whole texture bucket is all-reduced; 'sparse' = only the
+        # 768-byte tiles some rank's pixels touched (the dense bucket when more than half are); 'auto' = sparse when a periodic probe finds at
+        # most a quarter of the tiles touched, plainly dense otherwise (the benchmark views touch half of them: auto runs dense there).  pipeline: the
         # texture chunk's reduce runs under the NEXT iteration's geometry stage and is waited for in front of the texture lookup.
         # force_exchange: run the several-rank schedule with ONE rank (the fixed cost of the path; a one-rank RCCL pass when a process group exists).
         if exchange_mode not in ('auto', 'dense', 'sparse'):
@@ -531,7 +532,8 @@ class DirectLightingStep:
             groups = [[self.params[i] for i in idx] for idx in chunks]
             # tile-sparse: the texture chunk only ('dense' sends the whole bucket; 'sparse' / 'auto' send the touched tiles and fall back to
             # the dense bucket when more than half of the tiles are touched -- with the reference's mip-mapped textures they all would be)
-            sparse = [self.exchange_mode != 'dense' and len(chunks) == 2 and k == 1 for k in range(len(chunks))]
+            pol = {'dense': False, 'sparse': True, 'auto': 'auto'}[self.exchange_mode]
+            sparse = [pol if (len(chunks) == 2 and k == 1) else False for k in range(len(chunks))]
             self._ex = GradientExchange(groups, world_size, local_weight=self.nv, equal_shards=even, sparse=sparse)
             self._ex_chunks = chunks if self._fused_update else [None]
             # Several ranks: the texture lookup's adjoint scatter-adds straight into the exchange buckets (they are what the persistent
@@ -630,6 +632,7 @@ class DirectLightingStep:
             g2.replay()
             self._stage1_ready = False
             loss = self._loss_static
+            ex.compute_flags()          # (not captured: whether this round goes through the tiles is the exchange's decision, round by round)
         else:
             self._eager_steps += 1
             if not self._stage1_ready:
@@ -715,7 +718,6 @@ class DirectLightingStep:
             self._loss_static = self._stage2()
             ex.pack()
             self._packed_tex_grad()
-            ex.compute_flags()
         gbs = []
         n = len(self._ex_chunks)
         for k in range(n):

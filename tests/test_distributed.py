@@ -254,3 +254,61 @@ def test_tile_sparse_exchange_equals_the_dense_one(density):
             assert rep['bytes_sent'] == rep['bytes_dense'] + rep['tiles_total']
     assert got[0][3] == got[1][3]                           # both ranks hold the same sums
     assert got[0][2]['tiles_touched'] == got[1][2]['tiles_touched']
+
+
+def _worker_auto(rank, world, port, q, density):
+    """exchange policy 'auto': the first round probes the union of the touched tiles; the rounds behind it run sparse (few tiles) or plainly dense."""
+    from nvdiffrecmc_amd.parallel import GradientExchange
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    R = 128
+    gen = torch.Generator().manual_seed(7 + rank)
+    g = torch.zeros(R, R, 3)
+    n = int(density * R * R)
+    first = int(torch.randint(0, R * R - n, (1,), generator=gen))
+    g.view(-1, 3)[first:first + n] = torch.randn(n, 3, generator=gen)
+    tex, probe = torch.nn.Parameter(torch.zeros(R, R, 3)), torch.nn.Parameter(torch.zeros(8, 8, 3))
+    ex = GradientExchange([[probe], [tex]], world, sparse=[False, 'auto'], probe_every=4)
+    out = []
+    for rnd in range(6):
+        tex.grad = ex.slot(tex)
+        tex.grad.copy_(g * (rnd + 1))
+        probe.grad = torch.full((8, 8, 3), float(rank + 1))
+        ex.pack(); ex.compute_flags(); ex.start()
+        f0 = ex.wait(0)
+        ex.send(1)
+        f = ex.wait(1)
+        rep = ex.report()
+        out.append((rep['mode'], rep['bytes_sent'], float((tex.grad * f).double().sum()), float((probe.grad * f0).double().mean())))
+        tex.grad.zero_()
+    q.put((rank, out, ex.bytes_dense, float(g.double().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('density', [0.03, 0.6], ids=['few_tiles_sparse', 'many_tiles_dense'])
+def test_auto_policy_probes_and_settles(density):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_auto, args=(r, world, port, q, density)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = got[0][3] + got[1][3]
+    tiles = 128 * 128 // 64
+    for rank, out, dense, _ in got:
+        for rnd, (mode, sent, s, pm) in enumerate(out):
+            assert abs(s - 0.5 * total * (rnd + 1)) <= 1e-5 * abs(total) * (rnd + 1)          # the batch mean whichever way the bytes went
+            assert pm == 1.5
+            probe_round = rnd % 4 == 0
+            if density < 0.25:
+                assert mode == 'sparse' and sent < 0.3 * dense                              # flags + touched tiles every round
+            else:
+                assert mode == 'dense' and sent == dense + (tiles if probe_round else 0)    # the probe costs its flag bytes, the other rounds nothing

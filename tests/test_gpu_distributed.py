@@ -171,7 +171,7 @@ from nvdiffrecmc_amd.trainer import DirectLightingStep
 res, n = 96, 4
 out = {}
 for tag, kw in (('plain', {}), ('forced', {'force_exchange': True, 'exchange_mode': 'sparse', 'union_views': [1, 2]})):
-    st = DirectLightingStep('bob', res, n, view=[1], n_views=4, device='cuda:0', lr=0.03, tex_res=512, pixel_index_offset=res * res,
+    st = DirectLightingStep('bob', res, n, view=[1], n_views=4, device='cuda:0', lr=0.03, tex_res=1024, pixel_index_offset=res * res,
                             use_graph=(os.environ.get('USE_GRAPH') == '1'), **kw)
     losses = [float(st.step(1).item()) for _ in range(7)]
     st.finish()

@@ -694,6 +694,9 @@ def run(args):
     if not use_graph:
         step.ctx.set_profiling(True)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    multi = world > 1 or forced
+    if multi:
+        step.measure_exposed = True        # a pair of HIP events around every wait on the exchange (a microsecond each)
     barrier()
     t0 = time.perf_counter()
     for a, b in ev:
@@ -713,9 +716,6 @@ def run(args):
     # extended phase: more samples of the same iteration for the median (>= 50 steps and >= 3 s), then the same iteration
     # with the forward's visibility bits replayed in backward (identical gradients, no second traversal; an extra, never `value`)
     ext_ms, dt2, k2 = [], None, 0
-    multi = world > 1 or forced
-    if multi:
-        step.measure_exposed = True
     if not args.no_extended:
         t_ext = time.perf_counter()
         while True:

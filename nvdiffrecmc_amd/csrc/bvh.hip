@@ -234,20 +234,24 @@ __global__ void bvh_hierarchy_kernel(const uint32_t *__restrict__ keys, int n, u
 //     keeps the proven stack bound: h_max + NVDR_TREELET_CAP (bvh.h).
 // Refits (rebuild = 0) keep whatever topology the last build left.
 #ifndef NVDR_TREELET_W
-#define NVDR_TREELET_W 64           // leaves per treelet, <= 64 (0: plain Karras tree, A/B)
+#define NVDR_TREELET_W 64           // leaves per treelet of meshes up to NVDR_TREELET_LARGE triangles (0: plain Karras tree, A/B)
 #endif
+#ifndef NVDR_TREELET_W_LARGE
+#define NVDR_TREELET_W_LARGE 32     // ... and of larger ones: two treelets per wavefront (the search is quadratic in the treelet: 227 -> ~50 us on
+#endif                              // 684 k triangles alone on the GPU, where the build is on the critical path of a one-view iteration with trained
+#define NVDR_TREELET_LARGE 65536    // geometry; CPU model: -5.0 % instead of -6.0 % node steps on bob)
 
-__device__ __forceinline__ bool treelet_ok(uint2 r) { return r.y - r.x < (unsigned)NVDR_TREELET_W && (r.x / NVDR_FIT_BLOCK) == (r.y / NVDR_FIT_BLOCK); }
+__device__ __forceinline__ bool treelet_ok(uint2 r, unsigned w) { return r.y - r.x < w && (r.x / NVDR_FIT_BLOCK) == (r.y / NVDR_FIT_BLOCK); }
 
 // list the maximal subtrees that fit a treelet (>= 3 leaves: two leaves have one tree)
-__global__ void __launch_bounds__(1024) bvh_treelet_mark_kernel(const uint2 *__restrict__ range, const uint2 *__restrict__ up, int n_int, int *__restrict__ list,
-                                                                unsigned *__restrict__ ctl)
+__global__ void __launch_bounds__(1024) bvh_treelet_mark_kernel(const uint2 *__restrict__ range, const uint2 *__restrict__ up, int n_int, unsigned w,
+                                                                int *__restrict__ list, unsigned *__restrict__ ctl)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     bool is_root = false;
     if (v < n_int) {
         const uint2 r = range[v];
-        is_root = treelet_ok(r) && r.y - r.x >= 2u && (v == 0 || !treelet_ok(range[up[v].x >> 2]));
+        is_root = treelet_ok(r, w) && r.y - r.x >= 2u && (v == 0 || !treelet_ok(range[up[v].x >> 2], w));
     }
     __shared__ unsigned wave_cnt[16], wave_base[16];
     const unsigned long long m = __ballot(is_root);
@@ -264,23 +268,31 @@ __global__ void __launch_bounds__(1024) bvh_treelet_mark_kernel(const uint2 *__r
     if (is_root) list[wave_base[wave] + __popcll(m & ((1ull << lane) - 1ull))] = v;
 }
 
+// W leaves per treelet: 64 / W treelets per wavefront ("parts" of W lanes; everything below that says "own part" is per-lane state that is
+// uniform inside a part).  The candidates' boxes come through ds_bpermute (the source lane differs between the parts).
+template <int W>
 __global__ void __launch_bounds__(256) bvh_treelet_kernel(const float *__restrict__ verts, const int32_t *__restrict__ tris, const uint32_t *__restrict__ order, int n,
                                                           const uint2 *__restrict__ range, uint4 *__restrict__ nodes, uint2 *__restrict__ up,
                                                           const int *__restrict__ list, const unsigned *__restrict__ ctl)
 {
+    constexpr int G = 64 / W;
+    constexpr unsigned long long WMASK = W == 64 ? ~0ull : ((1ull << (W & 63)) - 1ull);
     __shared__ int m_id[4][64], m_l[4][64], m_r[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & (W - 1), pbase = lane & ~(W - 1);
     const unsigned count = ctl[OCT_CTL_TREELETS];
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
-    for (unsigned e = blockIdx.x * (blockDim.x >> 6) + wave; e < count; e += waves_total) {
-        const int root = list[e];
-        const uint2 rg = range[root];
-        const int lo = (int)rg.x, k = (int)(rg.y - rg.x) + 1;
-        bool active = lane < k;
-        int ref = ~(lo + lane), depth = 0;
+    for (unsigned e0 = (blockIdx.x * (blockDim.x >> 6) + wave) * G; e0 < count; e0 += waves_total * G) {
+        const unsigned e = e0 + (unsigned)(lane / W);
+        const bool has = e < count;
+        const int root = has ? list[e] : 0;
+        const uint2 rg = has ? range[root] : make_uint2(0u, 0u);
+        const int lo = (int)rg.x, k = has ? (int)(rg.y - rg.x) + 1 : 0;
+        bool active = sub < k;
+        int ref = ~(lo + sub), depth = 0;
         float bx0 = 0.0f, by0 = 0.0f, bz0 = 0.0f, bx1 = 0.0f, by1 = 0.0f, bz1 = 0.0f;
         if (active) {
-            const uint32_t t = order[lo + lane];
+            const uint32_t t = order[lo + sub];
             const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
             const float ax = verts[3 * i0], ay = verts[3 * i0 + 1], az = verts[3 * i0 + 2];
             const float bx = verts[3 * i1], by = verts[3 * i1 + 1], bz = verts[3 * i1 + 2];
@@ -289,48 +301,52 @@ __global__ void __launch_bounds__(256) bvh_treelet_kernel(const float *__restric
             bx1 = fmaxf(ax, fmaxf(bx, cx)); by1 = fmaxf(ay, fmaxf(by, cy)); bz1 = fmaxf(az, fmaxf(bz, cz));
         }
         int created = 0, n_act = k;
-        while (n_act > 1) {
-            // nearest neighbour by the surface area of the union; candidates in rising lane order, strict <: ties go to the lower lane
+        while (__ballot(n_act > 1) != 0ull) {
+            const unsigned long long m = __ballot(active);
+            const unsigned long long mine = (m >> pbase) & WMASK;                   // the live clusters of the own part, by position
+            unsigned long long visit = 0ull;                                        // positions some part has a live cluster at (wave-uniform)
+#pragma unroll
+            for (int g = 0; g < G; ++g) visit |= (m >> (g * W)) & WMASK;
+            // nearest neighbour by the surface area of the union; candidates in rising position, strict <: ties go to the lower one
             float best = 3.0e38f;
-            int best_j = lane;
-            for (unsigned long long mm = __ballot(active); mm; mm &= mm - 1ull) {
-                const int j = __builtin_ctzll(mm);
-                const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx0), j)), y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by0), j));
-                const float z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz0), j)), x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx1), j));
-                const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by1), j)), z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz1), j));
+            int best_j = sub;
+            for (unsigned long long vv = visit; vv; vv &= vv - 1ull) {
+                const int s2 = __builtin_ctzll(vv), src = pbase + s2;
+                const float x0 = __shfl(bx0, src), y0 = __shfl(by0, src), z0 = __shfl(bz0, src);
+                const float x1 = __shfl(bx1, src), y1 = __shfl(by1, src), z1 = __shfl(bz1, src);
                 const float ex = fmaxf(bx1, x1) - fminf(bx0, x0), ey = fmaxf(by1, y1) - fminf(by0, y0), ez = fmaxf(bz1, z1) - fminf(bz0, z0);
                 const float a = (ex * ey + ey * ez) + ez * ex;
-                if (j != lane && a < best) { best = a; best_j = j; }
+                if (((mine >> s2) & 1ull) && s2 != sub && a < best) { best = a; best_j = s2; }
             }
-            // the partner's choice and state (every lane takes part in the permutes; an inactive lane reads itself)
-            const int src = active ? best_j : lane;
+            const bool seeking = active && n_act > 1;
+            // the partner's choice and state (every lane takes part in the permutes; a lane without a partner reads itself)
+            const int src = pbase + (seeking ? best_j : sub);
             const int their = __shfl(best_j, src);
-            const bool mutual = active && best_j != lane && their == lane && __shfl((int)active, src) != 0;
-            const bool merger = mutual && lane < best_j;
+            const bool mutual = seeking && best_j != sub && their == sub;
+            const bool merger = mutual && sub < best_j;
             const int p_ref = __shfl(ref, src), p_depth = __shfl(depth, src);
             const float px0 = __shfl(bx0, src), py0 = __shfl(by0, src), pz0 = __shfl(bz0, src);
             const float px1 = __shfl(bx1, src), py1 = __shfl(by1, src), pz1 = __shfl(bz1, src);
-            const unsigned long long mg = __ballot(merger);
+            const unsigned long long mg = (__ballot(merger) >> pbase) & WMASK;      // the merging clusters of the own part
             const int merges = __popcll(mg);
             if (merger) {
-                const int idx = created + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mg >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mg, 0u));
-                const int nid = n_act == 2 ? root : lo + 1 + idx;       // the last merge is the treelet's root; the others take the ids lo + 1 .. hi - 1
-                m_id[wave][idx] = nid; m_l[wave][idx] = ref; m_r[wave][idx] = p_ref;
+                const int idx = created + __popcll(mg & ((1ull << sub) - 1ull));
+                const int nid = n_act == 2 ? root : lo + 1 + idx;           // the last merge is the treelet's root; the others take the ids lo + 1 .. hi - 1
+                m_id[wave][pbase + idx] = nid; m_l[wave][pbase + idx] = ref; m_r[wave][pbase + idx] = p_ref;
                 ref = nid;
                 depth = 1 + max(depth, p_depth);
                 bx0 = fminf(bx0, px0); by0 = fminf(by0, py0); bz0 = fminf(bz0, pz0);
                 bx1 = fmaxf(bx1, px1); by1 = fmaxf(by1, py1); bz1 = fmaxf(bz1, pz1);
             }
-            if (mutual && lane > best_j) active = false;
+            if (mutual && sub > best_j) active = false;
             created += merges;
-            n_act -= merges;
-            if (merges == 0) break;             // (cannot happen: the closest pair is mutual; a NaN box would land here and keep the Karras subtree)
+            n_act = (n_act > 1 && merges == 0) ? -1 : n_act - merges;      // (-1: cannot happen -- the closest pair is mutual; a NaN box lands here and keeps its Karras subtree)
         }
-        const unsigned long long last = __ballot(active);
-        const int top_depth = __builtin_amdgcn_readlane(depth, __builtin_ctzll(last | (1ull << 63)));
+        const unsigned long long last = (__ballot(active) >> pbase) & WMASK;
+        const int top_depth = __shfl(depth, pbase + (last ? __builtin_ctzll(last) : 0));
         __builtin_amdgcn_wave_barrier();
-        if (n_act == 1 && top_depth <= NVDR_TREELET_CAP && lane < k - 1) {
-            const int nid = m_id[wave][lane], l = m_l[wave][lane], r = m_r[wave][lane];
+        if (n_act == 1 && k >= 3 && top_depth <= NVDR_TREELET_CAP && sub < k - 1) {
+            const int nid = m_id[wave][pbase + sub], l = m_l[wave][pbase + sub], r = m_r[wave][pbase + sub];
             unsigned *rec = (unsigned *)(nodes + 2 * (int64_t)nid);
             rec[6] = (unsigned)l;
             rec[7] = (unsigned)r;
@@ -1292,9 +1308,14 @@ int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
             bvh_hierarchy_kernel<<<div_up(n - 1, 256), 256, 0, stream>>>(c->keys[1], n, c->nodes, c->up, c->flags, c->oct_ctl, (uint2 *)c->oct_scan);
 #if NVDR_TREELET_W >= 3
             if (n >= 4) {       // (the ranges live in oct_scan and the list in oct_task until the collapse, which runs behind the fit, takes them over)
-                bvh_treelet_mark_kernel<<<div_up(n - 1, 1024), 1024, 0, stream>>>((const uint2 *)c->oct_scan, c->up, n - 1, c->oct_task, c->oct_ctl);
+                const bool large = n > NVDR_TREELET_LARGE && NVDR_TREELET_W_LARGE < NVDR_TREELET_W;
+                const unsigned w = large ? NVDR_TREELET_W_LARGE : NVDR_TREELET_W;
+                bvh_treelet_mark_kernel<<<div_up(n - 1, 1024), 1024, 0, stream>>>((const uint2 *)c->oct_scan, c->up, n - 1, w, c->oct_task, c->oct_ctl);
                 const unsigned tb = min(div_up(n, 4 * 24), (unsigned)c->n_cus * 8u);
-                bvh_treelet_kernel<<<tb < 1u ? 1u : tb, 256, 0, stream>>>(verts, tris, c->vals[1], n, (const uint2 *)c->oct_scan, c->nodes, c->up, c->oct_task, c->oct_ctl);
+                if (large)
+                    bvh_treelet_kernel<NVDR_TREELET_W_LARGE><<<tb < 1u ? 1u : tb, 256, 0, stream>>>(verts, tris, c->vals[1], n, (const uint2 *)c->oct_scan, c->nodes, c->up, c->oct_task, c->oct_ctl);
+                else
+                    bvh_treelet_kernel<NVDR_TREELET_W><<<tb < 1u ? 1u : tb, 256, 0, stream>>>(verts, tris, c->vals[1], n, (const uint2 *)c->oct_scan, c->nodes, c->up, c->oct_task, c->oct_ctl);
             }
 #endif
         }

@@ -527,7 +527,8 @@ class DirectLightingStep:
         if getattr(self, '_ex', None) is None or self._ex.world != world_size:
             from .parallel import GradientExchange
             total = self.total_views
-            even = (total % world_size == 0) and (self.nv * world_size == total)
+            # (one rank under force_exchange: its views are the whole batch as far as the weighting goes)
+            even = world_size == 1 or ((total % world_size == 0) and (self.nv * world_size == total))
             chunks = self._chunk_indices() if self._fused_update else [list(range(len(self.params)))]
             groups = [[self.params[i] for i in idx] for idx in chunks]
             # tile-sparse: the texture chunk only ('dense' sends the whole bucket; 'sparse' / 'auto' send the touched tiles and fall back to

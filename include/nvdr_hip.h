@@ -72,6 +72,10 @@ int nvdr_ctx_set_allocator(nvdr_ctx *ctx, nvdr_alloc_fn alloc_fn, nvdr_free_fn f
  * the tree is called (env-shade: behind its sample generation), so that in a captured HIP graph of a launch-bound iteration the
  * caller's own front nodes come first.  The caller's buffers are copied inside nvdr_bvh_build in every mode. */
 int nvdr_ctx_set_build_mode(nvdr_ctx *ctx, int mode);
+/* Make `stream` wait (device side, no host synchronisation) for the build nvdr_bvh_build last enqueued -- what every consumer of the tree does by
+ * itself before its first launch.  For a caller that captures the build in a HIP graph of its own: a capture must not end with the side
+ * stream's work unjoined. */
+int nvdr_bvh_wait(nvdr_ctx *ctx, void *stream);
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
  * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);
  * rebuild == 0: refit the bounds of the existing hierarchy to moved vertices (OPTIX_BUILD_OPERATION_UPDATE). */

@@ -111,6 +111,7 @@ _SIGNATURES = {
     'nvdr_ctx_set_stream_budget': [c_void_p, c_int64],
     'nvdr_ctx_set_allocator': [c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_ctx_set_build_mode': [c_void_p, c_int],
+    'nvdr_bvh_wait': [c_void_p, c_void_p],
     'nvdr_bvh_build': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
     'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
     'nvdr_bvh_export': [c_void_p, c_void_p, c_void_p, c_void_p],

@@ -1018,6 +1018,12 @@ int ctx_wait_built(nvdr_ctx *c, hipStream_t stream)
     return 0;
 }
 
+extern "C" int nvdr_bvh_wait(nvdr_ctx *c, void *stream_)
+{
+    NVDR_REQUIRE(c != nullptr, "nvdr_bvh_wait: ctx is NULL");
+    return ctx_wait_built(c, (hipStream_t)stream_);
+}
+
 extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
 {
     NVDR_REQUIRE(c != nullptr, "nvdr_ctx_check: ctx is NULL");

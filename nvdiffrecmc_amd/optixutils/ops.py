@@ -76,6 +76,11 @@ class OptiXContext:
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_ctx_set_stream_budget(w.handle, int(megabytes) << 20), 'nvdr_ctx_set_stream_budget')
 
+    def wait_build(self):
+        """The current stream waits (on the device) for the last optix_build_bvh of this context; consumers of the tree do this by themselves."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_bvh_wait(w.handle, _lib.stream_ptr()), 'nvdr_bvh_wait')
+
     def set_build_mode(self, mode):
         """Where optix_build_bvh runs: 1 (default) side stream, 0 the caller's stream, 2 side stream with the launches deferred to the
         first consumer of the tree (HIP graphs of launch-bound iterations: the caller's own front nodes come first)."""

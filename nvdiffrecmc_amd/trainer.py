@@ -271,14 +271,16 @@ class DirectLightingStep:
             except (RuntimeError, TypeError):
                 self.opt = torch.optim.Adam(groups, lr=lr, capturable=use_graph)
         self.covered = int(self.mask.sum().item())
-        # Where the per-iteration BVH rebuild runs (OptiXContext.set_build_mode).  Launch-bound iterations captured in HIP graphs (one or two
-        # views per rank) defer the build's launches behind the sample generation's: the graph's front nodes are then the iteration's own.
+        # Where the per-iteration BVH rebuild runs (OptiXContext.set_build_mode): 1 = the context's side stream (default).  (Mode 2 -- the
+        # build's launches issued behind the sample generation's -- was measured on the one-view iteration in HIP graphs: 2.021 vs 2.018 ms, no
+        # difference; a replayed graph orders its nodes by their dependencies, not by the order they were captured in.)
         mode = self._build_mode
         if mode is None:
             env = _lib.tuning_env('NVDR_BUILD_MODE')
-            mode = int(env) if env is not None else (2 if (use_graph and self.nv <= 2 and not self.optimize_geometry) else 1)
-        self.ctx.check()                 # (the construction-time build and G-buffer are done: no build in flight)
-        self.ctx.set_build_mode(mode)
+            mode = int(env) if env is not None else 1
+        if mode != 1:
+            self.ctx.check()             # (the construction-time build and G-buffer are done: no build in flight)
+            self.ctx.set_build_mode(mode)
 
     def _set_gbuffer(self, gb):
         """Adopt a G-buffer dict (optixutils.render_gbuffer / render.gbuffer) as the iteration's inputs."""
@@ -435,14 +437,16 @@ class DirectLightingStep:
         rebuild (side stream), update_pdf, and with trained geometry getMesh (dlmesh.py:45-55) + rasterize / interpolate
         (render.py:208-234) from the moving vertices.  With several ranks it runs while the texture chunk of the previous iteration's
         gradient exchange is still on the wire (_step_multi).
-        defer_build (the several-rank schedule with LOCKED geometry): the rebuild is left to the start of stage 2, where it runs beside the
-        sample generation as in the one-rank iteration -- nothing in this stage would consume the tree, and a HIP graph of this stage alone
-        could not end with the side stream's work unjoined."""
+        join_build (the several-rank schedule): the stage ends with the main stream waiting for the rebuild -- a HIP graph of this stage alone
+        must not end with the side stream's work unjoined, and the rebuild then runs while the texture chunk is on the wire instead of beside
+        the sample generation."""
         # the rebuild first: it runs on the context's side stream, and the sooner it starts the less of it is left when the traversal
         # needs the tree (one view: the light's three small kernels used to run in front of it)
-        self._build_deferred = bool(defer_build) and not self.optimize_geometry
-        v_pos = self.mesh['v_pos'] if self._build_deferred else self._build_bvh()
+        self._build_deferred = False
+        v_pos = self._build_bvh()
         self.light.update_pdf()
+        if defer_build and not self.optimize_geometry:
+            self.ctx.wait_build()
         self._gb_live = None
         if self.material_set != 'r3' and self.optimize_geometry:
             v_nrm, v_tng = mesh_ops.mesh_frame(v_pos, self.topo)

@@ -97,7 +97,7 @@ GEOMETRY_NOTE = ('v_pos trained at lr %g: this measures the WORK SHAPE of geomet
                  '(dr.antialias, render.py:290) and a Laplacian regulariser (geometry/dlmesh.py:57-76), both outside the path' % BENCH_LR_POS)
 TEXTURE_NOTE = ('trained textures are sampled at the NEAREST texel (render/texture.py:57-68 uses dr.texture linear-mipmap-linear, outside the path): only the '
                 'texels some covered pixel looks up receive gradient, which the tile-sparse Adam and the tile-sparse exchange exploit; with the mip chain of the '
-                'reference every texel would receive gradient -- `adam_dense_ms` / exchange mode "dense" are the like-for-like figures')
+                'reference every texel would receive gradient -- config.adam.dense_ms and exchange mode "dense" are the like-for-like figures')
 
 
 def make_step(pre, args, dev, views, n_views, lock_pos, **kw):
@@ -363,6 +363,38 @@ def other_config_object(name, args, dev):
     return out
 
 
+def adam_object(step):
+    """The parameter update alone, as the iteration runs it (tile-sparse textures: tiles without gradient and without history are skipped) and
+    DENSE (every texel read and written: what the reference's mip-mapped textures, whose gradient reaches every texel, would cost): HIP-event
+    medians of the one launch.  Run at the very end: it moves the parameters by a few zero-gradient steps."""
+    import torch
+    opt = step.opt
+    if not hasattr(opt, 'active'):
+        return None
+    for p in step.params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    out = {}
+    saved = list(opt.active)
+    for tag in ('sparse', 'dense'):
+        if tag == 'dense':
+            opt.active = [None] * len(saved)
+        ms = []
+        for it in range(12):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            opt.step()
+            b.record()
+            b.synchronize()
+            if it >= 2:
+                ms.append(a.elapsed_time(b))
+        out[tag + '_ms'] = statistics.median(ms)
+    opt.active = saved
+    out['parameter_bytes'] = int(sum(p.numel() for p in step.params) * 4)
+    out['tiles_with_history'] = [int(a.sum().item()) if a is not None else None for a in saved]
+    return out
+
+
 def init_world1(dev):
     """A one-rank RCCL process group on this GPU (the only N a one-GPU box offers): the several-rank schedule then runs its real
     collectives -- a one-rank all-reduce moves nothing over xGMI, what it shows is the fixed cost of the path."""
@@ -381,6 +413,8 @@ def exchange_object(step, ms_exposed):
     rep = step._ex.report()
     rep['pipelined'] = bool(step.pipeline and len(step._ex_chunks) > 1)
     rep['exposed_ms'] = statistics.median(ms_exposed) if ms_exposed else None
+    s1 = step.stage1_ms()
+    rep['geometry_stage_ms'] = statistics.median(s1) if s1 else None      # main-stream time of the next iteration's geometry stage: the texture chunk's reduce runs under it
     rep['exposed_ms_note'] = ('median per iteration of the time the main stream waits on the exchange (HIP events around every wait: collectives not yet '
                               'finished + the scatter of the reduced tiles); the rest of the exchange runs under the next iteration\'s geometry stage')
     if getattr(step, '_union_views', None):
@@ -426,11 +460,14 @@ def one_view_object(args, dev, preset_name, eight_view_ms, lock=None):
             early = e['chunk_bytes_dense'][0] if len(e['chunk_bytes_dense']) > 1 else 0
             tex = e['bytes_sent'] - early
             wire = lambda nbytes, bw: 30e-6 + 2.0 * 7.0 / 8.0 * nbytes / (bw * 1e9)
-            lo, hi = [out[mode]['ms_per_step'] + 1e3 * (wire(early, bw) + wire(tex, bw)) for bw in (250.0, 150.0)]
-            proj[mode] = {'ms_per_step_with_wire_nothing_hidden': [lo, hi], 'speedup_vs_8_views_on_one_gpu': [eight_view_ms / hi, eight_view_ms / lo]}
+            # the early chunk's wire time is exposed; the texture chunk's only where it outlasts the geometry stage it runs under (measured here, on the main stream)
+            s1 = (e.get('geometry_stage_ms') or 0.0) * 1e-3
+            lo, hi = [out[mode]['ms_per_step'] + 1e3 * (wire(early, bw) + max(0.0, wire(tex, bw) - s1)) for bw in (250.0, 150.0)]
+            proj[mode] = {'ms_per_step_with_exposed_wire': [lo, hi], 'speedup_vs_8_views_on_one_gpu': [eight_view_ms / hi, eight_view_ms / lo]}
         out['projected_8gpu'] = dict(proj, eight_views_one_gpu_ms=eight_view_ms,
-                                     note='8 views on one GPU / (one view + exchange machinery measured here + ring all-reduce wire time at 150-250 GB/s bus bandwidth, '
-                                          'none of it assumed hidden); the measured scaling curve is the driver\'s SCALE file when an 8-GPU node exists')
+                                     note='8 views on one GPU / (one view under the several-rank schedule measured here, one-rank RCCL collectives included, + the ring '
+                                          'all-reduce wire time at 150-250 GB/s bus bandwidth that the pipelined geometry stage does not cover); a projection -- the measured '
+                                          'scaling curve is the driver\'s SCALE file when an 8-GPU node exists')
     finally:
         if own:
             import torch.distributed as dist
@@ -908,6 +945,11 @@ def run(args):
                 out['cpu_baseline_torch'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if multi:
             out['config']['exchange'] = exchange_object(step, exposed)
+        if not args.pmc_child and step._graphs is None and world == 1 and not forced:
+            try:
+                out['config']['adam'] = adam_object(step)
+            except Exception as e:
+                out['config']['adam'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and args.config == 'bob512' and not args.no_one_view and not args.pmc_child and args.res is None and args.subdiv is None and args.batch is None \
                 and not forced:
             step = None

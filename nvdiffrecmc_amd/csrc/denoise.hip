@@ -147,19 +147,22 @@ __global__ void __launch_bounds__(DN_BX * (PAIR ? DN_BY_PAIR : DN_BY)) bilateral
     // one tap: its weight from the guides, applied to the colour(s).  The sums run in tap order (rows of the window, left to right).
     auto tap = [&](const float4 &tAv, const float4 &tBv, const float4 &tCv, const float2 &tt) {
         const float w_xy = tt.x, dist = tt.y;
-        const float d = tBv.x * cB.x + tBv.y * cB.y + tBv.z * cB.z;
+        // explicit fused multiply-adds (the library is built with -ffp-contract=off for the sampling code; this filter is compared at 2e-5 --
+        // it already takes the hardware's exp and reciprocal -- and the reference's nvcc build contracts the same expressions): nine VALU
+        // instructions less per tap, of ~36
+        const float d = fmaf(tBv.z, cB.z, fmaf(tBv.y, cB.y, tBv.x * cB.x));
         const float w_normal = pow128(fminf(fmaxf(d, DN_EPS), 1.0f));
         const float dz = BACKWARD ? tBv.w : cB.w;
         const float w_depth = __expf(-(fabsf(tAv.w - cA.w) * __builtin_amdgcn_rcpf(fmaxf(dz * dist, DN_EPS))));
         const float w = w_xy * w_normal * w_depth;
-        ax += tAv.x * w;
-        ay += tAv.y * w;
-        az += tAv.z * w;
+        ax = fmaf(tAv.x, w, ax);
+        ay = fmaf(tAv.y, w, ay);
+        az = fmaf(tAv.z, w, az);
         aw += w;
         if (PAIR) {
-            bx += tCv.x * w;
-            by += tCv.y * w;
-            bz += tCv.z * w;
+            bx = fmaf(tCv.x, w, bx);
+            by = fmaf(tCv.y, w, by);
+            bz = fmaf(tCv.z, w, bz);
         }
     };
     if (TILED) {

@@ -132,7 +132,7 @@ class DirectLightingStep:
         # union_views (with force_exchange): the views of the WHOLE batch; the tile flags of this one rank are OR-ed with the tiles those views
         # touch, so that the one-rank run compacts, sends and scatters the bytes the several-rank run would (bench.py one_view)
         self._union_views = list(union_views) if (union_views is not None and force_exchange) else None
-        self.measure_exposed, self._exposed_events = False, []
+        self.measure_exposed, self._exposed_events, self._stage1_events = False, [], []
         self._stage1_ready, self._gb_live, self._pending = False, None, False
         self.fused = fused
         self.pair_filter = _lib.tuning_env('NVDR_PAIR_FILTER', '1') != '0'      # (A/B switch of the harness)
@@ -603,6 +603,13 @@ class DirectLightingStep:
         n = max(1, len(self._ex_chunks))
         return [sum(per_wait[i:i + n]) for i in range(0, len(per_wait) - n + 1, n)]
 
+    def stage1_ms(self):
+        """Durations of the pipelined geometry stage on the main stream since measure_exposed was set (a list; clears it)."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._stage1_events]
+        self._stage1_events = []
+        return out
+
     def _finish_pending(self, graphs=None):
         """The texture chunk of the previous iteration: wait for its all-reduce, scatter, Adam + clamps."""
         if not getattr(self, '_pending', False):
@@ -654,11 +661,17 @@ class DirectLightingStep:
             else:
                 self._update(subset=chunks[k], advance=False, grad_mult=f)
         if self.pipeline and last > 0:
+            if self.measure_exposed:        # how long the geometry stage keeps the main stream busy: what the texture chunk's wire time hides behind
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
             if graphs:
                 graphs[0].replay()
                 self._stage1_ready = True
             else:
                 self._stage1(defer_build=True)
+            if self.measure_exposed:
+                b.record()
+                self._stage1_events.append((a, b))
         ex.send(last)                               # sparse: the host reads the union's size here -- the GPU is busy with stage 1 meanwhile
         self._pending = True
         if not (self.pipeline and last > 0):

@@ -67,9 +67,23 @@ struct Tab {          // small strided table (light, pdf, rows, cols)
     int n0, n1, n2;
 };
 
+// A strided [N,H,W,3] view with 32-BIT element strides (the launcher checks that they fit): six scalar registers instead of the eleven of
+// common.h's View4.  The parameter block below is kept in scalar registers by every env-shade kernel, and at 88 of them for the eight views
+// alone the compiler spilled scalars into vector lanes -- 267 of the 1 965 vector instructions of the backward shading kernel were
+// v_readlane / v_writelane of that spill traffic (round 5).
+struct View4s {
+    const float *p;
+    int s0, s1, s2, s3;     // element strides, already zeroed for broadcast dims
+};
+__device__ __forceinline__ F3 fetch3(const View4s &v, int n, int h, int w)
+{
+    const float *q = v.p + ((int64_t)n * v.s0 + (int64_t)h * v.s1 + (int64_t)w * v.s2);
+    return f3(q[0], q[v.s3], q[2 * v.s3]);
+}
+
 struct ShadeParams {
-    View4 ro, pos, nrm, view_pos, kd, ks, dgrad, sgrad;
-    const float *mask; int64_t ms0, ms1, ms2;
+    View4s ro, pos, nrm, view_pos, kd, ks, dgrad, sgrad;
+    const float *mask; int ms0, ms1, ms2;
     Tab light, pdf, rows, cols;
     const int *perms; int perm_s0, perm_s1; unsigned n_perms;
     int N, H, W;
@@ -1826,6 +1840,18 @@ static size_t lg_lds_budget()
     return budget;
 }
 
+static int make_view4s(View4s &v, const nvdr_tensor &t, const char *name)
+{
+    for (int d = 0; d < 4; ++d)
+        NVDR_REQUIRE(t.size[d] == 1 || llabs(t.stride[d]) < (1ll << 31), "env_shade: %s has a stride beyond 2^31 elements", name);
+    v.p = (const float *)t.data;
+    v.s0 = t.size[0] == 1 ? 0 : (int)t.stride[0];
+    v.s1 = t.size[1] == 1 ? 0 : (int)t.stride[1];
+    v.s2 = t.size[2] == 1 ? 0 : (int)t.stride[2];
+    v.s3 = t.size[3] == 1 ? 0 : (int)t.stride[3];
+    return 0;
+}
+
 static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool backward, hipStream_t stream)
 {
     NVDR_REQUIRE(c && a, "env_shade: NULL argument");
@@ -1940,10 +1966,13 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
 
     ShadeParams p;
     memset(&p, 0, sizeof(p));
-    p.ro = make_view4(a->ro); p.pos = make_view4(a->gb_pos); p.nrm = make_view4(a->gb_normal);
-    p.view_pos = make_view4(a->gb_view_pos); p.kd = make_view4(a->gb_kd); p.ks = make_view4(a->gb_ks);
+    if ((r = make_view4s(p.ro, a->ro, "ro")) || (r = make_view4s(p.pos, a->gb_pos, "gb_pos")) || (r = make_view4s(p.nrm, a->gb_normal, "gb_normal")) ||
+        (r = make_view4s(p.view_pos, a->gb_view_pos, "gb_view_pos")) || (r = make_view4s(p.kd, a->gb_kd, "gb_kd")) || (r = make_view4s(p.ks, a->gb_ks, "gb_ks")))
+        return r;
     p.mask = (const float *)a->mask.data;
-    p.ms0 = a->mask.stride[0]; p.ms1 = a->mask.stride[1]; p.ms2 = a->mask.stride[2];
+    NVDR_REQUIRE(llabs(a->mask.stride[0]) < (1ll << 31) && llabs(a->mask.stride[1]) < (1ll << 31) && llabs(a->mask.stride[2]) < (1ll << 31),
+                 "env_shade: mask strides beyond 2^31 elements");
+    p.ms0 = (int)a->mask.stride[0]; p.ms1 = (int)a->mask.stride[1]; p.ms2 = (int)a->mask.stride[2];
     if ((r = make_tab(p.light, a->light, 3, "light"))) return r;
     if ((r = make_tab(p.pdf, a->pdf, 2, "pdf"))) return r;
     if ((r = make_tab(p.rows, a->rows, 1, "rows"))) return r;
@@ -1974,7 +2003,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
                      "env_shade_bwd: NULL output");
         if ((r = check_gb(a->diff_grad, N, H, W, "diff_grad"))) return r;
         if ((r = check_gb(a->spec_grad, N, H, W, "spec_grad"))) return r;
-        p.dgrad = make_view4(a->diff_grad); p.sgrad = make_view4(a->spec_grad);
+        if ((r = make_view4s(p.dgrad, a->diff_grad, "diff_grad")) || (r = make_view4s(p.sgrad, a->spec_grad, "spec_grad"))) return r;
         p.g_pos = a->gb_pos_grad; p.g_nrm = a->gb_normal_grad; p.g_kd = a->gb_kd_grad; p.g_ks = a->gb_ks_grad;
         p.g_light = a->light_grad;
         if (p.g_nrm == p.g_pos + 3 * npix && p.g_kd == p.g_nrm + 3 * npix && p.g_ks == p.g_kd + 3 * npix) {

@@ -99,6 +99,7 @@ struct ShadeParams {
     float4 *rays;             // (dir.xyz, pdf_light + pdf_bsdf)
     int *texel;               // ty * Wl + tx of the radiance lookup
     float4 *pix_origin;       // shadow-ray origin per compacted pixel
+    float4 *pix_setup;        // the G-buffer values of a compacted pixel every sample of it is shaded with, packed by stage 1 (4 x float4: see load_setup)
     uint8_t *vis;             // 1 = unoccluded
     uint32_t *live;           // compacted list of the stream slots stage 2 has to traverse
     unsigned *ray_count;      // its length (device counter)
@@ -695,6 +696,13 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         if (sub == 0 && valid) {
             const F3 ro = fetch3(p.ro, z, y, x);
             p.pix_origin[pi] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+            // what stage 3 shades this pixel's samples with, in one 64-byte record behind ONE pointer: its kernels then keep two strided
+            // views (the incoming gradients) in scalar registers instead of seven (round 5: the parameter block no longer spills)
+            float4 *su = p.pix_setup + 4 * (int64_t)pi;
+            su[0] = make_float4(pos.x, pos.y, pos.z, nrm.x);
+            su[1] = make_float4(nrm.y, nrm.z, view_pos.x, view_pos.y);
+            su[2] = make_float4(view_pos.z, kd.x, kd.y, kd.z);
+            su[3] = make_float4(ks.x, ks.y, ks.z, 0.0f);
             ring_a[ring_at] = make_float4(nrm.x, nrm.y, nrm.z, alpha);
             ring_b[ring_at] = make_float4(wo.x, wo.y, wo.z, pDiffuse);
             ring_pi[ring_at] = pi;
@@ -802,6 +810,13 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
 struct PixelSetup {
     F3 pos, nrm, view_pos, kd, ks, dgrad, sgrad;
 };
+// the record stage 1 packed for compacted pixel pi (env_gen_kernel)
+__device__ __forceinline__ void load_setup(const ShadeParams &p, unsigned pi, F3 &pos, F3 &nrm, F3 &view_pos, F3 &kd, F3 &ks)
+{
+    const float4 *su = p.pix_setup + 4 * (int64_t)pi;
+    const float4 a = su[0], b = su[1], c = su[2], d = su[3];
+    pos = f3(a.x, a.y, a.z); nrm = f3(a.w, b.x, b.y); view_pos = f3(b.z, b.w, c.x); kd = f3(c.y, c.z, c.w); ks = f3(d.x, d.y, d.z);
+}
 
 // One sample of process_sample (kernel.cu:403-461) -- ray direction and pdf sum `rd`, light texel, visibility -- shaded for pixel `px`.
 // Forward: its contribution is ADDED to (diff, spec).  Backward: its gradient terms are ADDED to (g_kd, g_ks, g_pos, g_nrm) in the order
@@ -950,11 +965,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         const unsigned pi = grp * G + slot;
         const bool valid = pi < P;
         const int lin = p.pix_list[p.pix_begin + (valid ? pi : 0u)];
-        const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
-        const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
-        const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
+        F3 pos, nrm, view_pos, kd, ks;
+        load_setup(p, valid ? pi : 0u, pos, nrm, view_pos, kd, ks);
         F3 dgrad = f3(0.0f), sgrad = f3(0.0f);
         if (BACKWARD) {
+            const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
             dgrad = fetch3(p.dgrad, z, y, x);
             sgrad = fetch3(p.sgrad, z, y, x);
         }
@@ -1177,12 +1192,13 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 ent = it % RING;
                 const unsigned pi = grp;
                 const int lin = p.pix_list[p.pix_begin + pi];
-                const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
                 // the pixel's set-up: in registers for this pass (every lane reads the same addresses), in LDS for the lanes that will
                 // shade its queued samples
-                pos = fetch3(p.pos, z, y, x); nrm = fetch3(p.nrm, z, y, x);
-                view_pos = fetch3(p.view_pos, z, y, x); kd = fetch3(p.kd, z, y, x); ks = fetch3(p.ks, z, y, x);
-                if (BACKWARD) { dgrad = fetch3(p.dgrad, z, y, x); sgrad = fetch3(p.sgrad, z, y, x); }
+                load_setup(p, pi, pos, nrm, view_pos, kd, ks);
+                if (BACKWARD) {
+                    const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
+                    dgrad = fetch3(p.dgrad, z, y, x); sgrad = fetch3(p.sgrad, z, y, x);
+                }
                 if (lane == 0) {
                     float *su = setup[ent];
                     su[0] = pos.x; su[1] = pos.y; su[2] = pos.z; su[3] = nrm.x; su[4] = nrm.y; su[5] = nrm.z;
@@ -1379,11 +1395,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     for (unsigned grp = grp_first; grp < grp_last; grp += grp_step) {
         const unsigned pi = grp;
         const int lin = p.pix_list[p.pix_begin + pi];
-        const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
-        const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
-        const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
+        F3 pos, nrm, view_pos, kd, ks;
+        load_setup(p, pi, pos, nrm, view_pos, kd, ks);
         F3 dgrad = f3(0.0f), sgrad = f3(0.0f);
         if (BACKWARD) {
+            const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
             dgrad = fetch3(p.dgrad, z, y, x);
             sgrad = fetch3(p.sgrad, z, y, x);
         }
@@ -1797,8 +1813,10 @@ static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, size_t own_slo
     }
     if (c->stream_cap_pixels < cap) {
         ctx_free(c, c->pix_origin);
+        ctx_free(c, c->pix_setup);
         c->stream_cap_pixels = 0;
         NVDR_HIP_TRY(ctx_malloc(c, &c->pix_origin, sizeof(float4) * cap, stream));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->pix_setup, sizeof(float4) * 4 * cap, stream));
         c->stream_cap_pixels = cap;
     }
     if (c->stream_cap_rays < rays) {
@@ -2046,7 +2064,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     }
     p.pix_list = c->pix_list;
     p.pix_count = &c->dinfo->pix_count;
-    p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.vis = c->vis;
+    p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.pix_setup = c->pix_setup; p.vis = c->vis;
     p.live = c->live;
     p.queues = c->queues;
 

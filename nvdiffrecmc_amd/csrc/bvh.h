@@ -163,6 +163,7 @@ struct nvdr_ctx {
     uint32_t *live = nullptr;      // stream slots of the rays that need traversal (dead samples left out)
     unsigned *queues = nullptr;    // [256][32] chunk counters of the traversal kernel, one 128-B line each (NVDR_TRACE_QUEUES)
     float4 *pix_origin = nullptr;
+    float4 *pix_grad = nullptr;    // [2 * stream_cap_pixels] backward: the incoming (diffuse, specular) gradients of a compacted pixel, packed in front of stage 3
     float4 *pix_setup = nullptr;   // [4 * stream_cap_pixels] per compacted pixel: (pos, nrm.x) (nrm.yz, view_pos.xy) (view_pos.z, kd) (ks, -), written by stage 1
     size_t stream_cap_rays = 0;    // slots of texel / vis / live
     size_t stream_cap_total = 0;   // slots of rays: the chunk's own + the spare blocks of the light-gradient records

@@ -1132,7 +1132,7 @@ extern "C" int nvdr_ctx_destroy(nvdr_ctx *c)
     hipFree(c->bounds_part);
     ctx_free(c, c->spill);
     ctx_free(c, c->pix_list);
-    ctx_free(c, c->rays); ctx_free(c, c->texel); ctx_free(c, c->vis); ctx_free(c, c->live); ctx_free(c, c->pix_origin); ctx_free(c, c->pix_setup); ctx_free(c, c->lg_part); ctx_free(c, c->lg_tags); ctx_free(c, c->cdf_guide);
+    ctx_free(c, c->rays); ctx_free(c, c->texel); ctx_free(c, c->vis); ctx_free(c, c->live); ctx_free(c, c->pix_origin); ctx_free(c, c->pix_setup); ctx_free(c, c->pix_grad); ctx_free(c, c->lg_part); ctx_free(c, c->lg_tags); ctx_free(c, c->cdf_guide);
     if (c->ovf_host) hipHostFree(c->ovf_host);
     delete c;
     return 0;

@@ -99,6 +99,7 @@ struct ShadeParams {
     float4 *rays;             // (dir.xyz, pdf_light + pdf_bsdf)
     int *texel;               // ty * Wl + tx of the radiance lookup
     float4 *pix_origin;       // shadow-ray origin per compacted pixel
+    float4 *pix_grad;         // backward: (diff_grad, spec_grad) of a compacted pixel (2 x float4), packed by pack_grads_kernel
     float4 *pix_setup;        // the G-buffer values of a compacted pixel every sample of it is shaded with, packed by stage 1 (4 x float4: see load_setup)
     uint8_t *vis;             // 1 = unoccluded
     uint32_t *live;           // compacted list of the stream slots stage 2 has to traverse
@@ -806,10 +807,29 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
 // ---------------------------------------------------------------------------------------------
 // stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
 
+// backward: the incoming gradients of the chunk's covered pixels, gathered through their strided views ONCE into two float4 per compacted
+// pixel; the shading kernels then hold no strided view at all in their scalar registers (a 5-us launch per chunk)
+__global__ void __launch_bounds__(256) pack_grads_kernel(ShadeParams p)
+{
+    const unsigned P = chunk_pixels(p);
+    for (unsigned pi = blockIdx.x * blockDim.x + threadIdx.x; pi < P; pi += gridDim.x * blockDim.x) {
+        const int lin = p.pix_list[p.pix_begin + pi];
+        const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
+        const F3 d = fetch3(p.dgrad, z, y, x), s = fetch3(p.sgrad, z, y, x);
+        p.pix_grad[2 * (int64_t)pi] = make_float4(d.x, d.y, d.z, 0.0f);
+        p.pix_grad[2 * (int64_t)pi + 1] = make_float4(s.x, s.y, s.z, 0.0f);
+    }
+}
+
 // The G-buffer values of one pixel that every sample of it is shaded with (, and the incoming gradients of the backward pass)
 struct PixelSetup {
     F3 pos, nrm, view_pos, kd, ks, dgrad, sgrad;
 };
+__device__ __forceinline__ void load_grads(const ShadeParams &p, unsigned pi, F3 &dgrad, F3 &sgrad)
+{
+    const float4 a = p.pix_grad[2 * (int64_t)pi], b = p.pix_grad[2 * (int64_t)pi + 1];
+    dgrad = f3(a.x, a.y, a.z); sgrad = f3(b.x, b.y, b.z);
+}
 // the record stage 1 packed for compacted pixel pi (env_gen_kernel)
 __device__ __forceinline__ void load_setup(const ShadeParams &p, unsigned pi, F3 &pos, F3 &nrm, F3 &view_pos, F3 &kd, F3 &ks)
 {
@@ -968,11 +988,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         F3 pos, nrm, view_pos, kd, ks;
         load_setup(p, valid ? pi : 0u, pos, nrm, view_pos, kd, ks);
         F3 dgrad = f3(0.0f), sgrad = f3(0.0f);
-        if (BACKWARD) {
-            const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
-            dgrad = fetch3(p.dgrad, z, y, x);
-            sgrad = fetch3(p.sgrad, z, y, x);
-        }
+        if (BACKWARD) load_grads(p, valid ? pi : 0u, dgrad, sgrad);
         const PixelSetup px = {pos, nrm, view_pos, kd, ks, dgrad, sgrad};
         F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
         F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
@@ -1195,10 +1211,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 // the pixel's set-up: in registers for this pass (every lane reads the same addresses), in LDS for the lanes that will
                 // shade its queued samples
                 load_setup(p, pi, pos, nrm, view_pos, kd, ks);
-                if (BACKWARD) {
-                    const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
-                    dgrad = fetch3(p.dgrad, z, y, x); sgrad = fetch3(p.sgrad, z, y, x);
-                }
+                if (BACKWARD) load_grads(p, pi, dgrad, sgrad);
                 if (lane == 0) {
                     float *su = setup[ent];
                     su[0] = pos.x; su[1] = pos.y; su[2] = pos.z; su[3] = nrm.x; su[4] = nrm.y; su[5] = nrm.z;
@@ -1398,11 +1411,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         F3 pos, nrm, view_pos, kd, ks;
         load_setup(p, pi, pos, nrm, view_pos, kd, ks);
         F3 dgrad = f3(0.0f), sgrad = f3(0.0f);
-        if (BACKWARD) {
-            const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
-            dgrad = fetch3(p.dgrad, z, y, x);
-            sgrad = fetch3(p.sgrad, z, y, x);
-        }
+        if (BACKWARD) load_grads(p, pi, dgrad, sgrad);
         const PixelSetup px = {pos, nrm, view_pos, kd, ks, dgrad, sgrad};
         F3 diffAccum = f3(0.0f), specAccum = f3(0.0f);
         F3 g_pos = f3(0.0f), g_nrm = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f);
@@ -1814,9 +1823,11 @@ static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, size_t own_slo
     if (c->stream_cap_pixels < cap) {
         ctx_free(c, c->pix_origin);
         ctx_free(c, c->pix_setup);
+        ctx_free(c, c->pix_grad);
         c->stream_cap_pixels = 0;
         NVDR_HIP_TRY(ctx_malloc(c, &c->pix_origin, sizeof(float4) * cap, stream));
         NVDR_HIP_TRY(ctx_malloc(c, &c->pix_setup, sizeof(float4) * 4 * cap, stream));
+        NVDR_HIP_TRY(ctx_malloc(c, &c->pix_grad, sizeof(float4) * 2 * cap, stream));
         c->stream_cap_pixels = cap;
     }
     if (c->stream_cap_rays < rays) {
@@ -2064,7 +2075,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     }
     p.pix_list = c->pix_list;
     p.pix_count = &c->dinfo->pix_count;
-    p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.pix_setup = c->pix_setup; p.vis = c->vis;
+    p.rays = c->rays; p.texel = c->texel; p.pix_origin = c->pix_origin; p.pix_setup = c->pix_setup; p.pix_grad = c->pix_grad; p.vis = c->vis;
     p.live = c->live;
     p.queues = c->queues;
 
@@ -2145,6 +2156,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         // stage 3
         NvdrRange r3(backward ? "nvdr:shade_bwd+light_grad" : "nvdr:shade_fwd");
         if (backward) {
+            pack_grads_kernel<<<min(div_up(cap, 256), 2048u), 256, 0, stream>>>(p);
             if (shade_queue) { if (c->debug) env_shade_queue_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_queue_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
             else if (shade_local) { if (c->debug) env_shade_local_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_local_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
             else { if (c->debug) env_shade_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }

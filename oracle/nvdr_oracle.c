@@ -62,14 +62,39 @@ static inline float vrcp_(float b)
     else if ((h & 3u) == 2u) y.u -= 1u;
     return y.f;
 }
+#if ORACLE_FAST_VALUE_MATH >= 3
+/* levels 3 / 4 (round 5): a FAITHFUL division -- the quotient off by at most one ulp, what rcp + one Newton step + a residual correction
+ * gives without the scaling / fix-up instructions of the IEEE sequence -- and the fp64 islands kept.  3: BSDF evaluation, its adjoints and
+ * the MIS weight (stage 3 of the GPU pipeline); 4: the pdfs of stage 1 as well. */
+static inline float vdiv1_(float a, float b)
+{
+    union { float f; uint32_t u; } q, h;
+    q.f = a / b;
+    h.f = a * 1.7f + b;
+    uint32_t k = h.u * 2654435761u;
+    k ^= k >> 15;
+    if (q.f == q.f && q.f != 0.0f && (q.u & 0x7f800000u) != 0x7f800000u) {
+        if ((k & 3u) == 1u) q.u += 1u;
+        else if ((k & 3u) == 2u) q.u -= 1u;
+    }
+    return q.f;
+}
+#define VDIV(a, b) (ORACLE_FAST_VALUE_MATH >= 4 ? vdiv1_((a), (b)) : ((a) / (b)))
+#define VFAST 0
+#define VDIV_FAITHFUL(a, b) vdiv1_((a), (b))
+#else
 #define VDIV(a, b) ((a) * vrcp_(b))
 #define VFAST 1
+#endif
 #else
 #define VDIV(a, b) ((a) / (b))
 #define VFAST 0
 #endif
 /* level 1: the pdfs and the MIS weight only; level 2: also the BSDF evaluation and its adjoints (VDIV_E / VFAST_E) */
-#if ORACLE_FAST_VALUE_MATH >= 2
+#if ORACLE_FAST_VALUE_MATH >= 3
+#define VDIV_E(a, b) VDIV_FAITHFUL(a, b)
+#define VFAST_E 0
+#elif ORACLE_FAST_VALUE_MATH >= 2
 #define VDIV_E(a, b) VDIV(a, b)
 #define VFAST_E 1
 #else
@@ -638,7 +663,11 @@ static void process_sample(const shade_env *e, int backward, f3 ro, f3 dir, f3 p
     const nvdr_tensor *L = &a->light;
     const float *lp = (const float *)L->data + ty * L->stride[0] + tx * L->stride[1];
     f3 light_col = L->size[2] == 1 ? mk3(lp[0], lp[0], lp[0]) : mk3(lp[0], lp[L->stride[2]], lp[2 * L->stride[2]]);
+#if ORACLE_FAST_VALUE_MATH >= 3
+    float mis_weight = VDIV_FAITHFUL(1.0f, fmaxf(pdfSum, 0.0001f));
+#else
     float mis_weight = VFAST ? VDIV(1.0f, fmaxf(pdfSum, 0.0001f)) : (float)(1.0 / (double)fmaxf(pdfSum, 0.0001f));
+#endif
     f3 _diff = mk3(0, 0, 0), _spec = mk3(0, 0, 0);
     if (a->bsdf == 1 || a->bsdf == 2) {
         float l = fwdLambert(nrm, dir);

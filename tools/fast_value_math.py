@@ -37,7 +37,12 @@ def run(lib, m, kw, bsdf, n, seed, dg, sg, nt):
 
 def main():
     orc.build()
-    for level, what in ((1, 'LEVEL 1: pdfs and the MIS weight only'), (2, 'LEVEL 2: + BSDF evaluation and its adjoints')):
+    levels = ((1, 'LEVEL 1: pdfs and the MIS weight only'), (2, 'LEVEL 2: + BSDF evaluation and its adjoints'),
+              (3, 'LEVEL 3 (round 5): FAITHFUL float divisions (quotient off by <= 1 ulp) in the BSDF evaluation, its adjoints and the MIS weight; fp64 islands kept'),
+              (4, 'LEVEL 4 (round 5): level 3 + the pdfs of stage 1'))
+    if len(sys.argv) > 1:
+        levels = tuple(l for l in levels if str(l[0]) in sys.argv[1:])
+    for level, what in levels:
         print('\n### %s\n' % what)
         table(build_fast(level))
 

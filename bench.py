@@ -976,6 +976,12 @@ def run(args):
                 out['large_mesh'] = large_mesh_object(args, dev)
             except Exception as e:      # never lose the headline line to the extra object
                 out['large_mesh'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if forced:      # (the one-rank group of --exchange-world1: torn down BEFORE the line is written -- RCCL's exit-time teardown has cut a line short)
+            step = None
+            import torch.distributed as _d
+            with _stdout_to_stderr():
+                if _d.is_initialized():
+                    _d.destroy_process_group()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -551,7 +551,11 @@ __device__ __forceinline__ unsigned flush_live(const unsigned *stage, unsigned s
     if (staged == 0) return 0;
     __builtin_amdgcn_wave_barrier();        // the staged entries were written by other lanes of this wavefront
     unsigned at = 0;
+#ifdef NVDR_GEN_FAKE_CLAIM     // (timing experiment only: claims spread over 64 counters, the list is garbage)
+    if (lane == 0) at = atomicAdd(p.queues + 32u * (64u + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u)), staged) % 1000000u;
+#else
     if (lane == 0) at = atomicAdd(p.ray_count, staged);
+#endif
     at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
     for (unsigned k = lane; k < staged; k += 64) p.live[at + k] = stage[k];
     __builtin_amdgcn_wave_barrier();

@@ -44,6 +44,13 @@ Extra objects on the JSON line:
                   CANONICAL binary walk over the same rays, measured by a counting kernel) over the same duration.
   cpu_baseline -- the reference's own raygen program compiled for the CPU (oracle/_ref; our plain-C restatement when it
                   did not travel), OpenMP over pixels, brute-force visibility, on a pixel subset of the same view.
+  config.ms_per_step_cached_visibility / iters_per_sec_cached_visibility -- the same iteration with the forward's visibility bits replayed in
+                  backward (exact when forward and backward share the seed; the harness default); never part of `value`.
+  config.adam     -- the parameter update alone, tile-sparse (as run) and dense (what mip-mapped textures would cost).
+  config.exchange -- (N > 1, or --exchange-world1) what the gradient exchange sent last round, the policy that decided it, the time the main stream
+                  stood still for it and the main-stream time of the geometry stage the texture chunk is reduced under.
+  config.one_view -- (default preset, N = 1) the per-GPU share of the 8-GPU run: one view in HIP graphs under the several-rank schedule with a
+                  one-rank RCCL group on the bytes eight ranks would send, + a priced (not measured) projection to 8 GPUs.
 """
 import argparse
 import json

@@ -108,7 +108,8 @@ per = len(views) // world
 mine = views[rank * per:(rank + 1) * per]
 st = DirectLightingStep('bob', res, n, view=mine, n_views=len(views), device='cuda:0', lr=0.03, tex_res=512,
                         pixel_index_offset=mine[0] * res * res, use_graph=(os.environ.get('USE_GRAPH') == '1'),
-                        exchange_mode=os.environ.get('EXCHANGE', 'auto'), pipeline=(os.environ.get('PIPELINE', '1') == '1'))
+                        exchange_mode=os.environ.get('EXCHANGE', 'auto'), pipeline=(os.environ.get('PIPELINE', '1') == '1'),
+                        optimize_geometry=(os.environ.get('GEOM') == '1'), lr_pos=1e-5, perturb_pos=0.002)
 losses = []
 for it in range(8):
     losses.append(float(st.step(world).item()))
@@ -118,6 +119,7 @@ kd = st.params[0].detach().double()
 rep = st._ex.report() if world > 1 else {}
 out = {'rank': rank, 'losses': losses, 'kd_sum': float(kd.sum()), 'kd_abs': float(kd.abs().sum()), 'light_sum': float(st.params[3].detach().double().sum()),
        'nrm_sum': float(st.params[2].detach().double().sum()), 'ks_sum': float(st.params[1].detach().double().sum()),
+       'vpos_sum': float(st.params[-1].detach().double().abs().sum()), 'n_params': len(st.params),
        'resident': bool(getattr(st, '_tex_grad_resident', False)), 'graph': st._graphs is not None, 'exchange': rep}
 print('RESULT ' + json.dumps(out))
 if world > 1:
@@ -126,16 +128,17 @@ if world > 1:
 '''
 
 
-@pytest.mark.parametrize('exchange,pipeline', [('dense', '0'), ('dense', '1'), ('sparse', '1')], ids=['dense_unpipelined', 'dense_pipelined', 'sparse_pipelined'])
+@pytest.mark.parametrize('exchange,pipeline,geom', [('dense', '0', '0'), ('dense', '1', '0'), ('sparse', '1', '0'), ('dense', '1', '1')],
+                         ids=['dense_unpipelined', 'dense_pipelined', 'sparse_pipelined', 'dense_pipelined_geometry_trained'])
 @pytest.mark.parametrize('graph', ['0', '1'], ids=['eager', 'hip_graphs'])
-def test_two_rank_training_follows_the_one_rank_run(graph, exchange, pipeline, dev):
+def test_two_rank_training_follows_the_one_rank_run(graph, exchange, pipeline, geom, dev):
     """Four views dealt over two ranks (gloo for the collective, both on this GPU) train like four views on one rank: the chunked
     exchange sums what the ranks' backward passes scatter-added INTO its buckets, the fused Adam of every chunk sees the batch-mean
     gradient.  Per step the mean of the two ranks' losses is the one-rank loss (each rank's loss is the mean over its own views), and
     the trained textures and probe agree up to the order of the additions."""
     def run(world, rank, port):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), USE_GRAPH=graph,
-                   EXCHANGE=exchange, PIPELINE=pipeline, HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   EXCHANGE=exchange, PIPELINE=pipeline, GEOM=geom, HSA_ENABLE_IPC_MODE_LEGACY='0')
         return subprocess.Popen([sys.executable, '-c', _TRAIN_SNIPPET % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
 
     def result(p):
@@ -152,7 +155,9 @@ def test_two_rank_training_follows_the_one_rank_run(graph, exchange, pipeline, d
         pair = 0.5 * (two[0]['losses'][it] + two[1]['losses'][it])
         assert abs(pair - one['losses'][it]) <= 2e-4 * abs(one['losses'][it]), (it, pair, one['losses'][it])
     assert one['losses'][-1] < one['losses'][0]
-    for k in ('kd_sum', 'ks_sum', 'nrm_sum', 'light_sum'):
+    if geom == '1':     # v_pos travels in the first chunk; the pipelined geometry stage (rebuild, vertex frames, G-buffer) runs from the reduced vertices
+        assert one['n_params'] == 5 and ex_chunk_sizes(two[0]) [0] > 256 * 256 * 3 * 4
+    for k in ('kd_sum', 'ks_sum', 'nrm_sum', 'light_sum') + (('vpos_sum',) if geom == '1' else ()):
         assert abs(two[0][k] - two[1][k]) <= 1e-9 * abs(two[0][k])             # the ranks hold the same parameters ...
         assert abs(two[0][k] - one[k]) <= 1e-4 * abs(one[k]), (k, two[0][k], one[k])      # ... and they are the one-rank parameters
     ex = two[0]['exchange']
@@ -162,6 +167,10 @@ def test_two_rank_training_follows_the_one_rank_run(graph, exchange, pipeline, d
         assert two[0]['exchange']['tiles_touched'] == two[1]['exchange']['tiles_touched']
     else:
         assert ex['bytes_sent'] == ex['bytes_dense']
+
+
+def ex_chunk_sizes(res):
+    return res['exchange']['chunk_bytes_dense']
 
 
 _FORCED_SNIPPET = r'''

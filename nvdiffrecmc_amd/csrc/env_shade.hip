@@ -1303,7 +1303,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 const PixelSetup px = {pos, nrm, view_pos, kd, ks, dgrad, sgrad};
                 F3 d = f3(0.0f), sp = f3(0.0f), g_kd = f3(0.0f), g_ks = f3(0.0f), g_pos = f3(0.0f), g_nrm = f3(0.0f), lg = f3(0.0f);
                 shade_sample<BACKWARD>(p, px, rd, texel, occluded, sample_frac, d, sp, g_kd, g_ks, g_pos, g_nrm, lg);
-                if (BACKWARD) {
+                if constexpr (BACKWARD) {
                     lg_has = !(dbg & 2u) && (lg.x != 0.0f || lg.y != 0.0f || lg.z != 0.0f);
                     lg_rec = make_float4(lg.x, lg.y, lg.z, __int_as_float(texel));
                     out[0] = g_kd.x; out[1] = g_kd.y; out[2] = g_kd.z; out[3] = g_ks.x; out[4] = g_ks.y; out[5] = g_ks.z;
@@ -1340,7 +1340,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 #pragma unroll
             for (int c = 0; c < NF; ++c) v[c] = group_sum(res[e][c][lane], 64);
             if (lane == 0) {
-                if (BACKWARD) {
+                if constexpr (BACKWARD) {
                     float *o = p.g_kd + (int64_t)lin * 3;
                     o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
                     o = p.g_ks + (int64_t)lin * 3;

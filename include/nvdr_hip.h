@@ -472,6 +472,12 @@ int nvdr_tile_scatter(const float *compact, const int32_t *list, const int32_t *
 
 /* ---- test hook: evaluate include/nvdr_detmath.h on device.  op: 0 sin, 1 cos, 2 acos, 3 atan2(x,y). */
 int nvdr_test_detmath(int op, const float *x, const float *y, int64_t n, float *out, void *stream);
+/* ---- test hook: csrc/ieee_arith.h (the correctly rounded division / square root of the shading kernels without the compiler's range
+ * scaling) against the compiler's own `/`, sqrtf, sqrt on the device: every float through the square root, 3 * 2^30 divisions inside
+ * the documented domain, the special values, fp64 on doubles made of floats.  counters: 7 uint64 in device memory (zeroed here):
+ * [0] sqrt mismatches in the domain, [1] among positive inputs below 2^-96 and negative denormals (outside it), [2] division, [3] special values, [4] fp64 division, [5] fp64 square
+ * root, [6] comparisons made.  [0], [2]-[5] must read 0. */
+int nvdr_test_arith(unsigned long long *counters, void *stream);
 
 #ifdef __cplusplus
 }

@@ -175,6 +175,7 @@ _SIGNATURES = {
     'nvdr_tile_gather': [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p],
     'nvdr_tile_scatter': [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p],
     'nvdr_test_detmath': [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+    'nvdr_test_arith': [c_void_p, c_void_p],
 }
 _RESTYPES = {'nvdr_last_error': ctypes.c_char_p, 'nvdr_image_loss_num_partials': c_int64, 'nvdr_abi_sizeof': ctypes.c_size_t}
 # nvdr_abi_sizeof(which) -> the ctypes mirror that must have that size (checked once at load: a stale library or a stale mirror is an error)

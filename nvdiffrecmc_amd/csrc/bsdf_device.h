@@ -7,10 +7,13 @@
 //
 // Arithmetic follows the reference's evaluation order and its float/double promotions (the
 // unsuffixed literals in bsdf.h make several sub-expressions fp64); the file is
-// built with -ffp-contract=off, so it rounds like the CPU oracle (oracle/nvdr_oracle.c).
+// built with -ffp-contract=off, so it rounds like the CPU oracle (oracle/nvdr_oracle.c).  Divisions and square roots whose operands are
+// bounded by construction go through ieee_arith.h (the same correctly rounded results in 9 instead of 11 / 17 instructions); the bound is
+// named at each site.
 #pragma once
 
 #include "common.h"
+#include "ieee_arith.h"
 
 #define NVDR_SPECULAR_EPSILON 1e-4f
 #define NVDR_PI_FLT 3.14159265358979323846f
@@ -21,7 +24,9 @@ __device__ __forceinline__ F3 cross3(F3 a, F3 b)
     return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
-__device__ __forceinline__ F3 div3(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+// (the callers' s: a length that passed `> 0` -- a square root, hence above 2^-75 --, a cosine above NVDR_SPECULAR_EPSILON, or a cosine whose
+// quotient is selected away unless it is above it: fwd_pbr_specular)
+__device__ __forceinline__ F3 div3(F3 a, float s) { return f3(nvdr_div(a.x, s), nvdr_div(a.y, s), nvdr_div(a.z, s)); }
 
 __device__ __forceinline__ void bwd_dot(F3 a, F3 b, F3 &d_a, F3 &d_b, float d_out)
 {
@@ -39,15 +44,17 @@ __device__ __forceinline__ void bwd_cross(F3 a, F3 b, F3 &d_a, F3 &d_b, F3 d_out
 }
 __device__ __forceinline__ F3 safe_normalize(F3 v)
 {
-    const float l = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const float l = nvdr_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
     return l > 0.0f ? div3(v, l) : f3(0.0f);
 }
 __device__ __forceinline__ void bwd_safe_normalize(F3 v, F3 &d_v, F3 d_out)
 {
     const float l2 = v.x * v.x + v.y * v.y + v.z * v.z;
-    const float l = sqrtf(l2);
+    const float l = nvdr_sqrt(l2);
     if (l > 0.0f) {
-        const float fac = 1.0f / (l2 * sqrtf(l2));      // == (float)(1.0 / (double)(.)) of the reference: a double quotient of floats rounds to the float quotient
+        // == (float)(1.0 / (double)(.)) of the reference: a double quotient of floats rounds to the float quotient.  (Plain `/`: l2 * l of a
+        // short vector may be denormal.)
+        const float fac = 1.0f / (l2 * l);
         d_v.x += (d_out.x * (v.y * v.y + v.z * v.z) - d_out.y * (v.x * v.y) - d_out.z * (v.x * v.z)) * fac;
         d_v.y += (d_out.y * (v.x * v.x + v.z * v.z) - d_out.x * (v.y * v.x) - d_out.z * (v.y * v.z)) * fac;
         d_v.z += (d_out.z * (v.x * v.x + v.y * v.y) - d_out.x * (v.z * v.x) - d_out.y * (v.z * v.y)) * fac;
@@ -57,10 +64,10 @@ __device__ __forceinline__ float luminance(F3 c) { return dot3(c, f3(0.2126f, 0.
 __device__ __forceinline__ float pow5f(float x) { const float x2 = x * x; return x2 * x2 * x; }
 
 // ---- Lambert -------------------------------------------------------------------------------
-__device__ __forceinline__ float fwd_lambert(F3 nrm, F3 wi) { return fmaxf(dot3(nrm, wi) / NVDR_PI_FLT, 0.0f); }
+__device__ __forceinline__ float fwd_lambert(F3 nrm, F3 wi) { return fmaxf(nvdr_div(dot3(nrm, wi), NVDR_PI_FLT), 0.0f); }
 __device__ __forceinline__ void bwd_lambert(F3 nrm, F3 wi, F3 &d_nrm, F3 &d_wi, float d_out)
 {
-    if (dot3(nrm, wi) > 0.0f) bwd_dot(nrm, wi, d_nrm, d_wi, d_out / NVDR_PI_FLT);
+    if (dot3(nrm, wi) > 0.0f) bwd_dot(nrm, wi, d_nrm, d_wi, nvdr_div(d_out, NVDR_PI_FLT));
 }
 
 // ---- Fresnel-Schlick (scalar and rgb) --------------------------------------------------------
@@ -107,7 +114,7 @@ __device__ __forceinline__ float fwd_ndf_ggx(float alphaSqr, float cosTheta)
 {
     const float c = clampf(cosTheta, NVDR_SPECULAR_EPSILON, 1.0f - NVDR_SPECULAR_EPSILON);
     const float d = (c * alphaSqr - c) * c + 1.0f;
-    return alphaSqr / (d * d * NVDR_PI_FLT);
+    return nvdr_div(alphaSqr, d * d * NVDR_PI_FLT);       // d = 1 - c^2 (1 - alphaSqr) >= 1 - (1 - 1e-4)^2 = 2e-4
 }
 __device__ __forceinline__ void bwd_ndf_ggx(float alphaSqr, float cosTheta, float &d_alphaSqr, float &d_cos, float d_out)
 {
@@ -115,9 +122,9 @@ __device__ __forceinline__ void bwd_ndf_ggx(float alphaSqr, float cosTheta, floa
     const float c2 = c * c;
     const float base = (float)(((double)alphaSqr - 1.0) * (double)c2 + 1.0);
     const float cube = base * base * base;
-    d_alphaSqr += d_out * (1.0f - (alphaSqr + 1.0f) * c2) / (NVDR_PI_FLT * cube);
+    d_alphaSqr += nvdr_div(d_out * (1.0f - (alphaSqr + 1.0f) * c2), NVDR_PI_FLT * cube);     // base >= 2e-4 as d above: cube >= 8e-12
     if (cosTheta > NVDR_SPECULAR_EPSILON && cosTheta < 1.0f - NVDR_SPECULAR_EPSILON)
-        d_cos += d_out * -(4.0f * (alphaSqr - 1.0f) * alphaSqr * cosTheta) / (NVDR_PI_FLT * cube);
+        d_cos += nvdr_div(d_out * -(4.0f * (alphaSqr - 1.0f) * alphaSqr * cosTheta), NVDR_PI_FLT * cube);
 }
 
 // ---- Smith Lambda / correlated masking -----------------------------------------------------------
@@ -125,28 +132,28 @@ __device__ __forceinline__ float fwd_lambda_ggx(float alphaSqr, float cosTheta)
 {
     const float c = clampf(cosTheta, NVDR_SPECULAR_EPSILON, 1.0f - NVDR_SPECULAR_EPSILON);
     const float c2 = c * c;
-    const float tan2 = (float)((1.0 - (double)c2) / (double)c2);
-    return 0.5f * (sqrtf(1.0f + alphaSqr * tan2) - 1.0f);
+    const float tan2 = (float)nvdr_ddiv(1.0 - (double)c2, (double)c2);        // c2 >= 1e-8
+    return 0.5f * (nvdr_sqrt(1.0f + alphaSqr * tan2) - 1.0f);
 }
 __device__ __forceinline__ void bwd_lambda_ggx(float alphaSqr, float cosTheta, float &d_alphaSqr, float &d_cos, float d_out)
 {
     const float c = clampf(cosTheta, NVDR_SPECULAR_EPSILON, 1.0f - NVDR_SPECULAR_EPSILON);
     const float c2 = c * c;
-    const float tan2 = (float)((1.0 - (double)c2) / (double)c2);
-    d_alphaSqr += (float)((double)d_out * (0.25 * (double)tan2) / (double)sqrtf(alphaSqr * tan2 + 1.0f));
+    const float tan2 = (float)nvdr_ddiv(1.0 - (double)c2, (double)c2);
+    d_alphaSqr += (float)nvdr_ddiv((double)d_out * (0.25 * (double)tan2), (double)nvdr_sqrt(alphaSqr * tan2 + 1.0f));
     if (cosTheta > NVDR_SPECULAR_EPSILON && cosTheta < 1.0f - NVDR_SPECULAR_EPSILON)
-        d_cos += (float)((double)d_out * -(0.5 * (double)alphaSqr) /
-                         (double)((c * c * c) * sqrtf(alphaSqr / c2 - alphaSqr + 1.0f)));
+        d_cos += (float)nvdr_ddiv((double)d_out * -(0.5 * (double)alphaSqr),
+                                  (double)((c * c * c) * nvdr_sqrt(nvdr_div(alphaSqr, c2) - alphaSqr + 1.0f)));     // c^3 >= 1e-12, the root >= 1
 }
 __device__ __forceinline__ float fwd_masking_smith(float alphaSqr, float cosI, float cosO)
 {
-    return 1.0f / (1.0f + fwd_lambda_ggx(alphaSqr, cosI) + fwd_lambda_ggx(alphaSqr, cosO));
+    return nvdr_div(1.0f, 1.0f + fwd_lambda_ggx(alphaSqr, cosI) + fwd_lambda_ggx(alphaSqr, cosO));     // 1 <= the sum <= 1e4
 }
 __device__ __forceinline__ void bwd_masking_smith(float alphaSqr, float cosI, float cosO, float &d_alphaSqr,
                                                   float &d_cosI, float &d_cosO, float d_out)
 {
     const float s = 1.0f + fwd_lambda_ggx(alphaSqr, cosI) + fwd_lambda_ggx(alphaSqr, cosO);
-    const float d_l = -d_out / (s * s);
+    const float d_l = nvdr_div(-d_out, s * s);
     bwd_lambda_ggx(alphaSqr, cosI, d_alphaSqr, d_cosI, d_l);
     bwd_lambda_ggx(alphaSqr, cosO, d_alphaSqr, d_cosO, d_l);
 }

@@ -255,7 +255,7 @@ __device__ __forceinline__ void lcg_skip_coeff(unsigned k, unsigned &am, unsigne
 __device__ __forceinline__ void branchless_onb(F3 n, F3 &b1, F3 &b2)
 {
     const float sign = copysignf(1.0f, n.z);
-    const float a = -1.0f / (sign + n.z);
+    const float a = nvdr_div(-1.0f, sign + n.z);         // n is a unit vector here: 1 <= |sign + n.z| <= 2
     const float b = n.x * n.y * a;
     b1 = f3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
     b2 = f3(b, sign + n.y * n.y * a, -n.y);
@@ -269,8 +269,8 @@ __device__ __forceinline__ F3 cosine_sample(F3 N, float u, float v, float &pdf)
     F3 dx, dy;
     branchless_onb(N, dx, dy);
     const float phi = (float)(2.0 * NVDR_PI_DBL * (double)u);
-    const float costheta = sqrtf(v);
-    const float sintheta = (float)sqrt(1.0 - (double)v);
+    const float costheta = nvdr_sqrt(v);                // v = (stratum + k 2^-24) / n: zero or above 2^-27
+    const float sintheta = (float)nvdr_dsqrt(1.0 - (double)v);
     float sp, cp;
     nvdr_sincosf(phi, &sp, &cp);
     const float x = cp * sintheta, y = sp * sintheta, z = costheta;
@@ -329,7 +329,7 @@ __device__ __forceinline__ float sample_cdf(const float *__restrict__ cdf, int s
         pdf = d0 - d1;
         sample = x - d1;
     }
-    return fminf(sample / pdf, 0.99999994f);
+    return fminf(nvdr_div(sample, pdf), 0.99999994f);       // pdf: a step of a normalised cumulative sum -- zero (the fix-up) or far above the denormals
 }
 // The same inversion through a GUIDE TABLE (cdf_guide_kernel): the bisection above returns the first entry above x (or the last
 // entry); guide[k] is the first entry above k / K for the cell k = floor(x * K) of x (K a power of two: the product is exact), which
@@ -354,7 +354,7 @@ __device__ __forceinline__ float sample_cdf_guided(const float *__restrict__ cdf
         pdf = d0 - d1;
         sample = x - d1;
     }
-    return fminf(sample / pdf, 0.99999994f);
+    return fminf(nvdr_div(sample, pdf), 0.99999994f);       // pdf: a step of a normalised cumulative sum -- zero (the fix-up) or far above the denormals
 }
 // one thread per (table row, cell): lower bound of cell / K in the row's CDF (rows < n_rows: the column CDF of that row; row n_rows:
 // the row CDF), cells K_cols resp. K_rows wide rows of `guide` (row pitch = max of the two)
@@ -391,7 +391,7 @@ __device__ __forceinline__ float light_pdf(const ShadeParams &p, F3 dir, int &tx
     ty = clampi((int)(cv * (float)p.light.n0), 0, p.light.n0 - 1);
     float s, c;
     nvdr_sincosf((float)((double)cv * NVDR_PI_DBL), &s, &c);
-    const float pdf_weight = (float)((double)(Hl * Wl) / (2.0 * NVDR_PI_DBL * NVDR_PI_DBL * (double)fmaxf(s, 0.0001f)));
+    const float pdf_weight = (float)nvdr_ddiv((double)(Hl * Wl), 2.0 * NVDR_PI_DBL * NVDR_PI_DBL * (double)fmaxf(s, 0.0001f));
     return p.pdf.p[y * p.pdf.s0 + x * p.pdf.s1] * pdf_weight;
 }
 // the direction of a light sample alone (light_sample without its pdf: the generation kernel asks for the pdf of live samples only)
@@ -403,14 +403,14 @@ __device__ __forceinline__ F3 light_sample_dir(const ShadeParams &p, float u, fl
                                  : sample_cdf(p.rows.p, p.rows.s0, p.rows.n0, v, y);
     const float rx = p.cdf_guide ? sample_cdf_guided(p.cols.p + (int64_t)y * p.cols.s0, p.cols.s1, p.cols.n1, u, p.cdf_guide + (int64_t)y * pitch, p.guide_log_cols, x)
                                  : sample_cdf(p.cols.p + (int64_t)y * p.cols.s0, p.cols.s1, p.cols.n1, u, x);
-    return tc_to_dir(((float)x + rx) / (float)p.pdf.n1, ((float)y + ry) / (float)p.pdf.n0);
+    return tc_to_dir(nvdr_div((float)x + rx, (float)p.pdf.n1), nvdr_div((float)y + ry, (float)p.pdf.n0));
 }
 __device__ __forceinline__ F3 light_sample(const ShadeParams &p, float u, float v, float &pdf, int &tx, int &ty)
 {
     unsigned x, y;
     const float ry = sample_cdf(p.rows.p, p.rows.s0, p.rows.n0, v, y);
     const float rx = sample_cdf(p.cols.p + (int64_t)y * p.cols.s0, p.cols.s1, p.cols.n1, u, x);
-    const F3 d = tc_to_dir(((float)x + rx) / (float)p.pdf.n1, ((float)y + ry) / (float)p.pdf.n0);
+    const F3 d = tc_to_dir(nvdr_div((float)x + rx, (float)p.pdf.n1), nvdr_div((float)y + ry, (float)p.pdf.n0));
     pdf = light_pdf(p, d, tx, ty);
     return d;
 }
@@ -418,35 +418,35 @@ __device__ __forceinline__ float eval_ndf_ggx(float alpha, float cosTheta)
 {
     const float a2 = alpha * alpha;
     const float d = ((cosTheta * a2 - cosTheta) * cosTheta + 1);
-    return (float)((double)a2 / ((double)(d * d) * NVDR_PI_DBL));
+    return (float)nvdr_ddiv((double)a2, (double)(d * d) * NVDR_PI_DBL);
 }
 __device__ __forceinline__ float eval_g1_ggx(float alphaSqr, float cosTheta)
 {
     if (cosTheta <= 0) return 0;
     const float c2 = cosTheta * cosTheta;
-    const float tan2 = fmaxf(1.0f - c2, 0.0f) / c2;
-    return 2 / (1 + sqrtf(1 + alphaSqr * tan2));
+    const float tan2 = fmaxf(1.0f - c2, 0.0f) / c2;         // (plain `/`: the square of an unclamped cosine may be denormal)
+    return nvdr_div(2.0f, 1 + nvdr_sqrt(1 + alphaSqr * tan2));
 }
 __device__ __forceinline__ float eval_pdf_ggx_vndf(float alpha, F3 wo, F3 h)
 {
     const float G1 = eval_g1_ggx(alpha * alpha, wo.z);
     const float D = eval_ndf_ggx(alpha, h.z);
-    return G1 * D * fmaxf(0.f, dot3(wo, h)) / wo.z;
+    return G1 * D * fmaxf(0.f, dot3(wo, h)) / wo.z;         // (plain `/` here and for `/ (4 woDotH)` below: unclamped cosines -- ieee_arith.h)
 }
 __device__ __forceinline__ F3 sample_ggx_vndf(float alpha, F3 wo, float ux, float uy, float &pdf)
 {
     const F3 Vh = safe_normalize(f3(alpha * wo.x, alpha * wo.y, wo.z));
     const F3 T1 = (Vh.z < 0.9999f) ? safe_normalize(cross3(f3(0.f, 0.f, 1.f), Vh)) : f3(1.f, 0.f, 0.f);
     const F3 T2 = cross3(Vh, T1);
-    const float r = sqrtf(ux);
+    const float r = nvdr_sqrt(ux);
     const float phi = (2.f * NVDR_PI_FLT) * uy;
     float sp, cp;
     nvdr_sincosf(phi, &sp, &cp);
     const float t1 = r * cp;
     float t2 = r * sp;
     const float s = 0.5f * (1.f + Vh.z);
-    t2 = (1.f - s) * sqrtf(1.f - t1 * t1) + s * t2;
-    const F3 Nh = (T1 * t1 + T2 * t2) + Vh * sqrtf(fmaxf(0.f, 1.f - t1 * t1 - t2 * t2));
+    t2 = (1.f - s) * nvdr_sqrt(1.f - t1 * t1) + s * t2;        // (differences of numbers of order one: zero or above 2^-25)
+    const F3 Nh = (T1 * t1 + T2 * t2) + Vh * nvdr_sqrt(fmaxf(0.f, 1.f - t1 * t1 - t2 * t2));
     const F3 h = safe_normalize(f3(alpha * Nh.x, alpha * Nh.y, fmaxf(0.f, Nh.z)));
     pdf = eval_pdf_ggx_vndf(alpha, wo, h);
     return h;
@@ -855,7 +855,7 @@ __device__ __forceinline__ void shade_sample(const ShadeParams &p, const PixelSe
     const F3 light_col = fetch_light_texel(p.light, texel);
     // (float)(1.0 / (double)f) of the reference == the IEEE float quotient 1.0f / f: rounding a double quotient of two floats
     // to float is innocuous double rounding (53 >= 2 * 24 + 2 bits)
-    const float mis_weight = 1.0f / fmaxf(pdfSum, 0.0001f);
+    const float mis_weight = nvdr_div(1.0f, fmaxf(pdfSum, 0.0001f));
     F3 _diff = f3(0.0f), _spec = f3(0.0f);
     if (p.bsdf == 1 || p.bsdf == 2)
         _diff = f3(fwd_lambert(px.nrm, dir));

@@ -541,7 +541,7 @@ __device__ __forceinline__ F3 fetch_light_texel(const Tab &t, int texel)
 // ---------------------------------------------------------------------------------------------
 // stage 1: sample generation (kernel.cu:463-526 minus process_sample)
 
-#define NVDR_GEN_STAGE 512u
+#define NVDR_GEN_STAGE 480u         // (with the ring's 11 KB and the queues' 20 KB: 40 448 bytes per workgroup, four of them in a CU's 160 KB)
 #define NVDR_GEN_RING 64u          // pixels whose set-up the queued samples of a wavefront may still refer to
 #define NVDR_GEN_QCAP 128u         // entries of one lobe queue (< 64 waiting + <= 64 pushed per round)
 
@@ -584,6 +584,9 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
     const unsigned S = p.S, n = p.n;
     const float strata_frac = 1.0f / (float)n;
+    // stratum / n as a multiplication: n_magic = ceil(2^32 / n) gives the exact quotient of every stratum < 2^16 (the error term
+    // stratum * (n_magic * n - 2^32) stays below 2^32); n = 1 wraps to 0, and its only stratum is 0
+    const unsigned n_magic = 0xFFFFFFFFu / n + 1u;
     // Live-ray list: a device-scope atomic per wavefront and round serialises on its one address (61 k of them cost
     // 0.4 ms); each wavefront therefore stages slots in LDS and claims list space once per NVDR_GEN_STAGE-128 entries.
     __shared__ unsigned stage_all[4][NVDR_GEN_STAGE];
@@ -598,14 +601,16 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     // A third queue does the same for the LIGHT samples: half of them point under the horizon -- known as soon as the direction is --
     // and need neither the light pdf (atan2, acos, sincos, pdf lookup) nor the BSDF pdf; the live ones are queued (direction, stratum,
     // pixel) and get both 64 at a time.
-    // (LDS of a workgroup: 38 KB, four workgroups per CU.)
+    // (LDS of a workgroup: 39.5 KB, four workgroups per CU.)
     __shared__ float4 ring_a_all[4][NVDR_GEN_RING], ring_b_all[4][NVDR_GEN_RING];      // (normal, alpha), (wo, pDiffuse)
     __shared__ unsigned ring_pi_all[4][NVDR_GEN_RING];                                  // the pixel's index in the chunk
+    __shared__ unsigned ring_rng_all[4][3][NVDR_GEN_RING];                              // the pixel's random state and its two permutation rows
     __shared__ float2 lobe_xy_all[4][2][NVDR_GEN_QCAP];                                 // BSDF tasks: (sx, sy) ...
     __shared__ unsigned lobe_key_all[4][2][NVDR_GEN_QCAP];                              // ... and stratum | ring entry << 16; [0] diffuse, [1] specular lobe
     __shared__ float4 lightq_all[4][NVDR_GEN_QCAP];                                     // live light samples: (direction, stratum | ring entry << 16)
     float4 *ring_a = ring_a_all[wave], *ring_b = ring_b_all[wave];
     unsigned *ring_pi = ring_pi_all[wave];
+    unsigned *ring_rng[3] = {ring_rng_all[wave][0], ring_rng_all[wave][1], ring_rng_all[wave][2]};
     float2 *lobe_xy[2] = {lobe_xy_all[wave][0], lobe_xy_all[wave][1]};
     unsigned *lobe_key[2] = {lobe_key_all[wave][0], lobe_key_all[wave][1]};
     float4 *lightq = lightq_all[wave];
@@ -682,40 +687,58 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         }
     };
 
+    // The per-pixel set-up (kernel.cu:490-505: five strided fetches, wo, the lobe probabilities, the pixel's random state) is the same for
+    // all lanes of a pixel, and a wavefront that ran it pixel by pixel spent a fifth of its instructions on it -- ~400 vector instructions
+    // with every lane computing the same numbers, and the fetches' latency in front of every pixel.  It now runs ONE PIXEL PER LANE for
+    // all the pixels of a ring cycle at once (the wavefront's next 64 >> log2(G) groups, when the ring wraps and the queues are empty)
+    // and leaves what the rounds need in the ring; a round then starts with four LDS reads.  Same arithmetic per pixel, same results.
+    const int log2G = 6 - p.log2L;
     for (unsigned grp = blockIdx.x * (blockDim.x >> 6) + wave; grp < n_groups; grp += waves_total) {
-        const unsigned pi = grp * G + slot;                 // index inside the chunk
-        const bool valid = pi < P;
-        const int lin = p.pix_list[p.pix_begin + (valid ? pi : 0u)];
-        const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
-        const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
-        const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
-        // per-pixel set-up (kernel.cu:490-505)
-        const float alpha = ks.y * ks.y;
-        const F3 wo = safe_normalize(view_pos - pos);
-        const float metallic = ks.z;
-        const F3 specColor = f3(0.04f) * (1.0f - metallic) + kd * metallic;
-        const float diffuseWeight = (1.f - metallic) * luminance(kd);
-        const float specularWeight = albedo(specColor, wo, nrm);
-        const float pDiffuse = (diffuseWeight + specularWeight) > 0.f ? diffuseWeight / (diffuseWeight + specularWeight) : 1.f;
-        const unsigned ring_at = (groups_done % ring_groups) * (unsigned)G + (unsigned)slot;
-        if (sub == 0 && valid) {
-            const F3 ro = fetch3(p.ro, z, y, x);
-            p.pix_origin[pi] = make_float4(ro.x, ro.y, ro.z, 0.0f);
-            // what stage 3 shades this pixel's samples with, in one 64-byte record behind ONE pointer: its kernels then keep two strided
-            // views (the incoming gradients) in scalar registers instead of seven (round 5: the parameter block no longer spills)
-            float4 *su = p.pix_setup + 4 * (int64_t)pi;
-            su[0] = make_float4(pos.x, pos.y, pos.z, nrm.x);
-            su[1] = make_float4(nrm.y, nrm.z, view_pos.x, view_pos.y);
-            su[2] = make_float4(view_pos.z, kd.x, kd.y, kd.z);
-            su[3] = make_float4(ks.x, ks.y, ks.z, 0.0f);
-            ring_a[ring_at] = make_float4(nrm.x, nrm.y, nrm.z, alpha);
-            ring_b[ring_at] = make_float4(wo.x, wo.y, wo.z, pDiffuse);
-            ring_pi[ring_at] = pi;
+        const unsigned in_cycle = groups_done % ring_groups;
+        if (in_cycle == 0u) {
+            const unsigned long long a_grp = (unsigned long long)grp + (unsigned long long)(lane >> log2G) * waves_total;
+            const unsigned a_pi = (unsigned)a_grp * (unsigned)G + ((unsigned)lane & (unsigned)(G - 1));
+            const bool a_valid = a_grp < n_groups && a_pi < P;
+            const int lin = p.pix_list[p.pix_begin + (a_valid ? a_pi : 0u)];
+            const int x = lin % p.W, y = (lin / p.W) % p.H, z = lin / (p.W * p.H);
+            const F3 pos = fetch3(p.pos, z, y, x), nrm = fetch3(p.nrm, z, y, x);
+            const F3 view_pos = fetch3(p.view_pos, z, y, x), kd = fetch3(p.kd, z, y, x), ks = fetch3(p.ks, z, y, x);
+            const float alpha = ks.y * ks.y;
+            const F3 wo = safe_normalize(view_pos - pos);
+            const float metallic = ks.z;
+            const F3 specColor = f3(0.04f) * (1.0f - metallic) + kd * metallic;
+            const float diffuseWeight = (1.f - metallic) * luminance(kd);
+            const float specularWeight = albedo(specColor, wo, nrm);
+            const float pDiffuse = (diffuseWeight + specularWeight) > 0.f ? diffuseWeight / (diffuseWeight + specularWeight) : 1.f;
+            unsigned a_seed = launch_seed(p), b_seed = (unsigned)lin + p.pix_offset;
+            unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
+            const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
+            const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
+            __builtin_amdgcn_wave_barrier();                // (the batches that read the previous cycle's entries have run: the queues are empty here)
+            if (a_valid) {
+                const F3 ro = fetch3(p.ro, z, y, x);
+                p.pix_origin[a_pi] = make_float4(ro.x, ro.y, ro.z, 0.0f);
+                // what stage 3 shades this pixel's samples with, in one 64-byte record behind ONE pointer: its kernels then keep two strided
+                // views (the incoming gradients) in scalar registers instead of seven (round 5: the parameter block no longer spills)
+                float4 *su = p.pix_setup + 4 * (int64_t)a_pi;
+                su[0] = make_float4(pos.x, pos.y, pos.z, nrm.x);
+                su[1] = make_float4(nrm.y, nrm.z, view_pos.x, view_pos.y);
+                su[2] = make_float4(view_pos.z, kd.x, kd.y, kd.z);
+                su[3] = make_float4(ks.x, ks.y, ks.z, 0.0f);
+            }
+            ring_a[lane] = make_float4(nrm.x, nrm.y, nrm.z, alpha);
+            ring_b[lane] = make_float4(wo.x, wo.y, wo.z, pDiffuse);
+            ring_pi[lane] = a_valid ? a_pi : 0xFFFFFFFFu;
+            ring_rng[0][lane] = rng0; ring_rng[1][lane] = lightIdx; ring_rng[2][lane] = bsdfIdx;
+            __builtin_amdgcn_wave_barrier();
         }
-        unsigned a_seed = launch_seed(p), b_seed = (unsigned)lin + p.pix_offset;
-        unsigned rng0 = rand_pcg(a_seed) ^ rand_pcg(b_seed);
-        const unsigned lightIdx = rand_pcg(rng0) % p.n_perms;
-        const unsigned bsdfIdx = rand_pcg(rng0) % p.n_perms;
+        const unsigned ring_at = in_cycle * (unsigned)G + (unsigned)slot;
+        const unsigned pi = ring_pi[ring_at];               // index inside the chunk
+        const bool valid = pi != 0xFFFFFFFFu;
+        const float4 ra = ring_a[ring_at];
+        const F3 nrm = f3(ra.x, ra.y, ra.z);
+        const float pDiffuse = ring_b[ring_at].w;
+        const unsigned rng0 = ring_rng[0][ring_at], lightIdx = ring_rng[1][ring_at], bsdfIdx = ring_rng[2][ring_at];
 
         for (unsigned base = 0; base < S; base += L) {
             const unsigned i = base + sub;
@@ -729,13 +752,15 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
                 unsigned rng = jm * rng0 + ja;
                 // light importance sample (kernel.cu:513-516)
                 const unsigned pl = (unsigned)p.perms[(int64_t)lightIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
-                float sx = ((float)(pl % n) + uniform_pcg(rng)) * strata_frac;
-                float sy = ((float)(pl / n) + uniform_pcg(rng)) * strata_frac;
+                const unsigned pl_y = __umulhi(pl, n_magic), pl_x = pl - pl_y * n;        // pl / n, pl % n
+                float sx = ((float)pl_x + uniform_pcg(rng)) * strata_frac;
+                float sy = ((float)pl_y + uniform_pcg(rng)) * strata_frac;
                 const F3 dirA = light_sample_dir(p, sx, sy);
                 // BSDF importance sample (kernel.cu:522-526): the numbers are drawn here, the lobe is sampled in run_batch
                 const unsigned pb = (unsigned)p.perms[(int64_t)bsdfIdx * p.perm_s0 + (int64_t)i * p.perm_s1];
-                sx = ((float)(pb % n) + uniform_pcg(rng)) * strata_frac;
-                sy = ((float)(pb / n) + uniform_pcg(rng)) * strata_frac;
+                const unsigned pb_y = __umulhi(pb, n_magic), pb_x = pb - pb_y * n;
+                sx = ((float)pb_x + uniform_pcg(rng)) * strata_frac;
+                sy = ((float)pb_y + uniform_pcg(rng)) * strata_frac;
                 const float sz = uniform_pcg(rng);
                 cosine = sz < pDiffuse;
                 task = make_float4(sx, sy, __uint_as_float(pb | (ring_at << 16)), 0.0f);

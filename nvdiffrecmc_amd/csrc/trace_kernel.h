@@ -142,6 +142,9 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     uint8_t *__restrict__ vis = a.vis;
     unsigned long long *counters = a.counters;
     const unsigned rays_per_pixel = a.rays_per_pixel;
+    // slot -> pixel: a shift when the pixel's 2 n^2 slots are a power of two (n_samples_x = 8, 16, ...), the division otherwise (wave-uniform)
+    const bool rpp_pow2 = (rays_per_pixel & (rays_per_pixel - 1u)) == 0u;
+    const unsigned rpp_shift = (unsigned)__builtin_ctz(rays_per_pixel | 0x80000000u);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     char *wbase = (char *)smem + wave * NVDR_TRACE_LDS_PER_WAVE;
     OctStack stack;
@@ -240,7 +243,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                     ray = (int)slot;
                     if (COUNT) n_ray++;
                     const float4 rd = rays[slot];
-                    const float4 ro = pix_origin[slot / rays_per_pixel];
+                    const float4 ro = pix_origin[rpp_pow2 ? slot >> rpp_shift : slot / rays_per_pixel];
                     ox = ro.x; oy = ro.y; oz = ro.z;
                     dx = rd.x; dy = rd.y; dz = rd.z;
                     g.ix = fminf(fmaxf(__builtin_amdgcn_rcpf(dx * gsx), -1.0e30f), 1.0e30f);

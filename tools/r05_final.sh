@@ -28,8 +28,6 @@ trace() { name=$1; shift; rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace -
   timeout 60 python $R/tools/rocpd_iteration.py /tmp/kt/r_results.db light_rows_kernel -8 > $O/${name}_iteration.txt 2>&1; head -1 $O/${name}_iteration.txt; }
 trace kernel_trace_bob512_8views --steps 20 --warmup 5
 trace kernel_trace_bob512_1view --batch 1 --graph on --steps 40 --warmup 10
-trace kernel_trace_bob512_1view_several_rank_schedule --batch 1 --graph on --steps 40 --warmup 10 --exchange-world1
-trace kernel_trace_dmtet800_1view_unlocked --config dmtet800 --batch 1 --graph on --steps 30 --warmup 8
 trace kernel_trace_dmtet800_8views_unlocked --config dmtet800 --steps 8 --warmup 3
 cd $R
 one() { name=$1; shift; timeout 300 python bench.py "$@" --no-cpu-baseline --no-pmc --no-large-mesh --no-other-configs --no-one-view --steps 100 --warmup 20 2>/dev/null | tail -1 > $O/$name.json
@@ -37,10 +35,8 @@ one() { name=$1; shift; timeout 300 python bench.py "$@" --no-cpu-baseline --no-
 import json; d=json.load(open('$O/$name.json')); e=d['config'].get('exchange') or {}
 print('$name', d['hip_graph'], round(d['ms_per_step'],3), round(d['median_ms_per_step'],3), d['steps_over_twice_the_median'], {k: e.get(k) for k in ('mode','policy','bytes_sent','exposed_ms','geometry_stage_ms')} if e else '')"; }
 one oneview_bob512_graph_on --batch 1 --graph on
-one oneview_bob512_graph_off --batch 1 --graph off
 one oneview_bob512_schedule_auto --batch 1 --graph on --exchange-world1
 one oneview_bob512_schedule_sparse --batch 1 --graph on --exchange-world1 --exchange sparse
-one oneview_bob512_schedule_dense_unpipelined --batch 1 --graph on --exchange-world1 --exchange dense --no-pipeline
 one oneview_dmtet800_unlocked_graph_on --config dmtet800 --batch 1 --graph on
 one oneview_dmtet800_unlocked_schedule --config dmtet800 --batch 1 --graph on --exchange-world1
 one oneview_dmtet800_locked_graph_on --config dmtet800 --batch 1 --graph on --lock-pos on

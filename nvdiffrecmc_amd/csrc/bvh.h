@@ -153,7 +153,7 @@ struct nvdr_ctx {
     // env-shade scratch
     int *pix_list = nullptr;       // [N*H*W] compacted indices of the covered pixels of the whole launch
     int64_t pix_cap = 0;
-    unsigned *chunk_counts = nullptr; // [NVDR_MAX_CHUNKS] live-ray count of every chunk of the ray stream
+    unsigned *chunk_counts = nullptr; // [NVDR_MAX_CHUNKS][544] per chunk of the ray stream, one counter per 128-byte line: the lengths of the live list's segments, their capacity (trace_kernel.h)
     int64_t stream_cap_pixels = 0; // pixels one chunk of the ray stream holds (x 2S rays)
     int64_t stream_budget = 8192ll << 20;   // bytes the ray stream may take (nvdr_ctx_set_stream_budget); 2.8 % of the HBM of an MI355X
     // ray stream of the three-stage env-shade (csrc/env_shade.hip)
@@ -165,7 +165,8 @@ struct nvdr_ctx {
     float4 *pix_origin = nullptr;
     float4 *pix_grad = nullptr;    // [2 * stream_cap_pixels] backward: the incoming (diffuse, specular) gradients of a compacted pixel, packed in front of stage 3
     float4 *pix_setup = nullptr;   // [4 * stream_cap_pixels] per compacted pixel: (pos, nrm.x) (nrm.yz, view_pos.xy) (view_pos.z, kd) (ks, -), written by stage 1
-    size_t stream_cap_rays = 0;    // slots of texel / vis / live
+    size_t stream_cap_rays = 0;    // slots of texel / vis
+    size_t stream_cap_live = 0;    // entries of live (its segments together, trace_kernel.h)
     size_t stream_cap_total = 0;   // slots of rays: the chunk's own + the spare blocks of the light-gradient records
     uint16_t *lg_tags = nullptr;   // (band, fill) of every block of 128 slots of `rays` (0xFFFF: no records)
     size_t lg_tags_cap = 0;

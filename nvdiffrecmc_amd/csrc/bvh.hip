@@ -1064,7 +1064,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         *c->ovf_host = 0;
         e = hipHostGetDevicePointer((void **)&c->ovf_dev, c->ovf_host, 0);
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&c->chunk_counts, sizeof(unsigned) * NVDR_MAX_CHUNKS);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->chunk_counts, sizeof(unsigned) * NVDR_MAX_CHUNKS * 544);
     if (e == hipSuccess) e = hipMalloc((void **)&c->queues, sizeof(unsigned) * 32 * 256);
     if (e == hipSuccess) e = hipMalloc((void **)&c->oct_ctl, sizeof(unsigned) * OCT_CTL_WORDS);
     if (e == hipSuccess) e = hipMalloc((void **)&c->bounds_part, sizeof(float) * 6 * BVH_BOUNDS_BLOCKS + 128);
@@ -1076,7 +1076,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
         nvdr_set_error("nvdr_ctx_create: allocation failed: %s", hipGetErrorString(e));
         return (int)e;
     }
-    hipMemset(c->chunk_counts, 0, sizeof(unsigned) * NVDR_MAX_CHUNKS);
+    hipMemset(c->chunk_counts, 0, sizeof(unsigned) * NVDR_MAX_CHUNKS * 544);
     hipMemset(c->queues, 0, sizeof(unsigned) * 32 * 256);
     if (const char *e = getenv("NVDR_STREAM_BUDGET_MB")) {
         const long long mb = atoll(e);

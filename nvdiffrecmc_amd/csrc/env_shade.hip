@@ -102,8 +102,8 @@ struct ShadeParams {
     float4 *pix_grad;         // backward: (diff_grad, spec_grad) of a compacted pixel (2 x float4), packed by pack_grads_kernel
     float4 *pix_setup;        // the G-buffer values of a compacted pixel every sample of it is shaded with, packed by stage 1 (4 x float4: see load_setup)
     uint8_t *vis;             // 1 = unoccluded
-    uint32_t *live;           // compacted list of the stream slots stage 2 has to traverse
-    unsigned *ray_count;      // its length (device counter)
+    uint32_t *live;           // compacted list of the stream slots stage 2 has to traverse: NVDR_LIVE_SEGS dense segments (trace_kernel.h)
+    unsigned *ray_count;      // the chunk's block of counters: the segments' lengths, [NVDR_LIVE_SEGS] their capacity
     float *g_light_xcd;       // [8][Hl*Wl*3] per-XCD private light-gradient accumulators (backward, atomics mode only)
     int light_elems;          // Hl*Wl*3
     unsigned debug;           // NVDR_DEBUG bits (read once per context): 1 skip tracing, 2 skip the light gradient
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) zero_outputs_kernel(float *b0, float *b1,
     }
 }
 
-__global__ void begin_launch_kernel(unsigned *pix_count, unsigned *chunk_counts, int n_chunks, int reuse, unsigned cap,
+__global__ void begin_launch_kernel(unsigned *pix_count, unsigned *chunk_counts, int n_chunks, int reuse, unsigned cap, unsigned seg_cap,
                                     unsigned *seed_counter, unsigned *seed_snapshot, unsigned seed_advance)
 {
     // the device-resident seed counter of shade() (render.py:112-116): this launch uses the value it finds (kept in the snapshot
@@ -221,7 +221,10 @@ __global__ void begin_launch_kernel(unsigned *pix_count, unsigned *chunk_counts,
     __syncthreads();
     if (!reuse && threadIdx.x == 0) *pix_count = 0;
     if (!keep)
-        for (int i = threadIdx.x; i < n_chunks; i += blockDim.x) chunk_counts[i] = 0;
+        for (int i = threadIdx.x; i < n_chunks * (NVDR_LIVE_SEGS + 1); i += blockDim.x) {
+            const int k = i / (NVDR_LIVE_SEGS + 1), w = i % (NVDR_LIVE_SEGS + 1);      // word 32 w of chunk k's block: a segment's length, or the capacity
+            chunk_counts[(size_t)k * NVDR_LIVE_WORDS + 32 * w] = w == NVDR_LIVE_SEGS ? seg_cap : 0u;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -553,17 +556,22 @@ __device__ __forceinline__ F3 fetch_light_texel(const Tab &t, int texel)
 #define NVDR_GEN_QCAP 128u         // entries of one lobe queue (< 64 waiting + <= 64 pushed per round)
 
 // one list-space claim for `staged` slots of a wavefront, then a coalesced copy out of LDS; returns the new fill (0)
-__device__ __forceinline__ unsigned flush_live(const unsigned *stage, unsigned staged, int lane, const ShadeParams &p)
+// capacity of one segment of the live-ray list: generation wavefront w appends to segment w % NVDR_LIVE_SEGS, so a segment takes at most the
+// slots of the groups of ceil(waves / SEGS) wavefronts (the launcher sizes the list with the same formula)
+__host__ __device__ static inline unsigned long long live_segment_capacity(unsigned long long gen_waves, unsigned long long max_groups, unsigned long long group_slots)
+{
+    const unsigned long long v = ((gen_waves + NVDR_LIVE_SEGS - 1) / NVDR_LIVE_SEGS) * ((max_groups + gen_waves - 1) / gen_waves) * group_slots;
+    return (v + 127ull) & ~127ull;
+}
+__device__ __forceinline__ unsigned flush_live(const unsigned *stage, unsigned staged, int lane, const ShadeParams &p, unsigned seg_cap)
 {
     if (staged == 0) return 0;
     __builtin_amdgcn_wave_barrier();        // the staged entries were written by other lanes of this wavefront
+    // this wavefront's segment of the list (trace_kernel.h: one claim counter per segment; one counter for all was the kernel's bound)
+    const unsigned seg = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % NVDR_LIVE_SEGS;
     unsigned at = 0;
-#ifdef NVDR_GEN_FAKE_CLAIM     // (timing experiment only: claims spread over 64 counters, the list is garbage)
-    if (lane == 0) at = atomicAdd(p.queues + 32u * (64u + ((blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u)), staged) % 1000000u;
-#else
-    if (lane == 0) at = atomicAdd(p.ray_count, staged);
-#endif
-    at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+    if (lane == 0) at = atomicAdd(p.ray_count + 32u * seg, staged);
+    at = (unsigned)__builtin_amdgcn_readfirstlane((int)at) + seg * seg_cap;
     for (unsigned k = lane; k < staged; k += 64) p.live[at + k] = stage[k];
     __builtin_amdgcn_wave_barrier();
     return 0;
@@ -590,6 +598,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     const unsigned n_groups = (P + G - 1) / G;
     const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
     const unsigned S = p.S, n = p.n;
+    const unsigned seg_cap = live_segment_capacity(waves_total, (p.pix_cap + (unsigned)G - 1u) / (unsigned)G, (unsigned)G * 2u * S);
     const float strata_frac = 1.0f / (float)n;
     // stratum / n as a multiplication: n_magic = ceil(2^32 / n) gives the exact quotient of every stratum < 2^16 (the error term
     // stratum * (n_magic * n - 2^32) stays below 2^32); n = 1 wraps to 0, and its only stratum is 0
@@ -634,7 +643,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
         const unsigned long long m = __ballot(live);
         if (live) stage[staged + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = r;
         staged += (unsigned)__popcll(m);
-        if (staged > NVDR_GEN_STAGE - 64u) staged = flush_live(stage, staged, lane, p);      // (room for the next append of <= 64)
+        if (staged > NVDR_GEN_STAGE - 64u) staged = flush_live(stage, staged, lane, p, seg_cap);      // (room for the next append of <= 64)
     };
     // one batch of `cnt` (<= 64) tasks of one lobe (wave-uniform arguments)
     auto run_batch = [&](int lobe, unsigned cnt) {
@@ -827,7 +836,7 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     if (q_count[0]) run_batch(0, q_count[0]);
     if (q_count[1]) run_batch(1, q_count[1]);
     if (q_count[2]) run_batch(2, q_count[2]);
-    flush_live(stage, staged, lane, p);
+    flush_live(stage, staged, lane, p, seg_cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1739,13 +1748,15 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) bvh2_count_kernel(BvhView bv
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const TravStack stack = make_stack(smem, spill, bvh.stack_max, bvh.overflow);
-    const unsigned total = *ray_count;
     unsigned nb = 0, nt = 0, nr = 0;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const unsigned slot = live[i];
-        const float4 rd = rays[slot], ro = pix_origin[slot / rays_per_pixel];
-        (void)bvh_any_hit<true>(bvh, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, stack, nb, nt);
-        nr++;
+    for (unsigned seg = 0; seg < NVDR_LIVE_SEGS; ++seg) {           // the list's segments, one after the other
+        const unsigned total = ray_count[32u * seg], base = seg * ray_count[32u * NVDR_LIVE_SEGS];
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const unsigned slot = live[base + i];
+            const float4 rd = rays[slot], ro = pix_origin[slot / rays_per_pixel];
+            (void)bvh_any_hit<true>(bvh, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, stack, nb, nt);
+            nr++;
+        }
     }
     for (int o = 32; o >= 1; o >>= 1) {
         nb += __shfl_xor(nb, o);
@@ -1836,7 +1847,7 @@ static int64_t stream_chunk_pixels(const nvdr_ctx *c, int64_t npix, unsigned S, 
 // `own_slots`: the chunk's stream slots (whole groups of pixels, rounded up to blocks of 128); `spare_slots`: the spare blocks of the
 // backward shading kernel's wavefronts behind them (light-gradient records, see env_shade_kernel<true>) -- only the 16-byte `rays`
 // array has them
-static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, size_t own_slots, size_t spare_slots, hipStream_t stream)
+static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, size_t own_slots, size_t spare_slots, size_t live_slots, hipStream_t stream)
 {
     const size_t rays = own_slots;
     const size_t n_tags = (own_slots + spare_slots) >> 7;
@@ -1869,12 +1880,16 @@ static int reserve_stream(nvdr_ctx *c, int64_t npix, int64_t cap, size_t own_slo
     if (c->stream_cap_rays < rays) {
         ctx_free(c, c->texel);
         ctx_free(c, c->vis);
-        ctx_free(c, c->live);
         c->stream_cap_rays = 0;
         NVDR_HIP_TRY(ctx_malloc(c, &c->texel, sizeof(int) * rays, stream));
         NVDR_HIP_TRY(ctx_malloc(c, &c->vis, rays, stream));
-        NVDR_HIP_TRY(ctx_malloc(c, &c->live, sizeof(uint32_t) * rays, stream));
         c->stream_cap_rays = rays;
+    }
+    if (c->stream_cap_live < live_slots) {
+        ctx_free(c, c->live);
+        c->stream_cap_live = 0;
+        NVDR_HIP_TRY(ctx_malloc(c, &c->live, sizeof(uint32_t) * live_slots, stream));
+        c->stream_cap_live = live_slots;
     }
     if (c->stream_cap_total < rays + spare_slots) {
         ctx_free(c, c->rays);
@@ -2101,7 +2116,13 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     }
     const size_t own_slots = ((size_t)max_groups * group_slots + 127) & ~(size_t)127;
     const size_t spare_blocks = (size_t)pb[2] * waves_per_block * lg_spw;
-    if ((r = reserve_stream(c, npix, cap, own_slots, spare_blocks * 128, stream))) return r;
+    // the live list's segments: generation wavefront w appends to segment w % NVDR_LIVE_SEGS, so a segment takes at most the slots of the
+    // groups of ceil(waves / SEGS) wavefronts
+    const int64_t gen_waves = pb[0] * waves_per_block;
+    const int64_t seg_cap64 = (int64_t)live_segment_capacity((unsigned long long)gen_waves, (unsigned long long)max_groups, (unsigned long long)group_slots);
+    NVDR_REQUIRE(seg_cap64 * NVDR_LIVE_SEGS < (1ll << 32), "nvdr_env_shade: the live-ray list of a chunk of %lld pixels does not fit 32-bit positions", (long long)cap);
+    const unsigned seg_cap = (unsigned)seg_cap64;
+    if ((r = reserve_stream(c, npix, cap, own_slots, spare_blocks * 128, (size_t)seg_cap64 * NVDR_LIVE_SEGS, stream))) return r;
     p.lg_tags = c->lg_tags;
     p.lg_spare_base = (unsigned)(own_slots >> 7);
     p.lg_spw = lg_spw;
@@ -2125,7 +2146,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     {
         const int64_t need = (cap * 2 * S + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
-        if (tblocks > need) tblocks = need < 1 ? 1 : need;
+        if (tblocks > need) tblocks = need < NVDR_TRACE_QUEUES / 4 ? NVDR_TRACE_QUEUES / 4 : need;     // (at least 64 wavefronts: one per dealing counter, trace_kernel.h)
     }
     const size_t trace_lds = NVDR_TRACE_LDS_BYTES(NVDR_QUERY_BLOCK);
     const size_t count_lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
@@ -2151,14 +2172,14 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         p.guide_log_cols = lc;
     }
     c->stream_id = 0; // invalid while being rewritten
-    begin_launch_kernel<<<1, 256, 0, stream>>>(&c->dinfo->pix_count, c->chunk_counts, n_chunks, p.reuse, p.pix_cap,
+    begin_launch_kernel<<<1, 256, 0, stream>>>(&c->dinfo->pix_count, c->chunk_counts, n_chunks, p.reuse, p.pix_cap, seg_cap,
                                                const_cast<unsigned *>(a->rnd_seed_offset), backward ? nullptr : a->rnd_seed_snapshot, a->rnd_seed_advance);
     if (!reuse)
         compact_pixels_kernel<<<div_up(npix, 256 * NVDR_COMPACT_ROUNDS), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
                                                                       &c->dinfo->pix_count, backward ? nullptr : p.diff, backward ? nullptr : p.spec);
     for (int k = 0; k < n_chunks; ++k) {
         p.pix_begin = (unsigned)((int64_t)k * cap);
-        p.ray_count = c->chunk_counts + k;
+        p.ray_count = c->chunk_counts + (size_t)k * NVDR_LIVE_WORDS;
         hipEvent_t *pe = nullptr;
         if (c->profiling && n_chunks <= NVDR_PROF_RING) {      // (a launch of more chunks than records would overwrite its own first chunks)
             const int slot = (int)(c->prof_n % NVDR_PROF_RING);
@@ -2227,7 +2248,7 @@ __global__ void pack_rays_kernel(const float *__restrict__ ro, const float *__re
                                  float4 *__restrict__ origin, uint32_t *__restrict__ live, unsigned *count, unsigned *queues)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *count = n;
+    if (i <= NVDR_LIVE_SEGS) count[32u * i] = (i == 0u || i == NVDR_LIVE_SEGS) ? n : 0u;       // one segment holds them all
     if (i < NVDR_TRACE_QUEUES) queues[i * 32u] = 0u;
     if (i >= n) return;
     rays[i] = make_float4(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2], 1.0f);
@@ -2243,7 +2264,7 @@ static int trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, 
     if (int r0 = ctx_check_overflow(c, who)) return r0;
     if (n_rays <= 0) return 0;
     NVDR_HIP_TRY(hipSetDevice(c->device));
-    int r = reserve_stream(c, n_rays, n_rays, ((size_t)n_rays * 2 + 127) & ~(size_t)127, 0, stream);
+    int r = reserve_stream(c, n_rays, n_rays, ((size_t)n_rays * 2 + 127) & ~(size_t)127, 0, (size_t)n_rays, stream);
     if (r) return r;
     c->stream_id = 0;
     if (int rw = ctx_wait_built(c, stream)) return rw;
@@ -2251,7 +2272,7 @@ static int trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, 
     int64_t tblocks = (int64_t)c->n_cus * 8;
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
-    if (tblocks > need) tblocks = need;
+    if (tblocks > need) tblocks = need < NVDR_TRACE_QUEUES / 4 ? NVDR_TRACE_QUEUES / 4 : need;
     launch_trace(c, (unsigned)tblocks, NVDR_TRACE_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u, counters);
     NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
     NVDR_LAUNCH_CHECK();

@@ -41,8 +41,8 @@ struct TraceLaunch {
     BvhView bvh;
     const float4 *rays;            // stream slot -> (dir.xyz, pdf sum)
     const float4 *pix_origin;      // compacted pixel -> shadow-ray origin
-    const uint32_t *live;          // the stream slots to traverse
-    const unsigned *ray_count;     // their number (device counter)
+    const uint32_t *live;          // the stream slots to traverse: NVDR_LIVE_SEGS dense segments
+    const unsigned *ray_count;     // the chunk's block of counters: NVDR_LIVE_SEGS segment lengths, the segment capacity (device memory)
     unsigned rays_per_pixel;
     uint8_t *vis;                  // stream slot -> 1 = unoccluded
     int *spill;                    // HBM part of the traversal stacks (bvh.h)
@@ -55,42 +55,66 @@ struct TraceLaunch {
 #define NVDR_TRACE_LDS_PER_WAVE (NVDR_OSTACK_LDS * 64 * 8 + NVDR_LEAFQ_CAP * 8)
 #define NVDR_TRACE_LDS_BYTES(threads) ((size_t)((threads) / 64) * NVDR_TRACE_LDS_PER_WAVE)
 
-// Chunk dealing: wave w uses counter w % 64 and receives the chunks q, q + 64, q + 128 ... of the list, so the whole chip works
-// inside ONE moving window of the list.  Every counter must be served by somebody: chunk c sits on counter c % 64 and the
-// launcher starts at least min(chunks, 2048) workgroups of 4 waves, so counter c % 64 < waves.
+// The live-ray list is NVDR_LIVE_SEGS SEGMENTS, each behind its own length counter (round 5): the generation kernel appends per wavefront,
+// ~400 entries per claim, and same-address atomics retire one every ~12 ns on this part -- 109 k claims on ONE counter were 1.3 ms of
+// serialised time, exactly the kernel's duration once its set-up no longer hid it (profiles/r05_ab_live_segments.md).  Generation wavefront w
+// appends to segment w % SEGS; segment s lives at live[s * seg_cap ...] and is dense.  A chunk's block of counters
+// (nvdr_ctx::chunk_counts, NVDR_LIVE_WORDS words per chunk of the ray stream): word 32 s = the length of segment s -- ONE COUNTER PER
+// 128-BYTE LINE: sixteen counters in one line serialise like one, and worse (7.8 instead of 1.3 ms) -- and word 32 SEGS = seg_cap.
+#define NVDR_LIVE_SEGS 16
+#define NVDR_LIVE_WORDS ((NVDR_LIVE_SEGS + 1) * 32)
+#define NVDR_LIVE_SUBS (NVDR_TRACE_QUEUES / NVDR_LIVE_SEGS)        // dealing counters per segment
+
+// Chunk dealing: counter q = t * SEGS + s hands out the chunks t, t + SUBS, t + 2 SUBS ... of segment s; wave w serves counter w % 64 --
+// the launcher starts at least 64 wavefronts, so every counter is served by somebody.  The waves of the chip thus work inside ONE moving window of every segment (the segments hold interleaved pixels:
+// neighbouring pixels -> the same subtrees stay in L2); the segments are equally long to a fraction of a percent -- the generation
+// wavefronts take the pixels round-robin -- so nobody steals.  (Letting a wavefront that has used its counter up walk on through all 64 --
+// two dependent loads per counter -- made the kernel 10 % slower at eight views and 22 % at one: every wavefront paid that walk at the end.)
 // (Measured and dropped, interleaved in-process A/B, profiles/r02_ab_traversal_variants.md: one contiguous eighth of the list per
 // XCD with stealing -- each L2 caching another region of the tree -- is 4-7 % SLOWER on bob and +-2 % on 684 k triangles; static
 // dealing without atomics (wave w walks the chunks w, w + waves, ...) is within 1 % of the claiming on 684 k triangles.)
 struct ChunkDealer {
-    unsigned *queue;               // this wave's counter
-    unsigned n_chunks, total, sub, shift;
+    // (kept small: these are wave-uniform, but every one of them the compiler cannot hold in a scalar register costs the kernel a vector
+    // register it does not have -- a dealer with ten fields spilled nine dwords and made the traversal 10 % slower)
+    unsigned *qp;                  // the wave's counter
+    unsigned first, end_abs;       // list position of that counter's first chunk, end of its segment
+    unsigned shift;                // log2 of the chunk size
 
     // Chunk size: NVDR_TRACE_QCHUNK rays, but a small launch (one view: 5 M rays over 8192 wavefronts = 2.6 chunks of 256 each) is
     // cut finer -- at least ~8 claims per wavefront, 64 rays at the least -- so that the wavefronts run out of work together.
-    __device__ __forceinline__ void init(unsigned *queues, unsigned total_, unsigned wid, unsigned n_waves)
+    // Returns the number of live rays of the launch.
+    __device__ __forceinline__ unsigned init(unsigned *queues, const unsigned *counts, unsigned wid, unsigned n_waves)
     {
-        total = total_;
+        unsigned total = 0u;
+#pragma unroll
+        for (int k = 0; k < NVDR_LIVE_SEGS; ++k) total += counts[k * 32];
         shift = 8u;                                                     // log2(NVDR_TRACE_QCHUNK)
 #ifndef NVDR_TRACE_COARSE_CHUNKS              // (A/B variants only)
-        while (shift > 6u && (total_ >> shift) < 8u * n_waves) --shift;
+        while (shift > 6u && (total >> shift) < 8u * n_waves) --shift;
 #endif
-        n_chunks = (total_ + (1u << shift) - 1u) >> shift;
-        sub = wid % NVDR_TRACE_QUEUES;
-        queue = queues + sub * 32u;
+        const unsigned q = wid % NVDR_TRACE_QUEUES;
+        qp = queues + q * 32u;
+        const unsigned seg = q % NVDR_LIVE_SEGS, t = q / NVDR_LIVE_SEGS;
+        const unsigned base = seg * counts[NVDR_LIVE_SEGS * 32];
+        first = base + (t << shift);
+        end_abs = base + counts[seg * 32u];
+        return total;
     }
-    // wave-uniform: claims the next chunk for the whole wave; false = the list is used up
+    // wave-uniform: claims the next chunk for the whole wave; false = the wave's counter is used up
     __device__ __forceinline__ bool claim(int lane, unsigned &next, unsigned &end)
     {
-        unsigned j = 0;
-        if (lane == 0) j = atomicAdd(queue, 1u);
+        unsigned j = 0u;
+        if (lane == 0) j = atomicAdd(qp, 1u);
         j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-        const unsigned c = j * NVDR_TRACE_QUEUES + sub;
-        if (c >= n_chunks) return false;
-        next = c << shift;
-        end = min(next + (1u << shift), total);
+        // chunk j of this counter = chunk j * SUBS + t of the segment
+        const unsigned pos = first + (j << (shift + 2u));           // (SUBS = 4; j stays far below 2^22: no wrap)
+        if (j >= 0x00400000u || pos >= end_abs) return false;
+        next = pos;
+        end = min(pos + (1u << shift), end_abs);
         return true;
     }
 };
+static_assert(NVDR_LIVE_SUBS == 4, "ChunkDealer::claim shifts by log2(NVDR_LIVE_SUBS) = 2");
 
 // 8-byte entries (low word, high word) in explicit address spaces: ds_write_b64 / global_store_dwordx2, no flat accesses
 typedef __attribute__((address_space(3))) unsigned long long lds_pair_t;
@@ -159,10 +183,9 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     const float gsx = info->g_scale[0], gsy = info->g_scale[1], gsz = info->g_scale[2];
     const float glx = info->g_lo[0], gly = info->g_lo[1], glz = info->g_lo[2];
 
-    const unsigned total = *a.ray_count;
     const unsigned wid = blockIdx.x * (blockDim.x >> 6) + wave;
     ChunkDealer dealer;
-    dealer.init(a.queues, total, wid, gridDim.x * (blockDim.x >> 6));
+    const unsigned total = dealer.init(a.queues, a.ray_count, wid, gridDim.x * (blockDim.x >> 6));
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
     bool more = total > 0;
     unsigned n_box = 0, n_tri = 0, n_ray = 0, n_step = 0, n_batch = 0;

@@ -833,7 +833,9 @@ def run(args):
                 'kernel': DOMINANT, 'kernel_ms_hip_events': trace_ms, 'launches_timed': n_f,
                 'rays_per_launch': n_traced, 'kernel_rays_per_sec': n_traced / (trace_ms * 1e-3),
                 'why_valu': 'rocprofv3 counters of this run: VALU issue dominates the kernel while its HBM and L2 fractions (hbm, l2 below) '
-                            'are small -- divergent traversal of a tree that is cache resident; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz',
+                            'are small -- divergent traversal of a tree that is cache resident; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz.  '
+                            'The fraction is the active-lane VALU rate, not a claim that the issue port is full: what sets the time is a wavefront\'s '
+                            'dependent chain per node step times the 8 wavefronts a SIMD holds (DESIGN.md section 5, profiles/r05_trace_l1_bound.md)',
                 'shader_clock_mhz_counting_launch': clock_mhz,
                 'algorithmic': {'model': 'SURVEY 8d: 32 B per BVH2 node visit + 36 B per triangle test of the canonical binary any-hit walk '
                                          '(counting kernel over the same live rays; equals a CPU walk of the exported tree, tests/test_gpu_bvh.py) '

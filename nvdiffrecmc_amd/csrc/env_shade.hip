@@ -604,7 +604,9 @@ __global__ void __launch_bounds__(256, NVDR_GEN_OCC) env_gen_kernel(ShadeParams 
     // stratum * (n_magic * n - 2^32) stays below 2^32); n = 1 wraps to 0, and its only stratum is 0
     const unsigned n_magic = 0xFFFFFFFFu / n + 1u;
     // Live-ray list: a device-scope atomic per wavefront and round serialises on its one address (61 k of them cost
-    // 0.4 ms); each wavefront therefore stages slots in LDS and claims list space once per NVDR_GEN_STAGE-128 entries.
+    // 0.4 ms); each wavefront therefore stages slots in LDS and claims list space once per NVDR_GEN_STAGE-64 entries -- and the list is
+    // NVDR_LIVE_SEGS segments with a counter each (flush_live; trace_kernel.h): even the 109 k staged claims of an 8-view launch were
+    // 1.3 ms on one counter.
     __shared__ unsigned stage_all[4][NVDR_GEN_STAGE];
     unsigned *stage = stage_all[wave];
     unsigned staged = 0;

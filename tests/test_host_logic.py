@@ -4,6 +4,7 @@ import inspect
 import math
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -261,6 +262,32 @@ def test_stack_bound_formula():
         subprocess.run(['g++', '-std=c++17', src, '-o', exe], check=True)
         got = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     assert got == [e for _, e in cases]
+
+
+def test_live_list_segments_hold_what_their_wavefronts_can_append():
+    """live_segment_capacity (csrc/env_shade.hip; host and device use the one formula): generation wavefront w takes the groups w, w + W, ...
+    and appends to segment w % 16, so a segment must hold the slots of all groups of its wavefronts -- for every launch shape, also ragged ones."""
+    import subprocess
+    import tempfile
+    text = open(os.path.join(ROOT, 'nvdiffrecmc_amd', 'csrc', 'env_shade.hip')).read()
+    body = _between(text, '__host__ __device__ static inline unsigned long long live_segment_capacity', '\n}\n') + '\n}\n'
+    body = body.replace('__host__ __device__ ', '')
+    cases = [(10240, 2097152, 128), (10240, 454278, 128), (16, 1, 128), (40, 7, 2048), (4096, 4097, 128), (7, 1000, 512), (10240, 61635, 128), (12, 100000, 128)]
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, 'c.cpp')
+        open(src, 'w').write('#include <stdio.h>\n#define NVDR_LIVE_SEGS 16\n' + body +
+                             'int main(){unsigned long long v[][3] = {%s}; for (auto &x : v) printf("%%llu ", live_segment_capacity(x[0], x[1], x[2])); return 0;}\n'
+                             % ', '.join('{%dull, %dull, %dull}' % c for c in cases))
+        exe = os.path.join(d, 'c')
+        subprocess.run(['g++', '-std=c++17', src, '-o', exe], check=True)
+        caps = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    for (waves, groups, slots), cap in zip(cases, caps):
+        assert cap % 128 == 0
+        # the most a segment can receive: every slot of every group of its wavefronts is a live ray
+        per_wave = np.array([len(range(w, groups, waves)) for w in range(waves)], dtype=np.int64)
+        per_seg = np.array([per_wave[s::16].sum() for s in range(16)]) * slots
+        assert per_seg.max() <= cap, (waves, groups, slots, int(per_seg.max()), cap)
+        assert cap == (-(-waves // 16) * -(-groups // waves) * slots + 127) // 128 * 128
 
 
 def _between(text, start, end):

@@ -44,13 +44,20 @@ __device__ __forceinline__ void bwd_cross(F3 a, F3 b, F3 &d_a, F3 &d_b, F3 d_out
 }
 __device__ __forceinline__ F3 safe_normalize(F3 v)
 {
-    const float l = nvdr_sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-    return l > 0.0f ? div3(v, l) : f3(0.0f);
+    const float l2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    // nvdr_sqrt equals sqrtf from 2^-96 upwards (ieee_arith.h); below that -- a vector shorter than 2^-48, e.g. the face normal of a sliver
+    // under trained geometry -- v_sqrt_f32 reads a denormal as zero and the +-1 ulp fix-up would hand nvdr_div a denormal denominator (NaN):
+    // the rare arm takes the compiler's square root and division, like the reference
+    if (__builtin_expect(!(l2 >= 0x1p-96f), 0)) {
+        const float l = sqrtf(l2);
+        return l > 0.0f ? f3(v.x / l, v.y / l, v.z / l) : f3(0.0f);
+    }
+    return div3(v, nvdr_sqrt(l2));
 }
 __device__ __forceinline__ void bwd_safe_normalize(F3 v, F3 &d_v, F3 d_out)
 {
     const float l2 = v.x * v.x + v.y * v.y + v.z * v.z;
-    const float l = nvdr_sqrt(l2);
+    const float l = l2 >= 0x1p-96f ? nvdr_sqrt(l2) : sqrtf(l2);      // (see safe_normalize)
     if (l > 0.0f) {
         // == (float)(1.0 / (double)(.)) of the reference: a double quotient of floats rounds to the float quotient.  (Plain `/`: l2 * l of a
         // short vector may be denormal.)

@@ -20,7 +20,7 @@
 // for bit.  v_div_fixup is kept: zeros, infinities and NaNs give exactly what `/` gives.  What differs: a numerator below 2^-103 or a
 // denormal quotient may be one ulp off (values of 1e-31 and less); a DENORMAL denominator or a quotient that overflows gives NaN where
 // `/` gives a huge number or infinity.  Hence the rule of use: nvdr_div only where the denominator is bounded away from the denormals
-// by construction (a clamped cosine, a length that passed `> 0`: the square root of any positive float is above 2^-75, 1 + x with
+// by construction (a clamped cosine, a length nvdr_sqrt returned for a square of 2^-96 or more -- i.e. >= 2^-48; sqrtf of any positive float is above 2^-75, but nvdr_sqrt of one below 2^-96 may be a denormal: safe_normalize (bsdf_device.h) sends those to sqrtf and `/` --, 1 + x with
 // x >= 0, an integer, pi) or where the quotient is selected away when it is not (fwd_pbr_specular); the sites whose denominator is an
 // unclamped cosine keep `/`.
 // nvdr_sqrt equals sqrtf for EVERY float (all 2^32 inputs compared on the device: nvdr_test_arith, tests/test_gpu_arith.py) except

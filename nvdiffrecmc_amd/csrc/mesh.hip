@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) interpolate_bwd_kernel(InterpBwd p)
     const int64_t tri = (int64_t)r.w - 1;
     // a G-buffer of another topology (a stale `rast`, an index buffer that does not belong to v_pos) must not read or add out of bounds:
     // such a pixel is skipped, like an uncovered one
-    if (tri >= p.n_tris) return;
+    if (tri < 0 || tri >= p.n_tris) return;            // (0 < w < 1 truncates to triangle -1)
     const float u = r.x, v = r.y, w2 = 1.0f - u - v;
     const int i0 = p.t_pos[3 * tri], i1 = p.t_pos[3 * tri + 1], i2 = p.t_pos[3 * tri + 2];
     if ((unsigned)i0 >= (uint64_t)p.n_verts || (unsigned)i1 >= (uint64_t)p.n_verts || (unsigned)i2 >= (uint64_t)p.n_verts) return;

@@ -42,7 +42,26 @@ __global__ void __launch_bounds__(256) adam_step_kernel(AdamTable tab, double lr
     for (int q = 1; q < tab.n; ++q)
         if ((int)blockIdx.x >= tab.first_block[q]) k = q;
     const nvdr_adam_tensor &T = tab.t[k];
-    if (T.frozen) return;
+    if (T.frozen) {
+        // A frozen tensor (lr_scale 0 on the host) takes no update, but its gradient is still CONSUMED: with zero_grad the producer
+        // scatter-adds into a persistent buffer that nobody else clears -- and with several ranks that buffer is the exchange bucket,
+        // all-reduced in place every step: left alone its content would grow by the world size per iteration until it overflows.
+        if (T.active && T.zero_grad) {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int64_t texels = T.n / 3, tiles = (texels + 63) / 64;
+            const int64_t t0 = ((int64_t)((int)blockIdx.x - tab.first_block[k]) * 4 + wave) * ADAM_SPARSE_TILES;
+            float *gw = const_cast<float *>(T.grad);
+            for (int j0 = 0; j0 < ADAM_SPARSE_TILES; ++j0) {
+                const int64_t tile = t0 + j0, t = tile * 64 + lane;
+                if (tile >= tiles) break;
+                const bool ok = t < texels;
+                const float g0 = ok ? T.grad[3 * t] : 0.0f, g1 = ok ? T.grad[3 * t + 1] : 0.0f, g2 = ok ? T.grad[3 * t + 2] : 0.0f;
+                // (a NaN compares unequal to zero: a poisoned tile is cleared as well)
+                if (__ballot(g0 != 0.0f || g1 != 0.0f || g2 != 0.0f) != 0ull && ok) { gw[3 * t] = 0.0f; gw[3 * t + 1] = 0.0f; gw[3 * t + 2] = 0.0f; }
+            }
+        }
+        return;
+    }
     const float step_size = step_size0 * (T.lr_scale == 0.0f ? 1.0f : T.lr_scale);   // (a zero-initialised block: the plain learning rate)        // this tensor's learning rate (train.py:336-338: position / material / light)
     const int64_t e0 = (int64_t)((int)blockIdx.x - tab.first_block[k]) * 256 * tab.per_thread;
     if (T.active) {

@@ -147,7 +147,7 @@ class GradientExchange:
         sparse = list(sparse) if sparse is not None else [False] * len(self.groups)
         sparse = [False if s in (False, None, 'dense') else s for s in sparse]
         self.auto = [s == 'auto' for s in sparse]
-        self.auto_fraction, self.probe_every, self._round = float(auto_fraction), int(probe_every), 0
+        self.auto_fraction, self.probe_every, self._round, self._flags_round = float(auto_fraction), int(probe_every), 0, -1
         self.sparse = [bool(s) and self.equal_shards and all(p.numel() % self.tile_floats == 0 for p in g) for s, g in zip(sparse, self.groups)]
         self._sp = {}
         for k, (s, b) in enumerate(zip(self.sparse, self.buckets)):
@@ -207,6 +207,7 @@ class GradientExchange:
 
     def compute_flags(self):
         """Sparse chunks: flag the non-zero tiles of this rank's bucket (after pack(); one launch per sparse chunk, capturable)."""
+        self._flags_round = self._round          # (start() checks that the flags belong to the round it sends)
         for k, sp in self._sp.items():
             sp['use'] = (not self.auto[k]) or sp['auto_sparse'] or self._round % self.probe_every == 0
             if not sp['use']:
@@ -225,6 +226,10 @@ class GradientExchange:
         self.handles = [None] * len(self.buckets)
         self._bytes_round = 0
         live = self.active and not (self.world == 1 and skip_single)
+        if self._sp and self._flags_round != self._round:
+            # pack() -> start() without compute_flags(): stale flags would leave touched tiles un-reduced and the ranks would
+            # diverge silently -- flag the tiles of THIS round here (one launch per sparse chunk)
+            self.compute_flags()
         self._round += 1
         for k, b in enumerate(self.buckets):
             if k in self._sp and self._sp[k]['use']:

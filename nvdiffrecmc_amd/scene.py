@@ -3,7 +3,8 @@
 Nothing here is on the hot path: it builds the INPUTS the reference gets from nvdiffrast,
 DatasetMesh and the HDR probes (none of which exist on ROCm / in this checkout):
 
-  * meshes        : assets/{bob,spot}.npz (CC0), vertex normals as render/mesh.py:150-178
+  * meshes        : assets/{bob,spot}.npz (CC0), vertex normals as render/mesh.py:150-178; assets/dmtet64_{init,mid}.npz: marching-tets
+                    extractions from the reference's tet grid with seeded SDFs (tools/make_dmtet_mesh.py)
   * cameras       : DatasetMesh._rotate_scene (dataset/dataset_mesh.py:62-71) with the matrices
                     of render/util.py:185-210 (perspective 45 deg, radius 3, rotate_x(-0.4))
   * env maps      : E0 uniform 0.5 (the trainable init, train.py:612) and E1 seeded "sky + suns"
@@ -23,8 +24,44 @@ import torch
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'assets')
 
 
+def dmtet_atlas(face_gidx, n_tets):
+    """Texture coordinates of a marching-tets mesh as the reference lays them out (geometry/dmtet.py:50-79 map_uv, called with
+    max_idx = 2 * num_tets): every tet owns one cell of an N x N atlas, N = ceil(sqrt(num_tets)); its (up to) two triangles are the two
+    halves of the cell's quad, shrunk by pad = 0.9 / N.  Returns (v_tex [4 N^2, 2] float32, t_tex_idx [F, 3] int32)."""
+    N = int(math.ceil(math.sqrt((2 * int(n_tets) + 1) // 2)))
+    lin = torch.linspace(0, 1 - (1 / N), N, dtype=torch.float32).numpy()      # (torch's float32 linspace, as the reference: numpy's rounds differently)
+    tex_y, tex_x = np.meshgrid(lin, lin, indexing='ij')
+    pad = np.float32(0.9 / N)
+    uvs = np.stack([tex_x, tex_y, tex_x + pad, tex_y, tex_x + pad, tex_y + pad, tex_x, tex_y + pad], -1).reshape(-1, 2).astype(np.float32)
+    g = np.asarray(face_gidx, dtype=np.int64)
+    tet, tri = g // 2, g % 2
+    idx = np.stack((tet * 4, tet * 4 + tri + 1, tet * 4 + tri + 2), -1).astype(np.int32)
+    return torch.from_numpy(uvs), torch.from_numpy(idx)
+
+
+def _procedural_kd(res=512, seed=4321):
+    """A smooth seeded albedo for the meshes that come without one (the DMTet extractions): low-frequency colour blobs in [0.15, 0.85]."""
+    rng = np.random.default_rng(seed)
+    y, x = np.meshgrid((np.arange(res) + 0.5) / res, (np.arange(res) + 0.5) / res, indexing='ij')
+    img = np.full((res, res, 3), 0.5)
+    for _ in range(12):
+        cx, cy, sig = rng.random(), rng.random(), 0.08 + 0.2 * rng.random()
+        col = rng.random(3) - 0.5
+        img += 0.6 * col * np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2 * sig ** 2))[..., None]
+    return torch.from_numpy(np.clip(img, 0.15, 0.85).astype(np.float32))
+
+
 def load_mesh(name='bob', device='cpu'):
     d = np.load(os.path.join(_ASSETS, name + '.npz'))
+    if 'face_gidx' in d.files:
+        # a marching-tets extraction (tools/make_dmtet_mesh.py): positions + triangles + the per-face global index the atlas is rebuilt from
+        m = {'v_pos': torch.from_numpy(d['v_pos']), 't_pos_idx': torch.from_numpy(d['t_pos_idx'])}
+        m['v_tex'], m['t_tex_idx'] = dmtet_atlas(d['face_gidx'], int(d['n_tets']))
+        m['ks'] = torch.tensor([0.0, 0.25, 0.0])
+        m['kd_tex'] = _procedural_kd()
+        m = {k: v.to(device) for k, v in m.items()}
+        m['name'] = name
+        return finish_mesh(m)
     m = {k: torch.from_numpy(d[k]) for k in ('v_pos', 'v_tex', 't_pos_idx', 't_tex_idx', 'ks')}
     m['kd_tex'] = torch.from_numpy(d['kd_tex'].astype(np.float32))
     m = {k: v.to(device) for k, v in m.items()}

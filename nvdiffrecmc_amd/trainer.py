@@ -482,7 +482,9 @@ class DirectLightingStep:
         return self._stage2()
 
     def set_lr_scale(self, name, value):
-        """Learning rate of one parameter tensor relative to lr (0 freezes it); names as in .param_names."""
+        """Learning rate of one parameter tensor relative to lr (0 freezes it); names as in .param_names.  Completes a pending
+        (pipelined) texture update first, so that the new rate applies from the next iteration on."""
+        self.finish()
         i = self.param_names.index(name)
         self._lr_scales[i] = float(value)
         if self._fused_update:
@@ -622,6 +624,21 @@ class DirectLightingStep:
             self._update(subset=self._ex_chunks[k], advance=True, grad_mult=f)
         self._pending = False
 
+    def parameters(self):
+        """{name: tensor} of the trained set in a CONSISTENT state: with several ranks step() returns with the texture chunk's update
+        still pending (see step()); this completes it first.  Use it (or call finish()) before a checkpoint, a validation render or any
+        other read of .params between steps."""
+        self.finish()
+        return dict(zip(self.param_names, self.params))
+
+    def __del__(self):
+        try:
+            if getattr(self, '_pending', False):
+                import warnings
+                warnings.warn('DirectLightingStep dropped with the last texture update still pending: call finish() after the last step()')
+        except Exception:
+            pass
+
     def finish(self):
         """Complete the parameter update of the last iteration (the pipelined texture chunk).  Call once after the last step()."""
         if getattr(self, '_pending', False):
@@ -738,11 +755,19 @@ class DirectLightingStep:
             self._packed_tex_grad()
         gbs = []
         n = len(self._ex_chunks)
+        # The B_k graphs get a pool of their own: the pipelined replay order (G2, B_0, G1, B_1) differs from the capture order, and with
+        # trained geometry the tensors G1's autograd graph saved must survive from G1 to G2's backward -- B_1 replays in between and must
+        # not be handed their memory.  (The fused update allocates nothing today: asserted below, so that a change of it is noticed.)
+        pool_b = None
         for k in range(n):
             f = self._point_grads(k)        # the .grad of chunk k = views into its bucket: what the captured update reads on every replay
             gk = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gk, pool=g1.pool()):
+            before = torch.cuda.memory_allocated(self.dev)
+            with torch.cuda.graph(gk, **({'pool': pool_b} if pool_b is not None else {})):
                 self._update(subset=self._ex_chunks[k], advance=(k == n - 1), grad_mult=f)
+            if self._fused_update and torch.cuda.memory_allocated(self.dev) != before:
+                raise RuntimeError('the captured parameter update of exchange chunk %d allocated memory' % k)
+            pool_b = gk.pool()
             gbs.append(gk)
         self._graphs = (g1, gbs, g2)
         self._stage1_ready = False
@@ -767,6 +792,10 @@ class DirectLightingStep:
         return ok
 
     def step(self, world_size=1):
+        """One iteration; returns the loss tensor.  With several ranks (or force_exchange) and pipeline=True the call RETURNS WITH THE
+        TEXTURE CHUNK'S ADAM UPDATE STILL PENDING: kd / ks / normal lag the probe and the vertices by one update until the next step()
+        or finish().  Read or change the trained state between steps only through parameters() / set_lr_scale() (they finish() first),
+        and call finish() after the last step -- a dropped object with a pending update warns."""
         multi = world_size > 1 or self.force_exchange
         if self.use_graph and not self.force_eager and self._graphs is None and self._eager_steps >= 3:
             err = None

@@ -210,3 +210,51 @@ def test_the_several_rank_schedule_with_one_rank_is_the_plain_iteration(graph, d
     ex = b['exchange']
     assert ex['mode'] == 'sparse'
     assert 0 < ex['tiles_touched'] < ex['tiles_total']          # the union of two views' tiles, not only this view's
+
+
+_FROZEN_SNIPPET = r'''
+import json, os, sys, torch
+sys.path.insert(0, %r)
+from nvdiffrecmc_amd.trainer import DirectLightingStep
+res, n = 96, 4
+out = {}
+for tag, kw in (('plain', {}), ('forced', {'force_exchange': True, 'exchange_mode': 'dense'})):
+    st = DirectLightingStep('bob', res, n, view=[1], n_views=4, device='cuda:0', lr=0.03, tex_res=512, pixel_index_offset=res * res, **kw)
+    st.step(1)
+    st.set_lr_scale('kd', 0.0)                      # (completes the pending texture update first)
+    kd0 = st.parameters()['kd'].detach().clone()
+    ks0 = st.parameters()['ks'].detach().clone()
+    peak = []
+    for _ in range(6):
+        st.step(1)
+        st.finish()
+        torch.cuda.synchronize()
+        peak.append(float(st._tex_grad[0].abs().max()))          # the persistent scatter-add buffer (= the exchange bucket when forced) of kd
+    frozen_same = bool(torch.equal(st.parameters()['kd'], kd0))
+    ks_moved = float((st.parameters()['ks'] - ks0).abs().max())
+    st.set_lr_scale('kd', 1.0)
+    for _ in range(2):
+        st.step(1)
+    st.finish()
+    torch.cuda.synchronize()
+    kd1 = st.parameters()['kd']
+    out[tag] = {'peak': peak, 'frozen_same': frozen_same, 'ks_moved': ks_moved, 'finite': bool(torch.isfinite(kd1).all()),
+                'moved': float((kd1 - kd0).abs().max()), 'resident': bool(getattr(st, '_tex_grad_resident', False))}
+print('RESULT ' + json.dumps(out))
+'''
+
+
+def test_a_frozen_texture_still_has_its_gradient_consumed(dev):
+    """set_lr_scale(name, 0): no update, but the persistent scatter-add buffer of the texture lookup's adjoint -- the exchange bucket under
+    the several-rank schedule, all-reduced in place every step -- must still be re-zeroed behind every iteration (ADVICE r5: it grew without
+    bound and fed garbage into Adam when the tensor was unfrozen)."""
+    r = subprocess.run([sys.executable, '-c', _FROZEN_SNIPPET % ROOT], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('RESULT ')][-1][7:])
+    assert out['forced']['resident'] and not out['plain']['resident']
+    for tag in ('plain', 'forced'):
+        o = out[tag]
+        assert o['peak'] == [0.0] * 6, (tag, o['peak'])          # consumed and cleared after every iteration
+        assert o['frozen_same'] and o['ks_moved'] > 0.0           # kd stood still, the rest of the set trained
+        assert o['finite'] and 0.0 < o['moved'] < 0.2             # unfrozen: two ordinary Adam steps at lr 0.03, not an explosion

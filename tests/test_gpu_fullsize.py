@@ -335,6 +335,36 @@ def test_config4_684k_mesh_800_chunked_sparse_subset_vs_oracle(dev):
     ctx.check()
 
 
+def test_config4_dmtet_extraction_800_sparse_subset_vs_oracle(dev):
+    """BASELINE configs[3] on a mesh of the kind DMTet produces (`bench.py --config dmtet64_800`: marching tets over the reference's tet
+    grid tiled to the 128^3 class, a seeded rough surface with floaters, 140 114 irregular triangles; tools/make_dmtet_mesh.py): 800x800,
+    n_samples_x = 8, a sparse pixel subset against the oracle's brute force over every triangle, forward and all five gradients, the launch
+    cut into chunks of the ray stream."""
+    res, n, seed = 800, 8, 21
+    mesh, ctx, kw, perms = _gpu_scene('dmtet64_mid', res, n, dev, view=6)
+    assert ctx.bvh_info()['n_tris'] == 140114
+    sub = torch.zeros_like(kw['mask'])
+    sub[:, 3::13, 5::17] = kw['mask'][:, 3::13, 5::17]
+    kws = dict(kw, mask=sub)
+    ctx.set_stream_budget(1)
+    g = torch.Generator().manual_seed(9)
+    dg, sg = torch.rand(1, res, res, 3, generator=g), torch.rand(1, res, res, 3, generator=g)
+    leaves = {k: kws[k].clone().requires_grad_(True) for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')}
+    d, s = _shade(ctx, dict(kws, **leaves), n, seed)
+    ((d * dg.to(dev)).sum() + (s * sg.to(dev)).sum()).backward()
+    cpu = {k: v.detach().cpu().contiguous() for k, v in kws.items()}
+    f = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, n_threads=NT)
+    b = orc.env_shade(mesh['v_pos'], mesh['t_pos_idx'], **cpu, perms=perms, n_samples_x=n, rnd_seed=seed, diff_grad=dg, spec_grad=sg, n_threads=NT)
+    assert 400 < f['covered'] < 3000
+    assert_close(d, f['diff'], 2e-6)
+    assert_close(s, f['spec'], 2e-6)
+    for k in ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks'):
+        ref = b[k + '_grad']
+        assert_close(leaves[k].grad, ref, 2e-4, floor=1e-3 * max(ref.abs().max().item(), 1e-3), what=k)
+    assert_close(leaves['light'].grad, b['light_grad'], 1e-4, floor=1e-3 * b['light_grad'].abs().max().item())
+    ctx.check()
+
+
 def test_dmtet_sized_mesh_800(dev):
     """configs[3] stand-in: 800x800, n_samples_x = 8 on a 171k-triangle mesh (bob subdivided twice): finite, deterministic,
     and identical visibility-driven result after a refit to the same vertices."""

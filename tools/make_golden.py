@@ -14,6 +14,9 @@
                       sys.modules and torch.arange stripped of device="cuda" (render/util.py:62-66 builds the pixel
                       grid on 'cuda'); probes E0 / E1 at 256x256 and 48x48, plus a probe with an all-zero row.
 
+  dmtet_reference.npz : the reference's own marching_tets / map_uv (geometry/dmtet.py:50-141) on an own 6^3 Kuhn tet grid with two
+                      seeded SDFs: the pin of the numpy restatement that extracts the DMTet benchmark meshes.
+
 Inputs of the env-shade / denoiser cases are NOT stored (they are regenerated from seeds by
 oracle/scene_cpu.py); a checksum of them is stored and re-checked by the tests.
 
@@ -252,8 +255,77 @@ def gen_mesh():
     np.savez_compressed(os.path.join(OUT, 'mesh_reference.npz'), **flat)
 
 
+def kuhn_tet_grid(k):
+    """An own small tet grid for the marching-tets pin (NOT reference data): the unit cube cut into k^3 cells of six Kuhn tetrahedra each."""
+    ax = np.arange(k + 1)
+    vid = lambda x, y, z: (x * (k + 1) + y) * (k + 1) + z
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing='ij')
+    verts = (np.stack((X, Y, Z), -1).reshape(-1, 3) / float(k) - 0.5).astype(np.float32)
+    import itertools
+    tets = []
+    for x in range(k):
+        for y in range(k):
+            for z in range(k):
+                for perm in itertools.permutations(range(3)):
+                    p = [x, y, z]
+                    tet = [vid(*p)]
+                    for a in perm:
+                        p[a] += 1
+                        tet.append(vid(*p))
+                    tets.append(tet)
+    return verts, np.asarray(tets, dtype=np.int64)
+
+
+def gen_dmtet():
+    """The reference's own marching_tets / map_uv (geometry/dmtet.py:50-141, the module imported unmodified with its renderer imports
+    stubbed and device='cuda' stripped from the tensor factories) on an own 6^3 Kuhn grid with two seeded SDFs: the pin of
+    tools/make_dmtet_mesh.py's numpy restatement and of nvdiffrecmc_amd/scene.py's atlas."""
+    import types
+    import importlib
+    for mod in ('nvdiffrast', 'nvdiffrast.torch', 'imageio', 'tinycudann', 'render.render', 'render.regularizer', 'render.optixutils'):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules['nvdiffrast'].torch = sys.modules['nvdiffrast.torch']
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    real = {n: getattr(torch, n) for n in ('tensor', 'ones', 'arange', 'linspace')}
+
+    def strip(fn):
+        def f(*a, **k):
+            k.pop('device', None)
+            return fn(*a, **k)
+        return f
+    for n, fn in real.items():
+        setattr(torch, n, strip(fn))
+    try:
+        import render as _render_pkg
+        for sub in ('render', 'regularizer', 'optixutils'):
+            setattr(_render_pkg, sub, sys.modules['render.' + sub])
+        dm = importlib.import_module('geometry.dmtet')       # /root/reference/geometry/dmtet.py, unmodified
+        verts, tets = kuhn_tet_grid(6)
+        flat = {'grid/vertices': verts, 'grid/indices': tets}
+        rng = np.random.default_rng(99)
+        sdfs = {'random': rng.random(verts.shape[0]).astype(np.float32) - np.float32(0.1),
+                'sphere': (0.37 - np.linalg.norm(verts + 0.03, axis=-1)).astype(np.float32)}
+        for name, sdf in sdfs.items():
+            v, f, uvs, uv_idx = dm.marching_tets(torch.from_numpy(verts) * 2.4, torch.from_numpy(sdf), torch.from_numpy(tets))
+            flat[name + '/sdf'] = sdf
+            flat[name + '/verts'] = v.numpy()
+            flat[name + '/faces'] = f.numpy().astype(np.int32)
+            flat[name + '/uv_idx'] = uv_idx.numpy().astype(np.int32)
+            flat[name + '/uvs_sha256'] = np.array(checksum(uvs))
+            flat[name + '/uvs_head'] = uvs[:64].numpy()
+            print('dmtet', name, tuple(v.shape), tuple(f.shape), tuple(uvs.shape))
+    finally:
+        for n, fn in real.items():
+            setattr(torch, n, fn)
+    np.savez_compressed(os.path.join(OUT, 'dmtet_reference.npz'), **flat)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dmtet':
+        gen_dmtet()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'light':
         gen_light()
         sys.exit(0)
@@ -263,6 +335,7 @@ if __name__ == '__main__':
     gen_renderutils()
     gen_light()
     gen_mesh()
+    gen_dmtet()
     gen_env_shade()
     gen_denoiser()
     for f in sorted(os.listdir(OUT)):

@@ -76,6 +76,10 @@ int nvdr_ctx_set_build_mode(nvdr_ctx *ctx, int mode);
  * itself before its first launch.  For a caller that captures the build in a HIP graph of its own: a capture must not end with the side
  * stream's work unjoined. */
 int nvdr_bvh_wait(nvdr_ctx *ctx, void *stream);
+/* The caller has ordered its streams behind the context's last build itself (e.g. the build was captured into a HIP graph of its own,
+ * joined inside that graph by nvdr_bvh_wait, and the replays are ordered by the caller's events): consumers issue no wait of their own
+ * until the next nvdr_bvh_build. */
+int nvdr_bvh_mark_joined(nvdr_ctx *ctx);
 /* ---- optix_build_bvh (torch_bindings.cpp:37-116).  verts f32[V,3] contiguous, tris i32[T,3]
  * contiguous.  rebuild > 0: full LBVH build (Morton codes, radix sort, hierarchy, bounds);
  * rebuild == 0: refit the bounds of the existing hierarchy to moved vertices (OPTIX_BUILD_OPERATION_UPDATE). */
@@ -212,7 +216,8 @@ int nvdr_texture_lookup_bwd(const nvdr_texture_args *args, void *stream);
 
 /* ---- env_shade_fwd / env_shade_bwd (torch_bindings.cpp:123-272; raygen program kernel.cu:463-542) */
 #define NVDR_COUNTERS_BVH2 (8 + 2 * 8192)
-#define NVDR_COUNTERS_LEN (NVDR_COUNTERS_BVH2 + 8)
+#define NVDR_COUNTERS_PHASES (NVDR_COUNTERS_BVH2 + 8)
+#define NVDR_COUNTERS_LEN (NVDR_COUNTERS_PHASES + 16)
 typedef struct nvdr_env_shade_args {
     nvdr_tensor mask;        /* f32 [N,H,W]    (>0 = covered)                     params.h:17 */
     nvdr_tensor ro;          /* f32 [N,H,W,3]  shadow-ray origins                 params.h:14 */
@@ -260,6 +265,14 @@ typedef struct nvdr_env_shade_args {
          the production walk is, checked against a CPU walk of the exported tree in tests/test_gpu_bvh.py.
          [NVDR_COUNTERS_BVH2 + 3] node steps of the production walk (one 64-byte node fetch + eight box tests each),
          [+4] triangle-test batches, [+5] lanes those batches filled (= triangle tests; / 64 / batches = their occupancy).
+         [NVDR_COUNTERS_PHASES + 0 .. 15] (round 6) shader-clock cycles of the wavefront loop by phase, summed over the wavefronts, from two
+         PHASE-CLOCK builds of the kernel that a counting launch runs behind the counting kernel on the same rays (trace_kernel.h):
+           build 1 (clock reads at wave-uniform points only, no vector register):  [0] refill (votes, chunk claims, ray fetch + set-up)
+             [1] node step (pop, address, node fetch, box arithmetic, hit masks, push)  [2] leaf-queue append rounds  [3] triangle batches
+             [4] loop iterations  [5] iterations with a node step in some lane  [6] total cycles of the wavefronts  [7] wavefronts
+           build 2 (waits for the node behind its loads and reads the clock inside the node step):  [8] refill  [9] node fetch (pop, address,
+             four 16-byte loads, wait)  [10] box arithmetic of the eight children  [11] hit masks + push + group bookkeeping  [12] queue rounds
+             [13] triangle batches  [14] total cycles  [15] loop iterations.
        Rays traversed < 2*S*pixels: samples with dot(n, wi) <= 0 contribute exactly zero through the BSDF's own
        gates whatever their visibility and are not traced (NVDR_DEBUG bit 8 traces them anyway). */
     unsigned long long *counters;
@@ -278,6 +291,12 @@ typedef struct nvdr_env_shade_args {
        pass needs (pass the snapshot as its rnd_seed_offset) without two extra launches per shade() call. */
     uint32_t *rnd_seed_snapshot;
     uint32_t  rnd_seed_advance;
+    /* forward only: 0 = the whole launch (default).  A caller that wants to put something between the sample generation and the first
+       kernel that reads the BVH -- trainer.py cuts its HIP graph there, so that a rebuild replayed on another stream is joined in front of
+       the traversal instead of in front of the whole launch -- issues the SAME arguments twice: phase 1 = everything up to and including
+       the sample generation, phase 2 = traversal and shading.  Only a launch that fits ONE chunk of the ray stream can be cut (the chunks
+       of a larger one interleave their stages): phase 1 of a larger launch enqueues nothing and phase 2 all of it. */
+    uint32_t  phase;
 } nvdr_env_shade_args;
 int nvdr_env_shade_fwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);
 int nvdr_env_shade_bwd(nvdr_ctx *ctx, const nvdr_env_shade_args *args, void *stream);

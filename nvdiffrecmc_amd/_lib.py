@@ -25,7 +25,8 @@ class NvdrBvhInfo(ctypes.Structure):
                 ('stack_max', ctypes.c_int32)]
 
 COUNTERS_BVH2 = 8 + 2 * 8192   # NVDR_COUNTERS_BVH2
-COUNTERS_LEN = COUNTERS_BVH2 + 8
+COUNTERS_PHASES = COUNTERS_BVH2 + 8  # NVDR_COUNTERS_PHASES
+COUNTERS_LEN = COUNTERS_PHASES + 16
 
 
 class NvdrEnvShadeArgs(ctypes.Structure):
@@ -37,7 +38,7 @@ class NvdrEnvShadeArgs(ctypes.Structure):
         ('diff_grad', NvdrTensor), ('spec_grad', NvdrTensor),
         ('gb_pos_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_kd_grad', c_void_p), ('gb_ks_grad', c_void_p),
         ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p), ('reuse_stream_id', ctypes.c_uint64), ('rnd_seed_offset', c_void_p),
-        ('rnd_seed_snapshot', c_void_p), ('rnd_seed_advance', ctypes.c_uint32)]
+        ('rnd_seed_snapshot', c_void_p), ('rnd_seed_advance', ctypes.c_uint32), ('phase', ctypes.c_uint32)]
 
 
 class NvdrGbufferArgs(ctypes.Structure):
@@ -112,6 +113,7 @@ _SIGNATURES = {
     'nvdr_ctx_set_allocator': [c_void_p, c_void_p, c_void_p, c_void_p],
     'nvdr_ctx_set_build_mode': [c_void_p, c_int],
     'nvdr_bvh_wait': [c_void_p, c_void_p],
+    'nvdr_bvh_mark_joined': [c_void_p],
     'nvdr_bvh_build': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p],
     'nvdr_bvh_info_get': [c_void_p, ctypes.POINTER(NvdrBvhInfo), c_void_p],
     'nvdr_bvh_export': [c_void_p, c_void_p, c_void_p, c_void_p],

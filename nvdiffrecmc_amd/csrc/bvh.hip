@@ -1024,6 +1024,15 @@ extern "C" int nvdr_bvh_wait(nvdr_ctx *c, void *stream_)
     return ctx_wait_built(c, (hipStream_t)stream_);
 }
 
+extern "C" int nvdr_bvh_mark_joined(nvdr_ctx *c)
+{
+    NVDR_REQUIRE(c != nullptr, "nvdr_bvh_mark_joined: ctx is NULL");
+    NVDR_REQUIRE(!c->queued, "nvdr_bvh_mark_joined: a deferred build has not been launched yet");
+    c->built_pending = false;
+    c->built_waited_valid = false;
+    return 0;
+}
+
 extern "C" int nvdr_ctx_check(nvdr_ctx *c, void *stream_)
 {
     NVDR_REQUIRE(c != nullptr, "nvdr_ctx_check: ctx is NULL");

@@ -851,6 +851,14 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
     env_trace_body<COUNT>(a, smem);
 }
 
+// the phase-clock builds of the same kernel (trace_kernel.h PH; counting launches only)
+template <int PH>
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_phase_kernel(TraceLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    env_trace_body<false, PH>(a, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // stage 3: shading (process_sample, kernel.cu:403-461) forward or backward
 
@@ -1610,6 +1618,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 
 #define NVDR_LG_THREADS 1024
 #define NVDR_LG_PER_BAND_MAX_SLOTS (192ll << 20)    // launches of up to this many stream slots (6 views of 512^2 x 64 spp) deal the CUs to the bands (measured: -13 % / -6 % / -2 % / +-0 of the backward shading + gather time at 1 / 2 / 4 / 8 views)
+#ifndef NVDR_LG_NB
+#define NVDR_LG_NB 4                     // blocks of 128 records a wavefront of the gather fetches together (1: A/B)
+#endif
 #ifndef NVDR_LG_NATIVE_ATOMICS
 #define NVDR_LG_NATIVE_ATOMICS 0        // 1: ds_add_f32 (A/B only)
 #endif
@@ -1682,29 +1693,30 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
             const bool mine = tag != 0xFFFFu && (tag & 0xFFu) == (unsigned)band;
             unsigned long long m = __ballot(mine);
             if (mine) tags[blk] = 0xFFFFu;                  // consumed: the array reads "no records" again for the next launch
-            // one block per step, the next block's two loads in flight while this one's records are added
-            float4 c0 = none, c1 = none;
-            if (m) {
-                const int j = __builtin_ctzll(m);
-                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)blk, j), f = (unsigned)__builtin_amdgcn_readlane((int)tag, j) >> 8;
-                if (lane < f) c0 = recs[(b << 7) + lane];
-                if (lane + 64u < f) c1 = recs[(b << 7) + 64u + lane];
-                m &= m - 1ull;
-            }
-            for (;;) {
-                float4 n0 = none, n1 = none;
-                const bool more = m != 0ull;
-                if (more) {
-                    const int j = __builtin_ctzll(m);
-                    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)blk, j), f = (unsigned)__builtin_amdgcn_readlane((int)tag, j) >> 8;
-                    if (lane < f) n0 = recs[(b << 7) + lane];
-                    if (lane + 64u < f) n1 = recs[(b << 7) + 64u + lane];
-                    m &= m - 1ull;
+            // NVDR_LG_NB blocks per step: their 2 NB loads are in flight together, then their records are added.  (Rounds 3-5 took one block
+            // per step with the next one's two loads in flight: a wavefront's 5-10 blocks were a chain of as many memory round trips, which
+            // is what a small launch's gather consisted of -- 76-88 us for the 2.6 M records of one view, 0.26 ms for the 21 M of eight.)
+            while (m != 0ull) {
+                unsigned bb[NVDR_LG_NB], ff[NVDR_LG_NB];
+#pragma unroll
+                for (int q = 0; q < NVDR_LG_NB; ++q) {
+                    bb[q] = 0u; ff[q] = 0u;
+                    if (m != 0ull) {
+                        const int j = __builtin_ctzll(m);
+                        bb[q] = (unsigned)__builtin_amdgcn_readlane((int)blk, j);
+                        ff[q] = (unsigned)__builtin_amdgcn_readlane((int)tag, j) >> 8;
+                        m &= m - 1ull;
+                    }
                 }
-                add(c0);
-                add(c1);
-                if (!more) break;
-                c0 = n0; c1 = n1;
+                float4 cc[2 * NVDR_LG_NB];
+#pragma unroll
+                for (int q = 0; q < NVDR_LG_NB; ++q) {
+                    cc[2 * q] = none; cc[2 * q + 1] = none;
+                    if (lane < ff[q]) cc[2 * q] = recs[(bb[q] << 7) + lane];
+                    if (lane + 64u < ff[q]) cc[2 * q + 1] = recs[(bb[q] << 7) + 64u + lane];
+                }
+#pragma unroll
+                for (int q = 0; q < 2 * NVDR_LG_NB; ++q) add(cc[q]);
             }
         }
         __syncthreads();
@@ -1818,9 +1830,15 @@ static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t s
     // reset them -- every traversal launch follows one of those (a backward pass that re-traces the forward's stream follows the
     // forward's stage 3; any other launch in between invalidates that stream).  NVDR_DEBUG bit 64 adds an explicit reset kernel.
     if (c->debug & 64u) zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
-    if (counters)
+    if (counters) {
         env_trace_kernel<true><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
-    else
+        // the same rays twice more through the phase-clock builds (the dealing counters are used up: reset in between; the visibility
+        // bytes are rewritten with the same values)
+        zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
+        env_trace_phase_kernel<1><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
+        zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
+        env_trace_phase_kernel<2><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
+    } else
         env_trace_kernel<false><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
 }
 
@@ -2040,6 +2058,11 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
                  "ray slots of one chunk of the ray stream (at most %d chunks per launch): render fewer views per launch",
                  (long long)npix, S, (long long)cap, NVDR_MAX_CHUNKS);
     const int n_chunks = (int)((npix + cap - 1) / cap);
+    // a->phase (forward): the launch issued in two calls, cut between the sample generation and the traversal (nvdr_hip.h)
+    NVDR_REQUIRE(a->phase <= 2u && !(backward && a->phase), "env_shade: phase %u (0 whole launch, 1 up to the sample generation, 2 the rest; forward only)", a->phase);
+    const bool cut = a->phase != 0u && n_chunks == 1;
+    if (a->phase == 1u && !cut) return 0;                       // a launch of several chunks cannot be cut: phase 2 runs all of it
+    const bool front = !(cut && a->phase == 2u), back = !(cut && a->phase == 1u);
     // the chunk is raised to npix / NVDR_MAX_CHUNKS when the byte budget asks for more chunks than that; chunk-local slot numbers
     // must still fit 31 bits (they are stored as unsigned / int in the live list, the light-gradient keys and the band gather)
     NVDR_REQUIRE(cap * 2 * (int64_t)S <= (1ll << 31) - 64,
@@ -2168,22 +2191,23 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             NVDR_HIP_TRY(ctx_malloc(c, &c->cdf_guide, sizeof(uint16_t) * need, stream));
             c->guide_cap = need;
         }
-        cdf_guide_kernel<<<div_up((int64_t)need, 256), 256, 0, stream>>>(p.rows, p.cols, lr, lc, c->cdf_guide);
+        if (front) cdf_guide_kernel<<<div_up((int64_t)need, 256), 256, 0, stream>>>(p.rows, p.cols, lr, lc, c->cdf_guide);
         p.cdf_guide = c->cdf_guide;
         p.guide_log_rows = lr;
         p.guide_log_cols = lc;
     }
     c->stream_id = 0; // invalid while being rewritten
+    if (front)
     begin_launch_kernel<<<1, 256, 0, stream>>>(&c->dinfo->pix_count, c->chunk_counts, n_chunks, p.reuse, p.pix_cap, seg_cap,
                                                const_cast<unsigned *>(a->rnd_seed_offset), backward ? nullptr : a->rnd_seed_snapshot, a->rnd_seed_advance);
-    if (!reuse)
+    if (!reuse && front)
         compact_pixels_kernel<<<div_up(npix, 256 * NVDR_COMPACT_ROUNDS), 256, 0, stream>>>(p.mask, p.ms0, p.ms1, p.ms2, p.N, p.H, p.W, c->pix_list,
                                                                       &c->dinfo->pix_count, backward ? nullptr : p.diff, backward ? nullptr : p.spec);
     for (int k = 0; k < n_chunks; ++k) {
         p.pix_begin = (unsigned)((int64_t)k * cap);
         p.ray_count = c->chunk_counts + (size_t)k * NVDR_LIVE_WORDS;
         hipEvent_t *pe = nullptr;
-        if (c->profiling && n_chunks <= NVDR_PROF_RING) {      // (a launch of more chunks than records would overwrite its own first chunks)
+        if (c->profiling && n_chunks <= NVDR_PROF_RING && !cut) {      // (a launch of more chunks than records would overwrite its own first chunks; a cut launch is not timed)
             const int slot = (int)(c->prof_n % NVDR_PROF_RING);
             pe = c->prof_ev[slot];
             c->prof_kind[slot] = (backward ? 1 : 0) | (k == 0 ? 2 : 0);
@@ -2192,12 +2216,13 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         }
         // stage 1 (skipped on the host when the forward's stream is known to be whole: one chunk covers the launch;
         // otherwise the kernel itself decides from the device-side pixel count)
-        if (!(reuse && n_chunks == 1)) {
+        if (!(reuse && n_chunks == 1) && front) {
             NvdrRange r("nvdr:gen");
             if (c->debug) env_gen_kernel<true><<<(unsigned)pb[0], 256, 0, stream>>>(p);
             else env_gen_kernel<false><<<(unsigned)pb[0], 256, 0, stream>>>(p);
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[1], stream));
+        if (!back) break;                                       // phase 1 of a cut launch ends here (one chunk)
         // stage 2 (the first launch of this call that needs the tree: a build may still be running on the context's side stream)
         if (!replay) {
             NvdrRange r("nvdr:trace");
@@ -2233,6 +2258,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         }
         if (pe) NVDR_HIP_TRY(hipEventRecord(pe[3], stream));
     }
+    if (!back) { NVDR_LAUNCH_CHECK(); return 0; }              // (the stream becomes valid when phase 2 has been enqueued)
     if (backward && p.lg_records) c->lg_tags_dirty = false;    // every chunk's gather consumed (and reset) the tags its shading kernel wrote
     if (backward && !p.lg_records && !(c->debug & 2u))
         light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, 8, p.g_light, 0, nullptr, 0);

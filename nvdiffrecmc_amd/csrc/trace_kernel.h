@@ -153,8 +153,13 @@ struct OctRay {
     float ix, iy, iz, nx, ny, nz;
 };
 
-// COUNT: the counting build (box / triangle tests, node steps, per-wave clocks)
-template <bool COUNT>
+// COUNT: the counting build (box / triangle tests, node steps, per-wave clocks).
+// PH: the PHASE-CLOCK builds (round 6; counting launches run them behind the counting kernel, on the same rays): shader-clock cycles of the
+// wavefront loop by phase, read at wave-uniform points only (PH = 1: eight scalar accumulators, no vector register, no per-lane counter -- the
+// counting build's 17 spilled dwords would drown what is being measured) or, PH = 2, additionally inside the node step with a wait for the
+// node behind its four loads (three more vector registers, and the production kernel's overlap of the fetch with the ray's frame set-up is
+// gone: this build only splits the node step of PH = 1 into fetch / box arithmetic / stack).
+template <bool COUNT, int PH = 0>
 __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
 {
     const BvhView &bvh = a.bvh;
@@ -189,8 +194,12 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
     bool more = total > 0;
     unsigned n_box = 0, n_tri = 0, n_ray = 0, n_step = 0, n_batch = 0;
+    // phase-clock builds: shader-clock cycles of this wavefront by phase of the loop (wave-uniform; nvdr_hip.h NVDR_COUNTERS_PHASES)
+    // (32-bit: a launch lasts a few million cycles, differences are taken modulo 2^32; eight scalar registers instead of sixteen)
+    unsigned ph_refill = 0u, ph_fetch = 0u, ph_box = 0u, ph_stack = 0u, ph_queue = 0u, ph_batch = 0u, ph_iters = 0u, ph_steps = 0u;
+    auto clk = [&]() -> unsigned { return PH ? (unsigned)__builtin_readcyclecounter() : 0u; };
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
-    const unsigned long long c_begin = COUNT ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
+    const unsigned long long c_begin = (COUNT || PH) ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
 
     // per-lane walk state.  ray < 0: idle.  ray >= 0 and (gbits | sp) == 0: the walk is over, queued tests decide ("draining").
     int ray = -1, sp = 0;
@@ -204,6 +213,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     // (visibility 0) whatever the owner is doing.  Entries of rays that have ended meanwhile test against the owner's stale
     // registers and can only "kill" an idle lane: harmless, because lanes are refilled only when the queue is empty.
     auto test_batch = [&](unsigned n) {
+        const unsigned tb0 = clk();
         __builtin_amdgcn_wave_barrier();                    // the entries were written by other lanes of this wavefront
         const unsigned first = q_count - n;
         const bool valid = (unsigned)lane < n;
@@ -235,6 +245,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             sp = 0;
             gbits = 0u;
         }
+        if (PH) ph_batch += clk() - tb0;
     };
 
     unsigned iters = 0;
@@ -246,6 +257,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             break;
         }
         // ---- refill: when enough lanes have no node to visit, decide the undecided rays and hand out new ones
+        const unsigned tr0 = clk(), bt0 = ph_batch;
         const unsigned long long busy = __ballot(ray >= 0 && (gbits | (unsigned)sp) != 0u);
         const int n_free = 64 - __popcll(busy);
         if (n_free >= NVDR_REFILL_MIN && next >= end && more) {
@@ -288,6 +300,14 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
 
         // ---- node step of every lane that has one
         unsigned leaf_bits = 0u, leaf_base = 0u;
+        unsigned tn0 = 0u;
+        unsigned dt_fetch = 0u, dt_box = 0u, dt_stack = 0u;     // (per lane: written under divergent control; one active lane's copy is read back below)
+        if (PH) {
+            tn0 = clk();
+            ph_refill += (tn0 - tr0) - (ph_batch - bt0);      // (the flush of the refill is accounted as triangle batches)
+            ph_iters++;
+            if (__ballot(ray >= 0 && (gbits | (unsigned)sp) != 0u) != 0ull) ph_steps++;
+        }
         if (ray >= 0 && (gbits | (unsigned)sp) != 0u) {
             if (gbits == 0u) {
                 sp--;
@@ -300,6 +320,12 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             const uint4 *nd = oct + 4 * (int64_t)(gbase + (unsigned)k);
             const uint4 h = nd[0], p1 = nd[1], p2 = nd[2], p3 = nd[3];
             if (COUNT) n_step++;
+            if (PH == 2) {
+                // (this build waits for the node here, so that the fetch has a phase of its own; the production kernel lets the
+                // compiler place the wait: the ray's set-up of the node frame overlaps part of it)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                dt_fetch = (unsigned)(clk() - tn0);
+            }
             // the node's frame: plane = org + q * 2^e  ->  t = q * (inv * 2^e) + (org * inv + noi)
             const float ax = __builtin_ldexpf(g.ix, (int)((h.y >> 16) & 15u)), bx = fmaf((float)(h.x & 0xffffu), g.ix, g.nx);
             const float ay = __builtin_ldexpf(g.iy, (int)((h.y >> 20) & 15u)), by = fmaf((float)(h.x >> 16), g.iy, g.ny);
@@ -332,6 +358,10 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             const unsigned n_int = h.z >> 28, n_leaf = h.w >> 28;
             const unsigned hits = ~miss & ((1u << (n_int + n_leaf)) - 1u);
             if (COUNT) n_box += n_int + n_leaf;
+            if (PH == 2) {
+                asm volatile("" :: "v"(hits));                 // (the box arithmetic ends here)
+                dt_box = (unsigned)(clk() - tn0) - dt_fetch;
+            }
             const unsigned hi = hits & ((1u << n_int) - 1u);
             leaf_bits = hits >> n_int;
             leaf_base = h.w & (NVDR_OCT_MAX_INDEX - 1u);
@@ -340,6 +370,26 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 if (gbits != 0u) sp = stack.push(sp, pack2(gbase, gbits));
                 gbase = h.z & (NVDR_OCT_MAX_INDEX - 1u);
                 gbits = hi;
+            }
+            if (PH == 2) {
+                asm volatile("" :: "v"(gbits), "v"(sp));
+                dt_stack = (unsigned)(clk() - tn0) - dt_fetch - dt_box;
+            }
+        }
+        unsigned tq0 = 0u, bq0 = 0u;
+        if (PH) {
+            tq0 = clk();
+            bq0 = ph_batch;
+            if (PH == 2) {
+                const unsigned long long am = __ballot(dt_fetch != 0u);
+                if (am != 0ull) {
+                    const int l = __builtin_ctzll(am);
+                    ph_fetch += (unsigned)__builtin_amdgcn_readlane((int)dt_fetch, l);
+                    ph_box += (unsigned)__builtin_amdgcn_readlane((int)dt_box, l);
+                    ph_stack += (unsigned)__builtin_amdgcn_readlane((int)dt_stack, l);
+                }
+            } else {
+                ph_fetch += tq0 - tn0;                         // PH = 1: the whole node step (fetch + box arithmetic + stack) in one figure
             }
         }
 
@@ -357,6 +407,30 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             if (q_count >= 64u) {
                 test_batch(64u);
                 if (ray < 0) leaf_bits = 0u;                // the owner was just found occluded: its other leaves do not matter
+            }
+        }
+        if (PH) ph_queue += (clk() - tq0) - (ph_batch - bq0);
+    }
+    if (PH) {
+        if (lane == 0) {
+            unsigned long long *pc = counters + NVDR_COUNTERS_PHASES + (PH == 2 ? 8 : 0);
+            const unsigned long long total = (unsigned long long)__builtin_readcyclecounter() - c_begin;
+            atomicAdd(&pc[0], (unsigned long long)ph_refill);
+            atomicAdd(&pc[1], (unsigned long long)ph_fetch);            // PH = 1: the whole node step
+            if (PH == 2) {
+                atomicAdd(&pc[2], (unsigned long long)ph_box);
+                atomicAdd(&pc[3], (unsigned long long)ph_stack);
+                atomicAdd(&pc[4], (unsigned long long)ph_queue);
+                atomicAdd(&pc[5], (unsigned long long)ph_batch);
+                atomicAdd(&pc[6], total);
+                atomicAdd(&pc[7], (unsigned long long)ph_iters);
+            } else {
+                atomicAdd(&pc[2], (unsigned long long)ph_queue);
+                atomicAdd(&pc[3], (unsigned long long)ph_batch);
+                atomicAdd(&pc[4], (unsigned long long)ph_iters);
+                atomicAdd(&pc[5], (unsigned long long)ph_steps);
+                atomicAdd(&pc[6], total);
+                atomicAdd(&pc[7], 1ull);
             }
         }
     }

@@ -69,6 +69,10 @@ class OptiXContext:
         self.pixel_index_offset = None
         self.seed_offset = None
         self.seed_advance = 0       # != 0 (with seed_offset and a fixed rnd_seed): every forward launch adds this to the device counter itself
+        #   split_hook         callable or None: the forward launch is issued in two calls (nvdr_env_shade_args.phase) and the hook runs between
+        #                      them, i.e. between the sample generation and the first kernel that reads the BVH (trainer.py ends one HIP
+        #                      graph and begins the next there)
+        self.split_hook = None
 
     def set_stream_budget(self, megabytes):
         """HBM the ray stream between the three env-shade stages may take (default 8192 MB); larger launches are processed
@@ -80,6 +84,11 @@ class OptiXContext:
         """The current stream waits (on the device) for the last optix_build_bvh of this context; consumers of the tree do this by themselves."""
         w = self.cpp_wrapper
         _lib.check(w.lib.nvdr_bvh_wait(w.handle, _lib.stream_ptr()), 'nvdr_bvh_wait')
+
+    def build_joined(self):
+        """The caller orders its streams behind the last build itself (nvdr_bvh_mark_joined): consumers issue no wait of their own."""
+        w = self.cpp_wrapper
+        _lib.check(w.lib.nvdr_bvh_mark_joined(w.handle), 'nvdr_bvh_mark_joined')
 
     def set_build_mode(self, mode):
         """Where optix_build_bvh runs: 1 (default) side stream, 0 the caller's stream, 2 side stream with the launches deferred to the
@@ -248,6 +257,12 @@ class _optix_env_shade_func(torch.autograd.Function):
             words = (n_samples_x * n_samples_x + 31) // 32
             vis = torch.empty(N * H * W * 2 * words, dtype=torch.int32, device=ro.device)
             a.vis_cache = vis.data_ptr()
+        hook = getattr(optix_ctx, 'split_hook', None)
+        if hook is not None:
+            a.phase = 1
+            _lib.check(w.lib.nvdr_env_shade_fwd(w.handle, ctypes.byref(a), _lib.stream_ptr()), 'env_shade_fwd')
+            hook()                  # (may change the current stream: a capture ends here and the next one begins)
+            a.phase = 2
         _lib.check(w.lib.nvdr_env_shade_fwd(w.handle, ctypes.byref(a), _lib.stream_ptr()), 'env_shade_fwd')
         sid = ctypes.c_uint64()
         _lib.check(w.lib.nvdr_env_shade_stream_id(w.handle, ctypes.byref(sid)), 'env_shade_stream_id')
@@ -526,5 +541,9 @@ def env_shade_traversal_counts(optix_ctx, mask, ro, gb_pos, gb_normal, gb_view_p
     env_shade_traversal_counts.xcd_mask = int(c[7])
     env_shade_traversal_counts.bvh2 = tuple(int(v) for v in c[_lib.COUNTERS_BVH2:_lib.COUNTERS_BVH2 + 3])
     env_shade_traversal_counts.node_steps = int(c[_lib.COUNTERS_BVH2 + 3])      # node visits of the production walk
+    # cycles by loop phase from the two phase-clock builds (nvdr_hip.h NVDR_COUNTERS_PHASES): [refill, node step, queue rounds, batches, iterations,
+    # node-step iterations, total cycles, wavefronts] and [refill, fetch, box, stack, queue rounds, batches, total cycles, iterations]
+    env_shade_traversal_counts.phases = [int(v) for v in c[_lib.COUNTERS_PHASES:_lib.COUNTERS_PHASES + 8]]
+    env_shade_traversal_counts.phases_split = [int(v) for v in c[_lib.COUNTERS_PHASES + 8:_lib.COUNTERS_PHASES + 16]]
     env_shade_traversal_counts.leaf_batches = (int(c[_lib.COUNTERS_BVH2 + 4]), int(c[_lib.COUNTERS_BVH2 + 5]))   # triangle-test batches, lanes they filled
     return int(npx.value), int(c[0]), int(c[1]), int(c[2])

@@ -262,7 +262,7 @@ class GradientExchange:
         b = self.buckets[k]
         cuda = b.is_cuda
         if cuda and self._side is None:
-            self._side = torch.cuda.Stream(device=b.device)
+            self._side = torch.cuda.Stream(device=b.device, priority=-1)     # (high priority: never on the main stream's hardware queue, trainer._capture)
         if cuda:
             self._side.wait_event(self._ev_start)        # the main stream as of start(), not as of now
         ctx = torch.cuda.stream(self._side) if cuda else _null_context()

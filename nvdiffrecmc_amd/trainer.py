@@ -109,7 +109,7 @@ class DirectLightingStep:
                  probe_res=256, denoise=True, retrace_backward=False, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
                  denoiser_demodulate=True, light_grad_scale=64.0, use_graph=False, material_set='full', tex_res=1024,
                  optimize_geometry=False, lr_pos=None, lr_light=None, perturb_pos=0.0, ks_min=(0.0, 0.08, 0.0), ks_max=(0.0, 1.0, 1.0),
-                 perturbed_nrm=True, exchange_mode='auto', pipeline=True, force_exchange=False, union_views=None, build_mode=None):
+                 perturbed_nrm=True, exchange_mode='auto', pipeline=True, force_exchange=False, union_views=None, build_mode=None, rebuild_every=1):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
@@ -129,11 +129,19 @@ class DirectLightingStep:
         if exchange_mode not in ('auto', 'dense', 'sparse'):
             raise ValueError("exchange_mode must be 'auto', 'dense' or 'sparse'")
         self.exchange_mode, self.pipeline, self.force_exchange = exchange_mode, bool(pipeline), bool(force_exchange)
+        # rebuild_every (trained geometry only): K > 1 = the tree is REBUILT every K-th iteration and REFITTED (rebuild=0: the topology of the
+        # last rebuild, new boxes, the eight-wide collapse redone) in between.  Visibility and closest hits are exact with any valid tree; the
+        # vertices move by a learning-rate step per iteration, so a refitted tree degrades slowly and a rebuild every few iterations
+        # restores it -- the practice OptiX documents for dynamic geometry.  1 = what the reference does (geometry/dlmesh.py:50 passes
+        # rebuild=1 every iteration) and the default.  Locked geometry is rebuilt every iteration whatever K (as the reference does).
+        self.rebuild_every = max(1, int(rebuild_every))
+        self._iter = 0
         # union_views (with force_exchange): the views of the WHOLE batch; the tile flags of this one rank are OR-ed with the tiles those views
         # touch, so that the one-rank run compacts, sends and scatters the bytes the several-rank run would (bench.py one_view)
         self._union_views = list(union_views) if (union_views is not None and force_exchange) else None
         self.measure_exposed, self._exposed_events, self._stage1_events = False, [], []
         self._stage1_ready, self._gb_live, self._pending = False, None, False
+        self.split_stage2 = False         # set by _capture: locked geometry under the pipelined several-rank schedule (stage 2 in two graphs)
         self.fused = fused
         self.pair_filter = _lib.tuning_env('NVDR_PAIR_FILTER', '1') != '0'      # (A/B switch of the harness)
         self.denoiser_demodulate = denoiser_demodulate    # FLAGS.denoiser_demodulate (train.py:525, default True)
@@ -426,27 +434,39 @@ class DirectLightingStep:
                 spec = ou.ops._bilateral_denoiser_func.apply(spec, nn, depth, self.denoiser.sigma)
         return ru.shade_composite(diff, spec, kd, ks)
 
-    def _build_bvh(self):
+    def _refit_now(self, ahead=0):
+        """Iteration _iter + ahead refits instead of rebuilding (rebuild_every; trained geometry only)."""
+        return self.optimize_geometry and self.rebuild_every > 1 and (self._iter + ahead) % self.rebuild_every != 0
+
+    def _build_bvh(self, rebuild=None, ahead=0):
         v_pos = self.v_pos if self.optimize_geometry else self.mesh['v_pos']
-        ou.optix_build_bvh(self.ctx, v_pos, self.mesh['t_pos_idx'], rebuild=1)
+        if rebuild is None:
+            rebuild = 0 if self._refit_now(ahead) else 1
+        ou.optix_build_bvh(self.ctx, v_pos, self.mesh['t_pos_idx'], rebuild=rebuild)
         self._build_deferred = False
         return v_pos
 
-    def _stage1(self, defer_build=False):
+    def _stage1(self, defer_build=False, build=True, ahead=0):
         """The geometry stage of an iteration -- everything that needs only the light probe and the vertices, not the textures: BVH
         rebuild (side stream), update_pdf, and with trained geometry getMesh (dlmesh.py:45-55) + rasterize / interpolate
         (render.py:208-234) from the moving vertices.  With several ranks it runs while the texture chunk of the previous iteration's
         gradient exchange is still on the wire (_step_multi).
-        join_build (the several-rank schedule): the stage ends with the main stream waiting for the rebuild -- a HIP graph of this stage alone
-        must not end with the side stream's work unjoined, and the rebuild then runs while the texture chunk is on the wire instead of beside
-        the sample generation."""
+        defer_build (a HIP graph of this stage alone, trained geometry or the unpipelined schedule): the stage ends with the main stream
+        waiting for the rebuild -- a graph must not end with the side stream's work unjoined.  With LOCKED geometry under the pipelined
+        schedule nothing of stage 2 but the traversal needs the tree, and the stage is cut differently (round 6, _capture): the rebuild is
+        a graph of its own replayed on a side stream as soon as the early chunks are updated -- it runs while the texture chunk is on the
+        wire AND, if it is not done by then, beside the lookups and the sample generation like in the one-rank iteration; the main stream
+        waits for it in front of the traversal kernel only."""
         # the rebuild first: it runs on the context's side stream, and the sooner it starts the less of it is left when the traversal
         # needs the tree (one view: the light's three small kernels used to run in front of it)
         self._build_deferred = False
-        v_pos = self._build_bvh()
+        if build:
+            v_pos = self._build_bvh(ahead=ahead)       # (ahead = 1: the pipelined geometry stage at the end of step i belongs to iteration i + 1)
+        else:       # (the rebuild / refit has been replayed as a graph of its own in front of this stage: _capture, rebuild_every)
+            v_pos = self.v_pos if self.optimize_geometry else self.mesh['v_pos']
         self.light.update_pdf()
         if defer_build and not self.optimize_geometry:
-            self.ctx.wait_build()
+            self.ctx.wait_build()            # (only the un-split HIP graph of this stage: it must not end with the side stream unjoined)
         self._gb_live = None
         if self.material_set != 'r3' and self.optimize_geometry:
             v_nrm, v_tng = mesh_ops.mesh_frame(v_pos, self.topo)
@@ -644,6 +664,7 @@ class DirectLightingStep:
         if getattr(self, '_pending', False):
             g = self._graphs[1] if (self._graphs is not None and not self.force_eager) else None
             self._finish_pending(g)
+        self._join_build_side()
 
     def _step_multi(self, world_size):
         ex = self._exchange(world_size)
@@ -651,21 +672,28 @@ class DirectLightingStep:
         graphs = self._graphs if (self._graphs is not None and not self.force_eager) else None
         if graphs is None and self._graphs is not None and not getattr(self, '_left_graphs', False):
             self._left_graphs, self._stage1_ready = True, False        # force_eager: the geometry stage is redone eagerly (its autograd graph too)
+            self._join_build_side()
         last = len(chunks) - 1
         self._finish_pending(graphs[1] if graphs else None)
+        split = graphs is not None and isinstance(graphs[2], tuple)      # (G2a, G2b): the stage-2 graph cut in front of the traversal
         if graphs:
             g1, gb, g2 = graphs[0], graphs[1], graphs[2]
             if not self._stage1_ready:
-                g1.replay()
+                self._replay_stage1(g1, split, 0)
                 self._stage1_ready = True
-            g2.replay()
+            if split:
+                g2[0].replay()                                           # update_pdf, lookups, shading frame, sample generation
+                torch.cuda.current_stream(self.dev).wait_event(self._ev_build)
+                g2[1].replay()                                           # traversal ... backward, bucket pack
+            else:
+                g2.replay()
             self._stage1_ready = False
             loss = self._loss_static
             ex.compute_flags()          # (not captured: whether this round goes through the tiles is the exchange's decision, round by round)
         else:
             self._eager_steps += 1
             if not self._stage1_ready:
-                self._stage1(defer_build=True)
+                self._stage1(defer_build=self.optimize_geometry or not self.pipeline)
             loss = self._stage2()
             ex.pack()
             self._packed_tex_grad()
@@ -682,10 +710,10 @@ class DirectLightingStep:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
             if graphs:
-                graphs[0].replay()
+                self._replay_stage1(graphs[0], split, 1)
                 self._stage1_ready = True
             else:
-                self._stage1(defer_build=True)
+                self._stage1(defer_build=self.optimize_geometry, ahead=1)
             if self.measure_exposed:
                 b.record()
                 self._stage1_events.append((a, b))
@@ -695,6 +723,31 @@ class DirectLightingStep:
             self._finish_pending(graphs[1] if graphs else None)
         self.allreduce_bytes = ex.bytes_per_step
         return loss
+
+    def _join_build_side(self):
+        """Split schedule: a rebuild replayed on the side stream may still be running with nobody but the next G2b waiting for it; whoever
+        touches the tree or rebuilds it outside the graphs (finish(), leaving graph mode) orders the main stream behind it first."""
+        if getattr(self, '_ev_build', None) is not None and self._graphs is not None and isinstance(self._graphs[2], tuple):
+            torch.cuda.current_stream(self.dev).wait_event(self._ev_build)
+
+    def _replay_stage1(self, g1, split, ahead=0):
+        """The geometry stage of the NEXT iteration.  Un-split: on the main stream (trained geometry: everything behind it needs its
+        G-buffer).  Split (locked geometry): the rebuild alone, on a side stream ordered behind this point of the main stream (the last
+        reader of the old tree -- the backward pass's traversal -- lies before it); the main stream moves on and meets it again in front
+        of the next traversal (_ev_build)."""
+        if not split:
+            gv = getattr(self, '_gb_variants', None)
+            if gv is not None:
+                # (ahead = 1: the geometry stage replayed at the end of step i belongs to iteration i + 1)
+                gv[1 if self._refit_now(ahead) else 0].replay()
+            g1.replay()
+            return
+        main = torch.cuda.current_stream(self.dev)
+        self._ev_main.record(main)
+        self._build_side.wait_event(self._ev_main)
+        with torch.cuda.stream(self._build_side):
+            g1.replay()
+            self._ev_build.record(self._build_side)
 
     def _tex_grad_guard(self):
         """One rank: FusedAdam zeroes the texture gradients it consumed, which clears the persistent scatter-add buffers only if
@@ -736,6 +789,24 @@ class DirectLightingStep:
             warn(False)
         multi = world_size > 1 or self.force_exchange
         if not multi:
+            if self.optimize_geometry and self.rebuild_every > 1:
+                # the whole iteration twice: with a rebuild and with a refit of the tree (each graph has its own pool: they never run together)
+                gas, losses = [], []
+                it = self._iter
+                for k in (0, 1):
+                    self._iter = k              # (_build_bvh reads the flag from the iteration counter)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._stage1_ready = False
+                        losses.append(self.forward_backward())
+                        self._update()
+                        self._tex_grad_guard()
+                    gas.append(g)
+                    self.opt.zero_grad(set_to_none=True)
+                self._iter = it
+                self._loss_static = losses
+                self._graphs = (tuple(gas), None, None)
+                return
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 self._stage1_ready = False
@@ -746,13 +817,69 @@ class DirectLightingStep:
             return
         ex = self._exchange(world_size)
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1):
-            self._stage1(defer_build=True)
-        g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g2, pool=g1.pool()):
-            self._loss_static = self._stage2()
-            ex.pack()
-            self._packed_tex_grad()
+        split = bool(self.pipeline and not self.optimize_geometry and len(self._ex_chunks) > 1 and self.material_set == 'full'
+                     and _lib.tuning_env('NVDR_SPLIT_STAGE2', '1') != '0')
+        if split:
+            # LOCKED geometry: G1 = the rebuild alone (joined inside the graph), replayed on a side stream; stage 2 = TWO graphs cut between
+            # the sample generation and the traversal (OptiXContext.split_hook: the env-shade launch is issued in two calls), so that the
+            # main stream waits for the tree where the one-rank iteration does.  (An external-event wait node inside ONE graph would do the
+            # same; this runtime does not capture them: torch refuses external events on ROCm, and hipStreamWaitEvent(.., hipEventWaitExternal)
+            # on a capturing stream joins the recording stream into the capture instead -- "capturing stream has unjoined work".)
+            if getattr(self, '_build_side', None) is None:
+                # HIGH priority: HIP deals its streams to four hardware queues per priority level, and a normal-priority stream created
+                # late in a process may share the main stream's queue -- the first measurement of this schedule showed the main stream
+                # standing still for the whole rebuild (tools/side_graph_probe.py: one in four fresh normal streams serialises with the
+                # main stream, none of the high-priority ones does); the rebuild is on the traversal's critical path anyway
+                self._build_side = torch.cuda.Stream(device=self.dev, priority=-1)
+                self._ev_build, self._ev_main = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.graph(g1):
+                self._build_bvh()
+                self.ctx.wait_build()
+            self.ctx.build_joined()              # replays are ordered by _ev_build: no consumer waits on the build's own event
+            g2a, g2b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            pool2 = torch.cuda.graph_pool_handle()       # (not G1's: that graph replays on another stream, concurrently with these two)
+            cm_a, cm_b = torch.cuda.graph(g2a, pool=pool2), torch.cuda.graph(g2b, pool=pool2)
+            cut = []
+
+            def hook():
+                cm_a.__exit__(None, None, None)
+                cut.append(True)
+                cm_b.__enter__()
+            self.ctx.split_hook = hook
+            cm_a.__enter__()
+            try:
+                self.light.update_pdf()
+                self._gb_live, self._stage1_ready = None, True
+                self._loss_static = self._stage2()
+                ex.pack()
+                self._packed_tex_grad()
+            finally:
+                self.ctx.split_hook = None
+                (cm_b if cut else cm_a).__exit__(None, None, None)
+            if not cut:
+                raise RuntimeError('the env-shade launch did not reach its split point')
+            g2 = (g2a, g2b)
+            self.split_stage2 = True
+        else:
+            self._gb_variants = None
+            if self.optimize_geometry and self.rebuild_every > 1:
+                # trained geometry with a refit policy: the tree's graph comes in two variants (rebuild, refit) replayed in front of the rest
+                # of the geometry stage -- nothing in them belongs to torch's allocator, so either may precede the same G1
+                gv = []
+                for rb in (1, 0):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._build_bvh(rebuild=rb)
+                        self.ctx.wait_build()
+                    gv.append(g)
+                self._gb_variants = tuple(gv)
+            with torch.cuda.graph(g1):
+                self._stage1(defer_build=True, build=self._gb_variants is None)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._loss_static = self._stage2()
+                ex.pack()
+                self._packed_tex_grad()
         gbs = []
         n = len(self._ex_chunks)
         # The B_k graphs get a pool of their own: the pipelined replay order (G2, B_0, G1, B_1) differs from the capture order, and with
@@ -818,15 +945,25 @@ class DirectLightingStep:
                 self.opt.zero_grad(set_to_none=True)
                 self._stage1_ready = False
         if multi:
-            return self._step_multi(world_size)
+            loss = self._step_multi(world_size)
+            self._iter += 1
+            return loss
         if self._graphs is not None and not self.force_eager:
-            self._graphs[0].replay()
+            ga = self._graphs[0]
+            if isinstance(ga, tuple):       # (rebuild_every: the iteration captured twice, with a rebuild and with a refit)
+                k = 1 if self._refit_now() else 0
+                ga[k].replay()
+                self._iter += 1
+                return self._loss_static[k]
+            ga.replay()
+            self._iter += 1
             return self._loss_static
         self._eager_steps += 1
         loss = self.forward_backward()
         self.allreduce_bytes = 0
         self._update()
         self._tex_grad_guard()
+        self._iter += 1
         return loss
 
 

@@ -42,7 +42,7 @@ class EnvShadeArgs(ctypes.Structure):  # mirrors nvdr_env_shade_args
         ('diff_grad', Tensor), ('spec_grad', Tensor),
         ('gb_pos_grad', c_void_p), ('gb_normal_grad', c_void_p), ('gb_kd_grad', c_void_p), ('gb_ks_grad', c_void_p),
         ('light_grad', c_void_p), ('vis_cache', c_void_p), ('counters', c_void_p), ('reuse_stream_id', ctypes.c_uint64), ('rnd_seed_offset', c_void_p),
-        ('rnd_seed_snapshot', c_void_p), ('rnd_seed_advance', ctypes.c_uint32)]
+        ('rnd_seed_snapshot', c_void_p), ('rnd_seed_advance', ctypes.c_uint32), ('phase', ctypes.c_uint32)]
 
 
 def build(force=False):

@@ -36,7 +36,7 @@ def test_python_binding_covers_the_header():
 
 
 def test_struct_layouts_match_the_header():
-    # nvdr_tensor: pointer + 4 sizes + 4 strides; the env-shade block: 12 tensors, 5 scalars (+pad), 2 ptrs, 2 tensors, 9 ptrs / words, snapshot ptr + advance (+pad)
+    # nvdr_tensor: pointer + 4 sizes + 4 strides; the env-shade block: 12 tensors, 5 scalars (+pad), 2 ptrs, 2 tensors, 9 ptrs / words, snapshot ptr + advance + phase
     assert ctypes.sizeof(_lib.NvdrTensor) == 8 + 4 * 8 + 4 * 8
     assert ctypes.sizeof(_lib.NvdrEnvShadeArgs) == 12 * 72 + 24 + 2 * 8 + 2 * 72 + 9 * 8 + 16
     from oracle import oracle as orc
@@ -55,13 +55,14 @@ def test_new_struct_layouts_against_the_c_compiler(tmp_path):
                    'sizeof(nvdr_mesh_args), sizeof(nvdr_interpolate_bwd_args), sizeof(nvdr_texture_args), offsetof(nvdr_interpolate_bwd_args, cam),'
                    'offsetof(nvdr_interpolate_bwd_args, v_tng_grad), offsetof(nvdr_texture_args, texc), offsetof(nvdr_texture_args, dtex));'
                    'printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(nvdr_adam_tensor), offsetof(nvdr_adam_tensor, lr_scale), offsetof(nvdr_adam_tensor, active),'
-                   'sizeof(nvdr_env_shade_args), offsetof(nvdr_env_shade_args, rnd_seed_snapshot), offsetof(nvdr_texture_args, accumulate));return 0;}\n')
+                   'sizeof(nvdr_env_shade_args), offsetof(nvdr_env_shade_args, rnd_seed_snapshot), offsetof(nvdr_texture_args, accumulate));'
+                   'printf("%zu\\n", offsetof(nvdr_env_shade_args, phase));return 0;}\n')
     exe = tmp_path / 'lay'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
     got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     A, T, D, E = _lib.NvdrInterpolateBwdArgs, _lib.NvdrTextureArgs, _lib.NvdrAdamTensor, _lib.NvdrEnvShadeArgs
     assert got == [ctypes.sizeof(_lib.NvdrMeshArgs), ctypes.sizeof(A), ctypes.sizeof(T), A.cam.offset, A.v_tng_grad.offset, T.texc.offset, T.dtex.offset,
-                   ctypes.sizeof(D), D.lr_scale.offset, D.active.offset, ctypes.sizeof(E), E.rnd_seed_snapshot.offset, T.accumulate.offset]
+                   ctypes.sizeof(D), D.lr_scale.offset, D.active.offset, ctypes.sizeof(E), E.rnd_seed_snapshot.offset, T.accumulate.offset, E.phase.offset]
 
 
 def test_no_cpu_fallback_errors_are_loud(monkeypatch):

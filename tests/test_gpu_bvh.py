@@ -84,6 +84,34 @@ def test_refit_equals_rebuild_and_single_triangle(dev):
         assert torch.equal(ou.trace_visibility(ctx, ro2.to(dev), rd2.to(dev)).cpu(), ref2)
 
 
+def test_refit_of_a_moved_684k_mesh_answers_like_a_rebuild(dev):
+    """The refit policy of the harness (trainer rebuild_every, round 6): the 684 032-triangle mesh with every vertex moved by a few
+    learning-rate steps' worth of noise, eight refits in a row on the topology of ONE rebuild -- visibility through the production
+    kernel after every refit == the binary walk == what a fresh rebuild answers, and on a ray sample == the oracle's brute force."""
+    from nvdiffrecmc_amd import optixutils as ou
+    mesh = sc.load_mesh('bob')
+    v0, t = sc.subdivide(mesh['v_pos'], mesh['t_pos_idx'], 3)
+    assert t.shape[0] == 684032
+    ctx, fresh = ou.OptiXContext(), ou.OptiXContext()
+    ou.optix_build_bvh(ctx, v0.to(dev), t.to(dev), rebuild=1)
+    g = torch.Generator().manual_seed(17)
+    ro, rd = _rays(300000, 5, 0.35)
+    ro, rd = ro.to(dev), rd.to(dev)
+    v = v0.clone()
+    for it in range(8):
+        v = (v + 2e-4 * torch.randn(v.shape, generator=g)).contiguous()           # ~20 Adam steps at the position rate of the benchmark
+        ou.optix_build_bvh(ctx, v.to(dev), t.to(dev), rebuild=0)
+        got = ou.trace_visibility_wide(ctx, ro, rd)
+        assert torch.equal(got, ou.trace_visibility(ctx, ro, rd))
+        if it in (0, 7):
+            ou.optix_build_bvh(fresh, v.to(dev), t.to(dev), rebuild=1)
+            assert torch.equal(got, ou.trace_visibility_wide(fresh, ro, rd)), 'refit %d differs from a rebuild' % it
+    ref = orc.visibility(v, t, ro[:4000].cpu(), rd[:4000].cpu(), n_threads=NT)
+    assert torch.equal(got[:4000].cpu(), ref)
+    _check_oct_tree(ctx, v, t)
+    ctx.check()
+
+
 def test_build_rejects_empty_mesh_like_the_reference(dev):
     from nvdiffrecmc_amd import optixutils as ou
     ctx = ou.OptiXContext()

@@ -109,7 +109,8 @@ mine = views[rank * per:(rank + 1) * per]
 st = DirectLightingStep('bob', res, n, view=mine, n_views=len(views), device='cuda:0', lr=0.03, tex_res=512,
                         pixel_index_offset=mine[0] * res * res, use_graph=(os.environ.get('USE_GRAPH') == '1'),
                         exchange_mode=os.environ.get('EXCHANGE', 'auto'), pipeline=(os.environ.get('PIPELINE', '1') == '1'),
-                        optimize_geometry=(os.environ.get('GEOM') == '1'), lr_pos=1e-5, perturb_pos=0.002)
+                        optimize_geometry=(os.environ.get('GEOM', '0') != '0'), lr_pos=1e-5, perturb_pos=0.002,
+                        rebuild_every=(3 if os.environ.get('GEOM') == '3' else 1))
 losses = []
 for it in range(8):
     losses.append(float(st.step(world).item()))
@@ -128,8 +129,8 @@ if world > 1:
 '''
 
 
-@pytest.mark.parametrize('exchange,pipeline,geom', [('dense', '0', '0'), ('dense', '1', '0'), ('sparse', '1', '0'), ('dense', '1', '1')],
-                         ids=['dense_unpipelined', 'dense_pipelined', 'sparse_pipelined', 'dense_pipelined_geometry_trained'])
+@pytest.mark.parametrize('exchange,pipeline,geom', [('dense', '0', '0'), ('dense', '1', '0'), ('sparse', '1', '0'), ('dense', '1', '1'), ('dense', '1', '3')],
+                         ids=['dense_unpipelined', 'dense_pipelined', 'sparse_pipelined', 'dense_pipelined_geometry_trained', 'geometry_trained_refit_policy'])
 @pytest.mark.parametrize('graph', ['0', '1'], ids=['eager', 'hip_graphs'])
 def test_two_rank_training_follows_the_one_rank_run(graph, exchange, pipeline, geom, dev):
     """Four views dealt over two ranks (gloo for the collective, both on this GPU) train like four views on one rank: the chunked
@@ -155,9 +156,9 @@ def test_two_rank_training_follows_the_one_rank_run(graph, exchange, pipeline, g
         pair = 0.5 * (two[0]['losses'][it] + two[1]['losses'][it])
         assert abs(pair - one['losses'][it]) <= 2e-4 * abs(one['losses'][it]), (it, pair, one['losses'][it])
     assert one['losses'][-1] < one['losses'][0]
-    if geom == '1':     # v_pos travels in the first chunk; the pipelined geometry stage (rebuild, vertex frames, G-buffer) runs from the reduced vertices
+    if geom != '0':     # v_pos travels in the first chunk; the pipelined geometry stage (rebuild, vertex frames, G-buffer) runs from the reduced vertices
         assert one['n_params'] == 5 and ex_chunk_sizes(two[0]) [0] > 256 * 256 * 3 * 4
-    for k in ('kd_sum', 'ks_sum', 'nrm_sum', 'light_sum') + (('vpos_sum',) if geom == '1' else ()):
+    for k in ('kd_sum', 'ks_sum', 'nrm_sum', 'light_sum') + (('vpos_sum',) if geom != '0' else ()):
         assert abs(two[0][k] - two[1][k]) <= 1e-9 * abs(two[0][k])             # the ranks hold the same parameters ...
         assert abs(two[0][k] - one[k]) <= 1e-4 * abs(one[k]), (k, two[0][k], one[k])      # ... and they are the one-rank parameters
     ex = two[0]['exchange']

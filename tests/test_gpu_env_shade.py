@@ -30,6 +30,9 @@ BWD_RTOL = 2e-4
     ('bob', 64, 64, 2, 'white', 8),
     ('bob', 32, 32, 16, 'diffuse', 9),     # S = 256: the pixel-local queue kernel on the Lambert arm
     ('spot', 32, 32, 16, 'pbr', 10),       # S = 256, metal
+    ('bob', 32, 32, 32, 'pbr', 11),        # S = 1024: the reference's VALIDATION sample count (train.py:263 n_samples = 32), 2 048 rays per pixel,
+                                           # sixteen rounds per pixel, the widest rows the light-gradient records take (a pixel's slots = 16 blocks of 128)
+    ('bob', 24, 24, 33, 'pbr', 12),        # S = 1089: beyond that limit -- the plain shading kernels with memory-side atomics for the light gradient
 ])
 def test_env_shade_fwd_bwd_vs_oracle(mesh, H, W, n, bsdf, seed, dev):
     inp = scene_cpu.make_inputs(mesh, H, W, n, view=seed % 8, probe_res=128, n_threads=NT)
@@ -41,9 +44,11 @@ def test_env_shade_fwd_bwd_vs_oracle(mesh, H, W, n, bsdf, seed, dev):
     ref_b = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf=bsdf, n_samples_x=n, rnd_seed=seed, diff_grad=dg, spec_grad=sg, n_threads=NT)
     ctx = make_ctx(m, dev)
     got = gpu_env_shade(ctx, kw, dev, bsdf, n, seed, dg, sg, cache_vis=False)
-    assert ref_f['covered'] > 100
+    assert ref_f['covered'] > 100 or (n > 32 and ref_f['covered'] > 50)
+    # (2 S additions per pixel in another order than the serial loop: the bound grows with their number)
+    fwd_rtol = FWD_RTOL * (4.0 if n * n > 256 else 1.0)
     for k in ('diff', 'spec'):
-        assert_close(got[k], ref_f[k], FWD_RTOL, what=k)
+        assert_close(got[k], ref_f[k], fwd_rtol, what=k)
         assert torch.equal(got[k][inp['mask'] <= 0], torch.zeros_like(got[k][inp['mask'] <= 0]))  # zero-initialised outputs
     for k in GRADS:
         assert_close(got[k], ref_b[k], BWD_RTOL, floor=1e-3 * max(1.0, ref_b[k].abs().max().item()), what=k)
@@ -208,6 +213,46 @@ def test_backward_after_another_forward_regenerates_the_stream(dev):
     g, out = fwd(None)
     got = grads(g, out)
     assert all(torch.isfinite(x).all() for x in got) and got[1].abs().sum().item() > 0 and got[4].abs().sum().item() > 0
+
+
+def test_decorrelated_seeds_forward_and_backward_vs_oracle(dev):
+    """rnd_seed=None (FLAGS.decorrelated; render/optixutils/ops.py:83,99): the forward pass and the backward pass each draw a fresh seed from
+    numpy's global generator, in that order.  With that generator seeded, the forward image must be the oracle's at the first draw and the
+    gradients the oracle's at the SECOND (other samples, other visibility: nothing of the forward's stream may be reused)."""
+    from nvdiffrecmc_amd import optixutils as ou
+    H = W = 48
+    n = 4
+    inp = scene_cpu.make_inputs('bob', H, W, n, view=5, probe_res=64, n_threads=NT)
+    kw = scene_cpu.shade_kwargs(inp)
+    m = inp['mesh']
+    ctx = make_ctx(m, dev)
+    ou.ops.set_permutation_table(n, kw['perms'].to(dev))
+    g = torch.Generator().manual_seed(21)
+    dg, sg = torch.rand(1, H, W, 3, generator=g), torch.rand(1, H, W, 3, generator=g)
+    np.random.seed(20240607)
+    s_fwd, s_bwd = int(np.random.randint(2**31)), int(np.random.randint(2**31))
+    assert s_fwd != s_bwd
+    for cache_vis in (False, True):         # (the visibility cache must not be consulted either: the seeds differ)
+        ou.ops._optix_env_shade_func.cache_visibility = cache_vis
+        d = {k: v.to(dev) for k, v in kw.items() if k != 'perms'}
+        leaves = ('gb_pos', 'gb_normal', 'gb_kd', 'gb_ks', 'light')
+        for k in leaves:
+            d[k] = d[k].clone().requires_grad_(True)
+        np.random.seed(20240607)
+        diff, spec = ou.optix_env_shade(ctx, d['mask'], d['ro'], d['gb_pos'], d['gb_normal'], d['gb_view_pos'], d['gb_kd'], d['gb_ks'],
+                                        d['light'], d['pdf'], d['rows'], d['cols'], BSDF='pbr', n_samples_x=n, rnd_seed=None)
+        ((diff * dg.to(dev)).sum() + (spec * sg.to(dev)).sum()).backward()
+        ref_f = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=s_fwd, n_threads=NT)
+        ref_b = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=s_bwd, diff_grad=dg, spec_grad=sg, n_threads=NT)
+        assert_close(diff, ref_f['diff'], FWD_RTOL, what='diff')
+        assert_close(spec, ref_f['spec'], FWD_RTOL, what='spec')
+        for k in leaves:
+            ref = ref_b[k + '_grad']
+            assert_close(d[k].grad, ref, BWD_RTOL, floor=1e-3 * max(1.0, ref.abs().max().item()), what=k)
+        # and they are NOT the gradients of the forward's samples
+        same = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=s_fwd, diff_grad=dg, spec_grad=sg, n_threads=NT)
+        assert (same['gb_kd_grad'] - ref_b['gb_kd_grad']).abs().max().item() > 1e-3 * ref_b['gb_kd_grad'].abs().max().item()
+    ou.ops._optix_env_shade_func.cache_visibility = True
 
 
 def test_stage_profiling_hooks(dev):

@@ -235,3 +235,22 @@ def test_geometry_unlocked_loss_decreases(dev):
     info = st.ctx.bvh_info()                                            # ... and the BVH was rebuilt from them
     assert info['n_tris'] == st.mesh['t_pos_idx'].shape[0]
     st.ctx.check()
+
+
+@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'hip_graphs'])
+def test_refit_policy_trains_like_a_rebuild_every_iteration(graph, dev):
+    """rebuild_every=4 (a rebuild, then three refits of its topology to the moved vertices, ...): visibility and primary hits are exact with
+    any valid tree, so the iteration computes the same image and the same gradients -- the losses follow the rebuild-every-iteration run step
+    by step (up to the order of atomic additions and, rarely, a primary ray grazing an edge picking the neighbouring triangle)."""
+    from nvdiffrecmc_amd.trainer import DirectLightingStep
+    runs = {}
+    for K in (1, 4):
+        st = DirectLightingStep('bob', 128, 4, view=[0, 3], device=dev, tex_res=256, optimize_geometry=True, perturb_pos=0.003, lr=0.01, lr_pos=1e-4,
+                                use_graph=graph, rebuild_every=K, subdiv=1)
+        runs[K] = [float(st.step().detach()) for _ in range(14)]
+        assert (st._graphs is not None) == graph
+        if graph and K > 1:
+            assert isinstance(st._graphs[0], tuple) and len(st._graphs[0]) == 2          # the iteration captured with a rebuild and with a refit
+        st.ctx.check()
+    for a, b in zip(runs[1], runs[4]):
+        assert abs(a - b) <= 2e-3 * abs(a), (runs[1], runs[4])

@@ -70,7 +70,7 @@ sys.path.insert(0, ROOT)
 
 from tools.bench_parts import (PRESETS, DOMINANT, GEOMETRY_NOTE, TEXTURE_NOTE, BENCH_LR_POS, HBM_PEAK_GBS, VALU_PEAK_TLANEOPS, make_step, algorithmic_bytes,
                                cpu_baseline, cpu_baseline_torch, collect_pmc, find_kernel, valu_figures, mem_figures, other_config_object, adam_object,
-                               init_world1, exchange_object, one_view_object, large_mesh_object, validation_object, flat_scaling_keys, bvh_policy_note, _stdout_to_stderr, _free_port)
+                               init_world1, exchange_object, flat_scaling_keys, bvh_policy_note, collect_extras, extras_child, _stdout_to_stderr, _free_port)
 
 
 def parse_args():
@@ -106,6 +106,8 @@ def parse_args():
     ap.add_argument('--no-one-view', action='store_true', help='skip the `one_view` object (per-GPU share of the 8-GPU run) of the default N = 1 line')
     ap.add_argument('--rebuild-every', type=int, default=None,
                     help='trained geometry: rebuild the BVH every K-th iteration and refit in between (default 8; 1 = a rebuild every iteration, what the reference does)')
+    ap.add_argument('--extras-timeout', type=int, default=420, help='seconds the extra objects of the default N = 1 line may take together (they run in a child process)')
+    ap.add_argument('--extras-child', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--no-validation', action='store_true', help='skip the `validation_n32` object (n_samples_x = 32, one view) of the default N = 1 line')
     ap.add_argument('--graph', choices=('auto', 'on', 'off'), default='auto',
                     help='capture the iteration in HIP graphs (auto: when a rank renders <= 2 views -- the launch-bound regime -- or there are several ranks)')
@@ -123,6 +125,9 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the hot path has no CPU fallback')
+    if args.extras_child is not None:
+        extras_child(args)
+        return
     if 'WORLD_SIZE' in os.environ:
         if int(os.environ['WORLD_SIZE']) != args.gpus:
             raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks' % (args.gpus, os.environ['WORLD_SIZE']))
@@ -447,40 +452,27 @@ def run(args):
                         and args.mesh is None and args.n_samples_x is None and not forced)
         eight_ms = dt / args.steps * 1e3
 
-        def extra(key, fn, *a, **k):       # never lose the headline line to an extra object
-            nonlocal step
+        if default_line:
+            # The extra objects run in a CHILD process behind a deadline, one JSON line per object as it completes: an object that raises, hangs
+            # or takes the GPU down costs that object (and the ones behind it), never the headline line above.  (Round 6: one of them hung a GPU
+            # queue during development; a bench line that never arrives would be the worst outcome of all.)
             step = None
             torch.cuda.empty_cache()
-            try:
-                out[key] = fn(*a, **k)
-            except Exception as e:
-                out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
-
-        if default_line and not args.no_one_view:
-            # the per-GPU share of the 8-GPU run, on the headline preset and on the 684 k-triangle mesh (trained and locked); the numbers that speak
-            # to north_star's ">= 6x at 8 GPUs" also go into FLAT config keys (the driver's record keeps no nested object of `config`)
-            with _stdout_to_stderr():
-                extra('_ov', one_view_object, args, dev, 'bob512', eight_ms)
-            out['config']['one_view'] = out.pop('_ov')
-            out['config'].update(flat_scaling_keys('one_view', out['config']['one_view']))
-        if default_line and not args.no_other_configs and not args.no_large_mesh:
-            out['other_configs'] = {}
-            for name in ('spot512x256', 'hotdog512x256'):
-                extra('_oc', other_config_object, name, args, dev)
-                out['other_configs'][name] = out.pop('_oc')
-        if default_line and not args.no_validation:
-            extra('validation_n32', validation_object, args, dev)
-        if default_line and not args.no_large_mesh:
-            extra('large_mesh', large_mesh_object, args, dev, 'dmtet64_800')
-            extra('large_mesh_regular', large_mesh_object, args, dev, 'dmtet800')
-            if not args.no_one_view:
-                for tag, lk in (('trained', False), ('locked', True)):
-                    eight = (out['large_mesh_regular'] or {}).get('ms_per_step') if tag == 'trained' else None
-                    with _stdout_to_stderr():
-                        extra('_ov', one_view_object, args, dev, 'dmtet800', eight, lock=lk, modes=('auto',))
-                    ov = out.pop('_ov')
-                    out['large_mesh_regular']['one_view_' + tag] = ov
-                    out['config'].update(flat_scaling_keys('large_mesh_one_view_' + tag, ov))
+            got, note = collect_extras(args, eight_ms)
+            for key, val in got:
+                if key == 'one_view':
+                    out['config']['one_view'] = val
+                    out['config'].update(flat_scaling_keys('one_view', val))
+                elif key.startswith('other_configs/'):
+                    out.setdefault('other_configs', {})[key.split('/', 1)[1]] = val
+                elif key.startswith('large_mesh_regular/one_view_'):
+                    tag = key.rsplit('_', 1)[1]
+                    (out.get('large_mesh_regular') or out.setdefault('large_mesh_regular', {}))['one_view_' + tag] = val
+                    out['config'].update(flat_scaling_keys('large_mesh_one_view_' + tag, val))
+                else:
+                    out[key] = val
+            if note:
+                out['extras_note'] = note
         if forced:      # (the one-rank group of --exchange-world1: torn down BEFORE the line is written -- RCCL's exit-time teardown has cut a line short)
             step = None
             import torch.distributed as _d

@@ -635,6 +635,7 @@ struct OctBuildArgs {
     unsigned long long *cnt;    // [n] per binary node: (internal slots << 32) | leaf slots of the wide node rooted there, 0 elsewhere
     unsigned long long *scan;   // [n] exclusive prefix sum of cnt
     unsigned *ctl;
+    int *ovf;               // the context's host-mapped fault word (bit 1: a loop of the build gave up at its iteration bound)
     const BvhDeviceInfo *info;
     int n_int_nodes;        // n_tris - 1
 };
@@ -670,7 +671,13 @@ __global__ void __launch_bounds__(1024) bvh_oct_budget_kernel(OctBuildArgs a)
         // dependent load was the kernel's time whatever the loads cost: 0.13 ms on 684 k triangles.)
         unsigned long long e = a.jump[v];
         unsigned G = (unsigned)(e >> 32), anc = (unsigned)e;
-        while (G != (G & 15u) * 0x11111111u) {
+        // (the bound -- far above the tree's depth, which bounds the jumps -- only turns inconsistent input into an error report
+        // instead of a hung queue)
+        for (unsigned guard = 0u; G != (G & 15u) * 0x11111111u; ++guard) {
+            if (guard > 4096u) {
+                atomicOr(a.ovf, 2);
+                break;
+            }
             const unsigned long long t = __hip_atomic_load(&a.jump[anc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned G2 = (unsigned)(t >> 32);
             unsigned H = 0u;
@@ -1298,6 +1305,12 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     return ctx_launch_build(c, stream);
 }
 
+__global__ void __launch_bounds__(1024) bvh_clear_flags_kernel(int *__restrict__ flags, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = 0;
+}
+
 // the kernels of a prepared build (nvdr_bvh_build), on the context's side stream -- or the caller's, without one
 int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
 {
@@ -1336,7 +1349,8 @@ int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
         }
     }
     const bool cleared = rebuild != 0 && n > 1;        // (the hierarchy kernel has cleared the counters and the control words)
-    if (!cleared) NVDR_HIP_TRY(hipMemsetAsync(c->flags, 0, sizeof(int) * n, stream));
+    // (a kernel, not hipMemsetAsync: the refit is replayed from HIP graphs, where memset / memcpy nodes are slow on this runtime)
+    if (!cleared) bvh_clear_flags_kernel<<<div_up(n, 1024), 1024, 0, stream>>>(c->flags, n);
     bvh_fit_kernel<<<div_up(n, NVDR_FIT_BLOCK), NVDR_FIT_BLOCK, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->up,
                                                                               c->flags, c->dinfo, c->dp_cost, c->oct_c_leaf, c->oct_jump);
     {
@@ -1344,7 +1358,7 @@ int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
         OctBuildArgs oa;
         oa.nodes = c->nodes; oa.tris = c->tris; oa.oct = c->oct; oa.tris8 = c->tris8; oa.up = c->up; oa.jump = c->oct_jump;
         oa.roots = c->oct_task; oa.wslot = c->oct_wslot; oa.cnt = c->oct_cnt; oa.scan = c->oct_scan; oa.ctl = c->oct_ctl;
-        oa.info = c->dinfo; oa.n_int_nodes = n - 1;
+        oa.info = c->dinfo; oa.n_int_nodes = n - 1; oa.ovf = c->ovf_dev;
         if (!cleared) bvh_oct_init_kernel<<<1, 64, 0, stream>>>(oa, n);
         if (n > 1) {
             bvh_oct_budget_kernel<<<div_up(n - 1, 1024), 1024, 0, stream>>>(oa);

@@ -2111,11 +2111,9 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if ((r = make_view4s(p.dgrad, a->diff_grad, "diff_grad")) || (r = make_view4s(p.sgrad, a->spec_grad, "spec_grad"))) return r;
         p.g_pos = a->gb_pos_grad; p.g_nrm = a->gb_normal_grad; p.g_kd = a->gb_kd_grad; p.g_ks = a->gb_ks_grad;
         p.g_light = a->light_grad;
-        if (p.g_nrm == p.g_pos + 3 * npix && p.g_kd == p.g_nrm + 3 * npix && p.g_ks == p.g_kd + 3 * npix) {
-            NVDR_HIP_TRY(hipMemsetAsync(p.g_pos, 0, sizeof(float) * 12 * npix, stream));   // caller packed the four outputs
-        } else {
-            zero_outputs_kernel<<<dim3(min(div_up(3 * npix, 1024), 2048u), 4), 256, 0, stream>>>(p.g_pos, p.g_nrm, p.g_kd, p.g_ks, 3 * npix);
-        }
+        // (a kernel, never hipMemsetAsync: this launch is replayed from HIP graphs, and a memset node inside a captured side branch was what
+        // stalled the refit graph of round 6 -- no memset or memcpy node on any path the harness captures)
+        zero_outputs_kernel<<<dim3(min(div_up(3 * npix, 1024), 2048u), 4), 256, 0, stream>>>(p.g_pos, p.g_nrm, p.g_kd, p.g_ks, 3 * npix);
         p.light_elems = 3 * n_texels;
         const size_t need = (size_t)p.light_elems * (size_t)(lg_rows > 8 ? lg_rows : 8);
         if (c->lg_cap < need) {
@@ -2127,7 +2125,10 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         }
         p.g_light_xcd = c->lg_part;
         if (!p.lg_records || (c->debug & 2u)) {
-            NVDR_HIP_TRY(hipMemsetAsync(c->lg_part, 0, sizeof(float) * (size_t)p.light_elems * 8, stream));
+            {
+                const int64_t q = 2 * (int64_t)p.light_elems;       // (the eight per-XCD copies as four quarters)
+                zero_outputs_kernel<<<dim3(min(div_up(q, 1024), 2048u), 4), 256, 0, stream>>>(c->lg_part, c->lg_part + q, c->lg_part + 2 * q, c->lg_part + 3 * q, q);
+            }
             if (c->debug & 2u) NVDR_HIP_TRY(hipMemsetAsync(p.g_light, 0, sizeof(float) * p.light_elems, stream));
         }
     }

@@ -116,7 +116,15 @@ __device__ __forceinline__ void store3(float *p, int64_t i, F3 v) { p[3 * i] = v
 // nvdiffrast's interpolation: u a0 + v a1 + (1 - u - v) a2
 __device__ __forceinline__ F3 interp3(F3 a0, F3 a1, F3 a2, float u, float v) { return (a0 * u + a1 * v) + a2 * (1.0f - u - v); }
 
-__global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, GbufferParams p, int *spill)
+// Work dealing (round 6).  Rounds 3-5 ran a grid-stride loop over the linear pixel index: a wavefront took a 64 x 1 strip, and a launch of
+// more pixels than 2048 workgroups x 256 (one 800^2 view: 2 500) left a fifth of the workgroups a second strip after the others had gone --
+// one view cost 2.2 x its share of the 8-view launch.  Now the unit is an 8 x 8 TILE per wavefront (neighbouring primary rays walk
+// the same nodes; a 64 x 1 strip when the extent is no multiple of eight) and the wavefronts CLAIM units: class q = unit % 64 behind its own
+// counter (one per 128-byte line: same-address atomics retire every ~12 ns), wavefront w serves class w % 64, a wavefront that drew
+// background tiles simply claims more.  The counters live in lines 128..255 of the context's counter block, zero between launches: the last
+// wavefront of a class to leave resets its pair.
+#define NVDR_GB_CLASSES 64u
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, GbufferParams p, int *spill, unsigned *queues)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     OctStack stack;             // per lane: NVDR_OSTACK_LDS (group, bits) entries in LDS, deeper ones in the context's spill columns
@@ -126,8 +134,31 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, 
     stack.ovf = bvh.overflow;
     stack.glb = (glb_pair_t *)spill + (int64_t)blockIdx.x * blockDim.x * max(bvh.oct_stack_max - NVDR_OSTACK_LDS, 0) + threadIdx.x;
     const int64_t total = (int64_t)p.N * p.H * p.W;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % p.W), y = (int)((i / p.W) % p.H), z = (int)(i / ((int64_t)p.W * p.H));
+    const bool tiled = (p.W & 7) == 0 && (p.H & 7) == 0;
+    const unsigned tiles_x = (unsigned)p.W >> 3, tiles_per_view = tiles_x * ((unsigned)p.H >> 3);
+    const unsigned n_units = (unsigned)((total + 63) >> 6);
+    const unsigned lane = threadIdx.x & 63u, wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    const unsigned cls = wid % NVDR_GB_CLASSES;
+    unsigned *claim = queues + (128u + cls) * 32u, *gone = queues + (192u + cls) * 32u;
+    for (;;) {
+        unsigned j = 0u;
+        if (lane == 0u) j = atomicAdd(claim, 1u);
+        j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+        const unsigned unit = cls + NVDR_GB_CLASSES * j;
+        if (unit >= n_units) break;
+        int64_t i;
+        int x, y, z;
+        if (tiled) {
+            const unsigned t = unit % tiles_per_view;
+            z = (int)(unit / tiles_per_view);
+            x = (int)(((t % tiles_x) << 3) + (lane & 7u));
+            y = (int)(((t / tiles_x) << 3) + (lane >> 3));
+            i = ((int64_t)z * p.H + y) * p.W + x;
+        } else {
+            i = (int64_t)unit * 64 + lane;
+            if (i >= total) continue;
+            x = (int)(i % p.W); y = (int)((i / p.W) % p.H); z = (int)(i / ((int64_t)p.W * p.H));
+        }
         const float X = ((float)x + 0.5f) / (float)p.W * 2.0f - 1.0f;      // NDC of the pixel centre; row 0 = Y -1 (rasteriser layout)
         const float Y = ((float)y + 0.5f) / (float)p.H * 2.0f - 1.0f;
         const float *cam = p.cam + 12 * z;
@@ -202,6 +233,15 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, 
         ((float4 *)p.gb_texc_db)[i] = make_float4(tdb[0], tdb[1], tdb[2], tdb[3]);
         p.gb_depth[2 * i] = z0; p.gb_depth[2 * i + 1] = zg;
     }
+    // the last wavefront of this class to leave puts the pair of counters back to zero for the next launch (the waves of a class: those
+    // with wid % 64 == cls)
+    if (lane == 0u) {
+        const unsigned mine = n_waves / NVDR_GB_CLASSES + (cls < n_waves % NVDR_GB_CLASSES ? 1u : 0u);
+        if (atomicAdd(gone, 1u) + 1u == mine) {
+            __hip_atomic_store(claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 unsigned query_grid(const nvdr_ctx *c, int64_t items);   // bvh.hip
@@ -228,7 +268,7 @@ extern "C" int nvdr_render_gbuffer(nvdr_ctx *c, const nvdr_gbuffer_args *a, void
     p.gb_tng = a->gb_tangent; p.gb_texc = a->gb_texc; p.gb_texc_db = a->gb_texc_deriv; p.gb_depth = a->gb_depth;
     const int64_t total = (int64_t)p.N * p.H * p.W;
     if (int rw = ctx_wait_built(c, (hipStream_t)stream_)) return rw;
-    gbuffer_kernel<<<query_grid(c, total), NVDR_QUERY_BLOCK, (NVDR_QUERY_BLOCK / 64) * NVDR_OSTACK_LDS * 64 * 8, (hipStream_t)stream_>>>(bvh_view(c), p, c->spill);
+    gbuffer_kernel<<<query_grid(c, total), NVDR_QUERY_BLOCK, (NVDR_QUERY_BLOCK / 64) * NVDR_OSTACK_LDS * 64 * 8, (hipStream_t)stream_>>>(bvh_view(c), p, c->spill, c->queues);
     NVDR_LAUNCH_CHECK();
     return 0;
 }

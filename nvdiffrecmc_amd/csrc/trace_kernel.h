@@ -17,6 +17,12 @@
 //     with their owner's generation, a FIFO queue, a per-lane count of the tests run so that a finished walk knows when its last
 //     verdict is in -- is bit-identical and 11-15 % SLOWER at every threshold: the extra permute, LDS counters and votes per iteration
 //     cost more than the lanes that idle until 16 are free.)
+//   (Measured and dropped, round 6, profiles/r06_ab_trace_split_coop_dup.md: (a) SPLIT WALKS in the drain -- when the chunk counter is used up, lanes with
+//   two or more pending items hand one to an idle lane, which takes a copy of the ray through 15 ds_bpermute; bit-identical, no gain at one view, 4.5 % slower
+//   at eight: a walk's remaining work is one deep path, not many subtrees.  (b) A QUAD-COOPERATIVE node fetch -- the four lanes of a quad load the four
+//   quarters of ONE node per instruction and transpose inside the quad with DPP quad permutes, a quarter of the cache lines per request: 22-25 % slower; the
+//   vector-memory path charges per lane-request, not per line.  (c) Doubling the node's four requests costs +14 ... +22 % on bob, +40 ... +45 % on 684 k
+//   triangles: the kernel is sensitive to the number of requests, most where the tree spills the L2.)
 #pragma once
 
 #include "bvh.h"
@@ -250,9 +256,9 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
 
     unsigned iters = 0;
     while (true) {
-        // every iteration retires work, so the loop ends by itself; the bound (far above any real launch: 2^26 node steps of one
-        // wavefront) only turns a bug into an error report instead of a hung GPU
-        if (++iters > (1u << 26)) {
+        // every iteration retires work, so the loop ends by itself; the bound (far above any real launch: 2^23 iterations of one
+        // wavefront, seconds; the 8-view benchmark launch takes ~750) only turns a bug into an error report instead of a hung GPU
+        if (++iters > (1u << 23)) {
             if (lane == 0) atomicOr(bvh.overflow, 4);
             break;
         }
@@ -319,6 +325,18 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             gbits &= gbits - 1u;
             const uint4 *nd = oct + 4 * (int64_t)(gbase + (unsigned)k);
             const uint4 h = nd[0], p1 = nd[1], p2 = nd[2], p3 = nd[3];
+#ifdef NVDR_TRACE_DUP_FETCH
+            // (A/B only: the same four 16-byte requests once more, results thrown away -- twice the L1 look-ups and returned lines per node
+            // step with nothing else changed: what a kernel bound by the L1's request rate slows down by, a latency-bound one barely notices)
+            {
+                const volatile uint4 *ndv = (const volatile uint4 *)nd;
+#pragma unroll
+                for (int q = 0; q < NVDR_TRACE_DUP_FETCH; ++q) {
+                    const uint4 d = const_cast<const uint4 &>(ndv[q]);
+                    asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+                }
+            }
+#endif
             if (COUNT) n_step++;
             if (PH == 2) {
                 // (this build waits for the node here, so that the fetch has a phase of its own; the production kernel lets the

@@ -251,7 +251,7 @@ def test_decorrelated_seeds_forward_and_backward_vs_oracle(dev):
             assert_close(d[k].grad, ref, BWD_RTOL, floor=1e-3 * max(1.0, ref.abs().max().item()), what=k)
         # and they are NOT the gradients of the forward's samples
         same = orc.env_shade(m['v_pos'], m['t_pos_idx'], **kw, bsdf='pbr', n_samples_x=n, rnd_seed=s_fwd, diff_grad=dg, spec_grad=sg, n_threads=NT)
-        assert (same['gb_kd_grad'] - ref_b['gb_kd_grad']).abs().max().item() > 1e-3 * ref_b['gb_kd_grad'].abs().max().item()
+        assert (same['gb_normal_grad'] - ref_b['gb_normal_grad']).abs().max().item() > 1e-3 * ref_b['gb_normal_grad'].abs().max().item()
     ou.ops._optix_env_shade_func.cache_visibility = True
 
 

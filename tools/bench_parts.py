@@ -637,6 +637,88 @@ def large_mesh_object(args, dev, preset_name='dmtet64_800'):
     return out
 
 
+def extras_child(args):
+    """Child process of the default N = 1 line (bench.py --extras-child <8-view ms>): the extra objects, most important first, each printed as
+    ONE line `EXTRA <key> <json>` the moment it is done."""
+    import torch
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    eight_ms = float(args.extras_child)
+
+    def emit(key, fn, *a, quiet=False, **k):
+        torch.cuda.empty_cache()
+        try:
+            if quiet:
+                with _stdout_to_stderr():
+                    val = fn(*a, **k)
+            else:
+                val = fn(*a, **k)
+        except Exception as e:
+            val = {'error': '%s: %s' % (type(e).__name__, e)}
+        print('EXTRA %s %s' % (key, json.dumps(val)), flush=True)
+        return val
+
+    if not args.no_one_view:
+        emit('one_view', one_view_object, args, dev, 'bob512', eight_ms, quiet=True)
+    reg = None
+    if not args.no_large_mesh:
+        emit('large_mesh', large_mesh_object, args, dev, 'dmtet64_800')
+        reg = emit('large_mesh_regular', large_mesh_object, args, dev, 'dmtet800')
+        if not args.no_one_view:
+            emit('large_mesh_regular/one_view_locked', one_view_object, args, dev, 'dmtet800', None, lock=True, modes=('auto',), quiet=True)
+            emit('large_mesh_regular/one_view_trained', one_view_object, args, dev, 'dmtet800', (reg or {}).get('ms_per_step'), lock=False, modes=('auto',), quiet=True)
+    if not args.no_validation:
+        emit('validation_n32', validation_object, args, dev)
+    if not args.no_other_configs and not args.no_large_mesh:
+        for name in ('spot512x256', 'hotdog512x256'):
+            emit('other_configs/' + name, other_config_object, name, args, dev)
+
+
+def collect_extras(args, eight_ms):
+    """Run extras_child in a subprocess and gather its `EXTRA` lines until it exits or --extras-timeout expires (then the child -- this exact
+    process -- is killed and what has arrived is kept).  Returns ([(key, value)], note)."""
+    import threading
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--extras-child', repr(float(eight_ms)), '--lock-pos', args.lock_pos, '--material-set', args.material_set,
+           '--exchange', args.exchange, '--pmc-timeout', str(args.pmc_timeout)]
+    for flag, on in (('--no-one-view', args.no_one_view), ('--no-large-mesh', args.no_large_mesh), ('--no-validation', args.no_validation),
+                     ('--no-other-configs', args.no_other_configs), ('--no-pmc', args.no_pmc), ('--no-pipeline', args.no_pipeline)):
+        if on:
+            cmd.append(flag)
+    for flag, v in (('--tex-res', args.tex_res), ('--rebuild-every', args.rebuild_every), ('--pmc-keep', args.pmc_keep)):
+        if v is not None:
+            cmd += [flag, str(v)]
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, text=True, env=env, cwd=ROOT)
+    got = []
+
+    def reader():
+        for line in proc.stdout:
+            if line.startswith('EXTRA '):
+                try:
+                    _, key, payload = line.split(' ', 2)
+                    got.append((key, json.loads(payload)))
+                except Exception:
+                    pass
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    note = None
+    try:
+        proc.wait(timeout=args.extras_timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.wait()
+        note = 'the extra objects were cut off after %d s (--extras-timeout); %d arrived: %s' % (args.extras_timeout, len(got), ', '.join(k for k, _ in got))
+    th.join(timeout=5)
+    if note is None and proc.returncode != 0:
+        note = 'the child process of the extra objects exited with code %s after %d object(s)' % (proc.returncode, len(got))
+    if note is None and not got:
+        note = 'no extra object arrived (%.0f s)' % (time.perf_counter() - t0)
+    return got, note
+
+
 class _stdout_to_stderr:
     """RCCL announces itself on STDOUT when it is loaded ("Librccl path : ..."); the one JSON line must stay the only thing there."""
 

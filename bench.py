@@ -98,7 +98,7 @@ def parse_args():
     ap.add_argument('--no-large-mesh', action='store_true', help='skip the `large_mesh` object (dmtet800: 684 k triangles) of the default N = 1 line')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the `other_configs` objects (spot512x256, hotdog512x256) of the default N = 1 line')
     ap.add_argument('--no-extended', action='store_true', help='skip the extended median phase and the cached-visibility loop')
-    ap.add_argument('--exchange', choices=('auto', 'dense', 'sparse'), default='auto',
+    ap.add_argument('--exchange', choices=('auto', 'dense', 'sparse'), default='dense',
                     help='gradient exchange of the texture chunk at N > 1: dense = the whole bucket, sparse / auto = the tiles some rank touched (falls back to dense by itself)')
     ap.add_argument('--no-pipeline', action='store_true', help='N > 1: wait for the texture chunk inside the iteration instead of under the next geometry stage')
     ap.add_argument('--exchange-world1', action='store_true',
@@ -320,10 +320,11 @@ def run(args):
         roof = {'bound': 'valu', 'achieved': None, 'peak': VALU_PEAK_TLANEOPS, 'unit': 'T lane-ops/s', 'frac': None, 'traffic': None,
                 'kernel': DOMINANT, 'kernel_ms_hip_events': trace_ms, 'launches_timed': n_f,
                 'rays_per_launch': n_traced, 'kernel_rays_per_sec': n_traced / (trace_ms * 1e-3),
-                'why_valu': 'rocprofv3 counters of this run: VALU issue dominates the kernel while its HBM and L2 fractions (hbm, l2 below) '
-                            'are small -- divergent traversal of a tree that is cache resident; peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz.  '
-                            'The fraction is the active-lane VALU rate, not a claim that the issue port is full: what sets the time is a wavefront\'s '
-                            'dependent chain per node step times the 8 wavefronts a SIMD holds (DESIGN.md section 5, profiles/r05_trace_l1_bound.md)',
+                'why_valu': 'the active-lane VALU rate is the ceiling with a datasheet number this kernel is nearest to (its HBM and L2 fractions -- hbm, l2 below -- are '
+                            'small: divergent traversal of a cache-resident tree); peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz.  It is NOT a claim that the issue port is '
+                            'full: the phase-clock builds of round 6 (profiles/r06_trace_phase_cycles.md) put half of a wavefront\'s cycles into the node FETCH (four '
+                            '16-byte requests per lane and step, waited for) and under a tenth into the box arithmetic, and doubling those requests costs +22 % here, '
+                            '+40 % on 684 k triangles (profiles/r06_ab_trace_split_coop_dup.md; DESIGN.md 4.6, 5)',
                 'shader_clock_mhz_counting_launch': clock_mhz,
                 'algorithmic': {'model': 'SURVEY 8d: 32 B per BVH2 node visit + 36 B per triangle test of the canonical binary any-hit walk '
                                          '(counting kernel over the same live rays; equals a CPU walk of the exported tree, tests/test_gpu_bvh.py) '

@@ -124,7 +124,7 @@ __device__ __forceinline__ F3 interp3(F3 a0, F3 a1, F3 a2, float u, float v) { r
 // background tiles simply claims more.  The counters live in lines 128..255 of the context's counter block, zero between launches: the last
 // wavefront of a class to leave resets its pair.
 #define NVDR_GB_CLASSES 64u
-__global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, GbufferParams p, int *spill, unsigned *queues)
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, GbufferParams p, int *spill, unsigned *queues, int mode)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     OctStack stack;             // per lane: NVDR_OSTACK_LDS (group, bits) entries in LDS, deeper ones in the context's spill columns
@@ -134,17 +134,27 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, 
     stack.ovf = bvh.overflow;
     stack.glb = (glb_pair_t *)spill + (int64_t)blockIdx.x * blockDim.x * max(bvh.oct_stack_max - NVDR_OSTACK_LDS, 0) + threadIdx.x;
     const int64_t total = (int64_t)p.N * p.H * p.W;
-    const bool tiled = (p.W & 7) == 0 && (p.H & 7) == 0;
+    // mode (NVDR_GB_MODE, A/B): bit 0 tiles, bit 1 claimed units (else dealt round-robin).  Tiles only for launches of several units per
+    // wavefront: with ~1 unit each (one 800^2 view) a covered tile is all deep walks and a background tile none, and the launch lasts as long as
+    // its dearest tiles -- strips mix the two (session 10: one view 0.250 ms in strips, 0.314 in tiles; eight views 0.089 / 0.085 per view; on the
+    // marching-tets mesh tiles win both: 0.247 against 0.326, 0.145 against 0.233)
+    const unsigned n_waves_all = gridDim.x * (blockDim.x >> 6);
+    const bool tiled = (mode & 1) && (p.W & 7) == 0 && (p.H & 7) == 0 && (mode & 4 ? true : ((total + 63) >> 6) >= 4 * (int64_t)n_waves_all);
     const unsigned tiles_x = (unsigned)p.W >> 3, tiles_per_view = tiles_x * ((unsigned)p.H >> 3);
     const unsigned n_units = (unsigned)((total + 63) >> 6);
     const unsigned lane = threadIdx.x & 63u, wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
     const unsigned cls = wid % NVDR_GB_CLASSES;
     unsigned *claim = queues + (128u + cls) * 32u, *gone = queues + (192u + cls) * 32u;
-    for (;;) {
-        unsigned j = 0u;
-        if (lane == 0u) j = atomicAdd(claim, 1u);
-        j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
-        const unsigned unit = cls + NVDR_GB_CLASSES * j;
+    for (unsigned round = 0u;; ++round) {
+        unsigned unit;
+        if (mode & 2) {
+            unsigned j = 0u;
+            if (lane == 0u) j = atomicAdd(claim, 1u);
+            j = (unsigned)__builtin_amdgcn_readfirstlane((int)j);
+            unit = cls + NVDR_GB_CLASSES * j;
+        } else {
+            unit = wid + round * n_waves;
+        }
         if (unit >= n_units) break;
         int64_t i;
         int x, y, z;
@@ -235,7 +245,7 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, 
     }
     // the last wavefront of this class to leave puts the pair of counters back to zero for the next launch (the waves of a class: those
     // with wid % 64 == cls)
-    if (lane == 0u) {
+    if (lane == 0u && (mode & 2)) {
         const unsigned mine = n_waves / NVDR_GB_CLASSES + (cls < n_waves % NVDR_GB_CLASSES ? 1u : 0u);
         if (atomicAdd(gone, 1u) + 1u == mine) {
             __hip_atomic_store(claim, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -245,6 +255,16 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK) gbuffer_kernel(BvhView bvh, 
 }
 
 unsigned query_grid(const nvdr_ctx *c, int64_t items);   // bvh.hip
+
+static int gb_mode()
+{
+    static int mode = -1;
+    if (mode < 0) {
+        mode = 3;
+        if (const char *e = nvdr_tuning_env("NVDR_GB_MODE")) mode = atoi(e) & 7;       // (bit 2: tiles whatever the launch size)
+    }
+    return mode;
+}
 
 extern "C" int nvdr_render_gbuffer(nvdr_ctx *c, const nvdr_gbuffer_args *a, void *stream_)
 {
@@ -268,7 +288,7 @@ extern "C" int nvdr_render_gbuffer(nvdr_ctx *c, const nvdr_gbuffer_args *a, void
     p.gb_tng = a->gb_tangent; p.gb_texc = a->gb_texc; p.gb_texc_db = a->gb_texc_deriv; p.gb_depth = a->gb_depth;
     const int64_t total = (int64_t)p.N * p.H * p.W;
     if (int rw = ctx_wait_built(c, (hipStream_t)stream_)) return rw;
-    gbuffer_kernel<<<query_grid(c, total), NVDR_QUERY_BLOCK, (NVDR_QUERY_BLOCK / 64) * NVDR_OSTACK_LDS * 64 * 8, (hipStream_t)stream_>>>(bvh_view(c), p, c->spill, c->queues);
+    gbuffer_kernel<<<query_grid(c, total), NVDR_QUERY_BLOCK, (NVDR_QUERY_BLOCK / 64) * NVDR_OSTACK_LDS * 64 * 8, (hipStream_t)stream_>>>(bvh_view(c), p, c->spill, c->queues, gb_mode());
     NVDR_LAUNCH_CHECK();
     return 0;
 }

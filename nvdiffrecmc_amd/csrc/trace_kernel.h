@@ -41,6 +41,18 @@
 #ifndef NVDR_TRACE_OCC
 #define NVDR_TRACE_OCC 8       // waves per SIMD the kernel is compiled for (= resident workgroups per CU of the persistent grid)
 #endif
+#ifndef NVDR_TRACE_STEALS
+#define NVDR_TRACE_STEALS 0    // counters of other wavefronts a wavefront tries once its own is used up (A/B only: measured a loss, see ChunkDealer::retarget)
+#endif
+#ifndef NVDR_TRACE_SPLIT
+#define NVDR_TRACE_SPLIT 0     // drain mode: walks hand their OLDEST pending group to idle lanes (A/B; see the split round in env_trace_body)
+#endif
+#ifndef NVDR_TRACE_SPLIT_FREE
+#define NVDR_TRACE_SPLIT_FREE 24   // ... when at least this many lanes have no node to visit
+#endif
+#ifndef NVDR_TRACE_SPLIT_EVERY
+#define NVDR_TRACE_SPLIT_EVERY 4   // ... every so many iterations of the drain (power of two)
+#endif
 #define NVDR_LEAFQ_CAP 128     // entries of a wavefront's triangle-test queue (< 64 before an append round, <= 64 appended per round)
 
 struct TraceLaunch {
@@ -105,6 +117,19 @@ struct ChunkDealer {
         first = base + (t << shift);
         end_abs = base + counts[seg * 32u];
         return total;
+    }
+    // Point the dealer at counter q (round 6: STEALING, an A/B switch -- NVDR_TRACE_STEALS -- that stays off).  The counting launch's per-wavefront
+    // clocks show the wavefronts of a one-view launch ending between 40 % and 100 % of the kernel's span, grouped by XCD (47-58 % against 70-82 %,
+    // profiles/r06_trace_phase_cycles.md "who ends when"), which looked like counters running dry at different times.  They do not: letting a used-up
+    // wavefront try 4 / 12 / 32 / 63 other counters, one per refill round, costs +0.7 ... +17 % at one view and +1 ... +2 % at eight (session 13) -- every
+    // counter is used up at about the same time, and what follows is each wavefront's own DRAIN: its last rays, a few of which walk 100+ node steps.
+    __device__ __forceinline__ void retarget(unsigned *queues, const unsigned *counts, unsigned q)
+    {
+        qp = queues + q * 32u;
+        const unsigned seg = q % NVDR_LIVE_SEGS, t = q / NVDR_LIVE_SEGS;
+        const unsigned base = seg * counts[NVDR_LIVE_SEGS * 32];
+        first = base + (t << shift);
+        end_abs = base + counts[seg * 32u];
     }
     // wave-uniform: claims the next chunk for the whole wave; false = the wave's counter is used up
     __device__ __forceinline__ bool claim(int lane, unsigned &next, unsigned &end)
@@ -198,6 +223,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     ChunkDealer dealer;
     const unsigned total = dealer.init(a.queues, a.ray_count, wid, gridDim.x * (blockDim.x >> 6));
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
+    unsigned steals = 0u;                                   // wave-uniform: other wavefronts' counters tried so far
     bool more = total > 0;
     unsigned n_box = 0, n_tri = 0, n_ray = 0, n_step = 0, n_batch = 0;
     // phase-clock builds: shader-clock cycles of this wavefront by phase of the loop (wave-uniform; nvdr_hip.h NVDR_COUNTERS_PHASES)
@@ -214,6 +240,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     OctRay g;
     g.ix = g.iy = g.iz = g.nx = g.ny = g.nz = 0.0f;
     unsigned q_count = 0;                                   // wave-uniform fill of the triangle-test queue
+    bool was_split = false;                                 // wave-uniform: some walk of this wavefront has been split (drain mode)
 
     // One batch of triangle tests: the top n entries of the queue, one per lane.  Returns nothing; a hit ends the owner's walk
     // (visibility 0) whatever the owner is doing.  Entries of rays that have ended meanwhile test against the owner's stale
@@ -239,13 +266,16 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
         if (COUNT) { n_tri += valid ? 1u : 0u; n_batch += lane == 0 ? 1u : 0u; }
         // owners of the hits, gathered on the scalar unit (hits are rare: one per occluded ray)
         unsigned long long hm = __ballot(hit), kill = 0ull;
+        bool same_ray = false;                              // (split walks: this lane holds a copy of a ray another lane just found occluded)
         while (hm) {
             const int l = __builtin_ctzll(hm);
             hm &= hm - 1ull;
-            kill |= 1ull << (unsigned)__builtin_amdgcn_readlane((int)e_own, l);
+            const unsigned own = (unsigned)__builtin_amdgcn_readlane((int)e_own, l);
+            kill |= 1ull << own;
+            if (NVDR_TRACE_SPLIT && was_split) same_ray = same_ray || ray == __builtin_amdgcn_readlane(ray, (int)own);
         }
         q_count = first;
-        if (((kill >> lane) & 1ull) && ray >= 0) {
+        if ((((kill >> lane) & 1ull) || same_ray) && ray >= 0) {
             vis[ray] = 0;
             ray = -1;
             sp = 0;
@@ -268,12 +298,19 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
         const int n_free = 64 - __popcll(busy);
         if (n_free >= NVDR_REFILL_MIN && next >= end && more) {
             more = dealer.claim(lane, next, end);
-            if (!more) next = end = 0u;
+            if (!more) {
+                next = end = 0u;
+                if (steals < NVDR_TRACE_STEALS) {           // this counter is used up: the next refill round asks another one
+                    ++steals;
+                    dealer.retarget(a.queues, a.ray_count, (wid + 17u * steals) % NVDR_TRACE_QUEUES);
+                    more = true;
+                }
+            }
         }
         if ((n_free >= NVDR_REFILL_MIN && next < end) || busy == 0ull) {
             while (q_count > 0u) test_batch(min(q_count, 64u));
             if (ray >= 0 && (gbits | (unsigned)sp) == 0u) {         // walk over, every queued test missed: unoccluded
-                vis[ray] = 1;
+                if (!NVDR_TRACE_SPLIT) vis[ray] = 1;                // (split walks: the byte was written at the fetch, a copy must not write it)
                 ray = -1;
             }
             if (next < end) {
@@ -282,6 +319,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 if (ray < 0 && take < end) {
                     const unsigned slot = live[take];
                     ray = (int)slot;
+                    if (NVDR_TRACE_SPLIT) vis[slot] = 1;             // unoccluded until some lane that holds the ray finds a hit
                     if (COUNT) n_ray++;
                     const float4 rd = rays[slot];
                     const float4 ro = pix_origin[rpp_pow2 ? slot >> rpp_shift : slot / rays_per_pixel];
@@ -304,6 +342,54 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             }
         }
 
+#if NVDR_TRACE_SPLIT
+        // ---- drain (A/B switch): no ray left to claim and many lanes without a node to visit -- every lane with two or more pending items hands its
+        // OLDEST one to an idle lane, which takes a copy of the ray and walks that group with a stack of its own.  An any-hit walk may visit its
+        // pending groups in any order and by any lane; the oldest group is the one nearest the root, i.e. the largest share of what is left.  (The
+        // first version, session 6, handed over the NEWEST stack entry -- the smallest subtree -- and gained nothing.)  The stack is a bag: the
+        // newest entry moves into the slot of the one given away.
+        if (!more && next >= end && n_free >= NVDR_TRACE_SPLIT_FREE && (iters & (NVDR_TRACE_SPLIT_EVERY - 1u)) == 0u &&
+            __ballot(ray >= 0 && (sp > 0 || (gbits & (gbits - 1u)) != 0u)) != 0ull) {
+            while (q_count > 0u) test_batch(min(q_count, 64u));      // the queue's entries refer to the lanes as they are now
+            if (ray >= 0 && (gbits | (unsigned)sp) == 0u) ray = -1;
+            const bool donor = ray >= 0 && (sp > 0 || (gbits & (gbits - 1u)) != 0u);
+            const unsigned long long dm = __ballot(donor), idle = __ballot(ray < 0);
+            const unsigned np = min((unsigned)__popcll(dm), (unsigned)__popcll(idle));      // pairs: the k-th idle lane takes from the k-th donor
+            if (np != 0u) {
+                const unsigned drank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)dm, 0u));
+                const unsigned irank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                unsigned gift_base = 0u, gift_bits = 0u;
+                if (donor && drank < np) {
+                    if (sp > 0) {                           // the oldest waiting group (entry 0); the newest takes its slot
+                        const unsigned long long bottom = stack.pop(0);
+                        gift_base = (unsigned)bottom;
+                        gift_bits = (unsigned)(bottom >> 32);
+                        sp--;
+                        if (sp > 0) stack.lds[0] = stack.pop(sp);
+                    } else {                                // the further children of the current group
+                        const unsigned keep = gbits & (0u - gbits);
+                        gift_base = gbase;
+                        gift_bits = gbits ^ keep;
+                        gbits = keep;
+                    }
+                    leafq[drank] = pack2((unsigned)lane, 0u);       // (the queue is empty: its LDS serves as the pairing table)
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool taker = ray < 0 && irank < np;
+                const int src = taker ? (int)((unsigned)leafq[irank] << 2) : (lane << 2);
+                __builtin_amdgcn_wave_barrier();
+                // (all lanes execute the permutes: a source lane must be active to be read.  A lane that takes nothing reads itself, so the
+                // ray state is permuted in place, one register at a time)
+                auto perm = [&](float &x) { x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(x))); };
+                const unsigned c_base = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)gift_base), c_bits = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)gift_bits);
+                ray = __builtin_amdgcn_ds_bpermute(src, ray);
+                perm(ox); perm(oy); perm(oz); perm(dx); perm(dy); perm(dz);
+                perm(g.ix); perm(g.iy); perm(g.iz); perm(g.nx); perm(g.ny); perm(g.nz);
+                if (taker) { gbase = c_base; gbits = c_bits; sp = 0; }
+                was_split = true;
+            }
+        }
+#endif
         // ---- node step of every lane that has one
         unsigned leaf_bits = 0u, leaf_base = 0u;
         unsigned tn0 = 0u;

@@ -262,7 +262,9 @@ class GradientExchange:
         b = self.buckets[k]
         cuda = b.is_cuda
         if cuda and self._side is None:
-            self._side = torch.cuda.Stream(device=b.device, priority=-1)     # (high priority: never on the main stream's hardware queue, trainer._capture)
+            # (normal priority, as in round 5: a HIGH-priority side stream here -- tried in round 6 to keep it off the main stream's hardware queue --
+            # went with a sporadic stall of the tile-sparse schedule, one run in three; the dense exchange has no side stream at all)
+            self._side = torch.cuda.Stream(device=b.device)
         if cuda:
             self._side.wait_event(self._ev_start)        # the main stream as of start(), not as of now
         ctx = torch.cuda.stream(self._side) if cuda else _null_context()

@@ -109,7 +109,7 @@ class DirectLightingStep:
                  probe_res=256, denoise=True, retrace_backward=False, pixel_index_offset=0, subdiv=0, lr=0.01, fused=True,
                  denoiser_demodulate=True, light_grad_scale=64.0, use_graph=False, material_set='full', tex_res=1024,
                  optimize_geometry=False, lr_pos=None, lr_light=None, perturb_pos=0.0, ks_min=(0.0, 0.08, 0.0), ks_max=(0.0, 1.0, 1.0),
-                 perturbed_nrm=True, exchange_mode='auto', pipeline=True, force_exchange=False, union_views=None, build_mode=None, rebuild_every=1):
+                 perturbed_nrm=True, exchange_mode='dense', pipeline=True, force_exchange=False, union_views=None, build_mode=None, rebuild_every=1):
         self.dev = torch.device(device)
         self.res, self.n, self.view = res, n_samples_x, view     # view: an index or a list of indices (a batch of views)
         self.pixel_index_offset = pixel_index_offset
@@ -121,7 +121,8 @@ class DirectLightingStep:
         # perturbed_nrm=False: FLAGS.no_perturbed_nrm (configs/spot_metal.json:20, render.py:92-93): no normal-map lookup; the normal texture
         # stays in the optimizer's list (train.py:185-197) but never receives a gradient, i.e. is never updated -- it is left out of the set here
         self.perturbed_nrm = bool(perturbed_nrm)
-        # Several ranks (parallel.GradientExchange).  exchange_mode: 'dense' = the whole texture bucket is all-reduced; 'sparse' = only the
+        # Several ranks (parallel.GradientExchange).  exchange_mode: 'dense' (default since round 6: what 'auto' settles on for the benchmark views, without
+        # its probe rounds) = the whole texture bucket is all-reduced; 'sparse' = only the
         # 768-byte tiles some rank's pixels touched (the dense bucket when more than half are); 'auto' = sparse when a periodic probe finds at
         # most a quarter of the tiles touched, plainly dense otherwise (the benchmark views touch half of them: auto runs dense there).  pipeline: the
         # texture chunk's reduce runs under the NEXT iteration's geometry stage and is waited for in front of the texture lookup.
@@ -817,8 +818,10 @@ class DirectLightingStep:
             return
         ex = self._exchange(world_size)
         g1 = torch.cuda.CUDAGraph()
+        # (not with a tile-sparse chunk: its send() blocks the host on a side stream in the middle of the schedule, and together with the rebuild's
+        # side stream that combination stalled a queue in round 6 -- session 10; the tile-sparse exchange keeps the un-split graphs)
         split = bool(self.pipeline and not self.optimize_geometry and len(self._ex_chunks) > 1 and self.material_set == 'full'
-                     and _lib.tuning_env('NVDR_SPLIT_STAGE2', '1') != '0')
+                     and not any(ex.sparse) and _lib.tuning_env('NVDR_SPLIT_STAGE2', '1') != '0')
         if split:
             # LOCKED geometry: G1 = the rebuild alone (joined inside the graph), replayed on a side stream; stage 2 = TWO graphs cut between
             # the sample generation and the traversal (OptiXContext.split_hook: the env-shade launch is issued in two calls), so that the

@@ -180,24 +180,25 @@ sys.path.insert(0, %r)
 from nvdiffrecmc_amd.trainer import DirectLightingStep
 res, n = 96, 4
 out = {}
-for tag, kw in (('plain', {}), ('forced', {'force_exchange': True, 'exchange_mode': 'sparse', 'union_views': [1, 2]})):
+for tag, kw in (('plain', {}), ('forced', {'force_exchange': True, 'exchange_mode': os.environ.get('EXCHANGE', 'sparse'), 'union_views': [1, 2]})):
     st = DirectLightingStep('bob', res, n, view=[1], n_views=4, device='cuda:0', lr=0.03, tex_res=1024, pixel_index_offset=res * res,
                             use_graph=(os.environ.get('USE_GRAPH') == '1'), **kw)
     losses = [float(st.step(1).item()) for _ in range(7)]
     st.finish()
     torch.cuda.synchronize()
     out[tag] = {'losses': losses, 'sums': [float(p.detach().double().sum()) for p in st.params], 'graph': st._graphs is not None,
-                'exchange': st._ex.report() if kw else None}
+                'exchange': st._ex.report() if kw else None, 'split': bool(getattr(st, 'split_stage2', False))}
 print('RESULT ' + json.dumps(out))
 '''
 
 
+@pytest.mark.parametrize('exchange', ['sparse', 'dense'])
 @pytest.mark.parametrize('graph', ['0', '1'], ids=['eager', 'hip_graphs'])
-def test_the_several_rank_schedule_with_one_rank_is_the_plain_iteration(graph, dev):
+def test_the_several_rank_schedule_with_one_rank_is_the_plain_iteration(graph, exchange, dev):
     """force_exchange: stage 2 | exchange of [probe] | its Adam | stage 1 of the NEXT iteration | tile-sparse texture chunk (flags, union list,
     gather, scatter) | texture Adam in front of the next lookup -- with one rank and no collective this must train exactly like the plain
     iteration: the same losses step by step and the same parameters up to the order of atomic additions (the pipelining moves launches, not arithmetic)."""
-    env = dict(os.environ, USE_GRAPH=graph, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, USE_GRAPH=graph, EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, '-c', _FORCED_SNIPPET % ROOT], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('RESULT ')][-1][7:])
@@ -209,8 +210,12 @@ def test_the_several_rank_schedule_with_one_rank_is_the_plain_iteration(graph, d
         assert abs(x - y) <= 1e-4 * abs(x), (a["sums"], b["sums"])      # (seven Adam steps at lr 0.03 amplify the last bits of a gradient)
     assert a['losses'][-1] < a['losses'][0]
     ex = b['exchange']
-    assert ex['mode'] == 'sparse'
-    assert 0 < ex['tiles_touched'] < ex['tiles_total']          # the union of two views' tiles, not only this view's
+    assert ex['mode'] == exchange
+    # with locked geometry the dense schedule replays the rebuild as a graph of its own on a side stream and cuts stage 2 in front of the traversal;
+    # the tile-sparse exchange keeps the un-split graphs (trainer._capture)
+    assert b['split'] == (graph == '1' and exchange == 'dense')
+    if exchange == 'sparse':
+        assert 0 < ex['tiles_touched'] < ex['tiles_total']          # the union of two views' tiles, not only this view's
 
 
 _FROZEN_SNIPPET = r'''

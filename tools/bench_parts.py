@@ -417,10 +417,10 @@ def exchange_object(step, ms_exposed):
     return rep
 
 
-def one_view_object(args, dev, preset_name, eight_view_ms, lock=None, modes=('auto', 'sparse')):
+def one_view_object(args, dev, preset_name, eight_view_ms, lock=None, modes=('dense', 'sparse')):
     """The per-GPU share of the 8-GPU run on THIS box (rank 0, N = 1): one view of the batch in HIP graphs, plain (`plain`) and under the
     several-rank schedule (chunks ordered by the next iteration's need, the texture chunk's reduce pipelined with the next iteration's
-    geometry stage; exchange policy `auto` = what a run would use, `sparse` / `dense` forced) with a one-rank RCCL group doing the real
+    geometry stage; exchange `dense` = the default, `sparse` = the tile-sparse texture chunk) with a one-rank RCCL group doing the real
     collectives on the bytes an 8-rank run would send (the tile flags are OR-ed with the tiles ALL eight views touch).
     No xGMI time is in it -- `projected_8gpu` prices the wire separately."""
     import torch
@@ -504,7 +504,7 @@ def one_view_object(args, dev, preset_name, eight_view_ms, lock=None, modes=('au
     return out
 
 
-def flat_scaling_keys(prefix, ov, policy='auto'):
+def flat_scaling_keys(prefix, ov, policy='dense'):
     """The one-view object's headline numbers as FLAT config keys (the driver's record keeps only flat keys of `config`): per-GPU share of the 8-GPU
     run plain and under the several-rank schedule, the main stream's wait on the exchange, the priced 8-GPU speed-up (lo = 150, hi = 250 GB/s)."""
     if not ov or 'error' in ov or policy not in ov:
@@ -665,8 +665,8 @@ def extras_child(args):
         emit('large_mesh', large_mesh_object, args, dev, 'dmtet64_800')
         reg = emit('large_mesh_regular', large_mesh_object, args, dev, 'dmtet800')
         if not args.no_one_view:
-            emit('large_mesh_regular/one_view_locked', one_view_object, args, dev, 'dmtet800', None, lock=True, modes=('auto',), quiet=True)
-            emit('large_mesh_regular/one_view_trained', one_view_object, args, dev, 'dmtet800', (reg or {}).get('ms_per_step'), lock=False, modes=('auto',), quiet=True)
+            emit('large_mesh_regular/one_view_locked', one_view_object, args, dev, 'dmtet800', None, lock=True, modes=('dense',), quiet=True)
+            emit('large_mesh_regular/one_view_trained', one_view_object, args, dev, 'dmtet800', (reg or {}).get('ms_per_step'), lock=False, modes=('dense',), quiet=True)
     if not args.no_validation:
         emit('validation_n32', validation_object, args, dev)
     if not args.no_other_configs and not args.no_large_mesh:

@@ -51,6 +51,15 @@ for case in cases:
     q = lambda x, p: float(torch.quantile(x, p))
     iters, step_iters, total1, total2 = ph[4], ph[5], ph[6], ps[6]
     prod_cycles = trace_ms * 1e-3 * f.clock_mhz * 1e6 * busy * waves          # wave-cycles of the production launch, estimated: duration x clock x slots busy
+    # who ends when: wavefront w serves dealing counter w % 64 (trace_kernel.h ChunkDealer); per counter and per XCD, the mean end of its wavefronts
+    wid = torch.arange(wt.shape[0])
+    per_counter = torch.stack([end[(wid % 64) == qq].mean() for qq in range(64)])
+    xcd = f.wave_xcd[:wt.shape[0]]
+    per_xcd = [float(end[xcd == k].mean()) if bool((xcd == k).any()) else float('nan') for k in range(8)]
+    spread_within = float(torch.stack([end[(wid % 64) == qq].std() for qq in range(64)]).mean())
+    who = ('mean end of the wavefronts of a dealing counter: min %.1f / median %.1f / max %.1f %% of the span over the 64 counters (spread inside a counter: %.1f %% std); per XCD: %s'
+           % (100 * float(per_counter.min()), 100 * float(per_counter.median()), 100 * float(per_counter.max()), 100 * spread_within,
+              ' '.join('%.1f' % (100 * v) for v in per_xcd)))
     lines += ['## %s, %dx%d, %d view(s): %d triangles, %d rays, %d wavefronts (%.0f rays each), %.2f node steps per ray'
               % (mesh + (' subdivided %dx' % subdiv if subdiv else ''), res, res, views, int(st.mesh['t_pos_idx'].shape[0]), n_traced, waves, n_traced / max(waves, 1),
                  f.node_steps / max(n_traced, 1)), '',
@@ -74,7 +83,7 @@ for case in cases:
               '(median / 90th / last), end at %.1f / %.1f / %.1f / 100 %% (10th / median / 90th / last); slots busy %.1f %% of span x wavefronts; '
               'the last 10 %% of the span holds %.1f %% of the wavefronts\' ends'
               % (span / 100.0, f.clock_mhz, 100 * q(begin, 0.5), 100 * q(begin, 0.9), 100 * float(begin.max()), 100 * q(end, 0.1), 100 * q(end, 0.5), 100 * q(end, 0.9),
-                 100.0 * busy, 100.0 * float((end > 0.9).double().mean())), '']
+                 100.0 * busy, 100.0 * float((end > 0.9).double().mean())), '', who, '']
     del st
     torch.cuda.empty_cache()
 out = '\n'.join(lines)

@@ -1075,9 +1075,10 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     }
     hipMemset(c->dinfo, 0, sizeof(BvhDeviceInfo));
     // host-mapped flag a traversal kernel raises when a stack push would exceed the context's bound (bvh.h)
-    e = hipHostMalloc((void **)&c->ovf_host, sizeof(int), hipHostMallocMapped);
+    e = hipHostMalloc((void **)&c->ovf_host, 2 * sizeof(int), hipHostMallocMapped);      // [0] the fault word, [1] live rays of the last traversal launch (launch_trace)
     if (e == hipSuccess) {
-        *c->ovf_host = 0;
+        c->ovf_host[0] = 0;
+        c->ovf_host[1] = 0;
         e = hipHostGetDevicePointer((void **)&c->ovf_dev, c->ovf_host, 0);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&c->chunk_counts, sizeof(unsigned) * NVDR_MAX_CHUNKS * 544);
@@ -1117,6 +1118,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     // workgroups per band, unset = by launch size
     if (const char *lm = nvdr_tuning_env("NVDR_LG_MODE")) c->lg_mode = atoi(lm) ? 1 : 0;
     if (const char *sq = nvdr_tuning_env("NVDR_SHADE_QUEUE")) c->shade_queue = atoi(sq) & 7;
+    if (const char *sm = nvdr_tuning_env("NVDR_TRACE_SPLIT_MODE")) c->trace_split_mode = atoi(sm);
     (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (c->n_cus <= 0) c->n_cus = 256;
     *out = c;

@@ -851,6 +851,13 @@ __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_ke
     env_trace_body<COUNT>(a, smem);
 }
 
+// the build with split walks in the drain (trace_kernel.h SPLIT): small launches
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_split_kernel(TraceLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    env_trace_body<false, 0, true>(a, smem);
+}
+
 // the phase-clock builds of the same kernel (trace_kernel.h PH; counting launches only)
 template <int PH>
 __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_phase_kernel(TraceLaunch a)
@@ -1618,6 +1625,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 
 #define NVDR_LG_THREADS 1024
 #define NVDR_LG_PER_BAND_MAX_SLOTS (192ll << 20)    // launches of up to this many stream slots (6 views of 512^2 x 64 spp) deal the CUs to the bands (measured: -13 % / -6 % / -2 % / +-0 of the backward shading + gather time at 1 / 2 / 4 / 8 views)
+#ifndef NVDR_LG_SKIP
+#define NVDR_LG_SKIP 0                   // timing-only A/B (wrong results): bit 0 no LDS adds, bit 1 no record loads, bit 2 no partial row written, bit 3 no zeroing of the accumulators
+#endif
 #ifndef NVDR_LG_NB
 #define NVDR_LG_NB 4                     // blocks of 128 records a wavefront of the gather fetches together (1: A/B)
 #endif
@@ -1655,7 +1665,7 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
     for (int band = band_first; band < band_last; ++band) {
         const int t_lo = band * band_texels, t_hi = min(t_lo + band_texels, n_texels);
         const int n_acc = (t_hi - t_lo) * 3;
-        for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) lg_acc[i] = 0.0f;
+        if (!(NVDR_LG_SKIP & 8)) for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) lg_acc[i] = 0.0f;
         __syncthreads();
         // fp32 add to LDS.  NOT ds_add_f32: gfx950 executes that at 0.8 lane-operations per CU and nanosecond, twenty times slower
         // than its integer LDS atomics (tools/ubench/lds_atomic.hip, profiles/r03_lds_atomic_ubench.txt) -- it was 0.55 ms of the
@@ -1712,16 +1722,21 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
 #pragma unroll
                 for (int q = 0; q < NVDR_LG_NB; ++q) {
                     cc[2 * q] = none; cc[2 * q + 1] = none;
-                    if (lane < ff[q]) cc[2 * q] = recs[(bb[q] << 7) + lane];
-                    if (lane + 64u < ff[q]) cc[2 * q + 1] = recs[(bb[q] << 7) + 64u + lane];
+                    if (!(NVDR_LG_SKIP & 2)) {
+                        if (lane < ff[q]) cc[2 * q] = recs[(bb[q] << 7) + lane];
+                        if (lane + 64u < ff[q]) cc[2 * q + 1] = recs[(bb[q] << 7) + 64u + lane];
+                    } else if (lane < ff[q]) cc[2 * q] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(t_lo + (int)((bb[q] * 64u + lane) % (unsigned)(t_hi - t_lo))));
                 }
 #pragma unroll
-                for (int q = 0; q < 2 * NVDR_LG_NB; ++q) add(cc[q]);
+                for (int q = 0; q < 2 * NVDR_LG_NB; ++q) {
+                    if (!(NVDR_LG_SKIP & 1)) add(cc[q]);
+                    else asm volatile("" :: "v"(cc[q].x), "v"(cc[q].w));
+                }
             }
         }
         __syncthreads();
         float *out = partials + (int64_t)g * n_texels * 3 + (int64_t)t_lo * 3;
-        for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) out[i] = lg_acc[i];
+        if (!(NVDR_LG_SKIP & 4)) for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) out[i] = lg_acc[i];
         __syncthreads();
     }
 }
@@ -1838,8 +1853,17 @@ static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t s
         env_trace_phase_kernel<1><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
         zero_queues_kernel<<<1, NVDR_TRACE_QUEUES, 0, stream>>>(c->queues);
         env_trace_phase_kernel<2><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, counters));
-    } else
-        env_trace_kernel<false><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
+    } else {
+        // Which build: the one with split walks in the drain pays for launches of few rays per wavefront and costs the others 3-6 % (trace_kernel.h).
+        // The host never learns a launch's live-ray count in time -- but every launch leaves it in the context's host-mapped word, and a context
+        // renders the same kind of launch again and again (a HIP-graph capture freezes the choice of its warm-up iterations): the LAST launch's count
+        // decides.  NVDR_TRACE_SPLIT_MODE (tuning, read when the context is created): 0 never, 1 always, 2 by the hint (default).
+        const int mode = c->trace_split_mode;
+        const unsigned hint = c->ovf_host ? (unsigned)((volatile int *)c->ovf_host)[1] : 0u;
+        const bool split = mode == 1 || (mode == 2 && hint != 0u && hint / (blocks * (NVDR_QUERY_BLOCK / 64u)) < NVDR_TRACE_SPLIT_BELOW);
+        if (split) env_trace_split_kernel<<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
+        else env_trace_kernel<false><<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
+    }
 }
 
 // Scratch for the ray stream.  Round 1 sized it for the worst case -- every pixel of the launch covered -- which was

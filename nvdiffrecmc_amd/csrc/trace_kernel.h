@@ -17,9 +17,8 @@
 //     with their owner's generation, a FIFO queue, a per-lane count of the tests run so that a finished walk knows when its last
 //     verdict is in -- is bit-identical and 11-15 % SLOWER at every threshold: the extra permute, LDS counters and votes per iteration
 //     cost more than the lanes that idle until 16 are free.)
-//   (Measured and dropped, round 6, profiles/r06_ab_trace_split_coop_dup.md: (a) SPLIT WALKS in the drain -- when the chunk counter is used up, lanes with
-//   two or more pending items hand one to an idle lane, which takes a copy of the ray through 15 ds_bpermute; bit-identical, no gain at one view, 4.5 % slower
-//   at eight: a walk's remaining work is one deep path, not many subtrees.  (b) A QUAD-COOPERATIVE node fetch -- the four lanes of a quad load the four
+//   (Round 6, profiles/r06_ab_trace_split_coop_dup.md: (a) SPLIT WALKS in the drain exist as a build of their own for small launches -- see the split round
+//   below.  Measured and dropped: (b) A QUAD-COOPERATIVE node fetch -- the four lanes of a quad load the four
 //   quarters of ONE node per instruction and transpose inside the quad with DPP quad permutes, a quarter of the cache lines per request: 22-25 % slower; the
 //   vector-memory path charges per lane-request, not per line.  (c) Doubling the node's four requests costs +14 ... +22 % on bob, +40 ... +45 % on 684 k
 //   triangles: the kernel is sensitive to the number of requests, most where the tree spills the L2.)
@@ -44,14 +43,15 @@
 #ifndef NVDR_TRACE_STEALS
 #define NVDR_TRACE_STEALS 0    // counters of other wavefronts a wavefront tries once its own is used up (A/B only: measured a loss, see ChunkDealer::retarget)
 #endif
-#ifndef NVDR_TRACE_SPLIT
-#define NVDR_TRACE_SPLIT 0     // drain mode: walks hand their OLDEST pending group to idle lanes (A/B; see the split round in env_trace_body)
-#endif
+// Split walks in the drain (env_trace_body<.., SPLIT = true>; the launcher picks that build for SMALL launches, env_shade.hip launch_trace)
 #ifndef NVDR_TRACE_SPLIT_FREE
-#define NVDR_TRACE_SPLIT_FREE 24   // ... when at least this many lanes have no node to visit
+#define NVDR_TRACE_SPLIT_FREE 8    // ... when at least this many lanes have no node to visit
 #endif
 #ifndef NVDR_TRACE_SPLIT_EVERY
-#define NVDR_TRACE_SPLIT_EVERY 4   // ... every so many iterations of the drain (power of two)
+#define NVDR_TRACE_SPLIT_EVERY 1   // ... every so many iterations of the drain (power of two)
+#endif
+#ifndef NVDR_TRACE_SPLIT_BELOW
+#define NVDR_TRACE_SPLIT_BELOW 3000u   // rays per wavefront of the context's last traversal launch below which the split build is launched
 #endif
 #define NVDR_LEAFQ_CAP 128     // entries of a wavefront's triangle-test queue (< 64 before an append round, <= 64 appended per round)
 
@@ -190,7 +190,7 @@ struct OctRay {
 // counting build's 17 spilled dwords would drown what is being measured) or, PH = 2, additionally inside the node step with a wait for the
 // node behind its four loads (three more vector registers, and the production kernel's overlap of the fetch with the ray's frame set-up is
 // gone: this build only splits the node step of PH = 1 into fetch / box arithmetic / stack).
-template <bool COUNT, int PH = 0>
+template <bool COUNT, int PH = 0, bool SPLIT = false>
 __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
 {
     const BvhView &bvh = a.bvh;
@@ -222,6 +222,9 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     const unsigned wid = blockIdx.x * (blockDim.x >> 6) + wave;
     ChunkDealer dealer;
     const unsigned total = dealer.init(a.queues, a.ray_count, wid, gridDim.x * (blockDim.x >> 6));
+    // (host-mapped word: the launcher's hint for the NEXT launch -- which build to start, env_shade.hip launch_trace; written here, in front of the loop,
+    // so that nothing of it stays live across the loop)
+    if (!COUNT && !PH && wid == 0u && lane == 0) bvh.overflow[1] = (int)min(total, 0x7fffffffu);
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
     unsigned steals = 0u;                                   // wave-uniform: other wavefronts' counters tried so far
     bool more = total > 0;
@@ -272,7 +275,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             hm &= hm - 1ull;
             const unsigned own = (unsigned)__builtin_amdgcn_readlane((int)e_own, l);
             kill |= 1ull << own;
-            if (NVDR_TRACE_SPLIT && was_split) same_ray = same_ray || ray == __builtin_amdgcn_readlane(ray, (int)own);
+            if (SPLIT && was_split) same_ray = same_ray || ray == __builtin_amdgcn_readlane(ray, (int)own);
         }
         q_count = first;
         if ((((kill >> lane) & 1ull) || same_ray) && ray >= 0) {
@@ -310,7 +313,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
         if ((n_free >= NVDR_REFILL_MIN && next < end) || busy == 0ull) {
             while (q_count > 0u) test_batch(min(q_count, 64u));
             if (ray >= 0 && (gbits | (unsigned)sp) == 0u) {         // walk over, every queued test missed: unoccluded
-                if (!NVDR_TRACE_SPLIT) vis[ray] = 1;                // (split walks: the byte was written at the fetch, a copy must not write it)
+                if (!SPLIT) vis[ray] = 1;                // (split walks: the byte was written at the fetch, a copy must not write it)
                 ray = -1;
             }
             if (next < end) {
@@ -319,7 +322,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 if (ray < 0 && take < end) {
                     const unsigned slot = live[take];
                     ray = (int)slot;
-                    if (NVDR_TRACE_SPLIT) vis[slot] = 1;             // unoccluded until some lane that holds the ray finds a hit
+                    if (SPLIT) vis[slot] = 1;             // unoccluded until some lane that holds the ray finds a hit
                     if (COUNT) n_ray++;
                     const float4 rd = rays[slot];
                     const float4 ro = pix_origin[rpp_pow2 ? slot >> rpp_shift : slot / rays_per_pixel];
@@ -342,13 +345,16 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             }
         }
 
-#if NVDR_TRACE_SPLIT
-        // ---- drain (A/B switch): no ray left to claim and many lanes without a node to visit -- every lane with two or more pending items hands its
-        // OLDEST one to an idle lane, which takes a copy of the ray and walks that group with a stack of its own.  An any-hit walk may visit its
-        // pending groups in any order and by any lane; the oldest group is the one nearest the root, i.e. the largest share of what is left.  (The
-        // first version, session 6, handed over the NEWEST stack entry -- the smallest subtree -- and gained nothing.)  The stack is a bag: the
-        // newest entry moves into the slot of the one given away.
-        if (!more && next >= end && n_free >= NVDR_TRACE_SPLIT_FREE && (iters & (NVDR_TRACE_SPLIT_EVERY - 1u)) == 0u &&
+        // ---- drain (the SPLIT build): no ray left to claim and lanes without a node to visit -- every lane with two or more pending items hands its
+        // OLDEST one to an idle lane, which takes a copy of the ray (15 ds_bpermute) and walks that group with a stack of its own.  An any-hit walk may
+        // visit its pending groups in any order and by any lane; the oldest group is the one nearest the root, i.e. the largest share of what is left
+        // (handing over the NEWEST entry -- the smallest subtree -- gained nothing, session 6).  The stack is a bag: the newest entry moves into the slot
+        // of the one given away.  A hit found by any copy ends all lanes that hold the ray; the "unoccluded" byte is written when a ray is FETCHED
+        // and only ever overwritten (a copy that ends without a hit must not write: another may have found one).
+        // Measured (session 14, in-process A/B): -4 ... -5 % per one-view launch of bob (700 rays per wavefront), -6 % on 684 k triangles (1 800 per
+        // wavefront), but +3 ... +6 % on launches of 5 000 rays per wavefront (the block's registers and tests are paid in every iteration, the drain
+        // is a tenth of such a launch): a build of its own, launched for small launches only.
+        if (SPLIT && !more && next >= end && n_free >= NVDR_TRACE_SPLIT_FREE && (iters & (NVDR_TRACE_SPLIT_EVERY - 1u)) == 0u &&
             __ballot(ray >= 0 && (sp > 0 || (gbits & (gbits - 1u)) != 0u)) != 0ull) {
             while (q_count > 0u) test_batch(min(q_count, 64u));      // the queue's entries refer to the lanes as they are now
             if (ray >= 0 && (gbits | (unsigned)sp) == 0u) ray = -1;
@@ -389,7 +395,6 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 was_split = true;
             }
         }
-#endif
         // ---- node step of every lane that has one
         unsigned leaf_bits = 0u, leaf_base = 0u;
         unsigned tn0 = 0u;

@@ -565,3 +565,34 @@ def test_dmtet_extraction_visibility_vs_bruteforce(mesh_name, dev):
     print('\n[%s] %d triangles, %d rays: %.1f node steps, %.1f box tests, %.1f triangle tests per ray, %.0f %% unoccluded'
           % (mesh_name, T, ref.numel(), n_step / n_ray, n_box / n_ray, n_tri / n_ray, 100.0 * ref.float().mean().item()))
     ctx.check()
+
+
+@pytest.mark.parametrize('mesh_name', ['bob', 'dmtet64_init'])
+def test_split_walk_build_of_the_traversal_kernel_vs_bruteforce(mesh_name, dev, monkeypatch):
+    """The traversal build with SPLIT WALKS in the drain (trace_kernel.h; the launcher starts it for launches of few rays per wavefront, by the
+    context's last launch): forced on for every launch, its visibility == the plain build's == the oracle's brute force, on random rays and on
+    a ray set made of a few thousand LONG walks (rays grazing the mesh: what a drain consists of) among short ones."""
+    from nvdiffrecmc_amd import optixutils as ou
+    mesh = sc.load_mesh(mesh_name)
+    v, t = mesh['v_pos'], mesh['t_pos_idx']
+    monkeypatch.setenv('NVDR_TUNING', '1')
+    monkeypatch.setenv('NVDR_TRACE_SPLIT_MODE', '1')
+    ctx_split = make_ctx(mesh, dev)
+    monkeypatch.setenv('NVDR_TRACE_SPLIT_MODE', '0')
+    ctx_plain = make_ctx(mesh, dev)
+    monkeypatch.delenv('NVDR_TRACE_SPLIT_MODE')
+    g = torch.Generator().manual_seed(23)
+    ro, rd = _rays(90000, 23, scale=0.5)
+    # grazing rays: from a vertex, along an edge of one of its triangles, lifted off the surface by a hair
+    tri = torch.randint(0, t.shape[0], (20000,), generator=g)
+    a, b = v[t[tri, 0].long()], v[t[tri, 1].long()]
+    ro[:20000] = a + 1e-4 * torch.randn(20000, 3, generator=g)
+    rd[:20000] = torch.nn.functional.normalize(b - a + 1e-3 * torch.randn(20000, 3, generator=g), dim=-1)
+    ref = orc.visibility(v, t, ro, rd, n_threads=NT)
+    for n in (ro.shape[0], 5000, 777):          # a launch of many rays per wavefront, of a few, of less than a wavefront each
+        got_s = ou.trace_visibility_wide(ctx_split, ro[:n].to(dev), rd[:n].to(dev)).cpu()
+        got_p = ou.trace_visibility_wide(ctx_plain, ro[:n].to(dev), rd[:n].to(dev)).cpu()
+        assert torch.equal(got_s, ref[:n]), '%d of %d rays differ (split build)' % (int((got_s != ref[:n]).sum()), n)
+        assert torch.equal(got_p, ref[:n])
+    ctx_split.check()
+    ctx_plain.check()

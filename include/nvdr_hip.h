@@ -264,7 +264,8 @@ typedef struct nvdr_env_shade_args {
          the same live rays (reference accounting layout: 32-B BVH2 node, 36-B triangle) -- invariant to how speculative
          the production walk is, checked against a CPU walk of the exported tree in tests/test_gpu_bvh.py.
          [NVDR_COUNTERS_BVH2 + 3] node steps of the production walk (one 64-byte node fetch + eight box tests each),
-         [+4] triangle-test batches, [+5] lanes those batches filled (= triangle tests; / 64 / batches = their occupancy).
+         [+4] triangle-test batches, [+5] lanes those batches filled (= triangle tests; / 64 / batches = their occupancy),
+         [+6] node steps served by the treetop table in LDS (round 6; the rest fetch their node through the vector memory path).
          [NVDR_COUNTERS_PHASES + 0 .. 15] (round 6) shader-clock cycles of the wavefront loop by phase, summed over the wavefronts, from two
          PHASE-CLOCK builds of the kernel that a counting launch runs behind the counting kernel on the same rays (trace_kernel.h):
            build 1 (clock reads at wave-uniform points only, no vector register):  [0] refill (votes, chunk claims, ray fetch + set-up)
@@ -425,6 +426,15 @@ int nvdr_shade_composite_fwd(const nvdr_tensor *diff, const nvdr_tensor *spec, c
 int nvdr_shade_composite_bwd(const nvdr_tensor *diff, const nvdr_tensor *spec, const nvdr_tensor *kd, const nvdr_tensor *ks,
                              int bsdf, const nvdr_tensor *d_out, float *diff_grad, float *spec_grad, float *kd_grad,
                              float *ks_grad, void *stream);
+
+/* Composite + mean image loss, forward and backward in ONE launch (additive, round 6: the tail of shade() and train.py:51-66 for a caller whose
+ * loss is the mean image loss of the composite): out_mean f32 [1] = mean over N H W of the loss of (composite(diff, spec, kd, ks), target), and
+ * the gradients of that mean -- times the upstream gradient *d_mean, a device scalar read by the launch -- with respect to diff, spec (channel
+ * count of their input), kd and ks (full extent).  partials: scratch of nvdr_image_loss_num_partials floats.  Same arithmetic as
+ * nvdr_shade_composite_fwd/bwd + nvdr_image_loss_mean_fwd/bwd, statement for statement. */
+int nvdr_shade_loss_fused(const nvdr_tensor *diff, const nvdr_tensor *spec, const nvdr_tensor *kd, const nvdr_tensor *ks, int bsdf,
+                          const nvdr_tensor *target, int loss, int tonemapper, const float *d_mean, float *partials, float *out_mean,
+                          float *diff_grad, float *spec_grad, float *kd_grad, float *ks_grad, void *stream);
 
 /* ---- rows of a table by index (additive; the nearest-texel lookup of a trained texture in the iteration harness):
  * out[i,:] = index[i] >= 0 ? table[index[i],:] : 0; the backward zeroes dtable [table_rows, channels] and accumulates. */

@@ -166,6 +166,7 @@ _SIGNATURES = {
     'nvdr_pbr_bsdf_bwd': [_T] * 6 + [c_float, c_int, _T] + [c_void_p] * 6 + [c_void_p],
     'nvdr_shade_composite_fwd': [_T] * 4 + [c_int, c_void_p, c_void_p],
     'nvdr_shade_composite_bwd': [_T] * 4 + [c_int, _T] + [c_void_p] * 4 + [c_void_p],
+    'nvdr_shade_loss_fused': [_T] * 4 + [c_int, _T, c_int, c_int] + [c_void_p] * 7 + [c_void_p],
     'nvdr_gather_rows_fwd': [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p],
     'nvdr_gather_rows_bwd': [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p],
     'nvdr_light_update_pdf': [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -817,6 +817,96 @@ extern "C" int nvdr_shade_composite_bwd(const nvdr_tensor *diff, const nvdr_tens
     });
 }
 
+// ---- composite + mean image loss, forward AND backward, in one launch (additive, round 6).  The tail of shade() and the loss of a training
+// iteration are five small launches per iteration -- composite, loss partials, their reduction, loss adjoint, composite adjoint: 40 us of
+// kernels and as many dependency gaps in a 1.8 ms one-view iteration -- and the adjoint of a MEAN does not need the mean: d loss / d pixel is
+// d_mean / (N H W) times a per-pixel factor.  One pass computes the composite, the pixel's loss term (block partial sums, reduced by the
+// launch behind it) and, with the upstream gradient of the mean read from a device scalar, the gradients of the four composite inputs.
+// The arithmetic is the separate kernels' statement for statement (same values bit for bit: tests/test_gpu_renderutils.py).
+__global__ void __launch_bounds__(LOSS_BLOCK) shade_loss_fused_kernel(Extent e, View4 a, View4 b, View4 c, View4 d, View4 tg, int bsdf, int loss, int tonemapper,
+                                                                       int cd, int cs, const float *__restrict__ d_mean, float mean_scale,
+                                                                       float *__restrict__ partials, float *__restrict__ diff_grad,
+                                                                       float *__restrict__ spec_grad, float *__restrict__ kd_grad, float *__restrict__ ks_grad)
+{
+    __shared__ float wsum[LOSS_BLOCK / 64];
+    const float d_out = d_mean[0] * mean_scale;
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e.total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % e.W), h = (int)((i / e.W) % e.H), n = (int)(i / ((int64_t)e.W * e.H));
+        float iwd, iws;
+        const F3 dn = fetch_rgb_over_w(a, n, h, w, iwd), sn = fetch_rgb_over_w(b, n, h, w, iws);
+        const F3 k = fetch3(c, n, h, w), arm = fetch3(d, n, h, w);
+        const F3 img = bsdf == 0 ? dn * (k * (1.0f - arm.z)) + sn : dn * k;                  // nvdr_shade_composite_fwd
+        const F3 tgt = fetch3(tg, n, h, w);
+        const float av[3] = {img.x, img.y, img.z}, bv[3] = {tgt.x, tgt.y, tgt.z};
+        float s = 0.0f, gi[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float x = clampf(av[ch], 0.0f, 65535.0f), t = clampf(bv[ch], 0.0f, 65535.0f);  // image_loss_fwd_kernel
+            if (tonemapper) {
+                x = tonemap_fwd(x);
+                t = tonemap_fwd(t);
+            }
+            s += loss_fwd1(loss, x, t);
+            float xu = av[ch], tu = bv[ch];                                                 // image_loss_bwd_impl (tonemaps the UNclamped value)
+            if (tonemapper) {
+                xu = tonemap_fwd(xu);
+                tu = tonemap_fwd(tu);
+            }
+            float dx, dt;
+            loss_bwd1(loss, xu, tu, d_out / 3.0f, dx, dt);
+            if (tonemapper) dx = tonemap_bwd(av[ch], dx);
+            if (av[ch] <= 0.0f || av[ch] >= 65535.0f) dx = 0;
+            gi[ch] = dx;
+        }
+        acc += s / 3.0f;
+        const F3 go = f3(gi[0], gi[1], gi[2]);                                              // nvdr_shade_composite_bwd
+        const float om = bsdf == 0 ? 1.0f - arm.z : 1.0f;
+        const F3 d_dn = go * (k * om);
+        const F3 d_sn = bsdf == 0 ? go : f3(0.0f);
+        float *pd = diff_grad + i * cd, *ps = spec_grad + i * cs;
+        pd[0] = d_dn.x * iwd; pd[1] = d_dn.y * iwd; pd[2] = d_dn.z * iwd;
+        if (cd == 4) pd[3] = -sum3(d_dn * dn) * iwd;
+        ps[0] = d_sn.x * iws; ps[1] = d_sn.y * iws; ps[2] = d_sn.z * iws;
+        if (cs == 4) ps[3] = -sum3(d_sn * sn) * iws;
+        store3(kd_grad, i, go * dn * om);
+        store3(ks_grad, i, f3(0.0f, 0.0f, bsdf == 0 ? -sum3(go * dn * k) : 0.0f));
+    }
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int q = 0; q < LOSS_BLOCK / 64; ++q) t += wsum[q];
+        partials[blockIdx.x] = t;
+    }
+}
+
+extern "C" int nvdr_shade_loss_fused(const nvdr_tensor *diff, const nvdr_tensor *spec, const nvdr_tensor *kd, const nvdr_tensor *ks, int bsdf,
+                                     const nvdr_tensor *target, int loss, int tonemapper, const float *d_mean, float *partials, float *out_mean,
+                                     float *diff_grad, float *spec_grad, float *kd_grad, float *ks_grad, void *stream)
+{
+    static const char *OP = "shade_loss_fused";
+    NVDR_REQUIRE(diff && spec && kd && ks && target && d_mean && partials && out_mean && diff_grad && spec_grad && kd_grad && ks_grad, "%s: NULL argument", OP);
+    NVDR_REQUIRE(bsdf == 0 || bsdf == 1, "%s: bsdf must be 0 (pbr) or 1 (diffuse only)", OP);
+    NVDR_REQUIRE(loss >= 0 && loss <= 4 && (tonemapper == 0 || tonemapper == 1), "%s: bad loss/tonemapper", OP);
+    const Extent e = make_extent(diff, spec, kd, ks, target);
+    int r;
+    if ((r = check_accum(diff, e, OP, "diff"))) return r;
+    if ((r = check_accum(spec, e, OP, "spec"))) return r;
+    CHECK_VIEW(kd, 3); CHECK_VIEW(ks, 3); CHECK_VIEW(target, 3);
+    NVDR_REQUIRE(kd->size[0] == e.N && kd->size[1] == e.H && kd->size[2] == e.W && ks->size[0] == e.N && ks->size[1] == e.H && ks->size[2] == e.W,
+                 "%s: kd / ks must have the full extent (their gradients are written at it)", OP);
+    const int64_t n = nvdr_image_loss_num_partials(e.N, e.H, e.W);
+    shade_loss_fused_kernel<<<(unsigned)n, LOSS_BLOCK, 0, (hipStream_t)stream>>>(e, make_view4(*diff), make_view4(*spec), make_view4(*kd), make_view4(*ks),
+                                                                                   make_view4(*target), bsdf, loss, tonemapper, (int)diff->size[3], (int)spec->size[3],
+                                                                                   d_mean, 1.0f / (float)((int64_t)e.N * e.H * e.W), partials, diff_grad, spec_grad,
+                                                                                   kd_grad, ks_grad);
+    image_loss_reduce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials, n, 1.0f / (float)((int64_t)e.N * e.H * e.W), out_mean);
+    NVDR_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Rows of a table by index (additive): out[i] = index[i] >= 0 ? table[index[i]] : 0 -- the nearest-texel lookup of the trained kd
 // texture in the iteration harness (trainer.py), which torch composes from zeros + index_select + index_copy (forward) and

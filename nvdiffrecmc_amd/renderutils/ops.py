@@ -436,6 +436,51 @@ class _shade_composite_func(torch.autograd.Function):
         return tuple(out) + (None,)
 
 
+class _shade_loss_fused_func(torch.autograd.Function):
+    """Composite + mean image loss with their adjoints in ONE launch (csrc/renderutils.hip shade_loss_fused_kernel): the forward already knows
+    the upstream gradient of the mean (`upstream`, a device scalar the caller will hand to backward()) and writes the four input gradients."""
+
+    @staticmethod
+    def forward(ctx, diff, spec, kd, ks, target, upstream, bsdf, loss, tonemapper):
+        for t, name in ((diff, 'diff'), (spec, 'spec')):
+            _lib.require_cuda_f32(t, name)
+            if t.dim() != 4 or t.shape[3] not in (3, 4):
+                raise RuntimeError("shade_loss: %s must be [N,H,W,3] or [N,H,W,4] (got %s)" % (name, tuple(t.shape)))
+        _check4(kd, 'shade_loss kd', 3)
+        _check4(ks, 'shade_loss ks', 3)
+        _check4(target, 'shade_loss target', 3)
+        _lib.require_cuda_f32(upstream, 'upstream')
+        N, H, W = _extent(diff, spec, kd, ks, target)
+        if tuple(kd.shape[:3]) != (N, H, W) or tuple(ks.shape[:3]) != (N, H, W):
+            raise RuntimeError('shade_loss: kd / ks must have the full extent')
+        lib = _lib.load()
+        part = torch.empty(lib.nvdr_image_loss_num_partials(N, H, W) + 1, dtype=torch.float32, device=diff.device)
+        grads = [torch.empty(N, H, W, c, dtype=torch.float32, device=diff.device) for c in (diff.shape[3], spec.shape[3], 3, 3)]
+        keep, refs = _views(diff, spec, kd, ks, target)
+        up = upstream.contiguous().view(1)
+        _lib.check(lib.nvdr_shade_loss_fused(*refs[:4], bsdf, refs[4], _LOSS.get(loss, 0), int(tonemapper == 'log_srgb'), _lib.ptr(up), _lib.ptr(part[1:]),
+                                             _lib.ptr(part), *[_lib.ptr(g) for g in grads], _lib.stream_ptr()), 'shade_loss_fused')
+        ctx.grads = grads
+        ctx.upstream = up
+        return part[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = ctx.grads
+        if dout.data_ptr() != ctx.upstream.data_ptr():
+            # another upstream gradient than the one the forward was told: rescale (the gradients are linear in it)
+            f = dout.reshape(()) / ctx.upstream.reshape(())
+            grads = [g * f for g in grads]
+        return grads[0], grads[1], grads[2], grads[3], None, None, None, None, None
+
+
+def shade_composite_loss(diffuse_accum, specular_accum, kd, ks, target, upstream, bsdf='pbr', loss='l1', tonemapper='none'):
+    """image_loss_mean(shade_composite(diffuse_accum, specular_accum, kd, ks, bsdf), target, loss, tonemapper) as ONE launch forward + backward (+ the
+    fixed-order reduction of the partial sums): the same values and gradients bit for bit.  `upstream`: the device scalar that will be passed to
+    `.backward(gradient=...)` (a resident tensor of ones in the training harness); target carries no gradient."""
+    return _finite(_shade_loss_fused_func.apply(diffuse_accum, specular_accum, kd, ks, target, upstream, 0 if bsdf == 'pbr' else 1, loss, tonemapper), 'image_loss')
+
+
 def shade_composite(diffuse_accum, specular_accum, kd, ks, bsdf='pbr', use_python=False):
     '''Final colour of the direct-lighting pass: (diffuse / w) * kd * (1 - metalness) + specular / w for 'pbr',
     (diffuse / w) * kd for 'diffuse' / 'white' (render.py:119-127).  diffuse_accum / specular_accum are either the

@@ -145,6 +145,7 @@ class DirectLightingStep:
         self.split_stage2 = False         # set by _capture: locked geometry under the pipelined several-rank schedule (stage 2 in two graphs)
         self.fused = fused
         self.pair_filter = _lib.tuning_env('NVDR_PAIR_FILTER', '1') != '0'      # (A/B switch of the harness)
+        self.fused_loss = _lib.tuning_env('NVDR_FUSED_LOSS', '1') != '0'        # (A/B switch: composite + loss + adjoints in one launch, renderutils.shade_composite_loss)
         self.denoiser_demodulate = denoiser_demodulate    # FLAGS.denoiser_demodulate (train.py:525, default True)
         self.light_grad_scale = light_grad_scale          # lgt.base.grad *= 64 (train.py:439-440)
         self.total_views = n_views if isinstance(n_views, int) else len(n_views)
@@ -385,7 +386,7 @@ class DirectLightingStep:
             return kd, ks, None
         return rd.texture_lookup((kd_tex, ks_tex, nrm_tex), texc, rast, grad_buffers=grad_buffers)
 
-    def _render_full(self, kd_tex, ks_tex, nrm_tex, light, gb=None, grad_buffers=None):
+    def _render_full(self, kd_tex, ks_tex, nrm_tex, light, gb=None, grad_buffers=None, loss_against=None):
         """shade() with the reference's material set (render.py:61-131): kd / ks / perturbed normal from three textures in one
         lookup launch, shading frame, env-shade, both lights filtered in one pass, composite.  gb: a differentiable G-buffer dict
         (optimize_geometry) or None = the cached one."""
@@ -433,6 +434,10 @@ class DirectLightingStep:
             else:
                 diff = ou.ops._bilateral_denoiser_func.apply(diff, nn, depth, self.denoiser.sigma)
                 spec = ou.ops._bilateral_denoiser_func.apply(spec, nn, depth, self.denoiser.sigma)
+        if loss_against is not None:
+            # the composite, the mean image loss and both adjoints in ONE launch (round 6: five small launches and their dependency gaps less per
+            # iteration; same values bit for bit).  loss_against = (target, upstream gradient of the mean: the resident scalar backward() is called with)
+            return ru.shade_composite_loss(diff, spec, kd, ks, loss_against[0], loss_against[1], loss='l1', tonemapper='log_srgb')
         return ru.shade_composite(diff, spec, kd, ks)
 
     def _refit_now(self, ahead=0):
@@ -485,12 +490,20 @@ class DirectLightingStep:
         self.opt.zero_grad(set_to_none=True)
         if self._tex_grad is not None and self._tex_grad.dirty:
             self._zero_tex_grad()           # a backward pass whose gradients no update consumed (forward_backward called on its own)
+        if getattr(self, '_one', None) is None:
+            self._one = torch.ones((), dtype=torch.float32, device=self.dev)
+        fuse_loss = (self.fused_loss and self.fused and self.dev.type == 'cuda' and self.material_set != 'r3'
+                     and (self.denoiser is None or self.denoiser_demodulate))
         if self.material_set == 'r3':
             img = self._render(self.kd_tex, self.ks, self.light)
         else:
-            img = self._render_full(self.kd_tex, self.ks_tex, self.nrm_tex, self.light, self._gb_live, grad_buffers=self._tex_grad if self.fused else None)
-        loss = (ru.image_loss_mean if (self.fused and self.dev.type == 'cuda') else ru.image_loss)(img, self.target, loss='l1', tonemapper='log_srgb')
-        if getattr(self, '_one', None) is None or self._one.shape != loss.shape or self._one.device != loss.device:
+            img = self._render_full(self.kd_tex, self.ks_tex, self.nrm_tex, self.light, self._gb_live, grad_buffers=self._tex_grad if self.fused else None,
+                                    loss_against=(self.target, self._one) if fuse_loss else None)
+        if fuse_loss:
+            loss = img
+        else:
+            loss = (ru.image_loss_mean if (self.fused and self.dev.type == 'cuda') else ru.image_loss)(img, self.target, loss='l1', tonemapper='log_srgb')
+        if self._one.shape != loss.shape or self._one.device != loss.device:
             self._one = torch.ones_like(loss)
         loss.backward(gradient=self._one)       # (a resident seed: no fill launch per iteration)
         self._gb_live = None

@@ -308,3 +308,38 @@ def test_lookup_rows_matches_torch_indexing(dev):
     out.backward(w)
     gref = torch.zeros(500, 3, device=dev).index_add_(0, idx.clamp(min=0).long(), w * (idx >= 0)[:, None])
     assert_close(tex.grad, gref, 1e-6, floor=1e-3)
+
+
+@pytest.mark.parametrize('channels', [4, 3], ids=['filter_output_rgbw', 'plain_rgb'])
+@pytest.mark.parametrize('loss,tonemapper', [('l1', 'log_srgb'), ('mse', 'none'), ('smape', 'log_srgb')])
+def test_fused_composite_and_mean_loss_equals_the_separate_kernels(loss, tonemapper, channels, dev):
+    """shade_composite_loss (round 6: composite + mean image loss + both adjoints in ONE launch) against shade_composite -> image_loss_mean and their
+    autograd adjoints: the loss and the four gradients bit for bit, for the (colour sum, weight) output of the filter kernel and for plain RGB,
+    with out-of-range pixels (the loss clamps in forward and zeroes the gradient there) and another upstream gradient than the one it was told."""
+    import nvdiffrecmc_amd.renderutils as ru
+    g = torch.Generator().manual_seed(31)
+    N, H, W = 2, 37, 53
+
+    def R(*s, lo=0.0, hi=1.0):
+        return (torch.rand(*s, generator=g) * (hi - lo) + lo).to(dev)
+    diff, spec = R(N, H, W, channels, lo=-0.2, hi=3.0), R(N, H, W, channels, lo=-0.2, hi=3.0)
+    if channels == 4:
+        diff[..., 3], spec[..., 3] = R(N, H, W, lo=0.3, hi=2.0), R(N, H, W, lo=0.3, hi=2.0)
+    diff[0, 0, 0, 0] = 7.0e4                                  # beyond the loss's clamp
+    kd, ks, target = R(N, H, W, 3), R(N, H, W, 3), R(N, H, W, 3, hi=2.0)
+    one = torch.ones((), device=dev)
+    leaves_a = [t.clone().requires_grad_(True) for t in (diff, spec, kd, ks)]
+    la = ru.image_loss_mean(ru.shade_composite(*leaves_a), target, loss=loss, tonemapper=tonemapper)
+    la.backward(gradient=one)
+    leaves_b = [t.clone().requires_grad_(True) for t in (diff, spec, kd, ks)]
+    lb = ru.shade_composite_loss(*leaves_b, target, one, loss=loss, tonemapper=tonemapper)
+    lb.backward(gradient=one)
+    assert torch.equal(la, lb)
+    for a, b, name in zip(leaves_a, leaves_b, ('diff', 'spec', 'kd', 'ks')):
+        assert torch.equal(a.grad, b.grad), name
+    # an upstream gradient other than the announced one: rescaled in backward
+    leaves_c = [t.clone().requires_grad_(True) for t in (diff, spec, kd, ks)]
+    lc = ru.shade_composite_loss(*leaves_c, target, one, loss=loss, tonemapper=tonemapper)
+    lc.backward(gradient=torch.full((), 2.5, device=dev))
+    for a, c in zip(leaves_a, leaves_c):
+        assert torch.allclose(2.5 * a.grad, c.grad, rtol=1e-6, atol=0.0)

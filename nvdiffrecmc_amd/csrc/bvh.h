@@ -70,6 +70,15 @@
 #define NVDR_TRAV_DONE 0x7fffffff            // traversal marker: nothing left (never a valid node / leaf id)
 #define NVDR_OSTACK_LDS 6                    // oct walk: (child group, hit bits) entries per lane kept in LDS (8 B each); deeper ones spill
 #define NVDR_OCT_MAX_INDEX (1 << 28)         // child_base / tri_base share their word with a 4-bit count
+// The TREETOP TABLE of the eight-wide tree (round 6; OFF by default -- measured no gain): the first K nodes in breadth-first order, copied
+// behind oct[] by bvh_oct_top_kernel with their child groups renumbered -- bit 27 of child_base says "this group lives in the table, at this
+// entry".  The TOP build of the shadow-ray kernel keeps the table in LDS (trace_kernel.h): every ray starts there, and a node step inside it
+// costs four LDS reads instead of four vector-memory requests.  K = NVDR_TRACE_TOP_NODES (tuning switch, read when the context is created;
+// 64 entries = 4 KB is what eight resident workgroups per CU leave free).  (Triangle count limit 2^27 so that bit 27 of a node index is free.)
+#ifndef NVDR_TRACE_TOP_MAX
+#define NVDR_TRACE_TOP_MAX 1024         // capacity of the table
+#endif
+#define NVDR_OCT_TOP_FLAG (1u << 27)
 #define NVDR_GRID_MAX 65531.0f               // usable span of the 16-bit box grid (2 cells of slack on both ends)
 
 struct BvhDeviceInfo {
@@ -109,6 +118,8 @@ struct nvdr_ctx {
     int64_t n_verts = 0;
     uint4 *nodes = nullptr;        // [2 * cap]
     uint4 *oct = nullptr;          // [4 * cap] eight-wide nodes collapsed from nodes[] (bvh_oct_emit_kernel)
+    uint4 *oct_top = nullptr;      // [4 * NVDR_TRACE_TOP_MAX] the treetop table (inside the oct allocation, behind its cap nodes)
+    int trace_top = 0;             // entries of the table the build fills and the shadow-ray kernel keeps in LDS (0: none, the default; NVDR_TRACE_TOP_NODES)
     float4 *tris8 = nullptr;       // [3 * cap] triangle records in oct-leaf order
     int *oct_task = nullptr;       // [cap] the wide roots: binary nodes that root an eight-wide node (bvh_oct_budget_kernel)
     unsigned long long *oct_jump = nullptr;   // [cap] (ancestor, budget map) per binary node: the budget resolution's pointer-jumping state
@@ -192,6 +203,7 @@ struct nvdr_ctx {
 struct BvhView {
     const uint4 *nodes;
     const uint4 *oct;
+    const uint4 *oct_top;
     const float4 *tris8;
     int oct_stack_max;
     const float4 *tris;
@@ -240,6 +252,7 @@ static inline BvhView bvh_view(const nvdr_ctx *c)
     BvhView v;
     v.nodes = c->nodes;
     v.oct = c->oct;
+    v.oct_top = c->oct_top;
     v.tris8 = c->tris8;
     v.oct_stack_max = c->oct_stack_max;
     v.tris = c->tris;

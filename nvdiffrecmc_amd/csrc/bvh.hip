@@ -993,6 +993,59 @@ __global__ void __launch_bounds__(OCT_THREADS) bvh_oct_emit_kernel(OctBuildArgs 
     if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[OCT_CTL_DONE] = n_roots;
 }
 
+// The treetop table (bvh.h): the first nodes of the eight-wide tree in breadth-first order, one workgroup, a thread per entry.
+// Level by level: the threads of a level read their node's header, a prefix sum over their internal-child counts places the children behind
+// the level; a node's group moves into the table only as a whole, and only while everything before it in the level did (the table is a
+// prefix of the breadth-first order).  Entries copy their node; the child_base of a group that moved points into the table (NVDR_OCT_TOP_FLAG).
+#if NVDR_TRACE_TOP_MAX
+__global__ void __launch_bounds__(NVDR_TRACE_TOP_MAX) bvh_oct_top_kernel(const uint4 *__restrict__ oct, uint4 *__restrict__ top, unsigned K)
+{
+    __shared__ unsigned gidx[NVDR_TRACE_TOP_MAX], scan_s[2][NVDR_TRACE_TOP_MAX];
+    __shared__ unsigned level_end;
+    const unsigned i = threadIdx.x;
+    if (i == 0) { gidx[0] = 0u; level_end = 1u; }
+    unsigned lo = 0u, hi = 1u, moved_to = 0u;
+    bool have = false, moved = false;
+    uint4 h = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    while (lo < hi) {
+        const bool mine = i >= lo && i < hi;
+        unsigned n_int = 0u, cb = 0u;
+        if (mine) {
+            h = oct[4 * (int64_t)gidx[i]];
+            have = true;
+            n_int = h.z >> 28;
+            cb = h.z & (NVDR_OCT_TOP_FLAG - 1u);
+        }
+        // inclusive prefix sum of n_int over the workgroup (Hillis-Steele, double-buffered)
+        int cur = 0;
+        scan_s[0][i] = n_int;
+        __syncthreads();
+        for (unsigned o = 1u; o < K; o <<= 1) {
+            scan_s[cur ^ 1][i] = scan_s[cur][i] + (i >= o ? scan_s[cur][i - o] : 0u);
+            cur ^= 1;
+            __syncthreads();
+        }
+        const unsigned inc = scan_s[cur][i];
+        if (mine && n_int != 0u && hi + inc <= K) {
+            moved = true;
+            moved_to = hi + inc - n_int;
+            for (unsigned c2 = 0u; c2 < n_int; ++c2) gidx[moved_to + c2] = cb + c2;
+            atomicMax(&level_end, hi + inc);
+        }
+        __syncthreads();
+        lo = hi;
+        hi = level_end;
+        __syncthreads();
+    }
+    if (have) {
+        const uint4 *src = oct + 4 * (int64_t)gidx[i];
+        if (moved) h.z = (h.z & 0xF0000000u) | NVDR_OCT_TOP_FLAG | moved_to;
+        top[4 * i + 0] = h; top[4 * i + 1] = src[1]; top[4 * i + 2] = src[2]; top[4 * i + 3] = src[3];
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // host side
 
@@ -1119,6 +1172,10 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     if (const char *lm = nvdr_tuning_env("NVDR_LG_MODE")) c->lg_mode = atoi(lm) ? 1 : 0;
     if (const char *sq = nvdr_tuning_env("NVDR_SHADE_QUEUE")) c->shade_queue = atoi(sq) & 7;
     if (const char *sm = nvdr_tuning_env("NVDR_TRACE_SPLIT_MODE")) c->trace_split_mode = atoi(sm);
+    if (const char *tt = nvdr_tuning_env("NVDR_TRACE_TOP_NODES")) {
+        const int k = atoi(tt);
+        c->trace_top = k < 0 ? 0 : (k > NVDR_TRACE_TOP_MAX ? NVDR_TRACE_TOP_MAX : k);
+    }
     (void)hipDeviceGetAttribute(&c->n_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (c->n_cus <= 0) c->n_cus = 256;
     *out = c;
@@ -1165,7 +1222,8 @@ static int ctx_reserve(nvdr_ctx *c, int64_t n_tris, hipStream_t stream)
     ctx_free_bvh(c);
     const int64_t cap = n_tris + n_tris / 2 + 64;
     NVDR_HIP_TRY(ctx_malloc(c, &c->nodes, sizeof(uint4) * 2 * cap, stream));
-    NVDR_HIP_TRY(ctx_malloc(c, &c->oct, sizeof(uint4) * 4 * cap, stream));
+    NVDR_HIP_TRY(ctx_malloc(c, &c->oct, sizeof(uint4) * 4 * (cap + NVDR_TRACE_TOP_MAX), stream));
+    c->oct_top = c->oct + 4 * cap;
     NVDR_HIP_TRY(ctx_malloc(c, &c->tris8, sizeof(float4) * 3 * cap, stream));
     NVDR_HIP_TRY(ctx_malloc(c, &c->oct_task, sizeof(int) * cap, stream));
     NVDR_HIP_TRY(ctx_malloc(c, &c->tris, sizeof(float4) * 3 * cap, stream));
@@ -1219,7 +1277,7 @@ extern "C" int nvdr_bvh_build(nvdr_ctx *c, const float *verts, int64_t n_verts, 
     NVDR_REQUIRE(c != nullptr, "nvdr_bvh_build: ctx is NULL");
     // same message as the Python asserts of the reference (render/optixutils/ops.py:131-132)
     NVDR_REQUIRE(n_tris > 0 && n_verts > 0, "Got empty training triangle mesh (unrecoverable discontinuity)");
-    NVDR_REQUIRE(n_tris < (long long)NVDR_OCT_MAX_INDEX, "nvdr_bvh_build: too many triangles (%lld, the limit is 2^28)", (long long)n_tris);
+    NVDR_REQUIRE(n_tris < (long long)NVDR_OCT_TOP_FLAG, "nvdr_bvh_build: too many triangles (%lld, the limit is 2^27)", (long long)n_tris);
     NVDR_REQUIRE(verts && tris, "nvdr_bvh_build: NULL geometry pointer");
     hipStream_t stream = (hipStream_t)stream_;
     NVDR_HIP_TRY(hipSetDevice(c->device));
@@ -1378,6 +1436,9 @@ int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
             }
             bvh_oct_emit_kernel<<<blocks < 1u ? 1u : blocks, OCT_THREADS, 0, stream>>>(oa);
         }
+#if NVDR_TRACE_TOP_MAX
+        if (c->trace_top > 0) bvh_oct_top_kernel<<<1, (unsigned)((c->trace_top + 63) & ~63), 0, stream>>>(c->oct, c->oct_top, (unsigned)c->trace_top);
+#endif
     }
     NVDR_LAUNCH_CHECK();
     if (c->async_build) NVDR_HIP_TRY(hipEventRecord(c->ev_built, c->build_stream));

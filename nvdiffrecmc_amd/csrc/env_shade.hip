@@ -848,7 +848,14 @@ template <bool COUNT>
 __global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_kernel(TraceLaunch a)
 {
     extern __shared__ __attribute__((aligned(16))) int smem[];
-    env_trace_body<COUNT>(a, smem);
+    env_trace_body<COUNT, 0, false, COUNT>(a, smem);      // (the counting build knows the treetop table, if the context has one)
+}
+
+// the build with the treetop table in LDS (bvh.h; contexts with NVDR_TRACE_TOP_NODES set)
+__global__ void __launch_bounds__(NVDR_QUERY_BLOCK, NVDR_TRACE_OCC) env_trace_top_kernel(TraceLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    env_trace_body<false, 0, false, true>(a, smem);
 }
 
 // the build with split walks in the drain (trace_kernel.h SPLIT): small launches
@@ -1835,7 +1842,17 @@ static TraceLaunch make_trace_launch(const nvdr_ctx *c, const unsigned *ray_coun
     L.rays = c->rays; L.pix_origin = c->pix_origin; L.live = c->live;
     L.ray_count = ray_count; L.rays_per_pixel = rays_per_pixel;
     L.vis = c->vis; L.spill = c->spill; L.counters = counters; L.queues = c->queues;
+    L.top_nodes = (unsigned)c->trace_top;
     return L;
+}
+
+// resident workgroups per CU of the persistent traversal grid: what the compiled occupancy allows and 160 KB of LDS hold (a treetop table
+// beyond 64 entries costs resident wavefronts; the grid must not hold workgroups that wait for a slot)
+static int trace_blocks_per_cu(size_t lds_bytes, int by_registers)
+{
+    const int by_lds = (int)((size_t)(160 * 1024) / (lds_bytes ? lds_bytes : 1));
+    const int v = by_lds < by_registers ? by_lds : by_registers;
+    return v < 1 ? 1 : v;
 }
 
 static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t stream, const unsigned *ray_count, unsigned rays_per_pixel,
@@ -1858,6 +1875,10 @@ static void launch_trace(nvdr_ctx *c, unsigned blocks, size_t lds, hipStream_t s
         // The host never learns a launch's live-ray count in time -- but every launch leaves it in the context's host-mapped word, and a context
         // renders the same kind of launch again and again (a HIP-graph capture freezes the choice of its warm-up iterations): the LAST launch's count
         // decides.  NVDR_TRACE_SPLIT_MODE (tuning, read when the context is created): 0 never, 1 always, 2 by the hint (default).
+        if (c->trace_top > 0) {
+            env_trace_top_kernel<<<blocks, NVDR_QUERY_BLOCK, lds, stream>>>(make_trace_launch(c, ray_count, rays_per_pixel, nullptr));
+            return;
+        }
         const int mode = c->trace_split_mode;
         const unsigned hint = c->ovf_host ? (unsigned)((volatile int *)c->ovf_host)[1] : 0u;
         const bool split = mode == 1 || (mode == 2 && hint != 0u && hint / (blocks * (NVDR_QUERY_BLOCK / 64u)) < NVDR_TRACE_SPLIT_BELOW);
@@ -2192,13 +2213,13 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
 #ifndef NVDR_TRACE_BLOCKS_PER_CU
 #define NVDR_TRACE_BLOCKS_PER_CU 8
 #endif
-    int64_t tblocks = (int64_t)c->n_cus * NVDR_TRACE_BLOCKS_PER_CU;
+    const size_t trace_lds = NVDR_TRACE_LDS_BYTES(NVDR_QUERY_BLOCK, c->trace_top);
+    int64_t tblocks = (int64_t)c->n_cus * trace_blocks_per_cu(trace_lds, NVDR_TRACE_BLOCKS_PER_CU);
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     {
         const int64_t need = (cap * 2 * S + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
         if (tblocks > need) tblocks = need < NVDR_TRACE_QUEUES / 4 ? NVDR_TRACE_QUEUES / 4 : need;     // (at least 64 wavefronts: one per dealing counter, trace_kernel.h)
     }
-    const size_t trace_lds = NVDR_TRACE_LDS_BYTES(NVDR_QUERY_BLOCK);
     const size_t count_lds = NVDR_STACK_LDS_BYTES(NVDR_QUERY_BLOCK);
     const bool replay = backward && p.vis_cache != nullptr;   // forward bits handed back by the caller: no traversal
 
@@ -2322,11 +2343,12 @@ static int trace_visibility_wide(nvdr_ctx *c, const float *ro, const float *rd, 
     c->stream_id = 0;
     if (int rw = ctx_wait_built(c, stream)) return rw;
     pack_rays_kernel<<<div_up(n_rays, 256), 256, 0, stream>>>(ro, rd, (unsigned)n_rays, c->rays, c->pix_origin, c->live, c->chunk_counts, c->queues);
-    int64_t tblocks = (int64_t)c->n_cus * 8;
+    const size_t trace_lds = NVDR_TRACE_LDS_BYTES(NVDR_QUERY_BLOCK, c->trace_top);
+    int64_t tblocks = (int64_t)c->n_cus * trace_blocks_per_cu(trace_lds, 8);
     if (tblocks > NVDR_QUERY_MAX_BLOCKS) tblocks = NVDR_QUERY_MAX_BLOCKS;
     const int64_t need = (n_rays + NVDR_QUERY_BLOCK - 1) / NVDR_QUERY_BLOCK;
     if (tblocks > need) tblocks = need < NVDR_TRACE_QUEUES / 4 ? NVDR_TRACE_QUEUES / 4 : need;
-    launch_trace(c, (unsigned)tblocks, NVDR_TRACE_LDS_BYTES(NVDR_QUERY_BLOCK), stream, c->chunk_counts, 1u, counters);
+    launch_trace(c, (unsigned)tblocks, trace_lds, stream, c->chunk_counts, 1u, counters);
     NVDR_HIP_TRY(hipMemcpyAsync(out_vis, c->vis, (size_t)n_rays, hipMemcpyDeviceToDevice, stream));
     NVDR_LAUNCH_CHECK();
     return 0;

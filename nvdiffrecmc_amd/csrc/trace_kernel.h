@@ -66,12 +66,14 @@ struct TraceLaunch {
     int *spill;                    // HBM part of the traversal stacks (bvh.h)
     unsigned long long *counters;  // counting build only (nvdr_hip.h NVDR_COUNTERS_*)
     unsigned *queues;              // [256][32] chunk counters, zeroed before every launch; the last line holds diagnostics
+    unsigned top_nodes;            // entries of the treetop table (bvh.h) this launch keeps in LDS; 0: none
 };
 
 // LDS of one workgroup of the traversal kernel: per wavefront the oct stack (NVDR_OSTACK_LDS x 64 lanes x 8 B) and the
 // triangle-test queue (NVDR_LEAFQ_CAP x 8 B)
+// ... and, per workgroup, the treetop table (bvh.h NVDR_TRACE_TOP_NODES: 64 bytes per node)
 #define NVDR_TRACE_LDS_PER_WAVE (NVDR_OSTACK_LDS * 64 * 8 + NVDR_LEAFQ_CAP * 8)
-#define NVDR_TRACE_LDS_BYTES(threads) ((size_t)((threads) / 64) * NVDR_TRACE_LDS_PER_WAVE)
+#define NVDR_TRACE_LDS_BYTES(threads, top_nodes) ((size_t)((threads) / 64) * NVDR_TRACE_LDS_PER_WAVE + (size_t)(top_nodes) * 64)
 
 // The live-ray list is NVDR_LIVE_SEGS SEGMENTS, each behind its own length counter (round 5): the generation kernel appends per wavefront,
 // ~400 entries per claim, and same-address atomics retire one every ~12 ns on this part -- 109 k claims on ONE counter were 1.3 ms of
@@ -150,6 +152,9 @@ static_assert(NVDR_LIVE_SUBS == 4, "ChunkDealer::claim shifts by log2(NVDR_LIVE_
 // 8-byte entries (low word, high word) in explicit address spaces: ds_write_b64 / global_store_dwordx2, no flat accesses
 typedef __attribute__((address_space(3))) unsigned long long lds_pair_t;
 typedef __attribute__((address_space(1))) unsigned long long glb_pair_t;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;           // (a plain vector: HIP's uint4 class does not live in address spaces)
+typedef __attribute__((address_space(3))) u32x4_t lds_uint4_t;
+__device__ __forceinline__ uint4 lds_load4(const lds_uint4_t *p) { const u32x4_t v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ unsigned long long pack2(unsigned lo, unsigned hi) { return (unsigned long long)lo | ((unsigned long long)hi << 32); }
 
 // the oct walk's stack of one lane: entry k at LDS word pair (k * 64 + lane), deeper entries in the HBM spill columns
@@ -190,7 +195,9 @@ struct OctRay {
 // counting build's 17 spilled dwords would drown what is being measured) or, PH = 2, additionally inside the node step with a wait for the
 // node behind its four loads (three more vector registers, and the production kernel's overlap of the fetch with the ray's frame set-up is
 // gone: this build only splits the node step of PH = 1 into fetch / box arithmetic / stack).
-template <bool COUNT, int PH = 0, bool SPLIT = false>
+// TOP: the build that keeps the treetop table in LDS (bvh.h, the treetop table; round 6, measured no gain: launched only when the context's table size is
+// set, NVDR_TRACE_TOP_NODES -- and by counting launches, whose build is this one so that it can report the steps the table serves).
+template <bool COUNT, int PH = 0, bool SPLIT = false, bool TOP = false>
 __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
 {
     const BvhView &bvh = a.bvh;
@@ -214,6 +221,12 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     stack.ovf = bvh.overflow;
     stack.glb = (glb_pair_t *)a.spill + (int64_t)blockIdx.x * blockDim.x * max(bvh.oct_stack_max - NVDR_OSTACK_LDS, 0) + threadIdx.x;
     lds_pair_t *leafq = (lds_pair_t *)(wbase + NVDR_OSTACK_LDS * 64 * 8);      // (triangle, owner lane) entries, used as a stack
+    // the treetop table, behind the wavefronts' regions: a straight copy of what the build left behind oct[] (bvh.hip bvh_oct_top_kernel)
+    lds_uint4_t *top = (lds_uint4_t *)((char *)smem + (blockDim.x >> 6) * NVDR_TRACE_LDS_PER_WAVE);
+    if (TOP) {
+        for (unsigned i = threadIdx.x; i < a.top_nodes * 4u; i += blockDim.x) { const uint4 v = bvh.oct_top[i]; u32x4_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; top[i] = w; }
+        __syncthreads();
+    }
     // the grid transform, wave-uniform (scalar registers)
     const BvhDeviceInfo *__restrict__ info = bvh.info;
     const float gsx = info->g_scale[0], gsy = info->g_scale[1], gsz = info->g_scale[2];
@@ -228,7 +241,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     unsigned next = 0, end = 0;                             // wave-uniform list positions of the claimed chunk
     unsigned steals = 0u;                                   // wave-uniform: other wavefronts' counters tried so far
     bool more = total > 0;
-    unsigned n_box = 0, n_tri = 0, n_ray = 0, n_step = 0, n_batch = 0;
+    unsigned n_box = 0, n_tri = 0, n_ray = 0, n_step = 0, n_batch = 0, n_top = 0;
     // phase-clock builds: shader-clock cycles of this wavefront by phase of the loop (wave-uniform; nvdr_hip.h NVDR_COUNTERS_PHASES)
     // (32-bit: a launch lasts a few million cycles, differences are taken modulo 2^32; eight scalar registers instead of sixteen)
     unsigned ph_refill = 0u, ph_fetch = 0u, ph_box = 0u, ph_stack = 0u, ph_queue = 0u, ph_batch = 0u, ph_iters = 0u, ph_steps = 0u;
@@ -244,6 +257,12 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
     g.ix = g.iy = g.iz = g.nx = g.ny = g.nz = 0.0f;
     unsigned q_count = 0;                                   // wave-uniform fill of the triangle-test queue
     bool was_split = false;                                 // wave-uniform: some walk of this wavefront has been split (drain mode)
+#ifdef NVDR_TRACE_TOUCH
+    unsigned touch = 0u;
+#endif
+#ifdef NVDR_TRACE_PRELIVE
+    unsigned pre = 0u, pre_base = 0u;                       // list entry pre_base + lane, fetched ahead (pre_base wave-uniform)
+#endif
 
     // One batch of triangle tests: the top n entries of the queue, one per lane.  Returns nothing; a hit ends the owner's walk
     // (visibility 0) whatever the owner is doing.  Entries of rays that have ended meanwhile test against the owner's stale
@@ -301,6 +320,9 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
         const int n_free = 64 - __popcll(busy);
         if (n_free >= NVDR_REFILL_MIN && next >= end && more) {
             more = dealer.claim(lane, next, end);
+#ifdef NVDR_TRACE_PRELIVE
+            if (more) { pre = live[min(next + (unsigned)lane, end - 1u)]; pre_base = next; }
+#endif
             if (!more) {
                 next = end = 0u;
                 if (steals < NVDR_TRACE_STEALS) {           // this counter is used up: the next refill round asks another one
@@ -319,8 +341,18 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             if (next < end) {
                 const unsigned long long idle = __ballot(ray < 0);
                 const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+#ifdef NVDR_TRACE_PRELIVE
+                // (A/B: the list entries of this refill were fetched behind the previous one -- entry pre_base + l waits in lane l -- so the chain
+                // list entry -> ray -> set-up starts one memory round trip later; entries beyond the 64 fetched ones are read directly)
+                const unsigned rel = take - pre_base;
+                const unsigned pre_slot = (unsigned)__builtin_amdgcn_ds_bpermute((int)((rel & 63u) << 2), (int)pre);
+#endif
                 if (ray < 0 && take < end) {
+#ifdef NVDR_TRACE_PRELIVE
+                    const unsigned slot = rel < 64u ? pre_slot : live[take];
+#else
                     const unsigned slot = live[take];
+#endif
                     ray = (int)slot;
                     if (SPLIT) vis[slot] = 1;             // unoccluded until some lane that holds the ray finds a hit
                     if (COUNT) n_ray++;
@@ -334,11 +366,14 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                     g.nx = -((ox - glx) * gsx + 2.0f) * g.ix;
                     g.ny = -((oy - gly) * gsy + 2.0f) * g.iy;
                     g.nz = -((oz - glz) * gsz + 2.0f) * g.iz;
-                    gbase = 0u;                             // the root is "child 0 of group 0"
+                    gbase = (TOP && a.top_nodes) ? NVDR_OCT_TOP_FLAG : 0u;    // the root is "child 0 of group 0" (of the treetop table, if there is one)
                     gbits = 1u;
                     sp = 0;
                 }
                 next += (unsigned)__popcll(idle);
+#ifdef NVDR_TRACE_PRELIVE
+                if (next < end) { pre = live[min(next + (unsigned)lane, end - 1u)]; pre_base = next; }
+#endif
             } else if (__ballot(ray >= 0) == 0ull) {
                 if (!more) break;
                 continue;                                   // nothing to do until the next claim
@@ -414,12 +449,21 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             }
             const int k = __builtin_ctz(gbits);
             gbits &= gbits - 1u;
-            const uint4 *nd = oct + 4 * (int64_t)(gbase + (unsigned)k);
-            const uint4 h = nd[0], p1 = nd[1], p2 = nd[2], p3 = nd[3];
+            const unsigned at = gbase + (unsigned)k;
+            const uint4 *nd = oct + 4 * (int64_t)at;
+            uint4 h, p1, p2, p3;
+            // a node of the treetop comes out of LDS: four ds_read_b128 instead of four vector-memory requests (the rays of a wavefront start at the
+            // same nodes: mostly broadcast reads)
+            if (TOP && (at & NVDR_OCT_TOP_FLAG)) {
+                const lds_uint4_t *tn = top + 4u * (at & (NVDR_OCT_TOP_FLAG - 1u));
+                h = lds_load4(tn); p1 = lds_load4(tn + 1); p2 = lds_load4(tn + 2); p3 = lds_load4(tn + 3);
+            } else {
+                h = nd[0]; p1 = nd[1]; p2 = nd[2]; p3 = nd[3];
+            }
 #ifdef NVDR_TRACE_DUP_FETCH
             // (A/B only: the same four 16-byte requests once more, results thrown away -- twice the L1 look-ups and returned lines per node
             // step with nothing else changed: what a kernel bound by the L1's request rate slows down by, a latency-bound one barely notices)
-            {
+            if (!TOP || !(at & NVDR_OCT_TOP_FLAG)) {
                 const volatile uint4 *ndv = (const volatile uint4 *)nd;
 #pragma unroll
                 for (int q = 0; q < NVDR_TRACE_DUP_FETCH; ++q) {
@@ -428,7 +472,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 }
             }
 #endif
-            if (COUNT) n_step++;
+            if (COUNT) { n_step++; n_top += (TOP && (at & NVDR_OCT_TOP_FLAG)) ? 1u : 0u; }
             if (PH == 2) {
                 // (this build waits for the node here, so that the fetch has a phase of its own; the production kernel lets the
                 // compiler place the wait: the ray's set-up of the node frame overlaps part of it)
@@ -484,6 +528,13 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 asm volatile("" :: "v"(gbits), "v"(sp));
                 dt_stack = (unsigned)(clk() - tn0) - dt_fetch - dt_box;
             }
+#ifdef NVDR_TRACE_TOUCH
+            // (A/B only: the node this lane visits NEXT is known here -- the first child of the group it just entered, or the next sibling -- while
+            // the leaf-queue rounds, a triangle batch and the refill votes still lie between this point and its fetch: one 4-byte request for its
+            // line now, never consumed, so that the fetch finds it in the L1)
+            asm volatile("" :: "v"(touch));
+            if (gbits != 0u && !(TOP && (gbase & NVDR_OCT_TOP_FLAG))) touch = ((const unsigned *)(oct + 4 * (int64_t)(gbase + (unsigned)__builtin_ctz(gbits))))[NVDR_TRACE_TOUCH - 1];
+#endif
         }
         unsigned tq0 = 0u, bq0 = 0u;
         if (PH) {
@@ -550,6 +601,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             n_ray += __shfl_xor(n_ray, o);
             n_step += __shfl_xor(n_step, o);
             n_batch += __shfl_xor(n_batch, o);
+            n_top += __shfl_xor(n_top, o);
         }
         if (lane == 0) {
             atomicAdd(&counters[0], (unsigned long long)n_box);
@@ -558,6 +610,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
             atomicAdd(&counters[NVDR_COUNTERS_BVH2 + 3], (unsigned long long)n_step);
             atomicAdd(&counters[NVDR_COUNTERS_BVH2 + 4], (unsigned long long)n_batch);
             atomicAdd(&counters[NVDR_COUNTERS_BVH2 + 5], (unsigned long long)n_tri);
+            atomicAdd(&counters[NVDR_COUNTERS_BVH2 + 6], (unsigned long long)n_top);
             // load balance: sum and maximum of the per-wave busy time (100 MHz ticks), wave count
             const unsigned long long dt = wall_clock64() - t_begin;
             atomicAdd(&counters[3], dt);

@@ -436,6 +436,7 @@ def trace_visibility_wide(optix_ctx, ro, rd, count=False):
     _lib.check(w.lib.nvdr_trace_visibility_wide_counted(w.handle, _lib.ptr(ro), _lib.ptr(rd), ro.shape[0], _lib.ptr(vis), _lib.ptr(cnt),
                                                         _lib.stream_ptr()), 'trace_visibility_wide_counted')
     c = cnt.cpu()
+    trace_visibility_wide.last_counters = c        # (the whole block, nvdr_hip.h NVDR_COUNTERS_*: tests and tools read more of it)
     return vis, (int(c[0]), int(c[1]), int(c[2]), int(c[_lib.COUNTERS_BVH2 + 3]))
 
 

@@ -596,3 +596,48 @@ def test_split_walk_build_of_the_traversal_kernel_vs_bruteforce(mesh_name, dev, 
         assert torch.equal(got_p, ref[:n])
     ctx_split.check()
     ctx_plain.check()
+
+
+@pytest.mark.parametrize('top_nodes', [0, 1, 9, 64, 300])
+def test_treetop_table_in_lds_leaves_the_visibility_unchanged(top_nodes, dev, monkeypatch):
+    """The first nodes of the eight-wide tree in breadth-first order live in LDS in the shadow-ray kernel (bvh.h NVDR_TRACE_TOP_NODES, bvh.hip
+    bvh_oct_top_kernel; a tuning switch, off by default): whatever the table's size -- none, the root alone, a level cut in the middle, more than the
+    default -- the production kernel's visibility == the oracle's brute force, after a build and after a refit of moved vertices; a one-triangle
+    mesh (a root without children) and the marching-tets mesh answer like the binary walk.  With a table, the counting build reports the node
+    steps it served."""
+    from nvdiffrecmc_amd import optixutils as ou
+    from nvdiffrecmc_amd import _lib
+    monkeypatch.setenv('NVDR_TUNING', '1')
+    monkeypatch.setenv('NVDR_TRACE_TOP_NODES', str(top_nodes))
+    mesh = sc.load_mesh('bob')
+    v, t = mesh['v_pos'], mesh['t_pos_idx']
+    ctx = make_ctx(mesh, dev)
+    ro, rd = _rays(60000, 31, scale=0.5)
+    ref = orc.visibility(v, t, ro, rd, n_threads=NT)
+    got, (n_box, n_tri, n_ray, n_step) = ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev), count=True)
+    assert torch.equal(got.cpu(), ref)
+    assert torch.equal(ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev)).cpu(), ref)
+    n_top = int(ou.trace_visibility_wide.last_counters[_lib.COUNTERS_BVH2 + 6])
+    print('\ntreetop of %d entries: %.1f %% of %d node steps' % (top_nodes, 100.0 * n_top / max(n_step, 1), n_step))
+    assert (n_top == 0) == (top_nodes == 0) and n_top <= n_step
+    if top_nodes:
+        assert n_top >= n_ray                       # every ray starts at the root, which is entry 0
+    # moved vertices, refit: the table is rewritten behind the re-emitted nodes
+    g = torch.Generator().manual_seed(5)
+    v2 = v + 0.02 * torch.randn(v.shape, generator=g)
+    ou.optix_build_bvh(ctx, v2.to(dev), t.to(dev).int(), rebuild=0)
+    ref2 = orc.visibility(v2, t, ro, rd, n_threads=NT)
+    assert torch.equal(ou.trace_visibility_wide(ctx, ro.to(dev), rd.to(dev)).cpu(), ref2)
+    ctx.check()
+    for other in ('single', 'dmtet64_init'):
+        if other == 'single':
+            vo = torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+            to = torch.tensor([[0, 1, 2]], dtype=torch.int32)
+        else:
+            m = sc.load_mesh(other)
+            vo, to = m['v_pos'], m['t_pos_idx']
+        c2 = ou.OptiXContext()
+        ou.optix_build_bvh(c2, vo.to(dev), to.to(dev).int(), rebuild=1)
+        r_o, r_d = _rays(30000, 37, scale=0.6)
+        assert torch.equal(ou.trace_visibility_wide(c2, r_o.to(dev), r_d.to(dev)), ou.ops.trace_visibility(c2, r_o.to(dev), r_d.to(dev))), other
+        c2.check()

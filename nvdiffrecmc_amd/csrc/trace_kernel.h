@@ -342,8 +342,9 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 const unsigned long long idle = __ballot(ray < 0);
                 const unsigned take = next + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
 #ifdef NVDR_TRACE_PRELIVE
-                // (A/B: the list entries of this refill were fetched behind the previous one -- entry pre_base + l waits in lane l -- so the chain
-                // list entry -> ray -> set-up starts one memory round trip later; entries beyond the 64 fetched ones are read directly)
+                // (A/B only, measured +2 ... +3.6 %, profiles/r06_ab_trace_prelive.md: the list entries of this refill were fetched behind the previous
+                // one -- entry pre_base + l waits in lane l -- so the chain list entry -> ray -> set-up starts one memory round trip later; entries
+                // beyond the 64 fetched ones are read directly)
                 const unsigned rel = take - pre_base;
                 const unsigned pre_slot = (unsigned)__builtin_amdgcn_ds_bpermute((int)((rel & 63u) << 2), (int)pre);
 #endif
@@ -529,7 +530,7 @@ __device__ __forceinline__ void env_trace_body(const TraceLaunch &a, int *smem)
                 dt_stack = (unsigned)(clk() - tn0) - dt_fetch - dt_box;
             }
 #ifdef NVDR_TRACE_TOUCH
-            // (A/B only: the node this lane visits NEXT is known here -- the first child of the group it just entered, or the next sibling -- while
+            // (A/B only, measured +3 ... +19 %, profiles/r06_ab_trace_treetop.md: the node this lane visits NEXT is known here -- the first child of the group it just entered, or the next sibling -- while
             // the leaf-queue rounds, a triangle batch and the refill votes still lie between this point and its fetch: one 4-byte request for its
             // line now, never consumed, so that the fetch finds it in the L1)
             asm volatile("" :: "v"(touch));

@@ -1635,6 +1635,9 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 #ifndef NVDR_LG_SKIP
 #define NVDR_LG_SKIP 0                   // timing-only A/B (wrong results): bit 0 no LDS adds, bit 1 no record loads, bit 2 no partial row written, bit 3 no zeroing of the accumulators
 #endif
+#ifndef NVDR_LG_BATCH
+#define NVDR_LG_BATCH 0                  // 1 (A/B only, measured +65 % on the gather: profiles/r06_ab_gather_batched_adds.md): the records of a step are added as ONE batch of compare-and-swaps
+#endif
 #ifndef NVDR_LG_NB
 #define NVDR_LG_NB 4                     // blocks of 128 records a wavefront of the gather fetches together (1: A/B)
 #endif
@@ -1669,6 +1672,11 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
     const unsigned v_lo = min((unsigned)g * per, n_all), v_hi = min(v_lo + per, n_all);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const float4 none = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+#if NVDR_LG_BATCH
+    // three words per thread behind the band's accumulators: where a lane without a record "adds" (x + 0.0 == x: they stay +0.0)
+    const int dummy_at = min(band_texels, n_texels) * 3 + (int)threadIdx.x * 3;        // (the launcher sizes the LDS for min(band, probe) texels + these)
+    lg_acc[dummy_at] = 0.0f; lg_acc[dummy_at + 1] = 0.0f; lg_acc[dummy_at + 2] = 0.0f;
+#endif
     for (int band = band_first; band < band_last; ++band) {
         const int t_lo = band * band_texels, t_hi = min(t_lo + band_texels, n_texels);
         const int n_acc = (t_hi - t_lo) * 3;
@@ -1734,11 +1742,76 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
                         if (lane + 64u < ff[q]) cc[2 * q + 1] = recs[(bb[q] << 7) + 64u + lane];
                     } else if (lane < ff[q]) cc[2 * q] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(t_lo + (int)((bb[q] * 64u + lane) % (unsigned)(t_hi - t_lo))));
                 }
+#if NVDR_LG_BATCH
+                // (A/B only.)  The records of the step are added TOGETHER: all their accumulator words are read, then all 6 NB compare-and-swaps are
+                // issued back to back, then their verdicts are looked at; what failed (another lane hit the same word in between) goes round
+                // again, still as one batch.  A lane without a record (beyond the block's fill) adds 0.0 to three words of its own behind the
+                // band: always succeeds, no branch around the batch.  Measured (session 23): the gather 72 -> 119 us at one view, 275 -> 466 at
+                // eight -- the sampler's hot texels make swaps fail far more often than the one-record-at-a-time loop lets on (its retry
+                // follows within a few instructions, with the word it just saw), and the batch pays 24 swaps for every lane, filled or not.
+                if (!(NVDR_LG_SKIP & 1)) {
+                    constexpr int Q = 2 * NVDR_LG_NB;
+                    unsigned *const base = (unsigned *)lg_acc;
+                    int ai[Q];
+                    unsigned o[Q][3];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const int t = __float_as_int(cc[q].w);
+                        const bool in = t >= t_lo && t < t_hi;
+                        ai[q] = in ? (t - t_lo) * 3 : dummy_at;
+                        if (!in) { cc[q].x = 0.0f; cc[q].y = 0.0f; cc[q].z = 0.0f; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) o[q][ch] = __hip_atomic_load(base + ai[q] + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    unsigned pend = 0u;
+                    {
+                        // (issue, THEN look: the verdict of a swap is "the word still held what was read", taken from the returned word in a second
+                        // loop -- asking each swap for its verdict made the compiler wait for every group of three)
+                        unsigned got[Q][3];
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) {
+                                const float r = ch == 0 ? cc[q].x : (ch == 1 ? cc[q].y : cc[q].z);
+                                got[q][ch] = o[q][ch];
+                                (void)__hip_atomic_compare_exchange_strong(base + ai[q] + ch, &got[q][ch], __float_as_uint(__uint_as_float(o[q][ch]) + r),
+                                                                           __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) {
+                                if (got[q][ch] != o[q][ch]) pend |= 1u << (3 * q + ch);
+                                o[q][ch] = got[q][ch];
+                            }
+                    }
+                    while (pend != 0u) {
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch)
+                                if (pend & (1u << (3 * q + ch))) {
+                                    const float r = ch == 0 ? cc[q].x : (ch == 1 ? cc[q].y : cc[q].z);
+                                    unsigned seen = o[q][ch];
+                                    if (__hip_atomic_compare_exchange_strong(base + ai[q] + ch, &seen, __float_as_uint(__uint_as_float(o[q][ch]) + r), __ATOMIC_RELAXED,
+                                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                                        pend &= ~(1u << (3 * q + ch));
+                                    o[q][ch] = seen;
+                                }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2 * NVDR_LG_NB; ++q) asm volatile("" :: "v"(cc[q].x), "v"(cc[q].w));
+                }
+#else
 #pragma unroll
                 for (int q = 0; q < 2 * NVDR_LG_NB; ++q) {
                     if (!(NVDR_LG_SKIP & 1)) add(cc[q]);
                     else asm volatile("" :: "v"(cc[q].x), "v"(cc[q].w));
                 }
+#endif
             }
         }
         __syncthreads();
@@ -1976,10 +2049,12 @@ static size_t lg_lds_budget()
     if (kb < 8) kb = 8;
     if (kb > 160) kb = 160;
     size_t want = kb * 1024;
-    if (want > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)light_grad_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess) {
+    const size_t extra = NVDR_LG_BATCH ? (size_t)NVDR_LG_THREADS * 12 : 0;          // the threads' own words behind the band
+    if (want + extra > 160 * 1024) want = 160 * 1024 - extra;
+    if (want + extra > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)light_grad_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(want + extra)) != hipSuccess) {
         (void)hipGetLastError();
-        want = 64 * 1024;
+        want = 64 * 1024 - extra;
     }
     budget = want;
     return budget;
@@ -2059,7 +2134,7 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         lg_records = (n_bands <= 16 && group_slots <= 16 * 128 && !(c->debug & 16u)) ? 1 : 0;
         if (lg_records) {
             if (band_texels > n_texels) band_texels = n_texels;
-            lg_lds = (size_t)band_texels * 12;
+            lg_lds = (size_t)band_texels * 12 + (NVDR_LG_BATCH ? (size_t)NVDR_LG_THREADS * 12 : 0);     // (+ three words per thread: light_grad_block_kernel)
             // one gather workgroup per CU (its accumulators take most of the CU's LDS): each walks all bands (large launches), or
             // the CUs are dealt to the bands (small launches: fewer passes and partial rows, at the price of uneven bands)
             const bool per_band = c->lg_mode >= 0 ? c->lg_mode == 1 : npix * 2 * (int64_t)S <= NVDR_LG_PER_BAND_MAX_SLOTS;

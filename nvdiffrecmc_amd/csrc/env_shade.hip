@@ -1635,9 +1635,8 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 #ifndef NVDR_LG_SKIP
 #define NVDR_LG_SKIP 0                   // timing-only A/B (wrong results): bit 0 no LDS adds, bit 1 no record loads, bit 2 no partial row written, bit 3 no zeroing of the accumulators
 #endif
-#ifndef NVDR_LG_BATCH
-#define NVDR_LG_BATCH 0                  // 1 (A/B only, measured +65 % on the gather: profiles/r06_ab_gather_batched_adds.md): the records of a step are added as ONE batch of compare-and-swaps
-#endif
+// (Round 6, measured and dropped, profiles/r06_ab_gather_batched_adds.md: all compare-and-swaps of a step issued as one batch, verdicts afterwards -- the
+// gather 72 -> 119 us at one view, 275 -> 466 at eight: a swap whose word was read a batch earlier fails far more often on the sampler's hot texels.)
 #ifndef NVDR_LG_NB
 #define NVDR_LG_NB 4                     // blocks of 128 records a wavefront of the gather fetches together (1: A/B)
 #endif
@@ -1645,6 +1644,14 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 #define NVDR_LG_NATIVE_ATOMICS 0        // 1: ds_add_f32 (A/B only)
 #endif
 
+// F64 (round 6; a tuning switch, NVDR_LG_F64=1, OFF by default): the accumulators are DOUBLES and a record is three ds_add_f64 -- no read, no loop, no retry.  gfx950 runs ds_add_f64 at nine times
+// the rate of ds_add_f32 and, on colliding addresses (the sampler's hot texels), at three times the rate of the compare-and-swap loop
+// (tools/ubench/lds_atomic.hip, profiles/r06_lds_atomic_ubench.txt); a band then holds half as many texels, so the launcher takes this build only
+// where the probe still fits 16 bands (the benchmark's 256 x 256 does), the fp32 build otherwise.  Sums of fp32 terms in fp64 are rounded once, when
+// the partial row is written: closer to the exact sum than the fp32 accumulation, and as independent of the order of the adds as one gets.
+// Measured (session 24, profiles/r06_ab_gather_f64.md): the gather 67 -> 45 us at one view (286 -> 289 at eight) -- and the backward shading kernel, which sorts
+// its records into twice as many bands, 289 -> 324 us at one view, 1.87 -> 2.05 ms at eight: a net loss of 1.6 ... 8.8 % of the two together.  Hence off.
+template <bool F64>
 __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint16_t *__restrict__ tags, const float4 *__restrict__ recs,
                                                                            const unsigned *__restrict__ pix_count, unsigned pix_begin, unsigned pix_cap,
                                                                            unsigned pixels_per_group, unsigned group_slots, unsigned spare_base,
@@ -1652,6 +1659,7 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
                                                                            float *__restrict__ partials)
 {
     extern __shared__ __attribute__((aligned(16))) float lg_acc[];
+    double *const lg_acc64 = (double *)lg_acc;
     const unsigned Ptot = *pix_count;
     if (Ptot <= pix_begin) return;                          // empty chunk (light_grad_reduce_kernel makes the same test)
     const unsigned P = chunk_span(Ptot, pix_begin, pix_cap);
@@ -1672,15 +1680,10 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
     const unsigned v_lo = min((unsigned)g * per, n_all), v_hi = min(v_lo + per, n_all);
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const float4 none = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-#if NVDR_LG_BATCH
-    // three words per thread behind the band's accumulators: where a lane without a record "adds" (x + 0.0 == x: they stay +0.0)
-    const int dummy_at = min(band_texels, n_texels) * 3 + (int)threadIdx.x * 3;        // (the launcher sizes the LDS for min(band, probe) texels + these)
-    lg_acc[dummy_at] = 0.0f; lg_acc[dummy_at + 1] = 0.0f; lg_acc[dummy_at + 2] = 0.0f;
-#endif
     for (int band = band_first; band < band_last; ++band) {
         const int t_lo = band * band_texels, t_hi = min(t_lo + band_texels, n_texels);
         const int n_acc = (t_hi - t_lo) * 3;
-        if (!(NVDR_LG_SKIP & 8)) for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) lg_acc[i] = 0.0f;
+        if (!(NVDR_LG_SKIP & 8)) for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) { if (F64) lg_acc64[i] = 0.0; else lg_acc[i] = 0.0f; }
         __syncthreads();
         // fp32 add to LDS.  NOT ds_add_f32: gfx950 executes that at 0.8 lane-operations per CU and nanosecond, twenty times slower
         // than its integer LDS atomics (tools/ubench/lds_atomic.hip, profiles/r03_lds_atomic_ubench.txt) -- it was 0.55 ms of the
@@ -1688,7 +1691,14 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
         // another lane hit the same word in between.
         auto add = [&](const float4 &r) {
             const int t = __float_as_int(r.w);
-            if (t >= t_lo && t < t_hi) {
+            if (F64) {
+                if (t >= t_lo && t < t_hi) {
+                    double *a = lg_acc64 + (t - t_lo) * 3;
+                    __hip_atomic_fetch_add(a + 0, (double)r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(a + 1, (double)r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(a + 2, (double)r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else if (t >= t_lo && t < t_hi) {
 #if NVDR_LG_NATIVE_ATOMICS
                 float *a = lg_acc + (t - t_lo) * 3;
                 __hip_atomic_fetch_add(a + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1742,81 +1752,16 @@ __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint1
                         if (lane + 64u < ff[q]) cc[2 * q + 1] = recs[(bb[q] << 7) + 64u + lane];
                     } else if (lane < ff[q]) cc[2 * q] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(t_lo + (int)((bb[q] * 64u + lane) % (unsigned)(t_hi - t_lo))));
                 }
-#if NVDR_LG_BATCH
-                // (A/B only.)  The records of the step are added TOGETHER: all their accumulator words are read, then all 6 NB compare-and-swaps are
-                // issued back to back, then their verdicts are looked at; what failed (another lane hit the same word in between) goes round
-                // again, still as one batch.  A lane without a record (beyond the block's fill) adds 0.0 to three words of its own behind the
-                // band: always succeeds, no branch around the batch.  Measured (session 23): the gather 72 -> 119 us at one view, 275 -> 466 at
-                // eight -- the sampler's hot texels make swaps fail far more often than the one-record-at-a-time loop lets on (its retry
-                // follows within a few instructions, with the word it just saw), and the batch pays 24 swaps for every lane, filled or not.
-                if (!(NVDR_LG_SKIP & 1)) {
-                    constexpr int Q = 2 * NVDR_LG_NB;
-                    unsigned *const base = (unsigned *)lg_acc;
-                    int ai[Q];
-                    unsigned o[Q][3];
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        const int t = __float_as_int(cc[q].w);
-                        const bool in = t >= t_lo && t < t_hi;
-                        ai[q] = in ? (t - t_lo) * 3 : dummy_at;
-                        if (!in) { cc[q].x = 0.0f; cc[q].y = 0.0f; cc[q].z = 0.0f; }
-                    }
-#pragma unroll
-                    for (int q = 0; q < Q; ++q)
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) o[q][ch] = __hip_atomic_load(base + ai[q] + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    unsigned pend = 0u;
-                    {
-                        // (issue, THEN look: the verdict of a swap is "the word still held what was read", taken from the returned word in a second
-                        // loop -- asking each swap for its verdict made the compiler wait for every group of three)
-                        unsigned got[Q][3];
-#pragma unroll
-                        for (int q = 0; q < Q; ++q)
-#pragma unroll
-                            for (int ch = 0; ch < 3; ++ch) {
-                                const float r = ch == 0 ? cc[q].x : (ch == 1 ? cc[q].y : cc[q].z);
-                                got[q][ch] = o[q][ch];
-                                (void)__hip_atomic_compare_exchange_strong(base + ai[q] + ch, &got[q][ch], __float_as_uint(__uint_as_float(o[q][ch]) + r),
-                                                                           __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
-#pragma unroll
-                        for (int q = 0; q < Q; ++q)
-#pragma unroll
-                            for (int ch = 0; ch < 3; ++ch) {
-                                if (got[q][ch] != o[q][ch]) pend |= 1u << (3 * q + ch);
-                                o[q][ch] = got[q][ch];
-                            }
-                    }
-                    while (pend != 0u) {
-#pragma unroll
-                        for (int q = 0; q < Q; ++q)
-#pragma unroll
-                            for (int ch = 0; ch < 3; ++ch)
-                                if (pend & (1u << (3 * q + ch))) {
-                                    const float r = ch == 0 ? cc[q].x : (ch == 1 ? cc[q].y : cc[q].z);
-                                    unsigned seen = o[q][ch];
-                                    if (__hip_atomic_compare_exchange_strong(base + ai[q] + ch, &seen, __float_as_uint(__uint_as_float(o[q][ch]) + r), __ATOMIC_RELAXED,
-                                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
-                                        pend &= ~(1u << (3 * q + ch));
-                                    o[q][ch] = seen;
-                                }
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 2 * NVDR_LG_NB; ++q) asm volatile("" :: "v"(cc[q].x), "v"(cc[q].w));
-                }
-#else
 #pragma unroll
                 for (int q = 0; q < 2 * NVDR_LG_NB; ++q) {
                     if (!(NVDR_LG_SKIP & 1)) add(cc[q]);
                     else asm volatile("" :: "v"(cc[q].x), "v"(cc[q].w));
                 }
-#endif
             }
         }
         __syncthreads();
         float *out = partials + (int64_t)g * n_texels * 3 + (int64_t)t_lo * 3;
-        if (!(NVDR_LG_SKIP & 4)) for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) out[i] = lg_acc[i];
+        if (!(NVDR_LG_SKIP & 4)) for (int i = threadIdx.x; i < n_acc; i += NVDR_LG_THREADS) out[i] = F64 ? (float)lg_acc64[i] : lg_acc[i];
         __syncthreads();
     }
 }
@@ -2049,12 +1994,11 @@ static size_t lg_lds_budget()
     if (kb < 8) kb = 8;
     if (kb > 160) kb = 160;
     size_t want = kb * 1024;
-    const size_t extra = NVDR_LG_BATCH ? (size_t)NVDR_LG_THREADS * 12 : 0;          // the threads' own words behind the band
-    if (want + extra > 160 * 1024) want = 160 * 1024 - extra;
-    if (want + extra > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)light_grad_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(want + extra)) != hipSuccess) {
+    if (want > 64 * 1024 &&
+        (hipFuncSetAttribute((const void *)light_grad_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess ||
+         hipFuncSetAttribute((const void *)light_grad_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) != hipSuccess)) {
         (void)hipGetLastError();
-        want = 64 * 1024 - extra;
+        want = 64 * 1024;
     }
     budget = want;
     return budget;
@@ -2125,16 +2069,22 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
     const int n_texels = (int)(a->light.size[0] * a->light.size[1]);
     int n_bands = 0, band_texels = 0, lg_rows = 8, lg_shift = 0, lg_records = 0, lg_grid_y = 1;
     size_t lg_lds = 0;
+    bool lg_f64 = false;
     {
         const size_t lds_budget = lg_lds_budget();
-        // a band = the largest power-of-two number of texels whose fp32 accumulators fit the LDS budget (band = texel >> shift)
+        // a band = the largest power-of-two number of texels whose accumulators fit the LDS budget (band = texel >> shift): fp64 accumulators
+        // (24 bytes per texel, the ds_add_f64 build of the gather) when the probe then still fits 16 bands, fp32 ones otherwise
         while ((size_t)(2 << lg_shift) * 12 <= lds_budget) ++lg_shift;
+        if (c->lg_f64 && lg_shift > 0 && (n_texels + (1 << (lg_shift - 1)) - 1) / (1 << (lg_shift - 1)) <= 16) {
+            lg_f64 = true;
+            --lg_shift;
+        }
         band_texels = 1 << lg_shift;
         n_bands = (n_texels + band_texels - 1) / band_texels;
         lg_records = (n_bands <= 16 && group_slots <= 16 * 128 && !(c->debug & 16u)) ? 1 : 0;
         if (lg_records) {
             if (band_texels > n_texels) band_texels = n_texels;
-            lg_lds = (size_t)band_texels * 12 + (NVDR_LG_BATCH ? (size_t)NVDR_LG_THREADS * 12 : 0);     // (+ three words per thread: light_grad_block_kernel)
+            lg_lds = (size_t)band_texels * (lg_f64 ? 24 : 12);
             // one gather workgroup per CU (its accumulators take most of the CU's LDS): each walks all bands (large launches), or
             // the CUs are dealt to the bands (small launches: fewer passes and partial rows, at the price of uneven bands)
             const bool per_band = c->lg_mode >= 0 ? c->lg_mode == 1 : npix * 2 * (int64_t)S <= NVDR_LG_PER_BAND_MAX_SLOTS;
@@ -2366,9 +2316,14 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
             else if (shade_local) { if (c->debug) env_shade_local_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_local_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
             else { if (c->debug) env_shade_kernel<true, true><<<(unsigned)pb[2], 256, 0, stream>>>(p); else env_shade_kernel<true, false><<<(unsigned)pb[2], 256, 0, stream>>>(p); }
             if (p.lg_records && !(c->debug & 2u)) {
-                light_grad_block_kernel<<<dim3((unsigned)lg_rows, (unsigned)lg_grid_y), NVDR_LG_THREADS, lg_lds, stream>>>(
-                    c->lg_tags, c->rays, p.pix_count, p.pix_begin, p.pix_cap, (unsigned)G, (unsigned)group_slots, p.lg_spare_base,
-                    (unsigned)spare_blocks, 1 << p.lg_shift, n_bands, n_texels, c->lg_part);
+                if (lg_f64)
+                    light_grad_block_kernel<true><<<dim3((unsigned)lg_rows, (unsigned)lg_grid_y), NVDR_LG_THREADS, lg_lds, stream>>>(
+                        c->lg_tags, c->rays, p.pix_count, p.pix_begin, p.pix_cap, (unsigned)G, (unsigned)group_slots, p.lg_spare_base,
+                        (unsigned)spare_blocks, 1 << p.lg_shift, n_bands, n_texels, c->lg_part);
+                else
+                    light_grad_block_kernel<false><<<dim3((unsigned)lg_rows, (unsigned)lg_grid_y), NVDR_LG_THREADS, lg_lds, stream>>>(
+                        c->lg_tags, c->rays, p.pix_count, p.pix_begin, p.pix_cap, (unsigned)G, (unsigned)group_slots, p.lg_spare_base,
+                        (unsigned)spare_blocks, 1 << p.lg_shift, n_bands, n_texels, c->lg_part);
                 light_grad_reduce_kernel<<<div_up(p.light_elems, 256), 256, 0, stream>>>(c->lg_part, p.light_elems, lg_rows, p.g_light,
                                                                                          k > 0 ? 1 : 0, p.pix_count, p.pix_begin);
             }

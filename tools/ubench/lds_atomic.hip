@@ -32,6 +32,12 @@ __global__ void __launch_bounds__(1024) k(float *out, int iters)
             acc[a] += 1.0f;
         } else if (OP == 4) {                                                   // packed: one 64-bit integer atomic
             __hip_atomic_fetch_add((unsigned long long *)acc + (a >> 1), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (OP == 5) {                                                   // round 6: fp64 (ds_add_f64) -- does it run at the integer rate?
+            __hip_atomic_fetch_add((double *)acc + (a >> 1), 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (OP == 6) {                                                   // round 6: the product's compare-and-swap loop on the bit pattern
+            unsigned *w = (unsigned *)acc + a;
+            unsigned o = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (!__hip_atomic_compare_exchange_strong(w, &o, __float_as_uint(__uint_as_float(o) + 1.0f), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {}
         }
     }
     __syncthreads();
@@ -74,6 +80,11 @@ int main()
     run<1, 0>("ds_add_u32, random words", 1);
     run<1, 2>("ds_add_u32, consecutive words", 1);
     run<4, 0>("ds_add_u64, random", 1);
+    run<5, 0>("ds_add_f64, random", 1);
+    run<5, 2>("ds_add_f64, consecutive", 1);
+    run<5, 3>("ds_add_f64, 8 lanes per address", 1);
+    run<6, 0>("compare-and-swap loop (f32 add), random words", 1);
+    run<6, 3>("compare-and-swap loop (f32 add), 8 lanes per address", 1);
     run<3, 0>("plain read + add + write, random words", 1);
     run<3, 2>("plain read + add + write, consecutive words", 1);
     return 0;

@@ -951,8 +951,17 @@ __device__ __forceinline__ void shade_sample(const ShadeParams &p, const PixelSe
 // it has already consumed (free_ptr .. free_end); until enough is consumed -- the first group, the up to n_bands blocks that are open at
 // any time, the alignment of the range to 128 slots -- it draws on lg_spw spare blocks of its own behind the chunk.  Per-band state
 // lives in the lanes of two registers (lane b: next slot to write / slots left in the open block of band b).
+#ifndef NVDR_LG_EMIT_ROUNDS
+#define NVDR_LG_EMIT_ROUNDS 0           // 1: rounds 3-5's placement, one round per band present among a pass pair's records (A/B)
+#endif
+#define NVDR_LG_NO_BLOCK 0xFFFFFF80u    // bpos of a band without an open block (aligned: "no slot left")
 struct RecordBlocks {
-    unsigned free_ptr, free_end, spare_next, bpos, bleft;
+    // bpos: lane b holds the next slot to write in the open block of band b.  The slots left in that block are (0 - bpos) & 127: a block ends at a
+    // multiple of 128, and an aligned bpos means "full" (the next record opens a new block).
+    unsigned free_ptr, free_end, spare_next, bpos;
+#if NVDR_LG_EMIT_ROUNDS
+    unsigned bleft;
+#endif
 
     // first_slot: the first stream slot this wavefront is going to consume; spare_first: its first spare block
     __device__ __forceinline__ void init(unsigned first_slot, unsigned spare_first)
@@ -960,12 +969,17 @@ struct RecordBlocks {
         free_ptr = (first_slot + 127u) & ~127u;
         free_end = first_slot;
         spare_next = spare_first;
+#if NVDR_LG_EMIT_ROUNDS
         bpos = 0xFFFFFFFFu;
         bleft = 0u;
+#else
+        bpos = NVDR_LG_NO_BLOCK;
+#endif
     }
+#if NVDR_LG_EMIT_ROUNDS
     // both record sets of a pass pair at once (A first: the light-sampled ones): one placement round per band present in either.
     // Called in converged control flow.
-    __device__ __forceinline__ void emit(const ShadeParams &p, int lane, bool hasA, const float4 &recA, bool hasB, const float4 &recB)
+    __device__ __forceinline__ void emit(const ShadeParams &p, int lane, bool hasA, const float4 &recA, bool hasB, const float4 &recB, unsigned *)
     {
         const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : -1;
         const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : -1;
@@ -1006,6 +1020,67 @@ struct RecordBlocks {
     {
         if (bpos != 0xFFFFFFFFu) p.lg_tags[(bpos + bleft - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - bleft) << 8));
     }
+#else
+    // Both record sets of a pass pair at once, in a FIXED number of steps (round 6; rounds 3-5 took one placement round of ~40 instructions per band
+    // present among the records, five or six of the eight on the benchmark probe -- a tenth of the backward shading kernel's instructions):
+    //   1. a record's rank inside its band = what an LDS counter of that band returns (the B records behind the A records: the light-sampled first);
+    //   2. lane b reads band b's count and does the block bookkeeping of that band in its own registers: does the open block overflow, and if so
+    //      which fresh block follows (the bands that need one are ranked by a ballot: consumed stream range first, then the spare blocks);
+    //   3. every record fetches its band's (slot, fresh block) from lane `band` with two ds_bpermute and is stored.
+    // cnt: 16 LDS words of this wavefront, all zero between calls.  Called in converged control flow.
+    __device__ __forceinline__ void emit(const ShadeParams &p, int lane, bool hasA, const float4 &recA, bool hasB, const float4 &recB, unsigned *cnt)
+    {
+        const int bandA = hasA ? (__float_as_int(recA.w) >> p.lg_shift) : 0;
+        const int bandB = hasB ? (__float_as_int(recB.w) >> p.lg_shift) : 0;
+        unsigned rankA = 0u, rankB = 0u;
+        if (hasA) rankA = __hip_atomic_fetch_add(cnt + bandA, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();                    // (LDS operations of a wavefront execute in order: the B ranks continue the A ranks)
+        if (hasB) rankB = __hip_atomic_fetch_add(cnt + bandB, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        unsigned c = 0u;
+        if (lane < 16) {
+            c = __hip_atomic_load(cnt + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(cnt + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // lane b: band b
+        const unsigned at_slot = bpos, left = (0u - bpos) & 127u;
+        const bool need = c > left;                           // the open block fills up: `left` records complete it, the rest open a new one (c = 0 for lanes >= 16)
+        const unsigned long long nm = __ballot(need);
+        unsigned fresh = 0u;
+        if (nm != 0ull) {
+            const unsigned k = __builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
+            const unsigned n_need = (unsigned)__popcll(nm);
+            const unsigned avail = free_end > free_ptr ? (free_end - free_ptr) >> 7 : 0u;      // whole blocks of the consumed stream range
+            const unsigned from_free = min(n_need, avail);
+            const unsigned blk = k < from_free ? (free_ptr >> 7) + k : spare_next + (k - from_free);
+            free_ptr += from_free << 7;
+            spare_next += n_need - from_free;
+            if (need) {
+                fresh = blk << 7;
+                if (at_slot != NVDR_LG_NO_BLOCK) p.lg_tags[(at_slot + left - 1u) >> 7] = (uint16_t)((unsigned)lane | (128u << 8));
+            }
+        }
+        if (c != 0u) bpos = need ? fresh + (c - left) : at_slot + c;
+        // the records: their band's slot and fresh block from lane `band` (all lanes execute the permutes: a source lane must be active to be read)
+        const unsigned atA = (unsigned)__builtin_amdgcn_ds_bpermute(bandA << 2, (int)at_slot), frA = (unsigned)__builtin_amdgcn_ds_bpermute(bandA << 2, (int)fresh);
+        const unsigned atB = (unsigned)__builtin_amdgcn_ds_bpermute(bandB << 2, (int)at_slot), frB = (unsigned)__builtin_amdgcn_ds_bpermute(bandB << 2, (int)fresh);
+        if (hasA) {
+            const unsigned l = (0u - atA) & 127u;
+            p.rays[rankA + (rankA < l ? atA : frA - l)] = recA;
+        }
+        if (hasB) {
+            const unsigned l = (0u - atB) & 127u;
+            p.rays[rankB + (rankB < l ? atB : frB - l)] = recB;
+        }
+    }
+    // the blocks still open when the wavefront runs out of pixels: lane b tags the one of band b with its fill
+    __device__ __forceinline__ void finish(const ShadeParams &p, int lane) const
+    {
+        const unsigned left = (0u - bpos) & 127u;
+        if (bpos != NVDR_LG_NO_BLOCK) p.lg_tags[(bpos + left - 1u) >> 7] = (uint16_t)((unsigned)lane | ((128u - left) << 8));
+    }
+#endif
 };
 
 // Tried in round 3 and dropped (session 29): fetching the next pixel's list entry one iteration ahead, and starting both samples'
@@ -1047,6 +1122,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     }
     // light-gradient records of this wavefront (RecordBlocks above)
     const unsigned gs = (unsigned)G * 2u * S;                           // stream slots of one group
+    // per-band record counters of this wavefront (RecordBlocks::emit): zero between calls
+    __shared__ unsigned lg_cnt_all[4][16];
+    unsigned *const lg_cnt = lg_cnt_all[wave];
+    if (BACKWARD && lane < 16) lg_cnt[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
     RecordBlocks rb;
     rb.init(grp_first * gs, p.lg_spare_base + wave_id * p.lg_spw);
 
@@ -1147,7 +1227,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             // No atomic leaves the workgroup in records mode (21 M addends per 8-view launch were 63 M memory-side fp32 atomics):
             // the addends of this round go to the band blocks, light-sampled ones first, in lane order
 #if NVDR_LG_EXPERIMENT == 0
-            if (BACKWARD && p.lg_records) rb.emit(p, lane, lg_hasA, lg_recA, lg_hasB, lg_recB);
+            if (BACKWARD && p.lg_records) rb.emit(p, lane, lg_hasA, lg_recA, lg_hasB, lg_recB, lg_cnt);
 #elif NVDR_LG_EXPERIMENT == 3           // records written in place, unsorted (what the shading kernel cost before the band blocks)
             if (BACKWARD && p.lg_records) {
                 if (lg_hasA) p.rays[rA] = lg_recA;
@@ -1247,6 +1327,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     }
     // light-gradient records of this wavefront (RecordBlocks above)
     const unsigned gs = 2u * S;
+    // per-band record counters of this wavefront (RecordBlocks::emit): zero between calls
+    __shared__ unsigned lg_cnt_all[4][16];
+    unsigned *const lg_cnt = lg_cnt_all[wave];
+    if (BACKWARD && lane < 16) lg_cnt[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
     RecordBlocks rb;
     rb.init(grp * gs, p.lg_spare_base + wave_id * p.lg_spw);
 
@@ -1393,7 +1478,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                 lg_has1 = lg_has;
             }
         }
-        if (BACKWARD && p.lg_records) rb.emit(p, lane, lg_has1, lg_rec1, lg_has0, lg_rec0);     // light-sampled records first, as above
+        if (BACKWARD && p.lg_records) rb.emit(p, lane, lg_has1, lg_rec1, lg_has0, lg_rec0, lg_cnt);     // light-sampled records first, as above
         // pixels whose samples are all shaded, in order: the row is summed over the lanes and written
         while (fin < it) {
             const unsigned e = fin % RING;
@@ -1471,6 +1556,11 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
         grp_step = 1;
     }
     const unsigned gs = 2u * S;
+    // per-band record counters of this wavefront (RecordBlocks::emit): zero between calls
+    __shared__ unsigned lg_cnt_all[4][16];
+    unsigned *const lg_cnt = lg_cnt_all[wave];
+    if (BACKWARD && lane < 16) lg_cnt[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
     RecordBlocks rb;
     rb.init(grp_first * gs, p.lg_spare_base + wave_id * p.lg_spw);
 
@@ -1571,12 +1661,12 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
                         lg_rec0 = lg_rec;
                         lg_has0 = lg_has;
                     } else {
-                        rb.emit(p, lane, lg_has, lg_rec, lg_has0, lg_rec0);     // light-sampled records first, as above
+                        rb.emit(p, lane, lg_has, lg_rec, lg_has0, lg_rec0, lg_cnt);     // light-sampled records first, as above
                         lg_has0 = false;
                     }
                 }
             }
-            if (BACKWARD) rb.emit(p, lane, false, lg_rec0, lg_has0, lg_rec0);   // (nothing left to place if a queue batch took them along)
+            if (BACKWARD) rb.emit(p, lane, false, lg_rec0, lg_has0, lg_rec0, lg_cnt);   // (nothing left to place if a queue batch took them along)
         }
         if (BACKWARD) rb.free_end = (grp + 1u) * gs;    // the rays of this pixel have all been read: its slots may hold records now
 

@@ -1170,7 +1170,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     // NVDR_LG_MODE: work split of the light-gradient gather (env_shade.hip): 0 every workgroup walks all bands, 1 one set of
     // workgroups per band, unset = by launch size
     if (const char *lm = nvdr_tuning_env("NVDR_LG_MODE")) c->lg_mode = atoi(lm) ? 1 : 0;
-    if (const char *lf = nvdr_tuning_env("NVDR_LG_F64")) c->lg_f64 = atoi(lf) != 0;
+    if (const char *lf = nvdr_tuning_env("NVDR_LG_F64")) c->lg_f64 = atoi(lf) > 0 ? 1 : (atoi(lf) < 0 ? -1 : 0);
     if (const char *sq = nvdr_tuning_env("NVDR_SHADE_QUEUE")) c->shade_queue = atoi(sq) & 7;
     if (const char *sm = nvdr_tuning_env("NVDR_TRACE_SPLIT_MODE")) c->trace_split_mode = atoi(sm);
     if (const char *tt = nvdr_tuning_env("NVDR_TRACE_TOP_NODES")) {

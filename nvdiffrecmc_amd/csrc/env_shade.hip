@@ -1734,13 +1734,15 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 #define NVDR_LG_NATIVE_ATOMICS 0        // 1: ds_add_f32 (A/B only)
 #endif
 
-// F64 (round 6; a tuning switch, NVDR_LG_F64=1, OFF by default): the accumulators are DOUBLES and a record is three ds_add_f64 -- no read, no loop, no retry.  gfx950 runs ds_add_f64 at nine times
+// F64 (round 6; the build of SMALL launches -- those whose workgroups are dealt to the bands; NVDR_LG_F64 = 0 / 1: never / wherever the bands allow): the
+// accumulators are DOUBLES and a record is three ds_add_f64 -- no read, no loop, no retry.  gfx950 runs ds_add_f64 at nine times
 // the rate of ds_add_f32 and, on colliding addresses (the sampler's hot texels), at three times the rate of the compare-and-swap loop
 // (tools/ubench/lds_atomic.hip, profiles/r06_lds_atomic_ubench.txt); a band then holds half as many texels, so the launcher takes this build only
 // where the probe still fits 16 bands (the benchmark's 256 x 256 does), the fp32 build otherwise.  Sums of fp32 terms in fp64 are rounded once, when
 // the partial row is written: closer to the exact sum than the fp32 accumulation, and as independent of the order of the adds as one gets.
-// Measured (session 24, profiles/r06_ab_gather_f64.md): the gather 67 -> 45 us at one view (286 -> 289 at eight) -- and the backward shading kernel, which sorts
-// its records into twice as many bands, 289 -> 324 us at one view, 1.87 -> 2.05 ms at eight: a net loss of 1.6 ... 8.8 % of the two together.  Hence off.
+// Measured (profiles/r06_ab_gather_f64.md): the gather 67 -> 45 us at one view, nothing at eight (sixteen passes per workgroup instead of eight).  While the
+// backward shading kernel still placed its records in one round per band (session 24) twice the bands cost it more than that; with the fixed-step placement
+// (RecordBlocks::emit) they cost nothing: backward shading + gather -6.2 % at one view of bob, -2.8 % on 684 k triangles, +1.1 % at eight views (session 27).
 template <bool F64>
 __global__ void __launch_bounds__(NVDR_LG_THREADS) light_grad_block_kernel(uint16_t *__restrict__ tags, const float4 *__restrict__ recs,
                                                                            const unsigned *__restrict__ pix_count, unsigned pix_begin, unsigned pix_cap,
@@ -2165,7 +2167,12 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         // a band = the largest power-of-two number of texels whose accumulators fit the LDS budget (band = texel >> shift): fp64 accumulators
         // (24 bytes per texel, the ds_add_f64 build of the gather) when the probe then still fits 16 bands, fp32 ones otherwise
         while ((size_t)(2 << lg_shift) * 12 <= lds_budget) ++lg_shift;
-        if (c->lg_f64 && lg_shift > 0 && (n_texels + (1 << (lg_shift - 1)) - 1) / (1 << (lg_shift - 1)) <= 16) {
+        // one gather workgroup per CU (its accumulators take most of the CU's LDS): each walks all bands (large launches), or
+        // the CUs are dealt to the bands (small launches: fewer passes and partial rows, at the price of uneven bands)
+        const bool per_band = c->lg_mode >= 0 ? c->lg_mode == 1 : npix * 2 * (int64_t)S <= NVDR_LG_PER_BAND_MAX_SLOTS;
+        // fp64 for the small launches only (NVDR_LG_F64: -1 this rule, 0 never, 1 wherever the bands allow): a workgroup that walks ALL bands pays
+        // for twice as many passes what ds_add_f64 saves (session 27: 8 views +1.1 %, one view -6.2 % of backward shading + gather)
+        if ((c->lg_f64 > 0 || (c->lg_f64 < 0 && per_band)) && lg_shift > 0 && (n_texels + (1 << (lg_shift - 1)) - 1) / (1 << (lg_shift - 1)) <= 16) {
             lg_f64 = true;
             --lg_shift;
         }
@@ -2175,9 +2182,6 @@ static int env_shade_launch(nvdr_ctx *c, const nvdr_env_shade_args *a, bool back
         if (lg_records) {
             if (band_texels > n_texels) band_texels = n_texels;
             lg_lds = (size_t)band_texels * (lg_f64 ? 24 : 12);
-            // one gather workgroup per CU (its accumulators take most of the CU's LDS): each walks all bands (large launches), or
-            // the CUs are dealt to the bands (small launches: fewer passes and partial rows, at the price of uneven bands)
-            const bool per_band = c->lg_mode >= 0 ? c->lg_mode == 1 : npix * 2 * (int64_t)S <= NVDR_LG_PER_BAND_MAX_SLOTS;
             // (per band, one view, round 4: 4 / 8 / 16 workgroups per band instead of n_cus / n_bands = 32: +61 / +27 / +9 % of the backward
             // shading + gather time -- the records, not the partial rows, are the work; 64: -0.5 %)
             lg_rows = per_band ? (c->n_cus / n_bands < 1 ? 1 : c->n_cus / n_bands) : c->n_cus;

@@ -187,6 +187,8 @@ struct nvdr_ctx {
     float oct_c_leaf = 0.45f;      // cost of a triangle test relative to a node step in the collapse DP
     int shade_queue = 3;           // shading kernels that queue the live light samples (NVDR_SHADE_QUEUE): S == 64 across pixels, bit 0 backward, bit 1 forward; S > 64 inside the pixel, bit 0 backward, bit 2 forward
     int trace_split_mode = 2;      // which traversal build a launch starts: 0 plain, 1 split walks in the drain, 2 by the last launch's rays per wavefront (NVDR_TRACE_SPLIT_MODE)
+    bool refit_keep_collapse = true;   // a refit keeps the eight-wide collapse of the last full build (NVDR_REFIT_KEEP_COLLAPSE=0: every refit runs the dynamic programme again)
+    bool collapse_valid = false;       // the collapse data of the current topology (slot splits, wide roots, prefix sums) is in the context
     int lg_f64 = -1;               // gather with fp64 accumulators + ds_add_f64: -1 for the launches whose workgroups are dealt to the bands (small ones), 0 never, 1 wherever the probe then fits 16 bands (NVDR_LG_F64)
     int lg_mode = -1;              // gather work split: -1 by launch size, 0 all bands per workgroup, 1 one set of workgroups per band (NVDR_LG_MODE)
     bool lg_tags_dirty = true;     // the array may hold tags nobody consumed (fresh allocation, a backward pass without gather)

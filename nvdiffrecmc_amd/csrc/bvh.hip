@@ -395,13 +395,17 @@ __device__ __forceinline__ unsigned oct_child_budget(unsigned rec, unsigned i, i
 //     drops the CU's L1 -- 1.4 M of each on the 684 k-triangle mesh, 7-8 ms for this kernel, and the sample-generation kernel that
 //     runs beside it on the other stream, whose stores those write-backs kept flushing, took 10.3 instead of 4 ms.)
 // `xchg`: [2 * n][8] floats, the memory-side record of the (left, right) child of a node: cost[0..6] of the collapse DP, then the height.
+// DP = false (round 6, the REFIT): boxes only.  The collapse into eight-wide nodes keeps the slot splits the last full build's dynamic programme chose (up[].y,
+// the wide roots, the prefix sums: all still in the context) -- any collapse of the binary tree is a valid tree, the moved boxes are exact, and the periodic
+// rebuild refreshes the choice -- so the DP tables, their 32-byte hand-off per level and the budget / scan kernels behind this one drop out of a refit.
+template <bool DP>
 __global__ void __launch_bounds__(NVDR_FIT_BLOCK) bvh_fit_kernel(const float *__restrict__ verts, const int32_t *__restrict__ tris,
                                const uint32_t *__restrict__ order, int n, float4 *__restrict__ tri_rec, uint4 *nodes,
                                uint2 *up, int *flags, BvhDeviceInfo *info,
                                float *xchg, float c_leaf, unsigned long long *jump)
 {
     __shared__ unsigned l_box[NVDR_FIT_BLOCK][2][3];
-    __shared__ float l_x[NVDR_FIT_BLOCK][2][8];
+    __shared__ float l_x[DP ? NVDR_FIT_BLOCK : 1][2][8];
     __shared__ int l_flag[NVDR_FIT_BLOCK];
     l_flag[threadIdx.x] = 0;
     __syncthreads();
@@ -440,8 +444,8 @@ __global__ void __launch_bounds__(NVDR_FIT_BLOCK) bvh_fit_kernel(const float *__
     //   c(v, 1) = A_v + min_k c(l, k) + c(r, 8 - k)            v becomes the root of a wide node; the argmin is kept as its root split
     //   c(v, i) = min(c(v, 1), min_k c(l, k) + c(r, i - k))    or its slots go to the children; the argmin (0 = stay one slot) is kept
     const float wxs = 1.0f / info->g_scale[0], wys = 1.0f / info->g_scale[1], wzs = 1.0f / info->g_scale[2];
-    float cost[7];
-    {
+    float cost[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (DP) {
         const float ex = (float)(qmx[0] - qmn[0]) * wxs, ey = (float)(qmx[1] - qmn[1]) * wys, ez = (float)(qmx[2] - qmn[2]) * wzs;
         const float leaf = (ex * ey + ey * ez + ez * ex) * c_leaf;
 #pragma unroll
@@ -457,16 +461,18 @@ __global__ void __launch_bounds__(NVDR_FIT_BLOCK) bvh_fit_kernel(const float *__
         box.y = (unsigned)qmn[2] | ((unsigned)qmx[0] << 16);
         box.z = (unsigned)qmx[1] | ((unsigned)qmx[2] << 16);
         unsigned s0, s1, s2;
-        float sib[7];
-        int sib_height;
+        float sib[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        int sib_height = 0;
         if (local) {
             // both subtrees are this workgroup's: the node record gets a plain store (nobody reads it in this kernel), the hand-off is LDS
             rec[3 * slot] = box.x; rec[3 * slot + 1] = box.y; rec[3 * slot + 2] = box.z;
             const int li = node & (NVDR_FIT_BLOCK - 1);                     // a Karras node lies inside its own leaf range
             l_box[li][slot][0] = box.x; l_box[li][slot][1] = box.y; l_box[li][slot][2] = box.z;
+            if (DP) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) l_x[li][slot][i] = cost[i];
-            l_x[li][slot][7] = __int_as_float(height);
+                for (int i = 0; i < 7; ++i) l_x[li][slot][i] = cost[i];
+                l_x[li][slot][7] = __int_as_float(height);
+            }
             // LDS-only ordering (s_waitcnt lgkmcnt): a workgroup-scope acq_rel atomic would also drain the global stores above, a trip to
             // memory per level -- exactly what this path is there to avoid
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -474,31 +480,37 @@ __global__ void __launch_bounds__(NVDR_FIT_BLOCK) bvh_fit_kernel(const float *__
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             if (old == 0) return; // first arriver: the sibling subtree finishes this node
             s0 = l_box[li][1 - slot][0]; s1 = l_box[li][1 - slot][1]; s2 = l_box[li][1 - slot][2];
+            if (DP) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) sib[i] = l_x[li][1 - slot][i];
-            sib_height = __float_as_int(l_x[li][1 - slot][7]);
+                for (int i = 0; i < 7; ++i) sib[i] = l_x[li][1 - slot][i];
+                sib_height = __float_as_int(l_x[li][1 - slot][7]);
+            }
         } else {
             store_sc1(rec + 3 * slot, box);
             float *xc = xchg + 8 * (2 * (int64_t)node + slot);
-            nvdr_f4 x0, x1;
-            x0.x = cost[0]; x0.y = cost[1]; x0.z = cost[2]; x0.w = cost[3];
-            x1.x = cost[4]; x1.y = cost[5]; x1.z = cost[6]; x1.w = __int_as_float(height);
-            store_sc1(xc, x0);
-            store_sc1(xc + 4, x1);
+            if (DP) {
+                nvdr_f4 x0, x1;
+                x0.x = cost[0]; x0.y = cost[1]; x0.z = cost[2]; x0.w = cost[3];
+                x1.x = cost[4]; x1.y = cost[5]; x1.z = cost[6]; x1.w = __int_as_float(height);
+                store_sc1(xc, x0);
+                store_sc1(xc + 4, x1);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the write-through stores have arrived ...
             const int old = __hip_atomic_fetch_add(&flags[node], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ... before the counter moves
             if (old == 0) return; // first arriver: the sibling subtree finishes this node
             const nvdr_u3 sb = load_sc1_u3(rec + 3 * (1 - slot));
-            const float *sx = xchg + 8 * (2 * (int64_t)node + (1 - slot));
-            const nvdr_f4 y0 = load_sc1_f4(sx), y1 = load_sc1_f4(sx + 4);
             s0 = sb.x; s1 = sb.y; s2 = sb.z;
-            sib[0] = y0.x; sib[1] = y0.y; sib[2] = y0.z; sib[3] = y0.w; sib[4] = y1.x; sib[5] = y1.y; sib[6] = y1.z;
-            sib_height = __float_as_int(y1.w);
+            if (DP) {
+                const float *sx = xchg + 8 * (2 * (int64_t)node + (1 - slot));
+                const nvdr_f4 y0 = load_sc1_f4(sx), y1 = load_sc1_f4(sx + 4);
+                sib[0] = y0.x; sib[1] = y0.y; sib[2] = y0.z; sib[3] = y0.w; sib[4] = y1.x; sib[5] = y1.y; sib[6] = y1.z;
+                sib_height = __float_as_int(y1.w);
+            }
         }
         qmn[0] = min(qmn[0], (int)(s0 & 0xffffu)); qmn[1] = min(qmn[1], (int)(s0 >> 16)); qmn[2] = min(qmn[2], (int)(s1 & 0xffffu));
         qmx[0] = max(qmx[0], (int)(s1 >> 16)); qmx[1] = max(qmx[1], (int)(s2 & 0xffffu)); qmx[2] = max(qmx[2], (int)(s2 >> 16));
         height = 1 + max(height, sib_height);
-        {
+        if (DP) {
             // (left, right) tables in tree order, whichever of the two this thread carried
             float Lc[7], Rc[7];
 #pragma unroll
@@ -542,7 +554,7 @@ __global__ void __launch_bounds__(NVDR_FIT_BLOCK) bvh_fit_kernel(const float *__
             if (node == 0) jump[0] = 0x8888888800000000ull;         // the tree root holds budget 8 whatever is asked
         }
         if (node == 0) {
-            info->height = height;
+            if (DP) info->height = height;
             return;
         }
         w = w_next;
@@ -1169,6 +1181,7 @@ extern "C" int nvdr_ctx_create(nvdr_ctx **out, int device)
     if (const char *cl = nvdr_tuning_env("NVDR_OCT_CLEAF")) { const float v = (float)atof(cl); if (v > 0.0f) c->oct_c_leaf = v; }
     // NVDR_LG_MODE: work split of the light-gradient gather (env_shade.hip): 0 every workgroup walks all bands, 1 one set of
     // workgroups per band, unset = by launch size
+    if (const char *rk = nvdr_tuning_env("NVDR_REFIT_KEEP_COLLAPSE")) c->refit_keep_collapse = atoi(rk) != 0;
     if (const char *lm = nvdr_tuning_env("NVDR_LG_MODE")) c->lg_mode = atoi(lm) ? 1 : 0;
     if (const char *lf = nvdr_tuning_env("NVDR_LG_F64")) c->lg_f64 = atoi(lf) > 0 ? 1 : (atoi(lf) < 0 ? -1 : 0);
     if (const char *sq = nvdr_tuning_env("NVDR_SHADE_QUEUE")) c->shade_queue = atoi(sq) & 7;
@@ -1412,16 +1425,29 @@ int ctx_launch_build(nvdr_ctx *c, hipStream_t stream)
     const bool cleared = rebuild != 0 && n > 1;        // (the hierarchy kernel has cleared the counters and the control words)
     // (a kernel, not hipMemsetAsync: the refit is replayed from HIP graphs, where memset / memcpy nodes are slow on this runtime)
     if (!cleared) bvh_clear_flags_kernel<<<div_up(n, 1024), 1024, 0, stream>>>(c->flags, n);
-    bvh_fit_kernel<<<div_up(n, NVDR_FIT_BLOCK), NVDR_FIT_BLOCK, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->up,
-                                                                              c->flags, c->dinfo, c->dp_cost, c->oct_c_leaf, c->oct_jump);
+    // A REFIT keeps the collapse of the last full build (bvh_fit_kernel<false>): boxes, the slots' order (count) and the nodes (emit) are redone,
+    // the dynamic programme, the budget resolution and the prefix sums are not.  NVDR_REFIT_KEEP_COLLAPSE=0 (tuning): every refit collapses anew.
+    const bool keep = rebuild == 0 && n > 1 && c->refit_keep_collapse && c->collapse_valid;
+    if (keep)
+        bvh_fit_kernel<false><<<div_up(n, NVDR_FIT_BLOCK), NVDR_FIT_BLOCK, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->up,
+                                                                                         c->flags, c->dinfo, c->dp_cost, c->oct_c_leaf, c->oct_jump);
+    else
+        bvh_fit_kernel<true><<<div_up(n, NVDR_FIT_BLOCK), NVDR_FIT_BLOCK, 0, stream>>>(verts, tris, c->vals[1], n, c->tris, c->nodes, c->up,
+                                                                                        c->flags, c->dinfo, c->dp_cost, c->oct_c_leaf, c->oct_jump);
+    c->collapse_valid = n > 1;
     {
         // eight-wide nodes for the shadow-ray walk: budgets -> counts -> prefix sum -> emit, no inter-thread dependency (see above)
         OctBuildArgs oa;
         oa.nodes = c->nodes; oa.tris = c->tris; oa.oct = c->oct; oa.tris8 = c->tris8; oa.up = c->up; oa.jump = c->oct_jump;
         oa.roots = c->oct_task; oa.wslot = c->oct_wslot; oa.cnt = c->oct_cnt; oa.scan = c->oct_scan; oa.ctl = c->oct_ctl;
         oa.info = c->dinfo; oa.n_int_nodes = n - 1; oa.ovf = c->ovf_dev;
-        if (!cleared) bvh_oct_init_kernel<<<1, 64, 0, stream>>>(oa, n);
-        if (n > 1) {
+        if (!cleared && !keep) bvh_oct_init_kernel<<<1, 64, 0, stream>>>(oa, n);
+        if (n > 1 && keep) {
+            // (the slots of a wide node are ordered by their boxes' areas: the positions of the children are recorded again, the counts come out the same)
+            const unsigned blocks = min(div_up((n + 3) / 4, OCT_THREADS), (unsigned)c->n_cus * 16u);
+            bvh_oct_count_kernel<<<blocks < 1u ? 1u : blocks, OCT_THREADS, 0, stream>>>(oa);
+            bvh_oct_emit_kernel<<<blocks < 1u ? 1u : blocks, OCT_THREADS, 0, stream>>>(oa);
+        } else if (n > 1) {
             bvh_oct_budget_kernel<<<div_up(n - 1, 1024), 1024, 0, stream>>>(oa);
             // wide roots are ~n / 4.9; the grid-stride loops of the two expansion kernels cover whatever the device-side count says
             const unsigned blocks = min(div_up((n + 3) / 4, OCT_THREADS), (unsigned)c->n_cus * 16u);

@@ -32,7 +32,7 @@ trace kernel_trace_bob512_1view --batch 1 --graph on --steps 40 --warmup 10
 trace kernel_trace_dmtet800_1view_unlocked --config dmtet800 --batch 1 --graph on --steps 30 --warmup 10
 trace kernel_trace_dmtet64_800_8views --config dmtet64_800 --steps 6 --warmup 3
 cd $R
-one() { name=$1; shift; timeout 300 python bench.py "$@" --no-cpu-baseline --no-pmc --no-large-mesh --no-other-configs --no-one-view --no-validation --steps 100 --warmup 20 2>/dev/null | tail -1 > $O/$name.json
+one() { name=$1; shift; timeout 300 python bench.py "$@" --no-cpu-baseline --no-pmc --no-large-mesh --no-other-configs --no-one-view --no-validation --steps 100 --warmup 20 2>$O/$name.err | tail -1 > $O/$name.json   # (stderr kept: one of these lines came back empty once, session 29 could not reproduce it)
   python -c "
 import json; d=json.load(open('$O/$name.json')); e=d['config'].get('exchange') or {}
 print('$name', d['hip_graph'], round(d['ms_per_step'],3), round(d['median_ms_per_step'],3), d['steps_over_twice_the_median'], {k: e.get(k) for k in ('mode','policy','bytes_sent','exposed_ms','geometry_stage_ms')} if e else '')"; }

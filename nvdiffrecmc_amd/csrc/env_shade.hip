@@ -1721,7 +1721,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 // Sorting at the source removes both: 0.34 GB of block reads, all lanes busy.
 
 #define NVDR_LG_THREADS 1024
-#define NVDR_LG_PER_BAND_MAX_SLOTS (192ll << 20)    // launches of up to this many stream slots (6 views of 512^2 x 64 spp) deal the CUs to the bands (measured: -13 % / -6 % / -2 % / +-0 of the backward shading + gather time at 1 / 2 / 4 / 8 views)
+#define NVDR_LG_PER_BAND_MAX_SLOTS (320ll << 20)    // launches of up to this many stream slots (ten views of 512^2 x 64 spp) deal the CUs to the bands.  Round 4, fp32 accumulators: -13 % / -6 % / -2 % / +-0 of the backward shading + gather time at 1 / 2 / 4 / 8 views of 512^2 (then: 192 Mi slots).  Round 6, with the fp64 build these launches get: -2.3 % at eight views of 512^2 (256 Mi slots), +1.3 % at eight of 800^2 (625 Mi) -- session 27
 #ifndef NVDR_LG_SKIP
 #define NVDR_LG_SKIP 0                   // timing-only A/B (wrong results): bit 0 no LDS adds, bit 1 no record loads, bit 2 no partial row written, bit 3 no zeroing of the accumulators
 #endif

@@ -46,6 +46,16 @@ from . import render as rd
 from . import _lib
 
 
+
+def _capture_graph(g, **kw):
+    """torch.cuda.graph(g, ...) with THREAD-LOCAL capture errors.  The default ('global') makes every "unsafe" HIP call of ANY thread an error while a
+    stream captures -- and the process group's watchdog thread polls its pending collectives with hipEventQuery: a capture that begins while a
+    collective of the warm-up iterations is still on the watchdog's list died, once in ~25 runs of the several-rank schedule, with "operation not
+    permitted when stream is capturing" (round 6, sessions 29-31; `tools/capture_mode_probe.py` shows it deterministically).  Thread-local mode keeps
+    the check for the capturing thread, which is the one whose calls end up in the graph."""
+    return torch.cuda.graph(g, capture_error_mode='thread_local', **kw)
+
+
 class _gather_rows(torch.autograd.Function):
     """tex[idx] with an index_add_ (atomic) backward.  torch's generic advanced-indexing backward sorts the
     indices and serialises on duplicates: 57 ms per iteration here, 20x the whole hot path."""
@@ -810,7 +820,7 @@ class DirectLightingStep:
                 for k in (0, 1):
                     self._iter = k              # (_build_bvh reads the flag from the iteration counter)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with _capture_graph(g):
                         self._stage1_ready = False
                         losses.append(self.forward_backward())
                         self._update()
@@ -822,7 +832,7 @@ class DirectLightingStep:
                 self._graphs = (tuple(gas), None, None)
                 return
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with _capture_graph(ga):
                 self._stage1_ready = False
                 self._loss_static = self.forward_backward()
                 self._update()
@@ -848,13 +858,13 @@ class DirectLightingStep:
                 # main stream, none of the high-priority ones does); the rebuild is on the traversal's critical path anyway
                 self._build_side = torch.cuda.Stream(device=self.dev, priority=-1)
                 self._ev_build, self._ev_main = torch.cuda.Event(), torch.cuda.Event()
-            with torch.cuda.graph(g1):
+            with _capture_graph(g1):
                 self._build_bvh()
                 self.ctx.wait_build()
             self.ctx.build_joined()              # replays are ordered by _ev_build: no consumer waits on the build's own event
             g2a, g2b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             pool2 = torch.cuda.graph_pool_handle()       # (not G1's: that graph replays on another stream, concurrently with these two)
-            cm_a, cm_b = torch.cuda.graph(g2a, pool=pool2), torch.cuda.graph(g2b, pool=pool2)
+            cm_a, cm_b = _capture_graph(g2a, pool=pool2), _capture_graph(g2b, pool=pool2)
             cut = []
 
             def hook():
@@ -884,15 +894,15 @@ class DirectLightingStep:
                 gv = []
                 for rb in (1, 0):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with _capture_graph(g):
                         self._build_bvh(rebuild=rb)
                         self.ctx.wait_build()
                     gv.append(g)
                 self._gb_variants = tuple(gv)
-            with torch.cuda.graph(g1):
+            with _capture_graph(g1):
                 self._stage1(defer_build=True, build=self._gb_variants is None)
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with _capture_graph(g2, pool=g1.pool()):
                 self._loss_static = self._stage2()
                 ex.pack()
                 self._packed_tex_grad()
@@ -906,7 +916,7 @@ class DirectLightingStep:
             f = self._point_grads(k)        # the .grad of chunk k = views into its bucket: what the captured update reads on every replay
             gk = torch.cuda.CUDAGraph()
             before = torch.cuda.memory_allocated(self.dev)
-            with torch.cuda.graph(gk, **({'pool': pool_b} if pool_b is not None else {})):
+            with _capture_graph(gk, **({'pool': pool_b} if pool_b is not None else {})):
                 self._update(subset=self._ex_chunks[k], advance=(k == n - 1), grad_mult=f)
             if self._fused_update and torch.cuda.memory_allocated(self.dev) != before:
                 raise RuntimeError('the captured parameter update of exchange chunk %d allocated memory' % k)

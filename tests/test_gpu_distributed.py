@@ -264,3 +264,46 @@ def test_a_frozen_texture_still_has_its_gradient_consumed(dev):
         assert o['peak'] == [0.0] * 6, (tag, o['peak'])          # consumed and cleared after every iteration
         assert o['frozen_same'] and o['ks_moved'] > 0.0           # kd stood still, the rest of the set trained
         assert o['finite'] and 0.0 < o['moved'] < 0.2             # unfrozen: two ordinary Adam steps at lr 0.03, not an explosion
+
+
+@pytest.mark.gpu
+def test_graph_capture_tolerates_event_queries_of_other_threads(dev):
+    """The harness captures its HIP graphs with thread-local capture errors (trainer._capture_graph): the process group's watchdog thread polls its
+    pending collectives with hipEventQuery, which the default ('global') mode turns into "operation not permitted when stream is capturing" whenever a
+    capture is open -- what ended one in ~25 runs of the several-rank schedule in round 6.  Here another thread queries an event for the whole length
+    of a capture made through the harness's helper: no error on either side, and the graph replays."""
+    import threading
+    import time
+    from nvdiffrecmc_amd import trainer
+    x = torch.zeros(1 << 18, device=dev)
+    side, ev = torch.cuda.Stream(), torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(100):
+            x.add_(1.0)
+        ev.record()
+    errors, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                ev.query()
+            except RuntimeError as e:
+                errors.append(str(e).split('\n')[0])
+                return
+            time.sleep(0.0005)
+
+    y = torch.zeros(1024, device=dev)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    t = threading.Thread(target=poll)
+    t.start()
+    with trainer._capture_graph(g):
+        for _ in range(20):
+            y.add_(1.0)
+        time.sleep(0.05)
+    stop.set()
+    t.join()
+    assert not errors, errors
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(y[0]) == 20.0

@@ -1288,6 +1288,12 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
 #define NVDR_SQ_RING_FWD 2u        // ring entries of the forward instantiation: 25 instead of 31 KB of LDS per workgroup, six resident per CU (forward shading 0.818 -> 0.800 ms per 8-view launch; 3: A/B)
 #endif
 #define NVDR_SQ_QCAP 128u
+#ifndef NVDR_SQ_ROW_ROT
+#define NVDR_SQ_ROW_ROT 1          // ... lane 4 c + q takes quarter (q + c) % 4 of row c (0: quarter q; A/B)
+#endif
+#ifndef NVDR_SQ_ROW_SUMS
+#define NVDR_SQ_ROW_SUMS 1         // backward: a pixel's twelve result rows summed by four lanes each from LDS (0: twelve 64-lane butterflies, A/B)
+#endif
 
 template <bool BACKWARD, bool DBG>
 __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_queue_kernel(ShadeParams p)
@@ -1305,7 +1311,7 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
     const bool save_bits = !BACKWARD && p.vis_cache != nullptr;
 
     constexpr unsigned RING = BACKWARD ? NVDR_SQ_RING : NVDR_SQ_RING_FWD;
-    __shared__ float res_all[4][RING][NF][64];
+    __shared__ __attribute__((aligned(16))) float res_all[4][RING][NF][64];
     __shared__ float setup_all[4][RING][NS + 3];
     __shared__ float4 q_rd_all[4][NVDR_SQ_QCAP];
     __shared__ unsigned q_meta_all[4][NVDR_SQ_QCAP];    // stratum | ring entry << 6 | occluded << 8
@@ -1486,24 +1492,45 @@ __global__ void __launch_bounds__(256, BACKWARD ? NVDR_SHADE_OCC : 1) env_shade_
             if (pend != 0u) break;
             const int lin = e == 0u ? lin0 : (e == 1u ? lin1 : lin2);
             __builtin_amdgcn_wave_barrier();
-            float v[NF];
+            if constexpr (BACKWARD && NVDR_SQ_ROW_SUMS) {
+                // The twelve row sums by 48 lanes (round 6): lane 4 c + q adds sixteen cells of row c -- four 16-byte LDS reads, fifteen adds in a fixed
+                // order; quarter (q + c) % 4, so that the rows spread over the LDS banks -- and the four quarters of a row meet through two quad
+                // permutes: ~35 instructions where twelve 64-lane butterflies (72 ds_bpermute + their adds) were ~200, a tenth of the kernel.
+                // Another fixed order than the butterfly: gradients agree with the plain kernel's to rounding.  (The FORWARD instantiation keeps the
+                // butterfly: with six rows the same change made it 19 % SLOWER -- session 34 --, and its images equal the plain kernel's bit for bit.)
+                const int c = lane >> 2, q = lane & 3;
+                float sum = 0.0f;
+                if (lane < 4 * NF) {
+                    const float4 *row = (const float4 *)&res[e][c][16 * ((q + NVDR_SQ_ROW_ROT * c) & 3)];
+                    const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+                    sum = (((r0.x + r0.y) + (r0.z + r0.w)) + ((r1.x + r1.y) + (r1.z + r1.w))) + (((r2.x + r2.y) + (r2.z + r2.w)) + ((r3.x + r3.y) + (r3.z + r3.w)));
+                }
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, true));       // quad_perm [1, 0, 3, 2]
+                sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, true));       // quad_perm [2, 3, 0, 1]
+                if (lane < 4 * NF && q == 0) {
+                    float *o = c < 3 ? p.g_kd : (c < 6 ? p.g_ks : (c < 9 ? p.g_pos : p.g_nrm));
+                    o[(int64_t)lin * 3 + (c - 3 * (c / 3))] = sum;
+                }
+            } else {
+                float v[NF];
 #pragma unroll
-            for (int c = 0; c < NF; ++c) v[c] = group_sum(res[e][c][lane], 64);
-            if (lane == 0) {
-                if constexpr (BACKWARD) {
-                    float *o = p.g_kd + (int64_t)lin * 3;
-                    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-                    o = p.g_ks + (int64_t)lin * 3;
-                    o[0] = v[3]; o[1] = v[4]; o[2] = v[5];
-                    o = p.g_pos + (int64_t)lin * 3;
-                    o[0] = v[6]; o[1] = v[7]; o[2] = v[8];
-                    o = p.g_nrm + (int64_t)lin * 3;
-                    o[0] = v[9]; o[1] = v[10]; o[2] = v[11];
-                } else {
-                    float *o = p.diff + (int64_t)lin * 3;
-                    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-                    o = p.spec + (int64_t)lin * 3;
-                    o[0] = v[3]; o[1] = v[4]; o[2] = v[5];
+                for (int c = 0; c < NF; ++c) v[c] = group_sum(res[e][c][lane], 64);
+                if (lane == 0) {
+                    if constexpr (BACKWARD) {
+                        float *o = p.g_kd + (int64_t)lin * 3;
+                        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+                        o = p.g_ks + (int64_t)lin * 3;
+                        o[0] = v[3]; o[1] = v[4]; o[2] = v[5];
+                        o = p.g_pos + (int64_t)lin * 3;
+                        o[0] = v[6]; o[1] = v[7]; o[2] = v[8];
+                        o = p.g_nrm + (int64_t)lin * 3;
+                        o[0] = v[9]; o[1] = v[10]; o[2] = v[11];
+                    } else {
+                        float *o = p.diff + (int64_t)lin * 3;
+                        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+                        o = p.spec + (int64_t)lin * 3;
+                        o[0] = v[3]; o[1] = v[4]; o[2] = v[5];
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();        // (the entry is free for the next pixel once its cells have been read)

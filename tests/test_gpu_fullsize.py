@@ -491,7 +491,7 @@ def test_light_gradient_records_vs_atomics_over_shapes(probe, n, res, mode, dev,
 def test_queue_shading_kernels_equal_the_plain_ones(cache_vis, dev, monkeypatch):
     """n_samples_x = 8 (S = 64): the shading kernels that queue the live light samples across pixels (env_shade_queue_kernel, the
     default there) against the plain ones (NVDR_SHADE_QUEUE=0): images bit for bit (per lane the same two addends), per-pixel
-    gradients up to the order in which a sample's own terms are added, the light gradient up to the order of the records."""
+    gradients up to the order in which a sample's own terms and a pixel's 64 lanes are added, the light gradient up to the order of the records."""
     n, res = 8, 160
     from nvdiffrecmc_amd import optixutils as ou
     seed, nv = 12, 3
@@ -519,8 +519,10 @@ def test_queue_shading_kernels_equal_the_plain_ones(cache_vis, dev, monkeypatch)
     d1, s1, g1 = run('3')
     assert d0.abs().sum().item() > 0
     assert torch.equal(d0, d1) and torch.equal(s0, s1)
+    # (5e-5: since round 6 the BACKWARD queue kernel adds a pixel's 64 per-lane results up in another fixed order -- quarter rows out of LDS -- than the plain
+    # kernel's butterfly; with the butterfly in both, 2e-5 held.  One element in 230 400 reached 3e-5.)
     for k in names[:4]:
-        assert_close(g1[k], g0[k], 2e-5, floor=1e-5 * g0[k].abs().max().item(), what=k)
+        assert_close(g1[k], g0[k], 5e-5, floor=1e-5 * g0[k].abs().max().item(), what=k)
     assert_close(g1['light'], g0['light'], 1e-4, floor=1e-3 * g0['light'].abs().max().item())
     # the same launch twice: deterministic
     d2, s2, g2 = run('3')

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6, GPU session 34: the row sums in the forward queue kernel as well: the whole GPU suite, A/B of the forward, then the measurement set
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out/r6s34; O=$R/gpurun_out/r6s34
+bash tools/build_variants.sh butterfly:"-DNVDR_SQ_ROW_SUMS=0" 2>&1 | tail -1
+ab() { out=$1; shift; env "$@" timeout 900 python tools/ab_inproc.py ${ROUNDS:-5} 2>&1 | grep -v "Warning\|tenancy\|amdgpu.ids" | head -5 | tee $O/$out.txt; }
+ab ab_bob8 PROBE_VIEWS=8
+ab ab_bob1 PROBE_VIEWS=1
+ab ab_684k_1 PROBE_VIEWS=1 PROBE_RES=800 PROBE_SUBDIV=3
+rm -f nvdiffrecmc_amd/csrc/build/variants/*
+bash tools/r06_final.sh

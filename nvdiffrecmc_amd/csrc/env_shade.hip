@@ -527,6 +527,10 @@ __device__ __forceinline__ float bsdf_pdf(float pDiffuse, float pSpecular, F3 N,
 }
 
 // butterfly sum over the L lanes that share a pixel (L a power of two <= 64)
+// (Round 6, session 37, measured and dropped: the same sums as DPP modifiers on the adds -- quad permutes, row_half_mirror, row_mirror, row_bcast15 / 31, the
+// last lane writing -- instead of __shfl_xor, which this compiler turns into ds_bpermute_b32.  No LDS round trips, and 8 % faster at 16 spp -- but at the 64 spp
+// of the benchmark the forward shading kernel got 3.6 % SLOWER (the compiler folds only a quarter of the permutes into their adds; the rest are v_mov_dpp + add
+// with hazard nops between dependent steps, where the six values' permutes used to pipeline), and the results were not the butterfly's bit for bit.)
 __device__ __forceinline__ float group_sum(float v, int L)
 {
     for (int o = L >> 1; o >= 1; o >>= 1) v += __shfl_xor(v, o);
